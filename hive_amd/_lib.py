@@ -1,0 +1,180 @@
+"""ctypes binding of ``libhive_mi355x.so`` (the C ABI in ``include/hive_mi355x.h``).
+
+There is no CPU fallback: if the shared library is missing, or no gfx950 device is visible when a
+context is requested, this module raises -- it never routes to numpy or to the test oracle.
+"""
+import ctypes
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libhive_mi355x.so")
+
+OK, ERR_INVALID, ERR_DEVICE, ERR_NOMEM, ERR_EMPTY, ERR_STATE = 0, -1, -2, -3, -4, -5
+MEM_HOST, MEM_DEVICE = 0, 1
+ROUND_HALF_EVEN, ROUND_HALF_AWAY = 0, 1
+F32, F16, BF16 = 0, 1, 2
+
+c_void_p, c_int, c_int64, c_float, c_double = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_double
+P = ctypes.POINTER
+
+# name -> (restype, argtypes); every symbol declared in include/hive_mi355x.h
+SIGNATURES = {
+    "hive_abi_version": (c_int, []),
+    "hive_ctx_create": (c_int, [c_int, c_void_p, P(c_void_p)]),
+    "hive_ctx_destroy": (c_int, [c_void_p]),
+    "hive_ctx_synchronize": (c_int, [c_void_p]),
+    "hive_last_error": (ctypes.c_char_p, [c_void_p]),
+    "hive_ctx_set_round_mode": (c_int, [c_void_p, c_int]),
+    "hive_ctx_set_timing": (c_int, [c_void_p, c_int]),
+    "hive_ctx_last_kernel_ms": (c_int, [c_void_p, P(c_float)]),
+    "hive_ctx_kernel_time_total": (c_int, [c_void_p, P(c_int), P(c_float)]),
+    "hive_tsdf_dims": (c_int, [c_void_p, c_double, c_void_p]),
+    "hive_tsdf_create": (c_int, [c_void_p, c_void_p, c_double, c_void_p, c_void_p, c_void_p, P(c_void_p)]),
+    "hive_tsdf_destroy": (c_int, [c_void_p]),
+    "hive_tsdf_reset": (c_int, [c_void_p]),
+    "hive_tsdf_info": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, P(c_float), P(c_float)]),
+    "hive_tsdf_device_ptrs": (c_int, [c_void_p, P(c_void_p), P(c_void_p), P(c_void_p)]),
+    "hive_tsdf_integrate": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_int,
+                                    P(ctypes.c_uint64)]),
+    "hive_tsdf_integrate_batch": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_float,
+                                          c_int]),
+    "hive_tsdf_get_volume": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "hive_tsdf_set_volume": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "hive_tsdf_extract_mesh": (c_int, [c_void_p, P(c_int64), P(c_int64)]),
+    "hive_tsdf_copy_mesh": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "hive_tsdf_copy_mesh_voxel_coords": (c_int, [c_void_p, c_void_p]),
+    "hive_tsdf_accum_reset": (c_int, [c_void_p, c_void_p]),
+    "hive_tsdf_accum_integrate": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_float,
+                                          c_int]),
+    "hive_tsdf_accum_finalize": (c_int, [c_void_p, c_void_p]),
+    "hive_view_frustum": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    "hive_unproject": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
+                               c_void_p, c_void_p, c_int64, P(c_int64)]),
+    "hive_image2world": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_double, c_int, c_void_p]),
+    "hive_project": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_double, c_int, c_void_p, c_void_p,
+                             c_void_p]),
+    "hive_dilate_mask": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "hive_depth_quantize": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+class HiveError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"libhive_mi355x error {code}: {message}")
+        self.code = code
+
+
+def load():
+    """Load the shared library (after torch, so that both share one HIP runtime: torch's bundled
+    libamdhip64.so.7 has the same soname as ROCm's)."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` or "
+                f"`make -C hive_amd/csrc`. hive_amd has no CPU fallback.")
+        try:
+            import torch  # noqa: F401  (loads torch's HIP runtime first)
+        except ImportError:
+            pass
+        lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+        for name, (restype, argtypes) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = restype
+            fn.argtypes = argtypes
+        if lib.hive_abi_version() != 1:
+            raise ImportError(f"{LIB_PATH}: ABI version {lib.hive_abi_version()} != 1")
+        _lib = lib
+        return _lib
+
+
+def ptr(a):
+    """Raw address of a numpy array / torch tensor / int / None."""
+    if a is None:
+        return None
+    if isinstance(a, int):
+        return a
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data
+    return a.data_ptr()
+
+
+def check(rc, ctx_handle=None):
+    if rc != OK:
+        msg = load().hive_last_error(ctx_handle)
+        raise HiveError(rc, msg.decode() if msg else "")
+
+
+class Context:
+    """One ``hive_ctx`` = one (GPU, stream).  By default it rides on torch's current stream of the
+    device so that hive kernels and torch kernels are ordered with each other."""
+
+    def __init__(self, device=0, stream="torch"):
+        lib = load()
+        self.device = int(device)
+        handle = c_void_p()
+        stream_ptr = None
+        if stream == "torch":
+            import torch
+            if not torch.cuda.is_available():
+                raise HiveError(ERR_DEVICE, "no HIP device visible to torch; hive_amd needs an MI355X (no CPU fallback)")
+            stream_ptr = torch.cuda.current_stream(self.device).cuda_stream
+        elif stream is not None:
+            stream_ptr = int(stream)
+        check(lib.hive_ctx_create(self.device, stream_ptr, ctypes.byref(handle)))
+        self.handle = handle
+        self.lib = lib
+
+    def check(self, rc):
+        check(rc, self.handle)
+
+    def synchronize(self):
+        self.check(self.lib.hive_ctx_synchronize(self.handle))
+
+    def set_round_mode(self, mode):
+        self.check(self.lib.hive_ctx_set_round_mode(self.handle, int(mode)))
+
+    def set_timing(self, enabled):
+        self.check(self.lib.hive_ctx_set_timing(self.handle, int(bool(enabled))))
+
+    def kernel_time_total(self):
+        n, ms = c_int(0), c_float(0)
+        self.check(self.lib.hive_ctx_kernel_time_total(self.handle, ctypes.byref(n), ctypes.byref(ms)))
+        return n.value, ms.value
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.hive_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ctx = {}
+_tls = threading.local()
+
+
+def default_context(device=None):
+    """Per-thread, per-device default context (the reference calls the geometric functions from a
+    ThreadPool, hive/pipeline.py:491; a hive_ctx is not re-entrant)."""
+    if device is None:
+        import torch
+        device = torch.cuda.current_device() if torch.cuda.is_available() else 0
+    cache = getattr(_tls, "ctx", None)
+    if cache is None:
+        cache = _tls.ctx = {}
+    if device not in cache:
+        cache[device] = Context(device)
+    return cache[device]

@@ -1,0 +1,190 @@
+// Context, error reporting, staging and timing plumbing of libhive_mi355x.so.
+#include "hive_internal.hpp"
+
+static thread_local std::string g_global_error;
+
+void hive_set_global_error(const char *msg) { g_global_error = msg ? msg : ""; }
+
+int hive_fail(hive_ctx *ctx, int code, const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx)
+        ctx->last_error = buf;
+    else
+        g_global_error = buf;
+    return code;
+}
+
+int hive_reserve_device(hive_ctx *ctx, void **ptr, size_t *cur, size_t bytes) {
+    if (*cur >= bytes && *ptr) return HIVE_OK;
+    if (*ptr) {
+        HIVE_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        HIVE_CHECK_HIP(ctx, hipFree(*ptr));
+        *ptr = nullptr;
+        *cur = 0;
+    }
+    HIVE_CHECK_HIP(ctx, hipMalloc(ptr, bytes));
+    *cur = bytes;
+    return HIVE_OK;
+}
+
+int hive_upload(hive_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    hive_staging_slot &s = ctx->slots[ctx->next_slot];
+    ctx->next_slot = (ctx->next_slot + 1) % hive_ctx::kSlots;
+    if (s.in_flight) {
+        HIVE_CHECK_HIP(ctx, hipEventSynchronize(s.done));
+        s.in_flight = false;
+    }
+    if (s.bytes < bytes) {
+        if (s.pinned) HIVE_CHECK_HIP(ctx, hipHostFree(s.pinned));
+        s.pinned = nullptr;
+        s.bytes = 0;
+        HIVE_CHECK_HIP(ctx, hipHostMalloc(&s.pinned, bytes, hipHostMallocDefault));
+        s.bytes = bytes;
+    }
+    if (!s.done) HIVE_CHECK_HIP(ctx, hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+    memcpy(s.pinned, src, bytes);
+    HIVE_CHECK_HIP(ctx, hipMemcpyAsync(dst, s.pinned, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIVE_CHECK_HIP(ctx, hipEventRecord(s.done, ctx->stream));
+    s.in_flight = true;
+    return HIVE_OK;
+}
+
+static int next_event(hive_ctx *ctx, hipEvent_t *ev) {
+    if (ctx->ev_used == ctx->ev_pool.size()) {
+        hipEvent_t e;
+        HIVE_CHECK_HIP(ctx, hipEventCreate(&e));
+        ctx->ev_pool.push_back(e);
+    }
+    *ev = ctx->ev_pool[ctx->ev_used++];
+    return HIVE_OK;
+}
+
+int hive_time_begin(hive_ctx *ctx) {
+    if (!ctx->timing) return HIVE_OK;
+    int rc = next_event(ctx, &ctx->last_start);
+    if (rc) return rc;
+    HIVE_CHECK_HIP(ctx, hipEventRecord(ctx->last_start, ctx->stream));
+    return HIVE_OK;
+}
+
+int hive_time_end(hive_ctx *ctx) {
+    if (!ctx->timing) return HIVE_OK;
+    int rc = next_event(ctx, &ctx->last_stop);
+    if (rc) return rc;
+    HIVE_CHECK_HIP(ctx, hipEventRecord(ctx->last_stop, ctx->stream));
+    return HIVE_OK;
+}
+
+extern "C" {
+
+int hive_abi_version(void) { return HIVE_ABI_VERSION; }
+
+int hive_ctx_create(int device_id, void *stream, hive_ctx **out) {
+    if (!out) return hive_fail(nullptr, HIVE_ERR_INVALID, "hive_ctx_create: out is NULL");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return hive_fail(nullptr, HIVE_ERR_DEVICE,
+                         "hive_ctx_create: no HIP device available (%s); libhive_mi355x has no CPU fallback",
+                         hipGetErrorString(e));
+    if (device_id < 0 || device_id >= count)
+        return hive_fail(nullptr, HIVE_ERR_INVALID, "hive_ctx_create: device %d out of range [0,%d)", device_id, count);
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device_id);
+    if (e != hipSuccess) return hive_fail(nullptr, HIVE_ERR_DEVICE, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return hive_fail(nullptr, HIVE_ERR_DEVICE, "hive_ctx_create: device %d is %s; this library is built for gfx950 only",
+                         device_id, prop.gcnArchName);
+    hive_ctx *ctx = new hive_ctx();
+    ctx->device = device_id;
+    e = hipSetDevice(device_id);
+    if (e == hipSuccess) {
+        if (stream) {
+            ctx->stream = (hipStream_t)stream;
+        } else {
+            e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+            ctx->owns_stream = true;
+        }
+    }
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_scalars, 64 * sizeof(unsigned));
+    if (e != hipSuccess) {
+        int rc = hive_fail(nullptr, HIVE_ERR_DEVICE, "hive_ctx_create: %s", hipGetErrorString(e));
+        delete ctx;
+        return rc;
+    }
+    *out = ctx;
+    return HIVE_OK;
+}
+
+int hive_ctx_destroy(hive_ctx *ctx) {
+    if (!ctx) return HIVE_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &s : ctx->slots) {
+        if (s.pinned) (void)hipHostFree(s.pinned);
+        if (s.done) (void)hipEventDestroy(s.done);
+    }
+    for (auto ev : ctx->ev_pool) (void)hipEventDestroy(ev);
+    if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+    if (ctx->d_frame) (void)hipFree(ctx->d_frame);
+    if (ctx->d_in) (void)hipFree(ctx->d_in);
+    if (ctx->d_scalars) (void)hipFree(ctx->d_scalars);
+    if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return HIVE_OK;
+}
+
+int hive_ctx_synchronize(hive_ctx *ctx) {
+    if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
+    HIVE_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return HIVE_OK;
+}
+
+const char *hive_last_error(hive_ctx *ctx) { return ctx ? ctx->last_error.c_str() : g_global_error.c_str(); }
+
+int hive_ctx_set_round_mode(hive_ctx *ctx, int mode) {
+    if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
+    HIVE_REQUIRE(ctx, mode == HIVE_ROUND_HALF_EVEN || mode == HIVE_ROUND_HALF_AWAY, "round mode must be 0 or 1, got %d", mode);
+    ctx->round_mode = mode;
+    return HIVE_OK;
+}
+
+int hive_ctx_set_timing(hive_ctx *ctx, int enabled) {
+    if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
+    ctx->timing = enabled != 0;
+    ctx->ev_used = 0;
+    ctx->last_start = ctx->last_stop = nullptr;
+    return HIVE_OK;
+}
+
+int hive_ctx_last_kernel_ms(hive_ctx *ctx, float *ms) {
+    if (!ctx || !ms) return hive_fail(ctx, HIVE_ERR_INVALID, "NULL argument");
+    HIVE_REQUIRE(ctx, ctx->last_start && ctx->last_stop, "no timed kernel has been launched on this context");
+    HIVE_CHECK_HIP(ctx, hipEventSynchronize(ctx->last_stop));
+    HIVE_CHECK_HIP(ctx, hipEventElapsedTime(ms, ctx->last_start, ctx->last_stop));
+    return HIVE_OK;
+}
+
+int hive_ctx_kernel_time_total(hive_ctx *ctx, int *n_launches, float *total_ms) {
+    if (!ctx || !n_launches || !total_ms) return hive_fail(ctx, HIVE_ERR_INVALID, "NULL argument");
+    HIVE_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    float total = 0.f;
+    int n = 0;
+    for (size_t i = 0; i + 1 < ctx->ev_used; i += 2) {
+        float ms = 0.f;
+        HIVE_CHECK_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev_pool[i], ctx->ev_pool[i + 1]));
+        total += ms;
+        ++n;
+    }
+    *n_launches = n;
+    *total_ms = total;
+    ctx->ev_used = 0;
+    return HIVE_OK;
+}
+
+}  // extern "C"

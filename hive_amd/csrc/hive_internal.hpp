@@ -1,0 +1,106 @@
+// Internal declarations shared by the translation units of libhive_mi355x.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/hive_mi355x.h"
+
+#define HIVE_WAVE 64
+
+struct hive_staging_slot {
+    void *pinned = nullptr;
+    size_t bytes = 0;
+    hipEvent_t done = nullptr;
+    bool in_flight = false;
+};
+
+struct hive_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool owns_stream = false;
+    int round_mode = HIVE_ROUND_HALF_EVEN;
+    std::string last_error;
+
+    // host -> device staging ring (pinned), so that a HOST call may return before the copy lands
+    static constexpr int kSlots = 4;
+    hive_staging_slot slots[kSlots];
+    int next_slot = 0;
+
+    // generic device scratch (grown on demand, never shrunk)
+    void *d_scratch = nullptr;
+    size_t scratch_bytes = 0;
+    // packed frame {depth bits, rgb} + per-frame scalars
+    void *d_frame = nullptr;
+    size_t frame_bytes = 0;
+    void *d_in = nullptr;  // device copy of host inputs
+    size_t in_bytes = 0;
+    unsigned *d_scalars = nullptr;  // [0]=max depth bits, [2..3]=u64 counter, ...
+
+    // HIP-event timing of the dominant kernel
+    bool timing = false;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    hipEvent_t last_start = nullptr, last_stop = nullptr;
+};
+
+int hive_fail(hive_ctx *ctx, int code, const char *fmt, ...);
+void hive_set_global_error(const char *msg);
+
+#define HIVE_CHECK_HIP(ctx, expr)                                                                        \
+    do {                                                                                                 \
+        hipError_t _e = (expr);                                                                          \
+        if (_e != hipSuccess)                                                                            \
+            return hive_fail((ctx), _e == hipErrorOutOfMemory ? HIVE_ERR_NOMEM : HIVE_ERR_DEVICE,        \
+                             "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+#define HIVE_REQUIRE(ctx, cond, ...)                                   \
+    do {                                                               \
+        if (!(cond)) return hive_fail((ctx), HIVE_ERR_INVALID, __VA_ARGS__); \
+    } while (0)
+
+// grows *ptr to at least `bytes` of device memory
+int hive_reserve_device(hive_ctx *ctx, void **ptr, size_t *cur, size_t bytes);
+// copies `bytes` from host memory to device memory `dst` through the pinned ring; returns once the
+// host buffer may be reused by the caller
+int hive_upload(hive_ctx *ctx, void *dst, const void *src, size_t bytes);
+// event helpers for kernel timing
+int hive_time_begin(hive_ctx *ctx);
+int hive_time_end(hive_ctx *ctx);
+
+struct hive_tsdf {
+    hive_ctx *ctx = nullptr;
+    int64_t dim[3] = {0, 0, 0};
+    int64_t n = 0;
+    double bnds[6] = {0, 0, 0, 0, 0, 0};
+    float origin[3] = {0, 0, 0};
+    float voxel_size = 0.f;
+    float trunc = 0.f;
+    float *d_tsdf = nullptr, *d_weight = nullptr, *d_color = nullptr;
+    bool owns = false;
+    // mesh extraction results (device)
+    int64_t n_verts = -1, n_faces = -1;
+    float *d_verts = nullptr, *d_norms = nullptr, *d_verts_vox = nullptr;
+    int32_t *d_faces = nullptr;
+    uint8_t *d_vcolors = nullptr;
+    // mesh scratch
+    uint32_t *d_vbase = nullptr;  // per voxel: first vertex id | axis mask << 29
+    size_t vbase_bytes = 0;
+    uint32_t *d_blk = nullptr;  // per block counts / offsets
+    size_t blk_bytes = 0;
+};
+
+void hive_tsdf_free_mesh(hive_tsdf *vol);
+
+// rounding shared by device code: RM = 0 half-even (np.round), 1 half-away (roundf)
+template <int RM>
+__device__ __forceinline__ float hive_round(float x) {
+    if (RM == 0) return rintf(x);
+    return roundf(x);
+}

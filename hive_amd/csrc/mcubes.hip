@@ -1,0 +1,370 @@
+// Marching cubes on the TSDF volume (level 0): wave-scan stream compaction, one vertex per
+// sign-changing grid edge.  gfx950 only.
+//
+// Replaces `fusion.TSDFVolume.get_mesh()` of the reference's (absent) third_party/tsdf_fusion_python
+// (call site /root/reference/hive/fusion.py:127), which wraps scikit-image's Lewiner marching cubes.
+// Table conventions and ordering: tools/gen_mc_tables.py and include/hive_mi355x.h.
+//
+// Passes (each a coalesced sweep over the float32 tsdf volume, 4 voxels per lane):
+//   count   per-block number of owned-edge vertices and of triangles
+//   scan    exclusive scan of the per-block counts (one workgroup)
+//   verts   per-block wave scan -> vertex id; writes position / normal / colour and, per voxel,
+//           vbase = first vertex id | owned-axis mask << 29 (only where the mask is non-zero)
+//   faces   per-block wave scan -> triangle id; vertex ids looked up through vbase
+#include "hive_internal.hpp"
+#include "../../include/hive_mc_tables.h"
+
+#include <algorithm>
+
+__constant__ unsigned char c_num_tris[256];
+__constant__ unsigned char c_tri_table[256][3 * HIVE_MC_MAX_TRIS];
+__constant__ unsigned char c_edge_owner[12][4];
+
+struct McParams {
+    const float *tsdf;
+    const float *color;
+    int X, Y, Z;
+    long long n;
+    float ox, oy, oz, vs;
+};
+
+constexpr int MC_VPT = 4;
+constexpr int MC_BLOCK = 256;
+constexpr int MC_TILE = MC_VPT * MC_BLOCK;
+
+struct VoxClass {
+    unsigned axis_mask;  // bit a set: the edge from this voxel towards +axis a carries a vertex
+    int cs;              // marching-cubes case of the cell whose corner 0 is this voxel, -1 if no cell
+};
+
+__device__ __forceinline__ VoxClass classify(const McParams &p, long long idx, int x, int y, int z) {
+    const long long sx = (long long)p.Y * p.Z, sy = p.Z;
+    const bool hx = x + 1 < p.X, hy = y + 1 < p.Y, hz = z + 1 < p.Z;
+    const float v0 = p.tsdf[idx];
+    const bool n0 = v0 < 0.0f;
+    const bool n1 = hx ? p.tsdf[idx + sx] < 0.0f : n0;
+    const bool n3 = hy ? p.tsdf[idx + sy] < 0.0f : n0;
+    const bool n4 = hz ? p.tsdf[idx + 1] < 0.0f : n0;
+    VoxClass c;
+    c.axis_mask = (unsigned)(n1 != n0) | ((unsigned)(n3 != n0) << 1) | ((unsigned)(n4 != n0) << 2);
+    c.cs = -1;
+    if (hx && hy && hz) {
+        const bool n2 = p.tsdf[idx + sx + sy] < 0.0f;
+        const bool n5 = p.tsdf[idx + sx + 1] < 0.0f;
+        const bool n6 = p.tsdf[idx + sx + sy + 1] < 0.0f;
+        const bool n7 = p.tsdf[idx + sy + 1] < 0.0f;
+        c.cs = (int)n0 | ((int)n1 << 1) | ((int)n2 << 2) | ((int)n3 << 3) | ((int)n4 << 4) | ((int)n5 << 5) | ((int)n6 << 6) |
+               ((int)n7 << 7);
+    }
+    return c;
+}
+
+__device__ __forceinline__ void decode(const McParams &p, long long idx, int &x, int &y, int &z) {
+    z = (int)(idx % p.Z);
+    const long long r = idx / p.Z;
+    y = (int)(r % p.Y);
+    x = (int)(r / p.Y);
+}
+
+// exclusive scan of one unsigned per thread over the 256-thread block; returns the block total in `total`
+__device__ __forceinline__ unsigned block_exclusive_scan(unsigned v, unsigned *lds4, unsigned &total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned inc = v;
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned o = (unsigned)__shfl_up((int)inc, off);
+        if (lane >= off) inc += o;
+    }
+    if (lane == 63) lds4[wave] = inc;
+    __syncthreads();
+    unsigned before = 0;
+    total = 0;
+    for (int w = 0; w < MC_BLOCK / 64; ++w) {
+        if (w < wave) before += lds4[w];
+        total += lds4[w];
+    }
+    __syncthreads();
+    return before + inc - v;
+}
+
+__global__ __launch_bounds__(MC_BLOCK) void mc_count_kernel(McParams p, unsigned *__restrict__ blk_v, unsigned *__restrict__ blk_t) {
+    __shared__ unsigned lds[8];
+    const long long base = (long long)blockIdx.x * MC_TILE + (long long)threadIdx.x * MC_VPT;
+    unsigned nv = 0, nt = 0;
+    for (int j = 0; j < MC_VPT; ++j) {
+        const long long idx = base + j;
+        if (idx >= p.n) break;
+        int x, y, z;
+        decode(p, idx, x, y, z);
+        const VoxClass c = classify(p, idx, x, y, z);
+        nv += __popc(c.axis_mask);
+        if (c.cs >= 0) nt += c_num_tris[c.cs];
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        nv += (unsigned)__shfl_xor((int)nv, off);
+        nt += (unsigned)__shfl_xor((int)nt, off);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        lds[wave] = nv;
+        lds[4 + wave] = nt;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        blk_v[blockIdx.x] = lds[0] + lds[1] + lds[2] + lds[3];
+        blk_t[blockIdx.x] = lds[4] + lds[5] + lds[6] + lds[7];
+    }
+}
+
+// exclusive scan of two arrays of nb counts in place; totals (u64) to totals[0], totals[1]
+__global__ __launch_bounds__(1024) void mc_scan_kernel(unsigned *__restrict__ a, unsigned *__restrict__ b, int nb,
+                                                       unsigned long long *totals) {
+    __shared__ unsigned long long part[2][1024];
+    const int t = threadIdx.x;
+    const int per = (nb + 1023) / 1024;
+    const int lo = min(t * per, nb), hi = min(lo + per, nb);
+    unsigned long long sa = 0, sb = 0;
+    for (int i = lo; i < hi; ++i) {
+        sa += a[i];
+        sb += b[i];
+    }
+    part[0][t] = sa;
+    part[1][t] = sb;
+    __syncthreads();
+    if (t == 0) {
+        unsigned long long ra = 0, rb = 0;
+        for (int i = 0; i < 1024; ++i) {
+            const unsigned long long ta = part[0][i], tb = part[1][i];
+            part[0][i] = ra;
+            part[1][i] = rb;
+            ra += ta;
+            rb += tb;
+        }
+        totals[0] = ra;
+        totals[1] = rb;
+    }
+    __syncthreads();
+    unsigned long long ra = part[0][t], rb = part[1][t];
+    for (int i = lo; i < hi; ++i) {
+        const unsigned va = a[i], vb = b[i];
+        a[i] = (unsigned)ra;
+        b[i] = (unsigned)rb;
+        ra += va;
+        rb += vb;
+    }
+}
+
+__device__ __forceinline__ float grad_axis(const McParams &p, int x, int y, int z, int axis) {
+    int lo[3] = {x, y, z}, hi[3] = {x, y, z};
+    const int d[3] = {p.X, p.Y, p.Z};
+    const int c = axis == 0 ? x : (axis == 1 ? y : z);
+    if (c > 0) lo[axis] -= 1;
+    if (c < d[axis] - 1) hi[axis] += 1;
+    const float a = p.tsdf[((long long)hi[0] * p.Y + hi[1]) * p.Z + hi[2]];
+    const float b = p.tsdf[((long long)lo[0] * p.Y + lo[1]) * p.Z + lo[2]];
+    const float span = (float)(hi[axis] - lo[axis]);
+    return span > 0.0f ? (a - b) / span : 0.0f;
+}
+
+__global__ __launch_bounds__(MC_BLOCK) void mc_verts_kernel(McParams p, const unsigned *__restrict__ blk_v,
+                                                            unsigned *__restrict__ vbase, float *__restrict__ verts,
+                                                            float *__restrict__ verts_vox, float *__restrict__ norms,
+                                                            uint8_t *__restrict__ colors) {
+    __shared__ unsigned lds[4];
+    const long long base = (long long)blockIdx.x * MC_TILE + (long long)threadIdx.x * MC_VPT;
+    unsigned mask[MC_VPT];
+    unsigned cnt = 0;
+#pragma unroll
+    for (int j = 0; j < MC_VPT; ++j) {
+        mask[j] = 0;
+        const long long idx = base + j;
+        if (idx < p.n) {
+            int x, y, z;
+            decode(p, idx, x, y, z);
+            mask[j] = classify(p, idx, x, y, z).axis_mask;
+        }
+        cnt += __popc(mask[j]);
+    }
+    unsigned total;
+    unsigned id = blk_v[blockIdx.x] + block_exclusive_scan(cnt, lds, total);
+#pragma unroll
+    for (int j = 0; j < MC_VPT; ++j) {
+        if (!mask[j]) continue;
+        const long long idx = base + j;
+        int x, y, z;
+        decode(p, idx, x, y, z);
+        vbase[idx] = id | (mask[j] << 29);
+        const float v0 = p.tsdf[idx];
+        const long long stride[3] = {(long long)p.Y * p.Z, p.Z, 1};
+        for (int a = 0; a < 3; ++a) {
+            if (!((mask[j] >> a) & 1u)) continue;
+            const float v1 = p.tsdf[idx + stride[a]];
+            const float t = v0 / (v0 - v1);
+            float pos[3] = {(float)x, (float)y, (float)z};
+            pos[a] = pos[a] + t;
+            int q[3] = {x, y, z};
+            q[a] += 1;
+            float g[3];
+            for (int r = 0; r < 3; ++r) {
+                const float g0 = grad_axis(p, x, y, z, r);
+                const float g1 = grad_axis(p, q[0], q[1], q[2], r);
+                g[r] = g0 + t * (g1 - g0);
+            }
+            const float len = sqrtf(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
+            const float org[3] = {p.ox, p.oy, p.oz};
+            const int dim[3] = {p.X, p.Y, p.Z};
+            int ci[3];
+            for (int r = 0; r < 3; ++r) {
+                verts_vox[3ll * id + r] = pos[r];
+                verts[3ll * id + r] = pos[r] * p.vs + org[r];
+                norms[3ll * id + r] = len > 0.0f ? g[r] / len : 0.0f;
+                ci[r] = min((int)rintf(pos[r]), dim[r] - 1);
+            }
+            const unsigned c = (unsigned)p.color[((long long)ci[0] * p.Y + ci[1]) * p.Z + ci[2]];
+            colors[3ll * id + 0] = (uint8_t)(c & 255u);
+            colors[3ll * id + 1] = (uint8_t)((c >> 8) & 255u);
+            colors[3ll * id + 2] = (uint8_t)(c >> 16);
+            ++id;
+        }
+    }
+}
+
+__global__ __launch_bounds__(MC_BLOCK) void mc_faces_kernel(McParams p, const unsigned *__restrict__ blk_t,
+                                                            const unsigned *__restrict__ vbase, int32_t *__restrict__ faces) {
+    __shared__ unsigned lds[4];
+    const long long base = (long long)blockIdx.x * MC_TILE + (long long)threadIdx.x * MC_VPT;
+    int cs[MC_VPT];
+    unsigned cnt = 0;
+#pragma unroll
+    for (int j = 0; j < MC_VPT; ++j) {
+        cs[j] = -1;
+        const long long idx = base + j;
+        if (idx < p.n) {
+            int x, y, z;
+            decode(p, idx, x, y, z);
+            cs[j] = classify(p, idx, x, y, z).cs;
+        }
+        if (cs[j] >= 0) cnt += c_num_tris[cs[j]];
+    }
+    unsigned total;
+    unsigned long long fid = blk_t[blockIdx.x] + block_exclusive_scan(cnt, lds, total);
+#pragma unroll
+    for (int j = 0; j < MC_VPT; ++j) {
+        if (cs[j] < 0) continue;
+        const int nt = c_num_tris[cs[j]];
+        const long long idx = base + j;
+        for (int k = 0; k < nt; ++k) {
+            for (int m = 0; m < 3; ++m) {
+                const int e = c_tri_table[cs[j]][3 * k + m];
+                const long long oi = idx + ((long long)c_edge_owner[e][0] * p.Y + c_edge_owner[e][1]) * p.Z + c_edge_owner[e][2];
+                const unsigned vb = vbase[oi];
+                const unsigned am = vb >> 29;
+                const int a = c_edge_owner[e][3];
+                faces[3 * fid + m] = (int32_t)((vb & 0x1fffffffu) + __popc(am & ((1u << a) - 1u)));
+            }
+            ++fid;
+        }
+    }
+}
+
+void hive_tsdf_free_mesh(hive_tsdf *v) {
+    if (v->d_verts) (void)hipFree(v->d_verts);
+    if (v->d_norms) (void)hipFree(v->d_norms);
+    if (v->d_verts_vox) (void)hipFree(v->d_verts_vox);
+    if (v->d_faces) (void)hipFree(v->d_faces);
+    if (v->d_vcolors) (void)hipFree(v->d_vcolors);
+    v->d_verts = v->d_norms = v->d_verts_vox = nullptr;
+    v->d_faces = nullptr;
+    v->d_vcolors = nullptr;
+    v->n_verts = v->n_faces = -1;
+}
+
+static bool g_tables_uploaded[64] = {false};
+
+static int upload_tables(hive_ctx *ctx) {
+    if (ctx->device < 64 && g_tables_uploaded[ctx->device]) return HIVE_OK;
+    HIVE_CHECK_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(c_num_tris), HIVE_MC_NUM_TRIS, sizeof(HIVE_MC_NUM_TRIS)));
+    HIVE_CHECK_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(c_tri_table), HIVE_MC_TRI_TABLE, sizeof(HIVE_MC_TRI_TABLE)));
+    HIVE_CHECK_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(c_edge_owner), HIVE_MC_EDGE_OWNER, sizeof(HIVE_MC_EDGE_OWNER)));
+    if (ctx->device < 64) g_tables_uploaded[ctx->device] = true;
+    return HIVE_OK;
+}
+
+extern "C" {
+
+int hive_tsdf_extract_mesh(hive_tsdf *v, int64_t *n_verts, int64_t *n_faces) {
+    if (!v) return hive_fail(nullptr, HIVE_ERR_INVALID, "vol is NULL");
+    hive_ctx *ctx = v->ctx;
+    HIVE_CHECK_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = upload_tables(ctx);
+    if (rc) return rc;
+    hive_tsdf_free_mesh(v);
+    McParams p;
+    p.tsdf = v->d_tsdf;
+    p.color = v->d_color;
+    p.X = (int)v->dim[0];
+    p.Y = (int)v->dim[1];
+    p.Z = (int)v->dim[2];
+    p.n = v->n;
+    p.ox = v->origin[0];
+    p.oy = v->origin[1];
+    p.oz = v->origin[2];
+    p.vs = v->voxel_size;
+    const long long nb = (v->n + MC_TILE - 1) / MC_TILE;
+    HIVE_REQUIRE(ctx, nb < (1ll << 31), "volume too large for mesh extraction");
+    if ((rc = hive_reserve_device(ctx, (void **)&v->d_blk, &v->blk_bytes, 2 * (size_t)nb * sizeof(unsigned)))) return rc;
+    unsigned *blk_v = v->d_blk, *blk_t = v->d_blk + nb;
+    unsigned long long *d_tot = (unsigned long long *)(ctx->d_scalars + 8);
+    hipLaunchKernelGGL(mc_count_kernel, dim3((unsigned)nb), dim3(MC_BLOCK), 0, ctx->stream, p, blk_v, blk_t);
+    hipLaunchKernelGGL(mc_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, blk_v, blk_t, (int)nb, d_tot);
+    HIVE_CHECK_HIP(ctx, hipGetLastError());
+    unsigned long long tot[2] = {0, 0};
+    HIVE_CHECK_HIP(ctx, hipMemcpyAsync(tot, d_tot, sizeof(tot), hipMemcpyDeviceToHost, ctx->stream));
+    HIVE_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (tot[0] == 0) {
+        v->n_verts = v->n_faces = -1;
+        return hive_fail(ctx, HIVE_ERR_EMPTY, "Surface level must be within volume data range.");
+    }
+    HIVE_REQUIRE(ctx, tot[0] < (1ull << 29) && 3 * tot[1] < (1ull << 31), "mesh too large: %llu vertices, %llu faces", tot[0],
+                 tot[1]);
+    if ((rc = hive_reserve_device(ctx, (void **)&v->d_vbase, &v->vbase_bytes, (size_t)v->n * sizeof(unsigned)))) return rc;
+    const size_t nv = tot[0], nf = tot[1];
+    HIVE_CHECK_HIP(ctx, hipMalloc((void **)&v->d_verts, nv * 3 * sizeof(float)));
+    HIVE_CHECK_HIP(ctx, hipMalloc((void **)&v->d_verts_vox, nv * 3 * sizeof(float)));
+    HIVE_CHECK_HIP(ctx, hipMalloc((void **)&v->d_norms, nv * 3 * sizeof(float)));
+    HIVE_CHECK_HIP(ctx, hipMalloc((void **)&v->d_vcolors, nv * 3));
+    HIVE_CHECK_HIP(ctx, hipMalloc((void **)&v->d_faces, std::max<size_t>(nf, 1) * 3 * sizeof(int32_t)));
+    hipLaunchKernelGGL(mc_verts_kernel, dim3((unsigned)nb), dim3(MC_BLOCK), 0, ctx->stream, p, blk_v, v->d_vbase, v->d_verts,
+                       v->d_verts_vox, v->d_norms, v->d_vcolors);
+    hipLaunchKernelGGL(mc_faces_kernel, dim3((unsigned)nb), dim3(MC_BLOCK), 0, ctx->stream, p, blk_t, v->d_vbase, v->d_faces);
+    HIVE_CHECK_HIP(ctx, hipGetLastError());
+    v->n_verts = (int64_t)nv;
+    v->n_faces = (int64_t)nf;
+    if (n_verts) *n_verts = v->n_verts;
+    if (n_faces) *n_faces = v->n_faces;
+    return HIVE_OK;
+}
+
+int hive_tsdf_copy_mesh(hive_tsdf *v, float *verts, int32_t *faces, float *norms, uint8_t *colors) {
+    if (!v) return hive_fail(nullptr, HIVE_ERR_INVALID, "vol is NULL");
+    hive_ctx *ctx = v->ctx;
+    if (v->n_verts < 0) return hive_fail(ctx, HIVE_ERR_STATE, "copy_mesh: call hive_tsdf_extract_mesh first");
+    const size_t nv = (size_t)v->n_verts, nf = (size_t)v->n_faces;
+    if (verts) HIVE_CHECK_HIP(ctx, hipMemcpyAsync(verts, v->d_verts, nv * 12, hipMemcpyDeviceToHost, ctx->stream));
+    if (norms) HIVE_CHECK_HIP(ctx, hipMemcpyAsync(norms, v->d_norms, nv * 12, hipMemcpyDeviceToHost, ctx->stream));
+    if (colors) HIVE_CHECK_HIP(ctx, hipMemcpyAsync(colors, v->d_vcolors, nv * 3, hipMemcpyDeviceToHost, ctx->stream));
+    if (faces && nf) HIVE_CHECK_HIP(ctx, hipMemcpyAsync(faces, v->d_faces, nf * 12, hipMemcpyDeviceToHost, ctx->stream));
+    HIVE_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return HIVE_OK;
+}
+
+int hive_tsdf_copy_mesh_voxel_coords(hive_tsdf *v, float *verts_vox) {
+    if (!v) return hive_fail(nullptr, HIVE_ERR_INVALID, "vol is NULL");
+    hive_ctx *ctx = v->ctx;
+    if (v->n_verts < 0) return hive_fail(ctx, HIVE_ERR_STATE, "copy_mesh_voxel_coords: call hive_tsdf_extract_mesh first");
+    HIVE_REQUIRE(ctx, verts_vox, "NULL argument");
+    HIVE_CHECK_HIP(ctx, hipMemcpyAsync(verts_vox, v->d_verts_vox, (size_t)v->n_verts * 12, hipMemcpyDeviceToHost, ctx->stream));
+    HIVE_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return HIVE_OK;
+}
+
+}  // extern "C"

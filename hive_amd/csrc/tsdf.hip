@@ -1,0 +1,557 @@
+// TSDF volume: create / integrate / accumulate / finalize.  gfx950 only.
+//
+// Replaces `fusion.TSDFVolume.{__init__,integrate,get_volume}` of the reference's (absent)
+// third_party/tsdf_fusion_python, call sites /root/reference/hive/fusion.py:104,124.
+//
+// Arithmetic contract (bit-exact against oracle/hive_oracle.c, build with -ffp-contract=off):
+//   pt = origin + idx*voxel ; t = pt - T ; cam = (R0*tx + R1*ty) + R2*tz ; cam_z > 0 ;
+//   pix = round(f*(cam/cam_z) + c) ; 0 <= pix < size ; depth != 0 ; depth - cam_z >= -trunc ;
+//   dist = min(1, diff/trunc) ; w' = w + ow ; tsdf' = (tsdf*w + ow*dist)/w' ;
+//   c' = min(255, round((c*w + ow*c_new)/w')) per channel.
+//
+// Kernel shape: HBM-bound voxel sweep.  The volume is [X][Y][Z] with z fastest, so one wave owns one
+// (x,y) row and sweeps z with 16-byte accesses per lane (1 KiB per wave instruction and volume).
+// Each row is clipped analytically against the view frustum first (the camera-space position is
+// affine in z), so voxels that cannot pass the inclusion tests cost nothing; the clip is padded and
+// every surviving voxel still runs the exact tests above, so results do not depend on it.
+#include "hive_internal.hpp"
+
+#include <algorithm>
+#include <cmath>
+
+struct FrameParams {
+    float R[9];  // cam_pose[r][c] for r,c < 3, row-major (camera-to-world rotation)
+    float T[3];  // cam_pose[r][3]
+    float fx, fy, cx, cy;
+    float ox, oy, oz, vs, trunc, obs_w;
+    int X, Y, Z, H, W;
+    const uint2 *frame;             // {depth bits, r | g<<8 | b<<16}
+    const unsigned *max_depth_bits;  // float bits of max(depth) of this frame
+    unsigned long long *n_updated;
+};
+
+// ---------------------------------------------------------------------------------------------
+// pre-pass: fuse depth f32 + colour u8x3 into one 8-byte texel and reduce max(depth)
+__global__ __launch_bounds__(256) void pack_frame_kernel(const float *__restrict__ depth, const uint8_t *__restrict__ color,
+                                                         int n, uint2 *__restrict__ out, unsigned *max_bits) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    float d = 0.f;
+    if (i < n) {
+        d = depth[i];
+        unsigned r = color[3 * i + 0], g = color[3 * i + 1], b = color[3 * i + 2];
+        out[i] = make_uint2(__float_as_uint(d), r | (g << 8) | (b << 16));
+    }
+    // max over non-negative floats == max over their bit patterns; NaN / negatives are ignored (treated as 0)
+    unsigned bits = (d > 0.f) ? __float_as_uint(d) : 0u;
+    for (int off = 32; off > 0; off >>= 1) bits = max(bits, (unsigned)__shfl_xor((int)bits, off));
+    if ((threadIdx.x & 63) == 0 && bits) atomicMax(max_bits, bits);
+}
+
+// ---------------------------------------------------------------------------------------------
+struct RowClip {
+    int z0, z1;  // half-open voxel range that may pass the inclusion tests
+};
+
+// Clip the row cam(tz) = a + b*tz against the padded frustum.  Conservative: pixel bounds widened by
+// half a pixel, the result by 2 voxels on each side.
+__device__ __forceinline__ RowClip clip_row(const FrameParams &p, float ax, float ay, float az, float far_z) {
+    const float bx = p.R[6], by = p.R[7], bz = p.R[8];
+    // tz range of the row: tz(z) = (oz + z*vs) - T2
+    float lo = (p.oz - p.T[2]) - p.vs;
+    float hi = (p.oz + (float)p.Z * p.vs - p.T[2]) + p.vs;
+    bool empty = false;
+    auto cut = [&](float alpha, float beta) {  // keep alpha + beta*tz >= 0
+        if (beta > 0.f) {
+            lo = fmaxf(lo, -alpha / beta);
+        } else if (beta < 0.f) {
+            hi = fminf(hi, -alpha / beta);
+        } else if (alpha < 0.f) {
+            empty = true;
+        }
+    };
+    cut(az, bz);                                                      // cam_z >= 0
+    cut(far_z - az, -bz);                                             // cam_z <= far
+    cut(p.fx * ax + (p.cx + 1.0f) * az, p.fx * bx + (p.cx + 1.0f) * bz);                    // px >= -1
+    cut(((float)p.W - p.cx) * az - p.fx * ax, ((float)p.W - p.cx) * bz - p.fx * bx);        // px <= W
+    cut(p.fy * ay + (p.cy + 1.0f) * az, p.fy * by + (p.cy + 1.0f) * bz);                    // py >= -1
+    cut(((float)p.H - p.cy) * az - p.fy * ay, ((float)p.H - p.cy) * bz - p.fy * by);        // py <= H
+    RowClip r;
+    if (empty || !(lo <= hi)) {
+        r.z0 = r.z1 = 0;
+        return r;
+    }
+    const float inv = 1.0f / p.vs;
+    float zf0 = floorf((lo + p.T[2] - p.oz) * inv) - 2.0f;
+    float zf1 = ceilf((hi + p.T[2] - p.oz) * inv) + 3.0f;
+    zf0 = fminf(fmaxf(zf0, 0.f), (float)p.Z);
+    zf1 = fminf(fmaxf(zf1, 0.f), (float)p.Z);
+    r.z0 = (int)zf0;
+    r.z1 = (int)zf1;
+    return r;
+}
+
+// per-voxel inclusion tests + sample fetch; returns false when the voxel is not updated
+template <int RM>
+__device__ __forceinline__ bool sample_voxel(const FrameParams &p, float ax, float ay, float az, int z, float &dist,
+                                             unsigned &rgb) {
+    const float pt_z = p.oz + (float)z * p.vs;
+    const float tz = pt_z - p.T[2];
+    const float cam_x = ax + p.R[6] * tz;
+    const float cam_y = ay + p.R[7] * tz;
+    const float cam_z = az + p.R[8] * tz;
+    bool ok = cam_z > 0.0f;
+    const float px = hive_round<RM>(p.fx * (cam_x / cam_z) + p.cx);
+    const float py = hive_round<RM>(p.fy * (cam_y / cam_z) + p.cy);
+    ok = ok && (px >= 0.0f) && (px < (float)p.W) && (py >= 0.0f) && (py < (float)p.H);
+    const int pix = ok ? ((int)py * p.W + (int)px) : 0;
+    const uint2 s = p.frame[pix];
+    const float depth = __uint_as_float(s.x);
+    const float diff = depth - cam_z;
+    ok = ok && (depth != 0.0f) && !(diff < -p.trunc);
+    dist = fminf(1.0f, diff / p.trunc);
+    rgb = s.y;
+    return ok;
+}
+
+template <int RM>
+__device__ __forceinline__ float blend_channel(float c_old, float w_old, float ow, float c_new, float w_new) {
+    return fminf(hive_round<RM>((c_old * w_old + ow * c_new) / w_new), 255.0f);
+}
+
+template <int RM>
+__device__ __forceinline__ void update_voxel(float &t, float &w, float &c, float dist, unsigned rgb, float ow) {
+    const float w_old = w;
+    const float w_new = w_old + ow;
+    w = w_new;
+    t = (t * w_old + ow * dist) / w_new;
+    const unsigned oc = (unsigned)c;  // exact: packed colour is an integer < 2^24
+    const float r = blend_channel<RM>((float)(oc & 255u), w_old, ow, (float)(rgb & 255u), w_new);
+    const float g = blend_channel<RM>((float)((oc >> 8) & 255u), w_old, ow, (float)((rgb >> 8) & 255u), w_new);
+    const float b = blend_channel<RM>((float)(oc >> 16), w_old, ow, (float)((rgb >> 16) & 255u), w_new);
+    c = (float)(((unsigned)b << 16) | ((unsigned)g << 8) | (unsigned)r);
+}
+
+// One wave per (x,y) row; VPT consecutive z voxels per lane (VPT = 4 needs Z % 4 == 0).
+// ACCUM = false: running-average update of (tsdf, weight, colour) -- the reference semantics.
+// ACCUM = true : add into the 5 accumulator planes [num, w, r, g, b] (frame-sharded fusion).
+template <int VPT, int RM, bool COUNT, bool ACCUM>
+__global__ __launch_bounds__(256) void integrate_kernel(FrameParams p, float *__restrict__ v0, float *__restrict__ v1,
+                                                        float *__restrict__ v2, long long plane) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= (long long)p.X * p.Y) return;
+    const int x = (int)(row / p.Y), y = (int)(row % p.Y);
+    // row constants, in the contract's operation order
+    const float tx = (p.ox + (float)x * p.vs) - p.T[0];
+    const float ty = (p.oy + (float)y * p.vs) - p.T[1];
+    const float ax = p.R[0] * tx + p.R[3] * ty;
+    const float ay = p.R[1] * tx + p.R[4] * ty;
+    const float az = p.R[2] * tx + p.R[5] * ty;
+    const float far_z = __uint_as_float(*p.max_depth_bits) + p.trunc;
+    const RowClip clip = clip_row(p, ax, ay, az, far_z);
+    if (clip.z0 >= clip.z1) return;
+    const long long base = row * p.Z;
+    unsigned n_upd = 0;
+    const int zstart = (clip.z0 / VPT) * VPT;
+    for (int zb = zstart + lane * VPT; zb < clip.z1; zb += 64 * VPT) {
+        float dist[VPT];
+        unsigned rgb[VPT];
+        bool ok[VPT];
+        bool any = false;
+#pragma unroll
+        for (int j = 0; j < VPT; ++j) {
+            ok[j] = (VPT == 1 || zb + j < p.Z) && sample_voxel<RM>(p, ax, ay, az, zb + j, dist[j], rgb[j]);
+            any = any || ok[j];
+        }
+        if (!any) continue;
+        const long long idx = base + zb;
+        if (!ACCUM) {
+            float t[VPT], w[VPT], c[VPT];
+            if (VPT == 4) {
+                *reinterpret_cast<float4 *>(t) = *reinterpret_cast<const float4 *>(v0 + idx);
+                *reinterpret_cast<float4 *>(w) = *reinterpret_cast<const float4 *>(v1 + idx);
+                *reinterpret_cast<float4 *>(c) = *reinterpret_cast<const float4 *>(v2 + idx);
+            } else {
+                t[0] = v0[idx];
+                w[0] = v1[idx];
+                c[0] = v2[idx];
+            }
+#pragma unroll
+            for (int j = 0; j < VPT; ++j)
+                if (ok[j]) {
+                    update_voxel<RM>(t[j], w[j], c[j], dist[j], rgb[j], p.obs_w);
+                    if (COUNT) ++n_upd;
+                }
+            if (VPT == 4) {
+                *reinterpret_cast<float4 *>(v0 + idx) = *reinterpret_cast<float4 *>(t);
+                *reinterpret_cast<float4 *>(v1 + idx) = *reinterpret_cast<float4 *>(w);
+                *reinterpret_cast<float4 *>(v2 + idx) = *reinterpret_cast<float4 *>(c);
+            } else {
+                v0[idx] = t[0];
+                v1[idx] = w[0];
+                v2[idx] = c[0];
+            }
+        } else {
+            // v0 = accumulator base, 5 planes of `plane` floats
+            float a[5][VPT];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                if (VPT == 4)
+                    *reinterpret_cast<float4 *>(a[k]) = *reinterpret_cast<const float4 *>(v0 + k * plane + idx);
+                else
+                    a[k][0] = v0[k * plane + idx];
+            }
+#pragma unroll
+            for (int j = 0; j < VPT; ++j)
+                if (ok[j]) {
+                    a[0][j] = a[0][j] + p.obs_w * dist[j];
+                    a[1][j] = a[1][j] + p.obs_w;
+                    a[2][j] = a[2][j] + p.obs_w * (float)(rgb[j] & 255u);
+                    a[3][j] = a[3][j] + p.obs_w * (float)((rgb[j] >> 8) & 255u);
+                    a[4][j] = a[4][j] + p.obs_w * (float)((rgb[j] >> 16) & 255u);
+                    if (COUNT) ++n_upd;
+                }
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                if (VPT == 4)
+                    *reinterpret_cast<float4 *>(v0 + k * plane + idx) = *reinterpret_cast<float4 *>(a[k]);
+                else
+                    v0[k * plane + idx] = a[k][0];
+            }
+        }
+    }
+    if (COUNT) {
+        for (int off = 32; off > 0; off >>= 1) n_upd += __shfl_xor((int)n_upd, off);
+        if (lane == 0 && n_upd) atomicAdd(p.n_updated, (unsigned long long)n_upd);
+    }
+}
+
+__global__ __launch_bounds__(256) void fill3_kernel(float *__restrict__ a, float *__restrict__ b, float *__restrict__ c,
+                                                    long long n, float va, float vb, float vc) {
+    const long long stride = (long long)gridDim.x * 256 * 4;
+    for (long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
+        if (i + 4 <= n && (((uintptr_t)(a + i) | (uintptr_t)(b + i) | (uintptr_t)(c + i)) & 15) == 0) {
+            *reinterpret_cast<float4 *>(a + i) = make_float4(va, va, va, va);
+            *reinterpret_cast<float4 *>(b + i) = make_float4(vb, vb, vb, vb);
+            *reinterpret_cast<float4 *>(c + i) = make_float4(vc, vc, vc, vc);
+        } else {
+            for (long long j = i; j < n && j < i + 4; ++j) {
+                a[j] = va;
+                b[j] = vb;
+                c[j] = vc;
+            }
+        }
+    }
+}
+
+template <int RM>
+__global__ __launch_bounds__(256) void finalize_kernel(const float *__restrict__ acc, long long n, float *__restrict__ tsdf,
+                                                       float *__restrict__ weight, float *__restrict__ color) {
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const float w = acc[1 * n + i];
+        float t = 1.0f, c = 0.0f;
+        if (w > 0.0f) {
+            t = acc[0 * n + i] / w;
+            const float r = fminf(hive_round<RM>(acc[2 * n + i] / w), 255.0f);
+            const float g = fminf(hive_round<RM>(acc[3 * n + i] / w), 255.0f);
+            const float b = fminf(hive_round<RM>(acc[4 * n + i] / w), 255.0f);
+            c = b * 65536.0f + g * 256.0f + r;
+        }
+        tsdf[i] = t;
+        weight[i] = w;
+        color[i] = c;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+static int fill_volume(hive_tsdf *v) {
+    hive_ctx *ctx = v->ctx;
+    const int blocks = (int)std::min<long long>((v->n / 4 + 255) / 256 + 1, 256 * 16);
+    hipLaunchKernelGGL(fill3_kernel, dim3(blocks), dim3(256), 0, ctx->stream, v->d_tsdf, v->d_weight, v->d_color,
+                       (long long)v->n, 1.0f, 0.0f, 0.0f);
+    HIVE_CHECK_HIP(ctx, hipGetLastError());
+    return HIVE_OK;
+}
+
+static int prepare_frame(hive_tsdf *v, const uint8_t *color, const float *depth, int H, int W, int mem,
+                         const uint8_t **d_color, const float **d_depth) {
+    hive_ctx *ctx = v->ctx;
+    const size_t npx = (size_t)H * W;
+    if (mem == HIVE_MEM_HOST) {
+        const size_t depth_bytes = npx * sizeof(float), color_bytes = npx * 3;
+        const size_t color_off = (depth_bytes + 255) & ~(size_t)255;
+        int rc = hive_reserve_device(ctx, &ctx->d_in, &ctx->in_bytes, color_off + color_bytes);
+        if (rc) return rc;
+        if ((rc = hive_upload(ctx, ctx->d_in, depth, depth_bytes))) return rc;
+        if ((rc = hive_upload(ctx, (char *)ctx->d_in + color_off, color, color_bytes))) return rc;
+        *d_depth = (const float *)ctx->d_in;
+        *d_color = (const uint8_t *)ctx->d_in + color_off;
+    } else {
+        *d_depth = depth;
+        *d_color = color;
+    }
+    int rc = hive_reserve_device(ctx, &ctx->d_frame, &ctx->frame_bytes, npx * sizeof(uint2));
+    if (rc) return rc;
+    HIVE_CHECK_HIP(ctx, hipMemsetAsync(ctx->d_scalars, 0, 16, ctx->stream));
+    hipLaunchKernelGGL(pack_frame_kernel, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, ctx->stream, *d_depth, *d_color,
+                       (int)npx, (uint2 *)ctx->d_frame, ctx->d_scalars);
+    HIVE_CHECK_HIP(ctx, hipGetLastError());
+    return HIVE_OK;
+}
+
+template <bool ACCUM>
+static int launch_integrate(hive_tsdf *v, float *accum, int H, int W, const float K[9], const double pose[16],
+                            float obs_weight, bool count) {
+    hive_ctx *ctx = v->ctx;
+    FrameParams p;
+    for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) p.R[3 * r + c] = (float)pose[4 * r + c];
+        p.T[r] = (float)pose[4 * r + 3];
+    }
+    p.fx = K[0];
+    p.fy = K[4];
+    p.cx = K[2];
+    p.cy = K[5];
+    p.ox = v->origin[0];
+    p.oy = v->origin[1];
+    p.oz = v->origin[2];
+    p.vs = v->voxel_size;
+    p.trunc = v->trunc;
+    p.obs_w = obs_weight;
+    p.X = (int)v->dim[0];
+    p.Y = (int)v->dim[1];
+    p.Z = (int)v->dim[2];
+    p.H = H;
+    p.W = W;
+    p.frame = (const uint2 *)ctx->d_frame;
+    p.max_depth_bits = ctx->d_scalars;
+    p.n_updated = (unsigned long long *)(ctx->d_scalars + 2);
+    const long long rows = (long long)p.X * p.Y;
+    const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    float *a0 = ACCUM ? accum : v->d_tsdf;
+    const bool vec = (p.Z % 4 == 0) && (((uintptr_t)a0 | (uintptr_t)v->d_weight | (uintptr_t)v->d_color) % 16 == 0);
+    int rc = hive_time_begin(ctx);
+    if (rc) return rc;
+#define HIVE_LAUNCH(VPT, RM, CNT)                                                                                          \
+    hipLaunchKernelGGL((integrate_kernel<VPT, RM, CNT, ACCUM>), grid, block, 0, ctx->stream, p, a0, v->d_weight, v->d_color, \
+                       (long long)v->n)
+    const int sel = (vec ? 4 : 0) | (ctx->round_mode ? 2 : 0) | (count ? 1 : 0);
+    switch (sel) {
+        case 0: HIVE_LAUNCH(1, 0, false); break;
+        case 1: HIVE_LAUNCH(1, 0, true); break;
+        case 2: HIVE_LAUNCH(1, 1, false); break;
+        case 3: HIVE_LAUNCH(1, 1, true); break;
+        case 4: HIVE_LAUNCH(4, 0, false); break;
+        case 5: HIVE_LAUNCH(4, 0, true); break;
+        case 6: HIVE_LAUNCH(4, 1, false); break;
+        case 7: HIVE_LAUNCH(4, 1, true); break;
+    }
+#undef HIVE_LAUNCH
+    HIVE_CHECK_HIP(ctx, hipGetLastError());
+    return hive_time_end(ctx);
+}
+
+static int check_frame_args(hive_tsdf *vol, const void *color, const void *depth, int H, int W, const float *K,
+                            const double *pose, int mem) {
+    if (!vol) return hive_fail(nullptr, HIVE_ERR_INVALID, "vol is NULL");
+    hive_ctx *ctx = vol->ctx;
+    HIVE_REQUIRE(ctx, color && depth && K && pose, "integrate: NULL argument");
+    HIVE_REQUIRE(ctx, H > 0 && W > 0 && (long long)H * W < (1ll << 30), "integrate: bad image size %dx%d", H, W);
+    HIVE_REQUIRE(ctx, mem == HIVE_MEM_HOST || mem == HIVE_MEM_DEVICE, "integrate: bad mem kind %d", mem);
+    HIVE_REQUIRE(ctx, K[0] != 0.f && K[4] != 0.f, "integrate: singular intrinsics");
+    return HIVE_OK;
+}
+
+extern "C" {
+
+int hive_tsdf_dims(const double vol_bnds[6], double voxel_size, int64_t vol_dim[3]) {
+    if (!vol_bnds || !vol_dim || !(voxel_size > 0)) return hive_fail(nullptr, HIVE_ERR_INVALID, "hive_tsdf_dims: bad argument");
+    for (int a = 0; a < 3; ++a) vol_dim[a] = (int64_t)ceil((vol_bnds[2 * a + 1] - vol_bnds[2 * a]) / voxel_size);
+    return HIVE_OK;
+}
+
+int hive_tsdf_create(hive_ctx *ctx, const double vol_bnds[6], double voxel_size, float *d_tsdf, float *d_weight,
+                     float *d_color, hive_tsdf **out) {
+    if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
+    HIVE_REQUIRE(ctx, out && vol_bnds, "hive_tsdf_create: NULL argument");
+    HIVE_REQUIRE(ctx, voxel_size > 0, "hive_tsdf_create: voxel_size must be positive, got %g", voxel_size);
+    *out = nullptr;
+    int64_t dim[3];
+    hive_tsdf_dims(vol_bnds, voxel_size, dim);
+    HIVE_REQUIRE(ctx, dim[0] > 0 && dim[1] > 0 && dim[2] > 0, "hive_tsdf_create: empty volume %lld x %lld x %lld",
+                 (long long)dim[0], (long long)dim[1], (long long)dim[2]);
+    HIVE_REQUIRE(ctx, dim[0] < (1 << 20) && dim[1] < (1 << 20) && dim[2] < (1 << 20), "hive_tsdf_create: dimension too large");
+    const bool external = d_tsdf || d_weight || d_color;
+    HIVE_REQUIRE(ctx, !external || (d_tsdf && d_weight && d_color), "hive_tsdf_create: pass all three volume pointers or none");
+    hive_tsdf *v = new hive_tsdf();
+    v->ctx = ctx;
+    for (int a = 0; a < 3; ++a) {
+        v->dim[a] = dim[a];
+        v->bnds[2 * a] = vol_bnds[2 * a];
+        v->bnds[2 * a + 1] = vol_bnds[2 * a] + (double)dim[a] * voxel_size;  // as the reference library adjusts them
+        v->origin[a] = (float)vol_bnds[2 * a];
+    }
+    v->n = dim[0] * dim[1] * dim[2];
+    v->voxel_size = (float)voxel_size;
+    v->trunc = (float)(5.0 * voxel_size);
+    if (external) {
+        v->d_tsdf = d_tsdf;
+        v->d_weight = d_weight;
+        v->d_color = d_color;
+    } else {
+        v->owns = true;
+        hipError_t e = hipSetDevice(ctx->device);
+        if (e == hipSuccess) e = hipMalloc((void **)&v->d_tsdf, v->n * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc((void **)&v->d_weight, v->n * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc((void **)&v->d_color, v->n * sizeof(float));
+        if (e != hipSuccess) {
+            int rc = hive_fail(ctx, HIVE_ERR_NOMEM, "hive_tsdf_create: allocating 3 x %lld floats failed: %s", (long long)v->n,
+                               hipGetErrorString(e));
+            hive_tsdf_destroy(v);
+            return rc;
+        }
+    }
+    int rc = fill_volume(v);
+    if (rc) {
+        hive_tsdf_destroy(v);
+        return rc;
+    }
+    *out = v;
+    return HIVE_OK;
+}
+
+int hive_tsdf_destroy(hive_tsdf *v) {
+    if (!v) return HIVE_OK;
+    (void)hipStreamSynchronize(v->ctx->stream);
+    hive_tsdf_free_mesh(v);
+    if (v->d_vbase) (void)hipFree(v->d_vbase);
+    if (v->d_blk) (void)hipFree(v->d_blk);
+    if (v->owns) {
+        if (v->d_tsdf) (void)hipFree(v->d_tsdf);
+        if (v->d_weight) (void)hipFree(v->d_weight);
+        if (v->d_color) (void)hipFree(v->d_color);
+    }
+    delete v;
+    return HIVE_OK;
+}
+
+int hive_tsdf_reset(hive_tsdf *v) {
+    if (!v) return hive_fail(nullptr, HIVE_ERR_INVALID, "vol is NULL");
+    return fill_volume(v);
+}
+
+int hive_tsdf_info(hive_tsdf *v, int64_t vol_dim[3], float origin[3], double vol_bnds[6], float *voxel_size,
+                   float *trunc_margin) {
+    if (!v) return hive_fail(nullptr, HIVE_ERR_INVALID, "vol is NULL");
+    for (int a = 0; a < 3; ++a) {
+        if (vol_dim) vol_dim[a] = v->dim[a];
+        if (origin) origin[a] = v->origin[a];
+    }
+    if (vol_bnds) memcpy(vol_bnds, v->bnds, sizeof(v->bnds));
+    if (voxel_size) *voxel_size = v->voxel_size;
+    if (trunc_margin) *trunc_margin = v->trunc;
+    return HIVE_OK;
+}
+
+int hive_tsdf_device_ptrs(hive_tsdf *v, float **d_tsdf, float **d_weight, float **d_color) {
+    if (!v) return hive_fail(nullptr, HIVE_ERR_INVALID, "vol is NULL");
+    if (d_tsdf) *d_tsdf = v->d_tsdf;
+    if (d_weight) *d_weight = v->d_weight;
+    if (d_color) *d_color = v->d_color;
+    return HIVE_OK;
+}
+
+int hive_tsdf_integrate(hive_tsdf *vol, const uint8_t *color, const float *depth, int H, int W, const float K[9],
+                        const double cam_pose[16], float obs_weight, int mem, uint64_t *n_updated) {
+    int rc = check_frame_args(vol, color, depth, H, W, K, cam_pose, mem);
+    if (rc) return rc;
+    hive_ctx *ctx = vol->ctx;
+    const uint8_t *d_color;
+    const float *d_depth;
+    if ((rc = prepare_frame(vol, color, depth, H, W, mem, &d_color, &d_depth))) return rc;
+    if ((rc = launch_integrate<false>(vol, nullptr, H, W, K, cam_pose, obs_weight, n_updated != nullptr))) return rc;
+    vol->n_verts = vol->n_faces = -1;
+    if (n_updated) {
+        unsigned long long n = 0;
+        HIVE_CHECK_HIP(ctx, hipMemcpyAsync(&n, ctx->d_scalars + 2, sizeof(n), hipMemcpyDeviceToHost, ctx->stream));
+        HIVE_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        *n_updated = n;
+    }
+    return HIVE_OK;
+}
+
+int hive_tsdf_integrate_batch(hive_tsdf *vol, int n, const uint8_t *color, const float *depth, int H, int W,
+                              const float K[9], const double *cam_poses, float obs_weight, int mem) {
+    int rc = check_frame_args(vol, color, depth, H, W, K, cam_poses, mem);
+    if (rc) return rc;
+    HIVE_REQUIRE(vol->ctx, n >= 0, "integrate_batch: n must be >= 0");
+    const size_t npx = (size_t)H * W;
+    for (int f = 0; f < n; ++f) {
+        const uint8_t *d_color;
+        const float *d_depth;
+        if ((rc = prepare_frame(vol, color + f * npx * 3, depth + f * npx, H, W, mem, &d_color, &d_depth))) return rc;
+        if ((rc = launch_integrate<false>(vol, nullptr, H, W, K, cam_poses + 16 * (size_t)f, obs_weight, false))) return rc;
+    }
+    vol->n_verts = vol->n_faces = -1;
+    return HIVE_OK;
+}
+
+int hive_tsdf_get_volume(hive_tsdf *v, float *h_tsdf, float *h_color, float *h_weight) {
+    if (!v) return hive_fail(nullptr, HIVE_ERR_INVALID, "vol is NULL");
+    hive_ctx *ctx = v->ctx;
+    const size_t bytes = (size_t)v->n * sizeof(float);
+    if (h_tsdf) HIVE_CHECK_HIP(ctx, hipMemcpyAsync(h_tsdf, v->d_tsdf, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (h_color) HIVE_CHECK_HIP(ctx, hipMemcpyAsync(h_color, v->d_color, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (h_weight) HIVE_CHECK_HIP(ctx, hipMemcpyAsync(h_weight, v->d_weight, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIVE_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return HIVE_OK;
+}
+
+int hive_tsdf_set_volume(hive_tsdf *v, const float *h_tsdf, const float *h_color, const float *h_weight) {
+    if (!v) return hive_fail(nullptr, HIVE_ERR_INVALID, "vol is NULL");
+    hive_ctx *ctx = v->ctx;
+    const size_t bytes = (size_t)v->n * sizeof(float);
+    if (h_tsdf) HIVE_CHECK_HIP(ctx, hipMemcpyAsync(v->d_tsdf, h_tsdf, bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (h_color) HIVE_CHECK_HIP(ctx, hipMemcpyAsync(v->d_color, h_color, bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (h_weight) HIVE_CHECK_HIP(ctx, hipMemcpyAsync(v->d_weight, h_weight, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIVE_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    v->n_verts = v->n_faces = -1;
+    return HIVE_OK;
+}
+
+int hive_tsdf_accum_reset(hive_tsdf *v, float *d_accum) {
+    if (!v) return hive_fail(nullptr, HIVE_ERR_INVALID, "vol is NULL");
+    HIVE_REQUIRE(v->ctx, d_accum, "accum_reset: d_accum is NULL");
+    HIVE_CHECK_HIP(v->ctx, hipMemsetAsync(d_accum, 0, 5 * (size_t)v->n * sizeof(float), v->ctx->stream));
+    return HIVE_OK;
+}
+
+int hive_tsdf_accum_integrate(hive_tsdf *vol, float *d_accum, const uint8_t *color, const float *depth, int H, int W,
+                              const float K[9], const double cam_pose[16], float obs_weight, int mem) {
+    int rc = check_frame_args(vol, color, depth, H, W, K, cam_pose, mem);
+    if (rc) return rc;
+    HIVE_REQUIRE(vol->ctx, d_accum, "accum_integrate: d_accum is NULL");
+    const uint8_t *d_color;
+    const float *d_depth;
+    if ((rc = prepare_frame(vol, color, depth, H, W, mem, &d_color, &d_depth))) return rc;
+    return launch_integrate<true>(vol, d_accum, H, W, K, cam_pose, obs_weight, false);
+}
+
+int hive_tsdf_accum_finalize(hive_tsdf *v, const float *d_accum) {
+    if (!v) return hive_fail(nullptr, HIVE_ERR_INVALID, "vol is NULL");
+    hive_ctx *ctx = v->ctx;
+    HIVE_REQUIRE(ctx, d_accum, "accum_finalize: d_accum is NULL");
+    const int blocks = (int)std::min<long long>((v->n + 255) / 256, 256 * 32);
+    if (ctx->round_mode)
+        hipLaunchKernelGGL(finalize_kernel<1>, dim3(blocks), dim3(256), 0, ctx->stream, d_accum, (long long)v->n, v->d_tsdf,
+                           v->d_weight, v->d_color);
+    else
+        hipLaunchKernelGGL(finalize_kernel<0>, dim3(blocks), dim3(256), 0, ctx->stream, d_accum, (long long)v->n, v->d_tsdf,
+                           v->d_weight, v->d_color);
+    HIVE_CHECK_HIP(ctx, hipGetLastError());
+    v->n_verts = v->n_faces = -1;
+    return HIVE_OK;
+}
+
+}  // extern "C"

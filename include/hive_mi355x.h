@@ -1,0 +1,172 @@
+/*
+ * hive_mi355x.h -- C ABI of libhive_mi355x.so: the MI355X (gfx950) implementation of HIVE's
+ * per-frame dense-compute path (depth-map -> TSDF volume fusion, view frusta, depth-to-point
+ * unprojection / projection, mask dilation, marching cubes, DPT ViT blocks).
+ *
+ * HIVE itself has no FFI: its boundary for this path is a set of plain Python call
+ * signatures.  Every entry point below cites the reference call site
+ * (file:line under /root/reference) whose arithmetic it replaces; INTEGRATION.md shows
+ * the ctypes binding a HIVE maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 (HIVE_OK) or a negative hive_status; the message for the
+ *     last failure on a context is returned by hive_last_error(ctx) (ctx may be NULL for
+ *     failures of hive_ctx_create itself: thread-local).
+ *   - plain pointers and sizes only; `mem` says whether image/point pointers are host
+ *     (HIVE_MEM_HOST: copied through a pinned staging buffer, the call returns after the
+ *     copy so the caller may overwrite its arrays -- hive/fusion.py:121 mutates depth_im
+ *     right before integrate) or device memory (HIVE_MEM_DEVICE: used in place, stream
+ *     ordered on the context's stream).
+ *   - one hive_ctx per (GPU, stream); contexts are independent, so Python threads may own
+ *     separate contexts (the reference calls the geometric functions from a ThreadPool,
+ *     hive/pipeline.py:491).  A single context is not re-entrant.
+ *   - volumes are three float32 arrays [X][Y][Z] (z fastest), as in the reference library:
+ *     tsdf (init 1), weight (init 0), colour packed b*65536 + g*256 + r (init 0).
+ *   - there is no CPU fallback: every compute entry point needs a gfx950 device.
+ */
+#ifndef HIVE_MI355X_H
+#define HIVE_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HIVE_ABI_VERSION 1
+
+typedef enum hive_status {
+    HIVE_OK = 0,
+    HIVE_ERR_INVALID = -1,   /* bad argument (shape, NULL, size)                 */
+    HIVE_ERR_DEVICE = -2,    /* HIP runtime failure; message has the hipError_t  */
+    HIVE_ERR_NOMEM = -3,     /* device / pinned allocation failed                */
+    HIVE_ERR_EMPTY = -4,     /* no surface: tsdf has no zero crossing (the reference raises
+                                ValueError there, scripts/experiments.py:165-168) */
+    HIVE_ERR_STATE = -5      /* call sequence error (e.g. copy_mesh before extract) */
+} hive_status;
+
+typedef enum hive_mem_kind { HIVE_MEM_HOST = 0, HIVE_MEM_DEVICE = 1 } hive_mem_kind;
+
+/* Rounding of real-valued pixel coordinates / colours to integers.
+ * HALF_EVEN = numpy's np.round (the reference library's CPU path and hive/geometric.py:176);
+ * HALF_AWAY = C roundf (the reference library's CUDA kernel).  SURVEY.md §7(b). */
+typedef enum hive_round_mode { HIVE_ROUND_HALF_EVEN = 0, HIVE_ROUND_HALF_AWAY = 1 } hive_round_mode;
+
+typedef struct hive_ctx hive_ctx;
+typedef struct hive_tsdf hive_tsdf;
+
+/* ---- library / context ------------------------------------------------------------ */
+int hive_abi_version(void);
+/* `stream` is a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) or NULL to let the
+ * context create and own a stream of its own. */
+int hive_ctx_create(int device_id, void *stream, hive_ctx **out);
+int hive_ctx_destroy(hive_ctx *ctx);
+int hive_ctx_synchronize(hive_ctx *ctx);
+const char *hive_last_error(hive_ctx *ctx);
+int hive_ctx_set_round_mode(hive_ctx *ctx, int mode);
+/* HIP-event timing of the most recent kernel launched by a *_timed call on this context. */
+int hive_ctx_set_timing(hive_ctx *ctx, int enabled);
+int hive_ctx_last_kernel_ms(hive_ctx *ctx, float *ms);
+/* Sum and count of the HIP-event durations of every dominant-kernel launch (integrate) made on
+ * this context since timing was enabled or since the previous call; synchronises the stream. */
+int hive_ctx_kernel_time_total(hive_ctx *ctx, int *n_launches, float *total_ms);
+
+/* ---- TSDF volume: replaces third_party/tsdf_fusion_python `fusion.TSDFVolume` ------ */
+/* fusion.TSDFVolume(vol_bnds, voxel_size)           -- hive/fusion.py:104
+ * vol_bnds is row-major [3][2] = {xmin,xmax, ymin,ymax, zmin,zmax} (float64, as hive/fusion.py:48).
+ * vol_dim = ceil((max-min)/voxel_size); origin = float32(min); trunc = 5*voxel_size.
+ * If d_tsdf/d_weight/d_color are non-NULL the volume lives in caller-owned device memory
+ * (e.g. torch tensors) of vol_dim[0]*vol_dim[1]*vol_dim[2] floats each; otherwise the
+ * library allocates.  The volume is initialised (1,0,0) either way. */
+int hive_tsdf_dims(const double vol_bnds[6], double voxel_size, int64_t vol_dim[3]);
+int hive_tsdf_create(hive_ctx *ctx, const double vol_bnds[6], double voxel_size,
+                     float *d_tsdf, float *d_weight, float *d_color, hive_tsdf **out);
+int hive_tsdf_destroy(hive_tsdf *vol);
+int hive_tsdf_reset(hive_tsdf *vol);
+int hive_tsdf_info(hive_tsdf *vol, int64_t vol_dim[3], float origin[3], double vol_bnds[6],
+                   float *voxel_size, float *trunc_margin);
+/* device pointers of the three volumes (for RCCL collectives / zero-copy views) */
+int hive_tsdf_device_ptrs(hive_tsdf *vol, float **d_tsdf, float **d_weight, float **d_color);
+
+/* TSDFVolume.integrate(color_im, depth_im, cam_intr, cam_pose, obs_weight) -- hive/fusion.py:124
+ * color u8 [H][W][3] RGB, depth f32 [H][W] metres (0 = invalid), K f32 row-major 3x3,
+ * cam_pose f64 row-major 4x4 camera-to-world.  n_updated (optional, host) receives the number
+ * of voxels written by this call (forces a stream sync). */
+int hive_tsdf_integrate(hive_tsdf *vol, const uint8_t *color, const float *depth, int H, int W,
+                        const float K[9], const double cam_pose[16], float obs_weight,
+                        int mem, uint64_t *n_updated);
+/* n frames back to back (frame f at color + f*H*W*3, depth + f*H*W, poses + f*16), in order:
+ * identical results to n calls of hive_tsdf_integrate. */
+int hive_tsdf_integrate_batch(hive_tsdf *vol, int n, const uint8_t *color, const float *depth,
+                              int H, int W, const float K[9], const double *cam_poses,
+                              float obs_weight, int mem);
+/* TSDFVolume.get_volume(): copies tsdf and colour (and weight) to host arrays (any may be NULL) */
+int hive_tsdf_get_volume(hive_tsdf *vol, float *h_tsdf, float *h_color, float *h_weight);
+int hive_tsdf_set_volume(hive_tsdf *vol, const float *h_tsdf, const float *h_color, const float *h_weight);
+
+/* TSDFVolume.get_mesh() -- hive/fusion.py:127.  Two steps because the sizes are data dependent:
+ * extract counts and builds the mesh on the device, copy_mesh copies it out.
+ * verts f32 [nv][3] world coordinates, faces i32 [nf][3], norms f32 [nv][3], colors u8 [nv][3] (RGB).
+ * Vertex order: ascending (voxel linear index, axis); face order: ascending cell linear index,
+ * then table order.  Returns HIVE_ERR_EMPTY when there is no zero crossing. */
+int hive_tsdf_extract_mesh(hive_tsdf *vol, int64_t *n_verts, int64_t *n_faces);
+int hive_tsdf_copy_mesh(hive_tsdf *vol, float *verts, int32_t *faces, float *norms, uint8_t *colors);
+/* vertices of the same extraction in voxel units (before x voxel_size + origin), f32 [nv][3] */
+int hive_tsdf_copy_mesh_voxel_coords(hive_tsdf *vol, float *verts_vox);
+
+/* Frame-sharded fusion (BASELINE.json north_star): a rank accumulates
+ * num = sum(w_i*dist_i), w = sum(w_i), rgb = sum(w_i*c_i) for its frames into 5 float planes
+ * [5][X][Y][Z]; planes are summed across ranks (RCCL all-reduce by the caller), then folded
+ * into the volume.  d_accum must hold 5*N floats of device memory, zeroed by accum_reset. */
+int hive_tsdf_accum_reset(hive_tsdf *vol, float *d_accum);
+int hive_tsdf_accum_integrate(hive_tsdf *vol, float *d_accum, const uint8_t *color, const float *depth,
+                              int H, int W, const float K[9], const double cam_pose[16],
+                              float obs_weight, int mem);
+int hive_tsdf_accum_finalize(hive_tsdf *vol, const float *d_accum);
+
+/* ---- fusion.get_view_frustum(depth_im, cam_intr, cam_pose) -- hive/fusion.py:59 ------ */
+/* out: float64 row-major [3][5] (apex + 4 corners at max(depth)), world coordinates */
+int hive_view_frustum(hive_ctx *ctx, const float *depth, int H, int W, const float K[9],
+                      const double cam_pose[16], int mem, double out[15]);
+
+/* ---- hive/geometric.py ------------------------------------------------------------- */
+/* point_cloud_from_depth(depth, mask, K, R, t)  -- hive/geometric.py:107-126 (+ image2world :183-206)
+ * valid = mask & (depth > 0); points in row-major (v,u) order; X = R^T (d * Kinv [u,v,1]^T - t).
+ * Kinv = np.linalg.inv(K) evaluated by the caller in K's dtype (geometric.py:203) and widened to f64.
+ * mask u8 [H][W] (non-zero = keep; NULL = all), R f64[9], t f64[3] (world-to-camera),
+ * out_xyz f64 [capacity][3] (host or device per `mem`), *n = number of points written.
+ * rgb (optional u8 [H][W][3]) / out_rgba (u8 [capacity][4], alpha 255): point_cloud_from_rgbd :129-152 */
+int hive_unproject(hive_ctx *ctx, const float *depth, const uint8_t *mask, const uint8_t *rgb,
+                   int H, int W, const double Kinv[9], const double R[9], const double t[3],
+                   int mem, double *out_xyz, uint8_t *out_rgba, int64_t capacity, int64_t *n);
+/* image2world(points, depth, K, R, t, scale_factor) -- hive/geometric.py:183-206, for an explicit
+ * list of pixel coordinates: uv f64 [n][2], depth f64 [n] -> out_xyz f64 [n][3] */
+int hive_image2world(hive_ctx *ctx, const double *uv, const double *depth, int64_t n, const double Kinv[9],
+                     const double R[9], const double t[3], double scale_factor, int mem, double *out_xyz);
+/* world2image(points, K, R, t, scale_factor, dtype) -- hive/geometric.py:155-180
+ * points f64 [n][3]; out_uv_i32 (rounded per ctx round mode, default half-even = np.round) or
+ * out_uv_f64 (exactly one non-NULL); out_depth f64 [n] */
+int hive_project(hive_ctx *ctx, const double *points, int64_t n, const double K[9], const double R[9],
+                 const double t[3], double scale_factor, int mem,
+                 int32_t *out_uv_i32, double *out_uv_f64, double *out_depth);
+
+/* ---- dilate_mask(mask, MaskDilationOptions(num_iterations)) -- hive/image_processing.py:30-45 */
+/* 3x3 rectangular structuring element applied `iterations` times == one (2*it+1)^2 box max
+ * (cv2.dilate border = no contribution from outside).  mask/out u8 [H][W], non-zero = set. */
+int hive_dilate_mask(hive_ctx *ctx, const uint8_t *mask, int H, int W, int iterations, int mem,
+                     uint8_t *out);
+
+/* ---- depth hand-off DPT -> TSDF ----------------------------------------------------- */
+/* dataset_adaptors.py:1432-1433 (x1000 -> uint16 truncation) then io.py:1032-1039
+ * (x 1/1000 as float32, > max_depth -> 0), optional mask (non-zero -> depth 0, fusion.py:121).
+ * in: f32 or f16/bf16 depth in metres [H][W] on the device; out_mm (optional u16) and out_m (f32). */
+typedef enum hive_dtype { HIVE_F32 = 0, HIVE_F16 = 1, HIVE_BF16 = 2 } hive_dtype;
+int hive_depth_quantize(hive_ctx *ctx, const void *d_depth, int dtype, int H, int W,
+                        float depth_scale, float max_depth, const uint8_t *d_mask,
+                        uint16_t *d_out_mm, float *d_out_m);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HIVE_MI355X_H */

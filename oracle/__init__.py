@@ -1,0 +1,244 @@
+"""CPU oracle for the HIVE depth->TSDF hot path: ctypes bindings over ``hive_oracle.c`` plus a
+vectorised numpy restatement of the integrate step.
+
+TEST INFRASTRUCTURE ONLY.  Importable from ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py``; never from ``hive_amd/``.  See the header of
+``hive_oracle.c`` for what is pinned by golden vectors (hive.geometric) and what is
+**parity unpinned** (everything restated from the absent third_party/tsdf_fusion_python).
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "libhive_oracle.so")
+_lib = None
+
+ROUND_HALF_EVEN = 0
+ROUND_HALF_AWAY = 1
+
+
+def build(force=False):
+    """Compile hive_oracle.c with gcc (seconds)."""
+    src = os.path.join(_HERE, "hive_oracle.c")
+    stale = (not os.path.exists(_LIB_PATH)) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src)
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        _lib = ctypes.CDLL(_LIB_PATH)
+        _lib.oracle_tsdf_integrate.restype = ctypes.c_uint64
+        _lib.oracle_tsdf_accum_integrate.restype = ctypes.c_uint64
+        _lib.oracle_unproject.restype = ctypes.c_int64
+        _lib.oracle_marching_cubes.restype = ctypes.c_int
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _c(a, dtype):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+def tsdf_dims(vol_bnds, voxel_size):
+    b = _c(vol_bnds, np.float64).reshape(6)
+    out = np.zeros(3, np.int64)
+    lib().oracle_tsdf_dims(_p(b), ctypes.c_double(voxel_size), _p(out))
+    return out
+
+
+def view_frustum(depth_im, cam_intr, cam_pose):
+    d = _c(depth_im, np.float32)
+    K = _c(cam_intr, np.float32).reshape(9)
+    P = _c(cam_pose, np.float64).reshape(16)
+    out = np.zeros(15, np.float64)
+    lib().oracle_view_frustum(_p(d), d.shape[0], d.shape[1], _p(K), _p(P), _p(out))
+    return out.reshape(3, 5)
+
+
+def unproject(depth, mask, Kinv, R, t, rgb=None):
+    d = _c(depth, np.float32)
+    H, W = d.shape
+    m = None if mask is None else _c(np.asarray(mask) != 0, np.uint8)
+    c = None if rgb is None else _c(rgb, np.uint8)
+    out = np.zeros((H * W, 3), np.float64)
+    rgba = None if rgb is None else np.zeros((H * W, 4), np.uint8)
+    n = lib().oracle_unproject(_p(d), _p(m), _p(c), H, W, _p(_c(Kinv, np.float64).reshape(9)),
+                               _p(_c(R, np.float64).reshape(9)), _p(_c(t, np.float64).reshape(3)), _p(out), _p(rgba))
+    return (out[:n].copy(), None if rgba is None else rgba[:n].copy())
+
+
+def project(points, K, R, t, scale_factor=1.0, integer=True, round_mode=ROUND_HALF_EVEN):
+    pts = _c(points, np.float64)
+    n = pts.shape[0]
+    uv_i = np.zeros((n, 2), np.int32) if integer else None
+    uv_f = None if integer else np.zeros((n, 2), np.float64)
+    depth = np.zeros(n, np.float64)
+    lib().oracle_project(_p(pts), ctypes.c_int64(n), _p(_c(K, np.float64).reshape(9)), _p(_c(R, np.float64).reshape(9)),
+                         _p(_c(t, np.float64).reshape(3)), ctypes.c_double(scale_factor), round_mode, _p(uv_i), _p(uv_f),
+                         _p(depth))
+    return (uv_i if integer else uv_f), depth
+
+
+def dilate_mask(mask, iterations):
+    m = _c(np.asarray(mask) != 0, np.uint8)
+    out = np.zeros_like(m)
+    lib().oracle_dilate_mask(_p(m), m.shape[0], m.shape[1], int(iterations), _p(out))
+    return out.astype(bool)
+
+
+def depth_quantize(depth_m, depth_scale=1.0 / 1000.0, max_depth=10.0, mask=None):
+    d = _c(depth_m, np.float32)
+    mm = np.zeros(d.shape, np.uint16)
+    m = np.zeros(d.shape, np.float32)
+    mk = None if mask is None else _c(np.asarray(mask) != 0, np.uint8)
+    lib().oracle_depth_quantize(_p(d), ctypes.c_int64(d.size), ctypes.c_float(depth_scale), ctypes.c_float(max_depth),
+                                _p(mk), _p(mm), _p(m))
+    return mm, m
+
+
+class TSDFVolume:
+    """CPU oracle with the call signatures of the reference library's ``fusion.TSDFVolume``
+    (call sites /root/reference/hive/fusion.py:104,124,127)."""
+
+    def __init__(self, vol_bnds, voxel_size, round_mode=ROUND_HALF_EVEN):
+        vol_bnds = np.asarray(vol_bnds, dtype=np.float64)
+        assert vol_bnds.shape == (3, 2), "[!] `vol_bnds` should be of shape (3, 2)."
+        self._voxel_size = float(voxel_size)
+        self._trunc_margin = 5 * self._voxel_size
+        self._vol_dim = tsdf_dims(vol_bnds, self._voxel_size)
+        self._vol_bnds = vol_bnds.copy()
+        self._vol_bnds[:, 1] = self._vol_bnds[:, 0] + self._vol_dim * self._voxel_size
+        self._vol_origin = self._vol_bnds[:, 0].astype(np.float32)
+        self.round_mode = round_mode
+        shape = tuple(int(v) for v in self._vol_dim)
+        self._tsdf = np.ones(shape, np.float32)
+        self._weight = np.zeros(shape, np.float32)
+        self._color = np.zeros(shape, np.float32)
+        self.last_n_updated = 0
+
+    def integrate(self, color_im, depth_im, cam_intr, cam_pose, obs_weight=1.):
+        d = _c(depth_im, np.float32)
+        c = _c(color_im, np.uint8)
+        H, W = d.shape
+        self.last_n_updated = lib().oracle_tsdf_integrate(
+            _p(self._tsdf), _p(self._weight), _p(self._color), _p(self._vol_dim), _p(self._vol_origin),
+            ctypes.c_float(self._voxel_size), ctypes.c_float(np.float32(self._trunc_margin)), _p(c), _p(d), H, W,
+            _p(_c(cam_intr, np.float32).reshape(9)), _p(_c(cam_pose, np.float64).reshape(16)),
+            ctypes.c_float(obs_weight), self.round_mode)
+
+    def get_volume(self):
+        return self._tsdf, self._color
+
+    def get_mesh(self, return_voxel_coords=False):
+        nv = ctypes.c_int64(0)
+        nf = ctypes.c_int64(0)
+        args = (_p(self._tsdf), _p(self._color), _p(self._vol_dim), _p(self._vol_origin),
+                ctypes.c_float(self._voxel_size), ctypes.byref(nv), ctypes.byref(nf))
+        lib().oracle_marching_cubes(*args, None, None, None, None, None)
+        if nv.value == 0:
+            raise ValueError("Surface level must be within volume data range.")
+        verts = np.zeros((nv.value, 3), np.float32)
+        faces = np.zeros((nf.value, 3), np.int32)
+        norms = np.zeros((nv.value, 3), np.float32)
+        colors = np.zeros((nv.value, 3), np.uint8)
+        vvox = np.zeros((nv.value, 3), np.float32)
+        lib().oracle_marching_cubes(*args, _p(verts), _p(faces), _p(norms), _p(colors), _p(vvox))
+        if return_voxel_coords:
+            return verts, faces, norms, colors, vvox
+        return verts, faces, norms, colors
+
+
+class AccumVolume:
+    """Oracle for the frame-sharded accumulate -> (sum over ranks) -> finalize path."""
+
+    def __init__(self, vol_bnds, voxel_size, round_mode=ROUND_HALF_EVEN):
+        self.vol = TSDFVolume(vol_bnds, voxel_size, round_mode)
+        self.accum = np.zeros((5,) + self.vol._tsdf.shape, np.float32)
+
+    def integrate(self, color_im, depth_im, cam_intr, cam_pose, obs_weight=1.):
+        v = self.vol
+        d = _c(depth_im, np.float32)
+        c = _c(color_im, np.uint8)
+        return lib().oracle_tsdf_accum_integrate(
+            _p(self.accum), _p(v._vol_dim), _p(v._vol_origin), ctypes.c_float(v._voxel_size),
+            ctypes.c_float(np.float32(v._trunc_margin)), _p(c), _p(d), d.shape[0], d.shape[1],
+            _p(_c(cam_intr, np.float32).reshape(9)), _p(_c(cam_pose, np.float64).reshape(16)),
+            ctypes.c_float(obs_weight), v.round_mode)
+
+    def finalize(self, accum=None):
+        v = self.vol
+        a = _c(self.accum if accum is None else accum, np.float32)
+        lib().oracle_tsdf_accum_finalize(_p(a), ctypes.c_int64(v._tsdf.size), _p(v._tsdf), _p(v._weight), _p(v._color),
+                                         v.round_mode)
+        return v
+
+
+def integrate_numpy(tsdf, weight, color, origin, voxel_size, trunc_margin, color_im, depth_im, cam_intr, cam_pose,
+                    obs_weight=1.0, round_mode=ROUND_HALF_EVEN, chunk_x=16):
+    """Vectorised numpy restatement of the integrate step, in the style of the reference library's
+    CPU path (whole-volume temporaries, boolean masks, fancy-index scatter) but with the float32
+    arithmetic contract of ``oracle_tsdf_integrate`` so the two agree bit for bit.
+    Processes ``chunk_x`` x-slabs at a time to bound the temporaries.  In place; returns n_updated.
+    This is the ``cpu_baseline`` ("port") that bench.py times on the host cores."""
+    f32 = np.float32
+    rnd = np.rint if round_mode == ROUND_HALF_EVEN else (lambda a: np.copysign(np.floor(np.abs(a) + f32(0.5)), a))
+    X, Y, Z = tsdf.shape
+    H, W = depth_im.shape
+    P = np.asarray(cam_pose, np.float64).astype(f32)
+    K = np.asarray(cam_intr, f32)
+    fx, fy, cx, cy = K[0, 0], K[1, 1], K[0, 2], K[1, 2]
+    vs, tm, ow = f32(voxel_size), f32(trunc_margin), f32(obs_weight)
+    origin = np.asarray(origin, f32)
+    cim = color_im.reshape(-1, 3)
+    dflat = np.ascontiguousarray(depth_im, f32).reshape(-1)
+    ys = (origin[1] + np.arange(Y, dtype=f32) * vs) - P[1, 3]
+    zs = (origin[2] + np.arange(Z, dtype=f32) * vs) - P[2, 3]
+    n_upd = 0
+    for x0 in range(0, X, chunk_x):
+        x1 = min(X, x0 + chunk_x)
+        xs = (origin[0] + np.arange(x0, x1, dtype=f32) * vs) - P[0, 3]
+        tx, ty, tz = xs[:, None, None], ys[None, :, None], zs[None, None, :]
+        cam_x = (P[0, 0] * tx + P[1, 0] * ty) + P[2, 0] * tz
+        cam_y = (P[0, 1] * tx + P[1, 1] * ty) + P[2, 1] * tz
+        cam_z = (P[0, 2] * tx + P[1, 2] * ty) + P[2, 2] * tz
+        with np.errstate(divide="ignore", invalid="ignore"):
+            px = rnd(fx * (cam_x / cam_z) + cx)
+            py = rnd(fy * (cam_y / cam_z) + cy)
+        valid = (cam_z > 0) & (px >= 0) & (px < W) & (py >= 0) & (py < H)
+        pix = np.zeros(valid.shape, np.int64)
+        pix[valid] = py[valid].astype(np.int64) * W + px[valid].astype(np.int64)
+        depth_val = np.zeros(valid.shape, f32)
+        depth_val[valid] = dflat[pix[valid]]
+        depth_diff = depth_val - cam_z
+        upd = valid & (depth_val != 0) & (depth_diff >= -tm)
+        if not upd.any():
+            continue
+        sl = (slice(x0, x1),)
+        dist = np.minimum(f32(1.0), depth_diff[upd] / tm)
+        w_old = weight[sl][upd]
+        w_new = w_old + ow
+        t_old = tsdf[sl][upd]
+        c_old = color[sl][upd]
+        tsdf[sl][upd] = (t_old * w_old + ow * dist) / w_new
+        weight[sl][upd] = w_new
+        old_b = np.floor(c_old / f32(65536.0))
+        old_g = np.floor((c_old - old_b * f32(65536.0)) / f32(256.0))
+        old_r = c_old - old_b * f32(65536.0) - old_g * f32(256.0)
+        new = cim[pix[upd]].astype(f32)
+        b = np.minimum(rnd((old_b * w_old + ow * new[:, 2]) / w_new), f32(255.0))
+        g = np.minimum(rnd((old_g * w_old + ow * new[:, 1]) / w_new), f32(255.0))
+        r = np.minimum(rnd((old_r * w_old + ow * new[:, 0]) / w_new), f32(255.0))
+        color[sl][upd] = b * f32(65536.0) + g * f32(256.0) + r
+        n_upd += int(upd.sum())
+    return n_upd

@@ -1,0 +1,159 @@
+"""Parity of the HIP TSDF path (through the C ABI) against the CPU oracle: bit-exact."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _volumes_equal(vol, ora):
+    tsdf, color, weight = vol.get_volume(with_weight=True)
+    assert np.array_equal(weight, ora._weight), "weight volume differs"
+    assert np.array_equal(color, ora._color), "colour volume differs"
+    assert np.array_equal(tsdf, ora._tsdf), "tsdf volume differs"
+
+
+@pytest.mark.parametrize("round_mode", [0, 1])
+@pytest.mark.parametrize("voxel", [0.08, 0.0641])  # 64^3 (vector path) and 80^3 with Z % 4 == 0; see below for odd Z
+def test_integrate_bit_exact(gpu_ctx, oracle_lib, small_sequence, round_mode, voxel):
+    from hive_amd import fusion, synthetic
+    seq = small_sequence
+    gpu_ctx.set_round_mode(round_mode)
+    try:
+        vol = fusion.TSDFVolume(synthetic.room_bounds(), voxel, ctx=gpu_ctx)
+        ora = oracle_lib.TSDFVolume(synthetic.room_bounds(), voxel, round_mode=round_mode)
+        assert np.array_equal(vol._vol_dim, ora._vol_dim)
+        assert np.array_equal(vol._vol_origin, ora._vol_origin)
+        for i in range(seq["depth"].shape[0]):
+            n = vol.integrate(seq["color"][i], seq["depth"][i], seq["K"], seq["poses"][i], return_n_updated=True)
+            ora.integrate(seq["color"][i], seq["depth"][i], seq["K"], seq["poses"][i])
+            assert n == ora.last_n_updated, f"frame {i}: N_upd {n} != oracle {ora.last_n_updated}"
+        _volumes_equal(vol, ora)
+    finally:
+        gpu_ctx.set_round_mode(0)
+
+
+def test_integrate_odd_dims_scalar_path(gpu_ctx, oracle_lib, small_sequence):
+    """Z not a multiple of 4 takes the one-voxel-per-lane kernel; ragged X/Y/Z."""
+    from hive_amd import fusion
+    seq = small_sequence
+    bnds = np.array([[0.3, 4.9], [0.0, 5.12], [0.1, 5.0]])
+    vol = fusion.TSDFVolume(bnds, 0.07, ctx=gpu_ctx)
+    ora = oracle_lib.TSDFVolume(bnds, 0.07)
+    assert vol._vol_dim[2] % 4 != 0
+    for i in range(4):
+        n = vol.integrate(seq["color"][i], seq["depth"][i], seq["K"], seq["poses"][i], obs_weight=2.0, return_n_updated=True)
+        ora.integrate(seq["color"][i], seq["depth"][i], seq["K"], seq["poses"][i], obs_weight=2.0)
+        assert n == ora.last_n_updated
+    _volumes_equal(vol, ora)
+
+
+def test_integrate_batch_and_device_inputs(gpu_ctx, oracle_lib, small_sequence):
+    import torch
+    from hive_amd import fusion, synthetic
+    seq = small_sequence
+    ora = oracle_lib.TSDFVolume(synthetic.room_bounds(), 0.08)
+    for i in range(8):
+        ora.integrate(seq["color"][i], seq["depth"][i], seq["K"], seq["poses"][i])
+    # host batch
+    vol = fusion.TSDFVolume(synthetic.room_bounds(), 0.08, ctx=gpu_ctx)
+    vol.integrate_batch(seq["color"], seq["depth"], seq["K"], seq["poses"])
+    _volumes_equal(vol, ora)
+    # device tensors, caller-owned storage
+    n = int(np.prod(ora._vol_dim))
+    storage = tuple(torch.empty(n, dtype=torch.float32, device="cuda") for _ in range(3))
+    vol2 = fusion.TSDFVolume(synthetic.room_bounds(), 0.08, ctx=gpu_ctx, storage=storage)
+    color_d = torch.from_numpy(seq["color"]).cuda()
+    depth_d = torch.from_numpy(seq["depth"]).cuda()
+    vol2.integrate_batch(color_d, depth_d, seq["K"], seq["poses"])
+    _volumes_equal(vol2, ora)
+    torch.cuda.synchronize()
+    assert np.array_equal(storage[0].cpu().numpy().reshape(ora._tsdf.shape), ora._tsdf)
+
+
+def test_empty_and_invalid_inputs(gpu_ctx, oracle_lib, small_sequence):
+    from hive_amd import fusion, synthetic
+    from hive_amd._lib import HiveError
+    seq = small_sequence
+    vol = fusion.TSDFVolume(synthetic.room_bounds(), 0.16, ctx=gpu_ctx)
+    # all-invalid depth: nothing is written, volume stays at its initial state
+    n = vol.integrate(seq["color"][0], np.zeros_like(seq["depth"][0]), seq["K"], seq["poses"][0], return_n_updated=True)
+    assert n == 0
+    tsdf, color, weight = vol.get_volume(with_weight=True)
+    assert (tsdf == 1).all() and (color == 0).all() and (weight == 0).all()
+    with pytest.raises(ValueError):
+        vol.get_mesh()
+    # camera looking away from the volume
+    pose = seq["poses"][0].copy()
+    pose[:3, 3] = [100.0, 100.0, 100.0]
+    assert vol.integrate(seq["color"][0], seq["depth"][0], seq["K"], pose, return_n_updated=True) == 0
+    with pytest.raises(AssertionError):
+        vol.integrate(seq["color"][0][:, :-1], seq["depth"][0], seq["K"], seq["poses"][0])
+    with pytest.raises(HiveError):
+        fusion.TSDFVolume(np.array([[0, 1.0], [0, 1.0], [0, 1.0]]), -1.0, ctx=gpu_ctx)
+    with pytest.raises(AssertionError):
+        fusion.TSDFVolume(np.zeros((2, 3)), 0.1, ctx=gpu_ctx)
+
+
+def test_pixel_ties_round_modes(gpu_ctx, oracle_lib):
+    """Axis-aligned camera with cx = 319.5-style half-pixel principal point: voxel centres project
+    exactly onto .5 pixel ties; the two rounding modes must differ from each other and each must
+    match the oracle."""
+    from hive_amd import fusion
+    H, W = 32, 32
+    K = np.array([[16.0, 0, 15.5], [0, 16.0, 15.5], [0, 0, 1]], np.float32)
+    pose = np.eye(4)
+    pose[:3, 3] = [0.5, 0.5, -1.0]
+    rng = np.random.default_rng(7)
+    depth = np.full((H, W), 2.0, np.float32) + rng.integers(0, 3, (H, W)).astype(np.float32) * 0.25
+    color = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    bnds = np.array([[0.0, 1.0], [0.0, 1.0], [0.0, 2.0]])
+    results = []
+    for rm in (0, 1):
+        gpu_ctx.set_round_mode(rm)
+        try:
+            vol = fusion.TSDFVolume(bnds, 0.0625, ctx=gpu_ctx)
+            ora = oracle_lib.TSDFVolume(bnds, 0.0625, round_mode=rm)
+            for _ in range(3):
+                vol.integrate(color, depth, K, pose)
+                ora.integrate(color, depth, K, pose)
+            _volumes_equal(vol, ora)
+            results.append(vol.get_volume()[0])
+        finally:
+            gpu_ctx.set_round_mode(0)
+    assert not np.array_equal(results[0], results[1]), "tie case not exercised"
+
+
+def test_accumulate_finalize_matches_oracle(gpu_ctx, oracle_lib, small_sequence):
+    import torch
+    from hive_amd import fusion, synthetic
+    seq = small_sequence
+    vol = fusion.TSDFVolume(synthetic.room_bounds(), 0.08, ctx=gpu_ctx)
+    acc = torch.empty(5 * vol.num_voxels, dtype=torch.float32, device="cuda")
+    vol.accum_reset(acc)
+    ora = oracle_lib.AccumVolume(synthetic.room_bounds(), 0.08)
+    for i in range(8):
+        vol.accum_integrate(acc, seq["color"][i], seq["depth"][i], seq["K"], seq["poses"][i])
+        ora.integrate(seq["color"][i], seq["depth"][i], seq["K"], seq["poses"][i])
+    torch.cuda.synchronize()
+    assert np.array_equal(acc.cpu().numpy().reshape(ora.accum.shape), ora.accum)
+    vol.accum_finalize(acc)
+    _volumes_equal(vol, ora.finalize())
+
+
+def test_mesh_matches_oracle(gpu_ctx, oracle_lib, small_sequence):
+    from hive_amd import fusion, synthetic
+    seq = small_sequence
+    vol = fusion.TSDFVolume(synthetic.room_bounds(), 0.08, ctx=gpu_ctx)
+    ora = oracle_lib.TSDFVolume(synthetic.room_bounds(), 0.08)
+    for i in range(8):
+        vol.integrate(seq["color"][i], seq["depth"][i], seq["K"], seq["poses"][i])
+        ora.integrate(seq["color"][i], seq["depth"][i], seq["K"], seq["poses"][i])
+    v, f, n, c, vv = vol.get_mesh(return_voxel_coords=True)
+    ov, of, on, oc, ovv = ora.get_mesh(return_voxel_coords=True)
+    assert v.shape == ov.shape and f.shape == of.shape
+    assert np.array_equal(f, of), "face indices (integer work) must be bit-exact"
+    assert np.array_equal(c, oc), "vertex colours must be bit-exact"
+    assert np.array_equal(vv, ovv) and np.array_equal(v, ov), "vertex positions differ"
+    np.testing.assert_allclose(n, on, rtol=0, atol=1e-6)
+    pc = vol.get_point_cloud()
+    assert pc.shape == (v.shape[0], 6)
