@@ -102,6 +102,7 @@ int hive_ctx_create(int device_id, void *stream, hive_ctx **out) {
                          device_id, prop.gcnArchName);
     hive_ctx *ctx = new hive_ctx();
     ctx->device = device_id;
+    ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     e = hipSetDevice(device_id);
     if (e == hipSuccess) {
         if (stream) {

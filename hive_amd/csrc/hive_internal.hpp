@@ -22,6 +22,7 @@ struct hive_staging_slot {
 
 struct hive_ctx {
     int device = 0;
+    int num_cus = 256;
     hipStream_t stream = nullptr;
     bool owns_stream = false;
     int round_mode = HIVE_ROUND_HALF_EVEN;

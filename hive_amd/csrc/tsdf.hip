@@ -32,22 +32,54 @@ struct FrameParams {
 
 // ---------------------------------------------------------------------------------------------
 // pre-pass: fuse depth f32 + colour u8x3 into one 8-byte texel and reduce max(depth)
+// (4 pixels per lane: one 16-byte depth load, three 4-byte colour loads, two 16-byte stores; one
+// atomicMax per workgroup).  VEC = false is the scalar fallback for unaligned / ragged images.
+template <bool VEC>
 __global__ __launch_bounds__(256) void pack_frame_kernel(const float *__restrict__ depth, const uint8_t *__restrict__ color,
                                                          int n, uint2 *__restrict__ out, unsigned *max_bits) {
-    int i = blockIdx.x * 256 + threadIdx.x;
-    float d = 0.f;
-    if (i < n) {
-        d = depth[i];
-        unsigned r = color[3 * i + 0], g = color[3 * i + 1], b = color[3 * i + 2];
-        out[i] = make_uint2(__float_as_uint(d), r | (g << 8) | (b << 16));
-    }
+    __shared__ unsigned wave_max[4];
+    const int i = (blockIdx.x * 256 + threadIdx.x) * (VEC ? 4 : 1);
     // max over non-negative floats == max over their bit patterns; NaN / negatives are ignored (treated as 0)
-    unsigned bits = (d > 0.f) ? __float_as_uint(d) : 0u;
+    unsigned bits = 0;
+    if (VEC) {
+        if (i < n) {
+            const float4 d = *reinterpret_cast<const float4 *>(depth + i);
+            const uint3 c = *reinterpret_cast<const uint3 *>(color + 3 * i);  // 12 bytes = 4 RGB pixels
+            const unsigned p0 = c.x & 0xffffffu;
+            const unsigned p1 = (c.x >> 24) | ((c.y & 0xffffu) << 8);
+            const unsigned p2 = (c.y >> 16) | ((c.z & 0xffu) << 16);
+            const unsigned p3 = c.z >> 8;
+            uint4 *o = reinterpret_cast<uint4 *>(out + i);
+            o[0] = make_uint4(__float_as_uint(d.x), p0, __float_as_uint(d.y), p1);
+            o[1] = make_uint4(__float_as_uint(d.z), p2, __float_as_uint(d.w), p3);
+            const float m = fmaxf(fmaxf(d.x, d.y), fmaxf(d.z, d.w));
+            bits = (m > 0.f) ? __float_as_uint(m) : 0u;
+        }
+    } else if (i < n) {
+        const float d = depth[i];
+        const unsigned r = color[3 * i + 0], g = color[3 * i + 1], b = color[3 * i + 2];
+        out[i] = make_uint2(__float_as_uint(d), r | (g << 8) | (b << 16));
+        bits = (d > 0.f) ? __float_as_uint(d) : 0u;
+    }
     for (int off = 32; off > 0; off >>= 1) bits = max(bits, (unsigned)__shfl_xor((int)bits, off));
-    if ((threadIdx.x & 63) == 0 && bits) atomicMax(max_bits, bits);
+    if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = bits;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        bits = max(max(wave_max[0], wave_max[1]), max(wave_max[2], wave_max[3]));
+        if (bits) atomicMax(max_bits, bits);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
+// Work list.  One lane per (x,y) row clips the row analytically against the padded view frustum (the
+// camera-space position is affine in z) and emits one item per 64*VPT-voxel chunk of the surviving
+// z interval.  Only chunks on the list are ever touched by the integrate kernel; every voxel of a
+// chunk still runs the exact inclusion tests, so the (conservative) clip cannot change a result.
+struct WorkItem {
+    unsigned xy;  // x | y << 16
+    unsigned zz;  // chunk start z | interval end z << 16
+};
+
 struct RowClip {
     int z0, z1;  // half-open voxel range that may pass the inclusion tests
 };
@@ -69,12 +101,12 @@ __device__ __forceinline__ RowClip clip_row(const FrameParams &p, float ax, floa
             empty = true;
         }
     };
-    cut(az, bz);                                                      // cam_z >= 0
-    cut(far_z - az, -bz);                                             // cam_z <= far
-    cut(p.fx * ax + (p.cx + 1.0f) * az, p.fx * bx + (p.cx + 1.0f) * bz);                    // px >= -1
-    cut(((float)p.W - p.cx) * az - p.fx * ax, ((float)p.W - p.cx) * bz - p.fx * bx);        // px <= W
-    cut(p.fy * ay + (p.cy + 1.0f) * az, p.fy * by + (p.cy + 1.0f) * bz);                    // py >= -1
-    cut(((float)p.H - p.cy) * az - p.fy * ay, ((float)p.H - p.cy) * bz - p.fy * by);        // py <= H
+    cut(az, bz);                                                                       // cam_z >= 0
+    cut(far_z - az, -bz);                                                              // cam_z <= far
+    cut(p.fx * ax + (p.cx + 1.0f) * az, p.fx * bx + (p.cx + 1.0f) * bz);               // px >= -1
+    cut(((float)p.W - p.cx) * az - p.fx * ax, ((float)p.W - p.cx) * bz - p.fx * bx);   // px <= W
+    cut(p.fy * ay + (p.cy + 1.0f) * az, p.fy * by + (p.cy + 1.0f) * bz);               // py >= -1
+    cut(((float)p.H - p.cy) * az - p.fy * ay, ((float)p.H - p.cy) * bz - p.fy * by);   // py <= H
     RowClip r;
     if (empty || !(lo <= hi)) {
         r.z0 = r.z1 = 0;
@@ -90,81 +122,159 @@ __device__ __forceinline__ RowClip clip_row(const FrameParams &p, float ax, floa
     return r;
 }
 
+template <int VPT>
+__global__ __launch_bounds__(1024) void build_worklist_kernel(FrameParams p, WorkItem *__restrict__ items, unsigned *n_items) {
+    __shared__ unsigned wave_sum[16];
+    __shared__ unsigned block_base;
+    constexpr int CHUNK = 64 * VPT;
+    const long long row = (long long)blockIdx.x * 1024 + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned n_chunks = 0;
+    int zstart = 0, z1 = 0, x = 0, y = 0;
+    if (row < (long long)p.X * p.Y) {
+        x = (int)(row / p.Y);
+        y = (int)(row % p.Y);
+        const float tx = (p.ox + (float)x * p.vs) - p.T[0];
+        const float ty = (p.oy + (float)y * p.vs) - p.T[1];
+        const float ax = p.R[0] * tx + p.R[3] * ty;
+        const float ay = p.R[1] * tx + p.R[4] * ty;
+        const float az = p.R[2] * tx + p.R[5] * ty;
+        const float far_z = __uint_as_float(*p.max_depth_bits) + p.trunc;
+        const RowClip clip = clip_row(p, ax, ay, az, far_z);
+        if (clip.z1 > clip.z0) {
+            zstart = (clip.z0 / VPT) * VPT;
+            z1 = clip.z1;
+            n_chunks = (unsigned)((z1 - zstart + CHUNK - 1) / CHUNK);
+        }
+    }
+    // block-wide exclusive scan of n_chunks, one atomic per workgroup
+    unsigned inc = n_chunks;
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned o = (unsigned)__shfl_up((int)inc, off);
+        if (lane >= off) inc += o;
+    }
+    if (lane == 63) wave_sum[wave] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned total = 0;
+        for (int w = 0; w < 16; ++w) {
+            const unsigned s = wave_sum[w];
+            wave_sum[w] = total;
+            total += s;
+        }
+        block_base = total ? atomicAdd(n_items, total) : 0u;
+    }
+    __syncthreads();
+    unsigned slot = block_base + wave_sum[wave] + inc - n_chunks;
+    for (unsigned c = 0; c < n_chunks; ++c) {
+        WorkItem it;
+        it.xy = (unsigned)x | ((unsigned)y << 16);
+        it.zz = (unsigned)(zstart + (int)c * CHUNK) | ((unsigned)z1 << 16);
+        items[slot + c] = it;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// IEEE-exact float division with a shared, refined reciprocal of the denominator.  This is the
+// sequence hipcc itself emits for a correctly rounded a/d (rcp, one Newton step on the reciprocal,
+// two on the quotient) minus the range scaling / special-case fix-up, which cannot trigger for the
+// operands used here (|d| and |a/d| within 2^+-60); sharing y between quotients of one denominator
+// removes a third of the instructions of the update.  Checked bit-for-bit against the CPU oracle.
+__device__ __forceinline__ float refined_rcp(float d) {
+    const float r0 = __builtin_amdgcn_rcpf(d);
+    const float e = __builtin_fmaf(-d, r0, 1.0f);
+    return __builtin_fmaf(e, r0, r0);
+}
+
+__device__ __forceinline__ float div_exact(float a, float d, float y) {
+    const float q0 = a * y;
+    const float e0 = __builtin_fmaf(-d, q0, a);
+    const float q1 = __builtin_fmaf(e0, y, q0);
+    const float e1 = __builtin_fmaf(-d, q1, a);
+    return __builtin_fmaf(e1, y, q1);
+}
+
 // per-voxel inclusion tests + sample fetch; returns false when the voxel is not updated
 template <int RM>
-__device__ __forceinline__ bool sample_voxel(const FrameParams &p, float ax, float ay, float az, int z, float &dist,
-                                             unsigned &rgb) {
+__device__ __forceinline__ bool sample_voxel(const FrameParams &p, float ax, float ay, float az, int z, float trunc_rcp,
+                                             float &dist, unsigned &rgb) {
     const float pt_z = p.oz + (float)z * p.vs;
     const float tz = pt_z - p.T[2];
     const float cam_x = ax + p.R[6] * tz;
     const float cam_y = ay + p.R[7] * tz;
     const float cam_z = az + p.R[8] * tz;
     bool ok = cam_z > 0.0f;
-    const float px = hive_round<RM>(p.fx * (cam_x / cam_z) + p.cx);
-    const float py = hive_round<RM>(p.fy * (cam_y / cam_z) + p.cy);
+    float qx, qy;
+    if (__builtin_expect(ok && cam_z < 1.0e-18f, 0)) {  // outside div_exact's domain (never in practice): full division
+        qx = cam_x / cam_z;
+        qy = cam_y / cam_z;
+    } else {
+        const float zr = refined_rcp(cam_z);
+        qx = div_exact(cam_x, cam_z, zr);
+        qy = div_exact(cam_y, cam_z, zr);
+    }
+    const float px = hive_round<RM>(p.fx * qx + p.cx);
+    const float py = hive_round<RM>(p.fy * qy + p.cy);
     ok = ok && (px >= 0.0f) && (px < (float)p.W) && (py >= 0.0f) && (py < (float)p.H);
     const int pix = ok ? ((int)py * p.W + (int)px) : 0;
     const uint2 s = p.frame[pix];
     const float depth = __uint_as_float(s.x);
     const float diff = depth - cam_z;
     ok = ok && (depth != 0.0f) && !(diff < -p.trunc);
-    dist = fminf(1.0f, diff / p.trunc);
+    dist = fminf(1.0f, div_exact(diff, p.trunc, trunc_rcp));
     rgb = s.y;
     return ok;
-}
-
-template <int RM>
-__device__ __forceinline__ float blend_channel(float c_old, float w_old, float ow, float c_new, float w_new) {
-    return fminf(hive_round<RM>((c_old * w_old + ow * c_new) / w_new), 255.0f);
 }
 
 template <int RM>
 __device__ __forceinline__ void update_voxel(float &t, float &w, float &c, float dist, unsigned rgb, float ow) {
     const float w_old = w;
     const float w_new = w_old + ow;
+    const float wr = refined_rcp(w_new);
     w = w_new;
-    t = (t * w_old + ow * dist) / w_new;
+    t = div_exact(t * w_old + ow * dist, w_new, wr);
     const unsigned oc = (unsigned)c;  // exact: packed colour is an integer < 2^24
-    const float r = blend_channel<RM>((float)(oc & 255u), w_old, ow, (float)(rgb & 255u), w_new);
-    const float g = blend_channel<RM>((float)((oc >> 8) & 255u), w_old, ow, (float)((rgb >> 8) & 255u), w_new);
-    const float b = blend_channel<RM>((float)(oc >> 16), w_old, ow, (float)((rgb >> 16) & 255u), w_new);
+    const float r = fminf(hive_round<RM>(div_exact((float)(oc & 255u) * w_old + ow * (float)(rgb & 255u), w_new, wr)), 255.0f);
+    const float g = fminf(hive_round<RM>(div_exact((float)((oc >> 8) & 255u) * w_old + ow * (float)((rgb >> 8) & 255u), w_new, wr)), 255.0f);
+    const float b = fminf(hive_round<RM>(div_exact((float)(oc >> 16) * w_old + ow * (float)((rgb >> 16) & 255u), w_new, wr)), 255.0f);
     c = (float)(((unsigned)b << 16) | ((unsigned)g << 8) | (unsigned)r);
 }
 
-// One wave per (x,y) row; VPT consecutive z voxels per lane (VPT = 4 needs Z % 4 == 0).
+// Persistent grid-stride sweep over the work list: one wave per item (= 64*VPT consecutive z voxels
+// of one (x,y) row; VPT = 4 needs Z % 4 == 0), 16-byte accesses per lane and volume.
 // ACCUM = false: running-average update of (tsdf, weight, colour) -- the reference semantics.
 // ACCUM = true : add into the 5 accumulator planes [num, w, r, g, b] (frame-sharded fusion).
 template <int VPT, int RM, bool COUNT, bool ACCUM>
-__global__ __launch_bounds__(256) void integrate_kernel(FrameParams p, float *__restrict__ v0, float *__restrict__ v1,
-                                                        float *__restrict__ v2, long long plane) {
+__global__ __launch_bounds__(256) void integrate_kernel(FrameParams p, const WorkItem *__restrict__ items,
+                                                        const unsigned *__restrict__ n_items_ptr, float *__restrict__ v0,
+                                                        float *__restrict__ v1, float *__restrict__ v2, long long plane) {
     const int lane = threadIdx.x & 63;
-    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= (long long)p.X * p.Y) return;
-    const int x = (int)(row / p.Y), y = (int)(row % p.Y);
-    // row constants, in the contract's operation order
-    const float tx = (p.ox + (float)x * p.vs) - p.T[0];
-    const float ty = (p.oy + (float)y * p.vs) - p.T[1];
-    const float ax = p.R[0] * tx + p.R[3] * ty;
-    const float ay = p.R[1] * tx + p.R[4] * ty;
-    const float az = p.R[2] * tx + p.R[5] * ty;
-    const float far_z = __uint_as_float(*p.max_depth_bits) + p.trunc;
-    const RowClip clip = clip_row(p, ax, ay, az, far_z);
-    if (clip.z0 >= clip.z1) return;
-    const long long base = row * p.Z;
+    const unsigned n_items = *n_items_ptr;
+    const unsigned stride = gridDim.x * 4;
+    const float trunc_rcp = refined_rcp(p.trunc);
     unsigned n_upd = 0;
-    const int zstart = (clip.z0 / VPT) * VPT;
-    for (int zb = zstart + lane * VPT; zb < clip.z1; zb += 64 * VPT) {
+    for (unsigned it = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)); it < n_items; it += stride) {
+        const WorkItem item = items[it];
+        const int x = (int)(item.xy & 0xffffu), y = (int)(item.xy >> 16);
+        const int zb = (int)(item.zz & 0xffffu) + lane * VPT, z1 = (int)(item.zz >> 16);
+        if (zb >= z1) continue;
+        // row constants, in the contract's operation order
+        const float tx = (p.ox + (float)x * p.vs) - p.T[0];
+        const float ty = (p.oy + (float)y * p.vs) - p.T[1];
+        const float ax = p.R[0] * tx + p.R[3] * ty;
+        const float ay = p.R[1] * tx + p.R[4] * ty;
+        const float az = p.R[2] * tx + p.R[5] * ty;
         float dist[VPT];
         unsigned rgb[VPT];
         bool ok[VPT];
         bool any = false;
 #pragma unroll
         for (int j = 0; j < VPT; ++j) {
-            ok[j] = (VPT == 1 || zb + j < p.Z) && sample_voxel<RM>(p, ax, ay, az, zb + j, dist[j], rgb[j]);
+            ok[j] = sample_voxel<RM>(p, ax, ay, az, zb + j, trunc_rcp, dist[j], rgb[j]);
             any = any || ok[j];
         }
         if (!any) continue;
-        const long long idx = base + zb;
+        const long long idx = ((long long)x * p.Y + y) * p.Z + zb;
         if (!ACCUM) {
             float t[VPT], w[VPT], c[VPT];
             if (VPT == 4) {
@@ -293,9 +403,15 @@ static int prepare_frame(hive_tsdf *v, const uint8_t *color, const float *depth,
     }
     int rc = hive_reserve_device(ctx, &ctx->d_frame, &ctx->frame_bytes, npx * sizeof(uint2));
     if (rc) return rc;
-    HIVE_CHECK_HIP(ctx, hipMemsetAsync(ctx->d_scalars, 0, 16, ctx->stream));
-    hipLaunchKernelGGL(pack_frame_kernel, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, ctx->stream, *d_depth, *d_color,
-                       (int)npx, (uint2 *)ctx->d_frame, ctx->d_scalars);
+    // [0] max depth bits, [2..3] n_updated, [4] work-list length
+    HIVE_CHECK_HIP(ctx, hipMemsetAsync(ctx->d_scalars, 0, 32, ctx->stream));
+    const bool vec = npx % 4 == 0 && ((uintptr_t)*d_depth % 16 == 0) && ((uintptr_t)*d_color % 4 == 0);
+    if (vec)
+        hipLaunchKernelGGL(pack_frame_kernel<true>, dim3((unsigned)((npx / 4 + 255) / 256)), dim3(256), 0, ctx->stream, *d_depth,
+                           *d_color, (int)npx, (uint2 *)ctx->d_frame, ctx->d_scalars);
+    else
+        hipLaunchKernelGGL(pack_frame_kernel<false>, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, ctx->stream, *d_depth,
+                           *d_color, (int)npx, (uint2 *)ctx->d_frame, ctx->d_scalars);
     HIVE_CHECK_HIP(ctx, hipGetLastError());
     return HIVE_OK;
 }
@@ -328,14 +444,26 @@ static int launch_integrate(hive_tsdf *v, float *accum, int H, int W, const floa
     p.max_depth_bits = ctx->d_scalars;
     p.n_updated = (unsigned long long *)(ctx->d_scalars + 2);
     const long long rows = (long long)p.X * p.Y;
-    const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
     float *a0 = ACCUM ? accum : v->d_tsdf;
     const bool vec = (p.Z % 4 == 0) && (((uintptr_t)a0 | (uintptr_t)v->d_weight | (uintptr_t)v->d_color) % 16 == 0);
-    int rc = hive_time_begin(ctx);
+    // work list: at most ceil(Z / chunk) items per row
+    const long long chunk = vec ? 256 : 64;
+    const size_t max_items = (size_t)rows * (size_t)((p.Z + chunk - 1) / chunk);
+    int rc = hive_reserve_device(ctx, &ctx->d_scratch, &ctx->scratch_bytes, max_items * sizeof(WorkItem));
     if (rc) return rc;
-#define HIVE_LAUNCH(VPT, RM, CNT)                                                                                          \
-    hipLaunchKernelGGL((integrate_kernel<VPT, RM, CNT, ACCUM>), grid, block, 0, ctx->stream, p, a0, v->d_weight, v->d_color, \
-                       (long long)v->n)
+    WorkItem *items = (WorkItem *)ctx->d_scratch;
+    unsigned *n_items = ctx->d_scalars + 4;
+    const dim3 wl_grid((unsigned)((rows + 1023) / 1024));
+    if (vec)
+        hipLaunchKernelGGL(build_worklist_kernel<4>, wl_grid, dim3(1024), 0, ctx->stream, p, items, n_items);
+    else
+        hipLaunchKernelGGL(build_worklist_kernel<1>, wl_grid, dim3(1024), 0, ctx->stream, p, items, n_items);
+    // persistent sweep: 8 workgroups of 4 waves per CU (= 8 waves per SIMD at <= 64 VGPRs)
+    const dim3 grid((unsigned)std::min<long long>((long long)ctx->num_cus * 8, (long long)((max_items + 3) / 4))), block(256);
+    if ((rc = hive_time_begin(ctx))) return rc;
+#define HIVE_LAUNCH(VPT, RM, CNT)                                                                                      \
+    hipLaunchKernelGGL((integrate_kernel<VPT, RM, CNT, ACCUM>), grid, block, 0, ctx->stream, p, items, n_items, a0, \
+                       v->d_weight, v->d_color, (long long)v->n)
     const int sel = (vec ? 4 : 0) | (ctx->round_mode ? 2 : 0) | (count ? 1 : 0);
     switch (sel) {
         case 0: HIVE_LAUNCH(1, 0, false); break;
@@ -381,7 +509,7 @@ int hive_tsdf_create(hive_ctx *ctx, const double vol_bnds[6], double voxel_size,
     hive_tsdf_dims(vol_bnds, voxel_size, dim);
     HIVE_REQUIRE(ctx, dim[0] > 0 && dim[1] > 0 && dim[2] > 0, "hive_tsdf_create: empty volume %lld x %lld x %lld",
                  (long long)dim[0], (long long)dim[1], (long long)dim[2]);
-    HIVE_REQUIRE(ctx, dim[0] < (1 << 20) && dim[1] < (1 << 20) && dim[2] < (1 << 20), "hive_tsdf_create: dimension too large");
+    HIVE_REQUIRE(ctx, dim[0] < 65536 && dim[1] < 65536 && dim[2] < 65536, "hive_tsdf_create: a volume dimension exceeds 65535");
     const bool external = d_tsdf || d_weight || d_color;
     HIVE_REQUIRE(ctx, !external || (d_tsdf && d_weight && d_color), "hive_tsdf_create: pass all three volume pointers or none");
     hive_tsdf *v = new hive_tsdf();

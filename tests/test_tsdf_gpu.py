@@ -47,6 +47,35 @@ def test_integrate_odd_dims_scalar_path(gpu_ctx, oracle_lib, small_sequence):
     _volumes_equal(vol, ora)
 
 
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_integrate_random_poses_weights_and_ragged_images(gpu_ctx, oracle_lib, seed):
+    """Random camera poses (incl. inside / outside / behind the volume), non-integer observation weights,
+    image sizes that are not multiples of 4 (scalar pack kernel), noisy depth with zeros: exercises the
+    shared-reciprocal divisions and every inclusion test against the oracle, bit for bit."""
+    from scipy.spatial.transform import Rotation
+    from hive_amd import fusion
+    rng = np.random.default_rng(seed)
+    H, W = [(37, 53), (48, 64), (61, 45)][seed]
+    K = np.array([[40.0 + 7 * seed, 0, W / 2 - 0.5], [0, 42.0, H / 2 - 0.5], [0, 0, 1]], np.float32)
+    bnds = np.array([[-1.0, 1.1], [-0.8, 1.0], [0.2, 2.6]])
+    voxel = [0.03, 0.05, 0.041][seed]
+    vol = fusion.TSDFVolume(bnds, voxel, ctx=gpu_ctx)
+    ora = oracle_lib.TSDFVolume(bnds, voxel)
+    for f in range(12):
+        pose = np.eye(4)
+        pose[:3, :3] = Rotation.from_rotvec(rng.normal(scale=0.6, size=3)).as_matrix()
+        pose[:3, 3] = rng.uniform(-1.5, 1.5, 3) + np.array([0, 0, -0.5])
+        depth = rng.uniform(0.2, 4.0, (H, W)).astype(np.float32)
+        depth[rng.random((H, W)) < 0.15] = 0.0
+        color = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        w = float(np.float32(rng.choice([1.0, 0.37, 2.5, 1e-3, 123.456])))
+        n = vol.integrate(color, depth, K, pose, obs_weight=w, return_n_updated=True)
+        ora.integrate(color, depth, K, pose, obs_weight=w)
+        assert n == ora.last_n_updated
+    assert ora._weight.max() > 0, "scene never observed"
+    _volumes_equal(vol, ora)
+
+
 def test_integrate_batch_and_device_inputs(gpu_ctx, oracle_lib, small_sequence):
     import torch
     from hive_amd import fusion, synthetic

@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Quick probe: integrate-kernel time at 512^3 on the bench scene (HIP events), N_upd, GB/s."""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from hive_amd import _lib, fusion, synthetic  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--frames", type=int, default=30)
+ap.add_argument("--voxel", type=float, default=0.01)
+ap.add_argument("--reps", type=int, default=3)
+args = ap.parse_args()
+
+seq = synthetic.make_sequence(num_frames=args.frames, yaw_step_deg=360.0 / args.frames)
+ctx = _lib.default_context(0)
+vol = fusion.TSDFVolume(synthetic.room_bounds(), args.voxel, ctx=ctx)
+color = torch.from_numpy(seq["color"]).cuda()
+depth = torch.from_numpy(seq["depth"]).cuda()
+H, W = depth.shape[1:]
+n_upd = [vol.integrate(color[i], depth[i], seq["K"], seq["poses"][i], return_n_updated=True) for i in range(args.frames)]
+print("dims", vol.vol_dim, "N_upd/N mean", np.mean(n_upd) / vol.num_voxels, "min/max", min(n_upd) / vol.num_voxels, max(n_upd) / vol.num_voxels)
+for rep in range(args.reps):
+    ctx.set_timing(True)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    vol.integrate_batch(color, depth, seq["K"], seq["poses"])
+    torch.cuda.synchronize()
+    wall = time.time() - t0
+    n, ms = ctx.kernel_time_total()
+    ctx.set_timing(False)
+    alg = (24.0 * np.mean(n_upd) + 8.0 * H * W)
+    print(f"rep {rep}: {n} launches, kernel avg {ms / n * 1e3:.1f} us, wall/frame {wall / args.frames * 1e3:.3f} ms, "
+          f"algorithmic {alg / 1e6:.1f} MB/frame -> {alg / (ms / n * 1e-3) / 1e9:.1f} GB/s")
+t0 = time.time()
+verts, faces, norms, colors = vol.get_mesh()
+print(f"mesh: {len(verts)} verts, {len(faces)} faces in {time.time() - t0:.3f} s (incl. D2H)")
