@@ -458,8 +458,9 @@ static int launch_integrate(hive_tsdf *v, float *accum, int H, int W, const floa
         hipLaunchKernelGGL(build_worklist_kernel<4>, wl_grid, dim3(1024), 0, ctx->stream, p, items, n_items);
     else
         hipLaunchKernelGGL(build_worklist_kernel<1>, wl_grid, dim3(1024), 0, ctx->stream, p, items, n_items);
-    // persistent sweep: 8 workgroups of 4 waves per CU (= 8 waves per SIMD at <= 64 VGPRs)
-    const dim3 grid((unsigned)std::min<long long>((long long)ctx->num_cus * 8, (long long)((max_items + 3) / 4))), block(256);
+    // grid-stride sweep: 4 x the resident wave count (8 workgroups of 4 waves per CU = 8 waves per SIMD at
+    // <= 64 VGPRs), so that the dispatcher evens out items of unequal cost (measured: 120 -> 110 us at 512^3)
+    const dim3 grid((unsigned)std::min<long long>((long long)ctx->num_cus * 8 * 4, (long long)((max_items + 3) / 4))), block(256);
     if ((rc = hive_time_begin(ctx))) return rc;
 #define HIVE_LAUNCH(VPT, RM, CNT)                                                                                      \
     hipLaunchKernelGGL((integrate_kernel<VPT, RM, CNT, ACCUM>), grid, block, 0, ctx->stream, p, items, n_items, a0, \
