@@ -3,8 +3,10 @@
 There is no CPU fallback: if the shared library is missing, or no gfx950 device is visible when a
 context is requested, this module raises -- it never routes to numpy or to the test oracle.
 """
+import atexit
 import ctypes
 import os
+import sys
 import threading
 
 import numpy as np
@@ -57,11 +59,35 @@ SIGNATURES = {
     "hive_project": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_double, c_int, c_void_p, c_void_p,
                              c_void_p]),
     "hive_dilate_mask": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "hive_vit_create": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, P(c_void_p)]),
+    "hive_vit_destroy": (c_int, [c_void_p]),
+    "hive_vit_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "hive_vit_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float]),
+    "hive_vit_linear": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int]),
+    "hive_vit_qkv": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int]),
+    "hive_vit_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int]),
+    "hive_dpt_preprocess": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_float, c_int, c_void_p]),
+    "hive_dpt_head_tail": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p, c_float, c_int, c_int, c_float, c_float,
+                                   c_void_p, c_float, c_float, c_void_p, c_void_p]),
     "hive_depth_quantize": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p]),
 }
 
 _lib = None
 _lock = threading.Lock()
+_shutdown = False
+
+
+@atexit.register
+def _mark_shutdown():
+    # Registered after torch's own atexit hooks, so it runs before them: from here on native handles are
+    # left to process teardown instead of calling into a HIP runtime that is being torn down.
+    global _shutdown
+    _shutdown = True
+
+
+def alive():
+    """False once the interpreter is exiting: destructors must not call the library any more."""
+    return not _shutdown and not sys.is_finalizing()
 
 
 class HiveError(RuntimeError):
@@ -115,20 +141,23 @@ def check(rc, ctx_handle=None):
 
 class Context:
     """One ``hive_ctx`` = one (GPU, stream).  By default it rides on torch's current stream of the
-    device so that hive kernels and torch kernels are ordered with each other."""
+    device so that hive kernels and torch kernels are ordered with each other (for torch's default
+    stream that is HIP's null stream, handle 0).  ``stream="own"`` creates a private non-blocking
+    stream; an int is taken as a ``hipStream_t``."""
 
     def __init__(self, device=0, stream="torch"):
         lib = load()
         self.device = int(device)
         handle = c_void_p()
-        stream_ptr = None
         if stream == "torch":
             import torch
             if not torch.cuda.is_available():
                 raise HiveError(ERR_DEVICE, "no HIP device visible to torch; hive_amd needs an MI355X (no CPU fallback)")
-            stream_ptr = torch.cuda.current_stream(self.device).cuda_stream
-        elif stream is not None:
-            stream_ptr = int(stream)
+            stream_ptr = c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        elif stream == "own":
+            stream_ptr = c_void_p(-1)  # HIVE_STREAM_OWN
+        else:
+            stream_ptr = c_void_p(int(stream or 0))
         check(lib.hive_ctx_create(self.device, stream_ptr, ctypes.byref(handle)))
         self.handle = handle
         self.lib = lib
@@ -151,9 +180,9 @@ class Context:
         return n.value, ms.value
 
     def close(self):
-        if getattr(self, "handle", None):
+        if getattr(self, "handle", None) and alive():
             self.lib.hive_ctx_destroy(self.handle)
-            self.handle = None
+        self.handle = None
 
     def __del__(self):
         try:

@@ -105,11 +105,11 @@ int hive_ctx_create(int device_id, void *stream, hive_ctx **out) {
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     e = hipSetDevice(device_id);
     if (e == hipSuccess) {
-        if (stream) {
-            ctx->stream = (hipStream_t)stream;
-        } else {
+        if (stream == HIVE_STREAM_OWN) {
             e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
             ctx->owns_stream = true;
+        } else {
+            ctx->stream = (hipStream_t)stream;  // NULL = the default stream
         }
     }
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_scalars, 64 * sizeof(unsigned));

@@ -1,0 +1,682 @@
+// ViT-B encoder blocks of DPT-Hybrid on gfx950: LayerNorm, bf16 MFMA GEMM with fused epilogues, and a
+// flash-style attention with LDS-tiled QK^T.  No vendor BLAS.
+//
+// Replaces the transformer blocks inside `dpt.models.DPTDepthModel.forward` of the reference's (absent)
+// third_party/dpt + timm==0.5.4 (call site /root/reference/hive/dataset_adaptors.py:1419):
+//     x = x + proj(softmax(q k^T / sqrt(64)) v),  q,k,v = qkv(LN1(x));   x = x + fc2(gelu(fc1(LN2(x))))
+//
+// Data layout (device, bf16 unless noted), sized for HBM residency of a whole batch:
+//   tokens      x      [B][Np][D]      Np = tokens per image padded to a multiple of 64 (pad rows are zero)
+//   q | k       qk     [B*Np][2D]      head h, channel c at column h*64 + c  (k at D + h*64 + c)
+//   v^T         vT     [B][H][64][Np]  written transposed by the QKV GEMM epilogue, so that P.V contracts
+//                                      over a contiguous axis and the attention needs no transposed reads
+//   weights            [out][in] row-major (nn.Linear), bias / LayerNorm affine in f32
+//
+// GEMM: C[M][N] = A[M][K] W[N][K]^T.  128 x 128 x 64 tiles, 4 waves (2 x 2), 16 MFMA 16x16x32 per wave and
+// 32-deep k-step, operands staged global -> registers -> LDS (XOR-swizzled 128-byte rows, conflict-free
+// ds_read_b128), double-buffered with the next tile's global loads issued before the MFMAs of the current.
+// The MFMA is issued as W.A^T so that a lane owns 4 consecutive output columns (8-byte stores); v^T tiles
+// use A.W^T so that a lane owns 4 consecutive tokens.
+//
+// Attention: one workgroup = 128 queries of one (image, head); each wave 32 queries.  S^T = K Q^T puts the
+// query on the lane and the keys in the accumulator registers, so softmax is in-register (one cross-half
+// shuffle) and the probabilities are already the B operand of O^T += V^T P^T.
+#include "hive_internal.hpp"
+
+#include <algorithm>
+#include <cmath>
+
+typedef __bf16 bf16;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RESIDUAL = 2, EPI_QKV = 3 };
+
+// byte offset of 16-byte chunk `c` (0..7) of row `r` in a tile with 128-byte rows; rows r and r+1 share a
+// 256-byte bank row, the chunk is XORed with (r >> 1) & 7 so that any 16 consecutive rows at one chunk
+// index land on 16 distinct 16-byte slots
+__device__ __forceinline__ int swz(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm over the last dimension D (multiple of 256), one wave per row, f32 statistics
+template <int CH>  // D = 256 * CH
+__global__ __launch_bounds__(256) void layernorm_kernel(const bf16 *__restrict__ x, const float *__restrict__ gamma,
+                                                        const float *__restrict__ beta, bf16 *__restrict__ out, int M, float eps) {
+    constexpr int D = 256 * CH;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const bf16 *xr = x + (size_t)row * D;
+    float v[4 * CH];
+    constexpr int n_chunks = CH;
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < n_chunks; ++i) {
+        const bf16x4 t = *reinterpret_cast<const bf16x4 *>(xr + i * 256 + lane * 4);
+        for (int j = 0; j < 4; ++j) {
+            v[4 * i + j] = (float)t[j];
+            sum += v[4 * i + j];
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+    const float mean = sum / (float)D;
+    float var = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4 * n_chunks; ++i) {
+        const float d = v[i] - mean;
+        var += d * d;
+    }
+    for (int off = 32; off > 0; off >>= 1) var += __shfl_xor(var, off);
+    const float rstd = rsqrtf(var / (float)D + eps);
+    bf16 *orow = out + (size_t)row * D;
+#pragma unroll
+    for (int i = 0; i < n_chunks; ++i) {
+        const int c = i * 256 + lane * 4;
+        const float4 g = *reinterpret_cast<const float4 *>(gamma + c);
+        const float4 b = *reinterpret_cast<const float4 *>(beta + c);
+        bf16x4 o;
+        o[0] = (bf16)((v[4 * i + 0] - mean) * rstd * g.x + b.x);
+        o[1] = (bf16)((v[4 * i + 1] - mean) * rstd * g.y + b.y);
+        o[2] = (bf16)((v[4 * i + 2] - mean) * rstd * g.z + b.z);
+        o[3] = (bf16)((v[4 * i + 3] - mean) * rstd * g.w + b.w);
+        *reinterpret_cast<bf16x4 *>(orow + c) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+struct GemmParams {
+    const bf16 *A;       // [M][K]
+    const bf16 *W;       // [N][K]
+    const float *bias;   // [N]
+    const bf16 *residual;  // [M][ldc] (EPI_BIAS_RESIDUAL)
+    bf16 *C;             // [M][ldc]
+    bf16 *vT;            // EPI_QKV: [B][H][64][Np]
+    int M, N, K, ldc;
+    int Np, H;           // EPI_QKV: tokens per image (padded), heads
+    int n_split;         // EPI_QKV: columns >= n_split are V columns
+};
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
+
+__device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // 2 stages x (A tile, W tile)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;  // wave -> 64 x 64 sub-tile
+    const int tiles_n = p.N / BN;
+    const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x % tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const bool v_tile = (EPI == EPI_QKV) && n0 >= p.n_split;
+
+    // staging: 1024 16-byte chunks per operand tile, 4 per thread; chunk id -> (row, chunk-in-row)
+    int st_row[4], st_c[4];
+    const bf16 *a_src[4], *w_src[4];
+    for (int i = 0; i < 4; ++i) {
+        const int id = tid + 256 * i;
+        st_row[i] = id >> 3;
+        st_c[i] = id & 7;
+        const int am = min(m0 + st_row[i], p.M - 1);  // clamp: rows >= M are never stored
+        a_src[i] = p.A + (size_t)am * p.K + st_c[i] * 8;
+        w_src[i] = p.W + (size_t)(n0 + st_row[i]) * p.K + st_c[i] * 8;
+    }
+    uint4 a_reg[4], w_reg[4];
+    auto load_global = [&](int kt) {
+        for (int i = 0; i < 4; ++i) {
+            a_reg[i] = *reinterpret_cast<const uint4 *>(a_src[i] + kt * BK);
+            w_reg[i] = *reinterpret_cast<const uint4 *>(w_src[i] + kt * BK);
+        }
+    };
+    auto store_lds = [&](int stage) {
+        unsigned char *a_t = lds + stage * 2 * TILE_BYTES, *w_t = a_t + TILE_BYTES;
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<uint4 *>(a_t + swz(st_row[i], st_c[i])) = a_reg[i];
+            *reinterpret_cast<uint4 *>(w_t + swz(st_row[i], st_c[i])) = w_reg[i];
+        }
+    };
+
+    f32x4 acc[4][4];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int KT = p.K / BK;
+    load_global(0);
+    store_lds(0);
+    __syncthreads();
+    const int fr = lane & 15, fq = lane >> 4;
+    for (int kt = 0; kt < KT; ++kt) {
+        const int stage = kt & 1;
+        if (kt + 1 < KT) load_global(kt + 1);
+        const unsigned char *a_t = lds + stage * 2 * TILE_BYTES, *w_t = a_t + TILE_BYTES;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            bf16x8 af[4], wf[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                af[t] = *reinterpret_cast<const bf16x8 *>(a_t + swz(wr * 64 + t * 16 + fr, sub * 4 + fq));
+                wf[t] = *reinterpret_cast<const bf16x8 *>(w_t + swz(wc * 64 + t * 16 + fr, sub * 4 + fq));
+            }
+            if (!v_tile) {
+                // acc[nt][mt] = W_frag . A_frag^T : rows = n, cols = m
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt)
+                        acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], af[mt], acc[nt][mt], 0, 0, 0);
+            } else {
+                // acc[mt][nt] = A_frag . W_frag^T : rows = m, cols = n
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], wf[nt], acc[mt][nt], 0, 0, 0);
+            }
+        }
+        if (kt + 1 < KT) store_lds(stage ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue
+    if (!v_tile) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int n = n0 + wc * 64 + nt * 16 + fq * 4;
+            const float4 b = *reinterpret_cast<const float4 *>(p.bias + n);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const int m = m0 + wr * 64 + mt * 16 + fr;
+                if (m >= p.M) continue;
+                float o[4] = {acc[nt][mt][0] + b.x, acc[nt][mt][1] + b.y, acc[nt][mt][2] + b.z, acc[nt][mt][3] + b.w};
+                if (EPI == EPI_BIAS_GELU)
+                    for (int j = 0; j < 4; ++j) o[j] = gelu_exact(o[j]);
+                bf16 *dst = p.C + (size_t)m * p.ldc + n;
+                if (EPI == EPI_BIAS_RESIDUAL) {
+                    const bf16x4 r = *reinterpret_cast<const bf16x4 *>(p.residual + (size_t)m * p.ldc + n);
+                    for (int j = 0; j < 4; ++j) o[j] += (float)r[j];
+                }
+                bf16x4 ov;
+                for (int j = 0; j < 4; ++j) ov[j] = (bf16)o[j];
+                *reinterpret_cast<bf16x4 *>(dst) = ov;
+            }
+        }
+    } else {
+        // v^T[b][h][c][token]: a lane owns 4 consecutive tokens (rows m) of one channel (col n)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int n = n0 + wc * 64 + nt * 16 + fr;
+            const float b = p.bias[n];
+            const int vc = n - p.n_split, head = vc >> 6, ch = vc & 63;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const int m = m0 + wr * 64 + mt * 16 + fq * 4;  // multiple of 4; Np is a multiple of 64
+                if (m >= p.M) continue;
+                const int img = m / p.Np, tok = m % p.Np;
+                bf16x4 ov;
+                for (int j = 0; j < 4; ++j) ov[j] = (bf16)(acc[mt][nt][j] + b);
+                *reinterpret_cast<bf16x4 *>(p.vT + (((size_t)img * p.H + head) * 64 + ch) * p.Np + tok) = ov;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+struct AttnParams {
+    const bf16 *qk;  // [B*Np][2D]
+    const bf16 *vT;  // [B][H][64][Np]
+    bf16 *out;       // [B*Np][D]
+    int B, H, N, Np, D;
+    float scale_log2e;  // head_dim^-0.5 * log2(e)
+};
+
+constexpr int ATT_KV = 64;  // keys per tile
+
+__global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * ATT_KV * 128];  // 2 stages x (K tile, V^T tile)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q_blocks = (p.Np + 127) / 128;
+    const int qb = blockIdx.x % q_blocks;
+    const int head = (blockIdx.x / q_blocks) % p.H;
+    const int img = blockIdx.x / (q_blocks * p.H);
+    const int lq = lane & 31, hh = lane >> 5;
+    const int q_row = qb * 128 + wave * 32 + lq;                 // token index of this lane's query
+    const int q_tok = min(q_row, p.Np - 1);
+    const size_t row0 = (size_t)img * p.Np;
+    const int ld = 2 * p.D;
+
+    // Q as the B operand of S^T = K Q^T: lane holds Q[q][16 ks + 8 hh + j]
+    bf16x8 qf[4];
+    for (int ks = 0; ks < 4; ++ks)
+        qf[ks] = *reinterpret_cast<const bf16x8 *>(p.qk + (row0 + q_tok) * ld + head * 64 + ks * 16 + hh * 8);
+
+    // staging of one K tile [64 keys][64 ch] and one V^T tile [64 ch][64 keys]: 512 chunks each, 2 per thread
+    const bf16 *k_base = p.qk + row0 * ld + p.D + head * 64;
+    const bf16 *v_base = p.vT + ((size_t)img * p.H + head) * 64 * p.Np;
+    uint4 k_reg[2], v_reg[2];
+    auto load_global = [&](int t) {
+        for (int i = 0; i < 2; ++i) {
+            const int id = tid + 256 * i, r = id >> 3, c = id & 7;
+            k_reg[i] = *reinterpret_cast<const uint4 *>(k_base + (size_t)(t * ATT_KV + r) * ld + c * 8);
+            v_reg[i] = *reinterpret_cast<const uint4 *>(v_base + (size_t)r * p.Np + t * ATT_KV + c * 8);
+        }
+    };
+    auto store_lds = [&](int stage) {
+        unsigned char *k_t = lds + stage * 2 * ATT_KV * 128, *v_t = k_t + ATT_KV * 128;
+        for (int i = 0; i < 2; ++i) {
+            const int id = tid + 256 * i, r = id >> 3, c = id & 7;
+            *reinterpret_cast<uint4 *>(k_t + swz(r, c)) = k_reg[i];
+            // V^T rows are read 8 bytes at a time with 32 different rows per access: swizzle the 8-byte unit
+            // index with (r >> 1) & 15 so that 32 consecutive rows cover the 32 slots of a bank row
+            const int u0 = (2 * c) ^ ((r >> 1) & 15), u1 = (2 * c + 1) ^ ((r >> 1) & 15);
+            *reinterpret_cast<uint2 *>(v_t + r * 128 + u0 * 8) = make_uint2(v_reg[i].x, v_reg[i].y);
+            *reinterpret_cast<uint2 *>(v_t + r * 128 + u1 * 8) = make_uint2(v_reg[i].z, v_reg[i].w);
+        }
+    };
+
+    f32x16 oacc[2];
+    for (int i = 0; i < 16; ++i) oacc[0][i] = oacc[1][i] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int n_tiles = p.Np / ATT_KV;
+    load_global(0);
+    store_lds(0);
+    __syncthreads();
+    for (int t = 0; t < n_tiles; ++t) {
+        const int stage = t & 1;
+        if (t + 1 < n_tiles) load_global(t + 1);
+        const unsigned char *k_t = lds + stage * 2 * ATT_KV * 128, *v_t = k_t + ATT_KV * 128;
+        // S^T[key][q] for 64 keys x 32 queries: rows (keys) in registers, query on the lane
+        f32x16 sacc[2];
+        for (int i = 0; i < 16; ++i) sacc[0][i] = sacc[1][i] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(k_t + swz(kb * 32 + lq, ks * 2 + hh));
+                sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[kb], 0, 0, 0);
+            }
+        // online softmax (base 2); key row of register i: 32 kb + (i & 3) + 8 (i >> 2) + 4 hh
+        float m_tile = -INFINITY;
+        const int key0 = t * ATT_KV + 4 * hh;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int key = key0 + kb * 32 + (i & 3) + 8 * (i >> 2);
+                const float s = key < p.N ? sacc[kb][i] * p.scale_log2e : -INFINITY;
+                sacc[kb][i] = s;
+                m_tile = fmaxf(m_tile, s);
+            }
+        m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32));
+        const float m_new = fmaxf(m_run, m_tile);  // finite: every tile holds at least one valid key for t = 0
+        const float alpha = exp2f(m_run - m_new);
+        m_run = m_new;
+        float l_tile = 0.f;
+        bf16x8 pf[2][2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float e = exp2f(sacc[kb][i] - m_new);
+                l_tile += e;
+                pf[kb][i >> 3][i & 7] = (bf16)e;
+            }
+        l_run = l_run * alpha + l_tile;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            oacc[0][i] *= alpha;
+            oacc[1][i] *= alpha;
+        }
+        // O^T[ch][q] += V^T[ch][key] P^T[key][q]; k index j of half hh <-> key 32 kb + 16 s + 8 (j >> 2) + 4 hh + (j & 3)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    const int r = db * 32 + lq;
+                    const int u = (kb * 32 + s * 16 + 4 * hh) >> 2;  // 8-byte unit of the first 4 keys; second group is u + 2
+                    const uint2 lo = *reinterpret_cast<const uint2 *>(v_t + r * 128 + ((u ^ ((r >> 1) & 15)) << 3));
+                    const uint2 hi = *reinterpret_cast<const uint2 *>(v_t + r * 128 + (((u + 2) ^ ((r >> 1) & 15)) << 3));
+                    uint4 raw = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                    const bf16x8 vf = *reinterpret_cast<const bf16x8 *>(&raw);
+                    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kb][s], oacc[db], 0, 0, 0);
+                }
+        if (t + 1 < n_tiles) store_lds(stage ^ 1);
+        __syncthreads();
+    }
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = 1.0f / l_tot;
+    if (q_row < p.Np) {
+        bf16 *o = p.out + (row0 + q_row) * p.D + head * 64;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16x4 ov;
+                for (int j = 0; j < 4; ++j) ov[j] = (bf16)(oacc[db][4 * g + j] * inv);
+                *reinterpret_cast<bf16x4 *>(o + db * 32 + 8 * g + 4 * hh) = ov;
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// token (un)padding: [B][N][D] <-> [B][Np][D], pad rows zero
+__global__ __launch_bounds__(256) void pad_tokens_kernel(const bf16 *__restrict__ src, bf16 *__restrict__ dst, int B, int N, int Np,
+                                                         int D, int to_padded) {
+    const size_t chunks_per_row = D / 8;
+    const size_t total = (size_t)B * Np * chunks_per_row;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t row = i / chunks_per_row, c = i % chunks_per_row;
+        const int img = (int)(row / Np), tok = (int)(row % Np);
+        if (to_padded) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (tok < N) v = *reinterpret_cast<const uint4 *>(src + ((size_t)img * N + tok) * D + c * 8);
+            *reinterpret_cast<uint4 *>(dst + row * D + c * 8) = v;
+        } else if (tok < N) {
+            *reinterpret_cast<uint4 *>(dst + ((size_t)img * N + tok) * D + c * 8) = *reinterpret_cast<const uint4 *>(src + row * D + c * 8);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// DPT head tail, fused and in f32: the last 1x1 convolution (C -> 1) of the depth head on the bf16 / f16
+// channels-last feature map, ReLU (non_negative), depth = 1 / max(scale * x + shift, 1e-8) (invert), and
+// optionally the uint16-millimetre hand-off of dataset_adaptors.py:1432-1433 + io.py:1032-1039.
+struct HeadTailParams {
+    float w[64];
+    float bias, scale, shift;
+    int C, non_negative, invert;
+    long long n_px;
+    float depth_scale, max_depth;  // quantised outputs
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void head_tail_kernel(const T *__restrict__ feat, HeadTailParams p, float *__restrict__ out_depth,
+                                                        uint16_t *__restrict__ out_mm, float *__restrict__ out_m) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= p.n_px) return;
+    const T *f = feat + i * p.C;
+    float acc = p.bias;
+    for (int c = 0; c < p.C; c += 8) {
+        const uint4 raw = *reinterpret_cast<const uint4 *>(f + c);
+        const T *v = reinterpret_cast<const T *>(&raw);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc += (float)v[j] * p.w[c + j];
+    }
+    if (p.non_negative) acc = fmaxf(acc, 0.0f);
+    float depth = acc;
+    if (p.invert) depth = 1.0f / fmaxf(p.scale * acc + p.shift, 1e-8f);
+    if (out_depth) out_depth[i] = depth;
+    if (out_mm || out_m) {
+        const uint16_t mm = (uint16_t)(int)fminf(fmaxf(depth * 1000.0f, 0.0f), 65535.0f);
+        float m = p.depth_scale * (float)mm;
+        if (m > p.max_depth) m = 0.0f;
+        if (out_mm) out_mm[i] = mm;
+        if (out_m) out_m[i] = m;
+    }
+}
+
+// uint8 RGB [n] -> network input, channels-last: ((x / 255) - mean) / std per element (dataset_adaptors.py:1407-1417)
+template <typename T>
+__global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t *__restrict__ rgb, long long n, float mean, float std,
+                                                         T *__restrict__ out) {
+    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    if (i + 4 <= n) {
+        const uchar4 v = *reinterpret_cast<const uchar4 *>(rgb + i);
+        T o[4] = {(T)(((float)v.x / 255.0f - mean) / std), (T)(((float)v.y / 255.0f - mean) / std),
+                  (T)(((float)v.z / 255.0f - mean) / std), (T)(((float)v.w / 255.0f - mean) / std)};
+        *reinterpret_cast<uint2 *>(out + i) = *reinterpret_cast<const uint2 *>(o);
+    } else {
+        for (long long j = i; j < n; ++j) out[j] = (T)(((float)rgb[j] / 255.0f - mean) / std);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+struct hive_vit {
+    hive_ctx *ctx = nullptr;
+    int depth = 0, dim = 0, heads = 0, mlp = 0;
+    float eps = 1e-6f;
+    std::vector<hive_vit_block_weights> blocks;
+    // workspace
+    void *ws = nullptr;
+    size_t ws_bytes = 0;
+};
+
+static int launch_layernorm(hive_ctx *ctx, const bf16 *x, const float *g, const float *b, bf16 *out, int M, int D, float eps) {
+    const dim3 grid((M + 3) / 4), block(256);
+    switch (D / 256) {
+        case 1: hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, ctx->stream, x, g, b, out, M, eps); break;
+        case 2: hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, ctx->stream, x, g, b, out, M, eps); break;
+        case 3: hipLaunchKernelGGL(layernorm_kernel<3>, grid, block, 0, ctx->stream, x, g, b, out, M, eps); break;
+        case 4: hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, ctx->stream, x, g, b, out, M, eps); break;
+        default: return hive_fail(ctx, HIVE_ERR_INVALID, "layernorm: unsupported D %d", D);
+    }
+    HIVE_CHECK_HIP(ctx, hipGetLastError());
+    return HIVE_OK;
+}
+
+static int launch_gemm(hive_ctx *ctx, int epi, const GemmParams &p) {
+    const dim3 grid((unsigned)(((p.M + BM - 1) / BM) * (p.N / BN))), block(256);
+    const size_t lds_bytes = 4 * TILE_BYTES;
+    switch (epi) {
+        case EPI_BIAS: hipLaunchKernelGGL(gemm_kernel<EPI_BIAS>, grid, block, lds_bytes, ctx->stream, p); break;
+        case EPI_BIAS_GELU: hipLaunchKernelGGL(gemm_kernel<EPI_BIAS_GELU>, grid, block, lds_bytes, ctx->stream, p); break;
+        case EPI_BIAS_RESIDUAL: hipLaunchKernelGGL(gemm_kernel<EPI_BIAS_RESIDUAL>, grid, block, lds_bytes, ctx->stream, p); break;
+        case EPI_QKV: hipLaunchKernelGGL(gemm_kernel<EPI_QKV>, grid, block, lds_bytes, ctx->stream, p); break;
+        default: return hive_fail(ctx, HIVE_ERR_INVALID, "gemm: unknown epilogue %d", epi);
+    }
+    HIVE_CHECK_HIP(ctx, hipGetLastError());
+    return HIVE_OK;
+}
+
+static int launch_attention(hive_ctx *ctx, const AttnParams &p) {
+    const int q_blocks = (p.Np + 127) / 128;
+    hipLaunchKernelGGL(attention_kernel, dim3((unsigned)(p.B * p.H * q_blocks)), dim3(256), 0, ctx->stream, p);
+    HIVE_CHECK_HIP(ctx, hipGetLastError());
+    return HIVE_OK;
+}
+
+static bool g_gemm_attr_set[64] = {false};
+
+static int ensure_gemm_attrs(hive_ctx *ctx) {
+    if (ctx->device < 64 && g_gemm_attr_set[ctx->device]) return HIVE_OK;
+    const int bytes = 4 * TILE_BYTES;
+    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)gemm_kernel<EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)gemm_kernel<EPI_BIAS_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)gemm_kernel<EPI_BIAS_RESIDUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)gemm_kernel<EPI_QKV>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    if (ctx->device < 64) g_gemm_attr_set[ctx->device] = true;
+    return HIVE_OK;
+}
+
+static inline int pad64(int n) { return (n + 63) / 64 * 64; }
+
+extern "C" {
+
+int hive_vit_layernorm(hive_ctx *ctx, const void *x, const float *gamma, const float *beta, void *out, int M, int D, float eps) {
+    if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
+    HIVE_REQUIRE(ctx, x && gamma && beta && out, "layernorm: NULL argument");
+    HIVE_REQUIRE(ctx, M > 0 && D > 0 && D % 256 == 0 && D <= 1024, "layernorm: D must be a multiple of 256 and <= 1024, got %d", D);
+    return launch_layernorm(ctx, (const bf16 *)x, gamma, beta, (bf16 *)out, M, D, eps);
+}
+
+int hive_vit_linear(hive_ctx *ctx, const void *A, const void *W, const float *bias, const void *residual, void *C, int M, int N,
+                    int K, int epilogue) {
+    if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
+    HIVE_REQUIRE(ctx, A && W && bias && C, "linear: NULL argument");
+    HIVE_REQUIRE(ctx, M > 0 && N > 0 && K > 0 && N % BN == 0 && K % BK == 0, "linear: need N %% 128 == 0 and K %% 64 == 0 (M=%d N=%d K=%d)", M, N, K);
+    HIVE_REQUIRE(ctx, epilogue == EPI_BIAS || epilogue == EPI_BIAS_GELU || (epilogue == EPI_BIAS_RESIDUAL && residual),
+                 "linear: bad epilogue %d", epilogue);
+    int rc = ensure_gemm_attrs(ctx);
+    if (rc) return rc;
+    GemmParams p{};
+    p.A = (const bf16 *)A;
+    p.W = (const bf16 *)W;
+    p.bias = bias;
+    p.residual = (const bf16 *)residual;
+    p.C = (bf16 *)C;
+    p.M = M;
+    p.N = N;
+    p.K = K;
+    p.ldc = N;
+    return launch_gemm(ctx, epilogue, p);
+}
+
+int hive_vit_qkv(hive_ctx *ctx, const void *x, const void *W, const float *bias, void *qk, void *vT, int B, int Np, int D, int H) {
+    if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
+    HIVE_REQUIRE(ctx, x && W && bias && qk && vT, "qkv: NULL argument");
+    HIVE_REQUIRE(ctx, B > 0 && Np > 0 && Np % 64 == 0 && D == H * 64 && D % 128 == 0, "qkv: need Np %% 64 == 0, D == 64 H, D %% 128 == 0");
+    int rc = ensure_gemm_attrs(ctx);
+    if (rc) return rc;
+    GemmParams p{};
+    p.A = (const bf16 *)x;
+    p.W = (const bf16 *)W;
+    p.bias = bias;
+    p.C = (bf16 *)qk;
+    p.vT = (bf16 *)vT;
+    p.M = B * Np;
+    p.N = 3 * D;
+    p.K = D;
+    p.ldc = 2 * D;
+    p.Np = Np;
+    p.H = H;
+    p.n_split = 2 * D;
+    return launch_gemm(ctx, EPI_QKV, p);
+}
+
+int hive_vit_attention(hive_ctx *ctx, const void *qk, const void *vT, void *out, int B, int N, int Np, int D, int H) {
+    if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
+    HIVE_REQUIRE(ctx, qk && vT && out, "attention: NULL argument");
+    HIVE_REQUIRE(ctx, B > 0 && N > 0 && N <= Np && Np % 64 == 0 && D == H * 64, "attention: need N <= Np, Np %% 64 == 0, head dim 64");
+    AttnParams p{};
+    p.qk = (const bf16 *)qk;
+    p.vT = (const bf16 *)vT;
+    p.out = (bf16 *)out;
+    p.B = B;
+    p.H = H;
+    p.N = N;
+    p.Np = Np;
+    p.D = D;
+    p.scale_log2e = 0.125f * 1.44269504088896340736f;
+    return launch_attention(ctx, p);
+}
+
+int hive_dpt_preprocess(hive_ctx *ctx, const uint8_t *d_rgb, int64_t n_values, float mean, float std, int dtype, void *d_out) {
+    if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
+    HIVE_REQUIRE(ctx, d_rgb && d_out && n_values > 0 && std != 0.f, "dpt_preprocess: bad arguments");
+    HIVE_REQUIRE(ctx, ((uintptr_t)d_rgb % 4 == 0) && ((uintptr_t)d_out % 8 == 0), "dpt_preprocess: unaligned buffers");
+    const dim3 grid((unsigned)((n_values / 4 + 256) / 256));
+    if (dtype == HIVE_BF16)
+        hipLaunchKernelGGL(preprocess_kernel<bf16>, grid, dim3(256), 0, ctx->stream, d_rgb, (long long)n_values, mean, std, (bf16 *)d_out);
+    else if (dtype == HIVE_F16)
+        hipLaunchKernelGGL(preprocess_kernel<_Float16>, grid, dim3(256), 0, ctx->stream, d_rgb, (long long)n_values, mean, std, (_Float16 *)d_out);
+    else
+        return hive_fail(ctx, HIVE_ERR_INVALID, "dpt_preprocess: dtype must be HIVE_F16 or HIVE_BF16");
+    HIVE_CHECK_HIP(ctx, hipGetLastError());
+    return HIVE_OK;
+}
+
+int hive_dpt_head_tail(hive_ctx *ctx, const void *d_feat, int dtype, int64_t n_px, int C, const float *h_weight, float bias,
+                       int non_negative, int invert, float scale, float shift, float *d_depth, float depth_scale, float max_depth,
+                       uint16_t *d_out_mm, float *d_out_m) {
+    if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
+    HIVE_REQUIRE(ctx, d_feat && h_weight && n_px > 0, "dpt_head_tail: bad arguments");
+    HIVE_REQUIRE(ctx, C > 0 && C <= 64 && C % 8 == 0, "dpt_head_tail: C must be a multiple of 8 and <= 64, got %d", C);
+    HIVE_REQUIRE(ctx, d_depth || d_out_mm || d_out_m, "dpt_head_tail: no output requested");
+    HeadTailParams p{};
+    memcpy(p.w, h_weight, sizeof(float) * C);
+    p.bias = bias;
+    p.scale = scale;
+    p.shift = shift;
+    p.C = C;
+    p.non_negative = non_negative;
+    p.invert = invert;
+    p.n_px = n_px;
+    p.depth_scale = depth_scale;
+    p.max_depth = max_depth;
+    const dim3 grid((unsigned)((n_px + 255) / 256));
+    if (dtype == HIVE_BF16)
+        hipLaunchKernelGGL(head_tail_kernel<bf16>, grid, dim3(256), 0, ctx->stream, (const bf16 *)d_feat, p, d_depth, d_out_mm, d_out_m);
+    else if (dtype == HIVE_F16)
+        hipLaunchKernelGGL(head_tail_kernel<_Float16>, grid, dim3(256), 0, ctx->stream, (const _Float16 *)d_feat, p, d_depth, d_out_mm, d_out_m);
+    else
+        return hive_fail(ctx, HIVE_ERR_INVALID, "dpt_head_tail: dtype must be HIVE_F16 or HIVE_BF16");
+    HIVE_CHECK_HIP(ctx, hipGetLastError());
+    return HIVE_OK;
+}
+
+int hive_vit_create(hive_ctx *ctx, int depth, int dim, int heads, int mlp_dim, float ln_eps, const hive_vit_block_weights *blocks,
+                    hive_vit **out) {
+    if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
+    HIVE_REQUIRE(ctx, out && blocks && depth > 0, "vit_create: NULL argument");
+    HIVE_REQUIRE(ctx, dim == heads * 64 && dim % 256 == 0 && dim <= 1024 && mlp_dim % 128 == 0,
+                 "vit_create: need head dim 64, dim %% 256 == 0, dim <= 1024, mlp %% 128 == 0 (dim=%d heads=%d mlp=%d)", dim, heads, mlp_dim);
+    for (int i = 0; i < depth; ++i) {
+        const hive_vit_block_weights &b = blocks[i];
+        HIVE_REQUIRE(ctx, b.ln1_g && b.ln1_b && b.qkv_w && b.qkv_b && b.proj_w && b.proj_b && b.ln2_g && b.ln2_b && b.fc1_w && b.fc1_b &&
+                              b.fc2_w && b.fc2_b, "vit_create: block %d has a NULL weight pointer", i);
+    }
+    hive_vit *v = new hive_vit();
+    v->ctx = ctx;
+    v->depth = depth;
+    v->dim = dim;
+    v->heads = heads;
+    v->mlp = mlp_dim;
+    v->eps = ln_eps;
+    v->blocks.assign(blocks, blocks + depth);
+    *out = v;
+    return HIVE_OK;
+}
+
+int hive_vit_destroy(hive_vit *v) {
+    if (!v) return HIVE_OK;
+    (void)hipStreamSynchronize(v->ctx->stream);
+    if (v->ws) (void)hipFree(v->ws);
+    delete v;
+    return HIVE_OK;
+}
+
+int hive_vit_forward(hive_vit *v, const void *x, int B, int N, const int *tap_blocks, int n_taps, void *const *tap_out) {
+    if (!v) return hive_fail(nullptr, HIVE_ERR_INVALID, "vit is NULL");
+    hive_ctx *ctx = v->ctx;
+    HIVE_REQUIRE(ctx, x && B > 0 && N > 0, "vit_forward: bad arguments");
+    HIVE_REQUIRE(ctx, n_taps >= 0 && (n_taps == 0 || (tap_blocks && tap_out)), "vit_forward: bad taps");
+    int rc = ensure_gemm_attrs(ctx);
+    if (rc) return rc;
+    const int D = v->dim, H = v->heads, Np = pad64(N), M = B * Np;
+    const size_t tok = (size_t)M * D * sizeof(bf16);
+    // workspace: x (residual stream), ln, qk (2D), vT (D), attn, hidden (mlp)
+    const size_t off_x = 0, off_ln = off_x + tok, off_qk = off_ln + tok, off_vt = off_qk + 2 * tok, off_attn = off_vt + tok,
+                 off_hid = off_attn + tok, total = off_hid + (size_t)M * v->mlp * sizeof(bf16);
+    if ((rc = hive_reserve_device(ctx, &v->ws, &v->ws_bytes, total))) return rc;
+    char *ws = (char *)v->ws;
+    bf16 *xs = (bf16 *)(ws + off_x), *ln = (bf16 *)(ws + off_ln), *qk = (bf16 *)(ws + off_qk), *vt = (bf16 *)(ws + off_vt),
+         *attn = (bf16 *)(ws + off_attn), *hid = (bf16 *)(ws + off_hid);
+    const int cp_blocks = std::min<int>((int)(((size_t)M * D / 8 + 255) / 256), ctx->num_cus * 8);
+    hipLaunchKernelGGL(pad_tokens_kernel, dim3(cp_blocks), dim3(256), 0, ctx->stream, (const bf16 *)x, xs, B, N, Np, D, 1);
+    HIVE_CHECK_HIP(ctx, hipGetLastError());
+    for (int i = 0; i < v->depth; ++i) {
+        const hive_vit_block_weights &w = v->blocks[i];
+        if ((rc = launch_layernorm(ctx, xs, (const float *)w.ln1_g, (const float *)w.ln1_b, ln, M, D, v->eps))) return rc;
+        if ((rc = hive_vit_qkv(ctx, ln, w.qkv_w, (const float *)w.qkv_b, qk, vt, B, Np, D, H))) return rc;
+        if ((rc = hive_vit_attention(ctx, qk, vt, attn, B, N, Np, D, H))) return rc;
+        if ((rc = hive_vit_linear(ctx, attn, w.proj_w, (const float *)w.proj_b, xs, xs, M, D, D, EPI_BIAS_RESIDUAL))) return rc;
+        if ((rc = launch_layernorm(ctx, xs, (const float *)w.ln2_g, (const float *)w.ln2_b, ln, M, D, v->eps))) return rc;
+        if ((rc = hive_vit_linear(ctx, ln, w.fc1_w, (const float *)w.fc1_b, nullptr, hid, M, v->mlp, D, EPI_BIAS_GELU))) return rc;
+        if ((rc = hive_vit_linear(ctx, hid, w.fc2_w, (const float *)w.fc2_b, xs, xs, M, D, v->mlp, EPI_BIAS_RESIDUAL))) return rc;
+        for (int t = 0; t < n_taps; ++t)
+            if (tap_blocks[t] == i) {
+                hipLaunchKernelGGL(pad_tokens_kernel, dim3(cp_blocks), dim3(256), 0, ctx->stream, (const bf16 *)xs, (bf16 *)tap_out[t], B,
+                                   N, Np, D, 0);
+                HIVE_CHECK_HIP(ctx, hipGetLastError());
+            }
+    }
+    return HIVE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,509 @@
+"""DPT-Hybrid (ViT-B/16 + ResNetV2-50 stem) monocular depth network for the MI355X.
+
+Replaces ``dpt.models.DPTDepthModel`` of the reference's (absent) third_party/dpt (AnthonyDickson/DPT,
+a fork of isl-org/DPT, with timm==0.5.4's ``vit_base_resnet50_384``); call sites
+/root/reference/hive/dataset_adaptors.py:51,1366-1374,1419.  The module tree and parameter names are
+those of the published checkpoints (``pretrained.model.*``, ``pretrained.act_postprocess*``,
+``scratch.*``), so ``dpt_hybrid_nyu-2ce69ec7.pt`` loads with ``load_state_dict`` unchanged; without a
+checkpoint (``path=None``) the network is randomly initialised -- parity unpinned.
+
+What runs where:
+  * ViT encoder blocks (LayerNorm, QKV / proj / MLP GEMMs, attention): hand-written HIP kernels for
+    gfx950 (bf16 MFMA, LDS-tiled QK^T) behind the C ABI -- ``hive_amd/csrc/vit.hip``.  ``engine="hip"``.
+  * convolutions (ResNetV2 stem, reassemble, RefineNet fusion, head), GroupNorm, bilinear resize:
+    PyTorch-ROCm ops (MIOpen / hipBLASLt), as SURVEY.md §7 step 7 plans for the first rounds.
+  * ``engine="torch"`` runs the ViT blocks with plain PyTorch ops too: it is the fp32 reference that
+    the numerics tests compare the HIP engine against, not a fallback -- ``engine="hip"`` raises if
+    the extension is missing.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+# ------------------------------------------------------------------------------------------------
+# ResNetV2-50 (layers 3, 4, 9; weight-standardised "same"-padded convs, GroupNorm) -- timm 0.5.4
+def _same_pad(size, k, s):
+    return max((math.ceil(size / s) - 1) * s + k - size, 0)
+
+
+class StdConv2dSame(nn.Conv2d):
+    """Conv2d with weight standardisation and TensorFlow "SAME" padding (timm ``StdConv2dSame``, eps=1e-8
+    for the ViT hybrids).  The standardised weight is cached in eval mode (weights are frozen there)."""
+
+    def __init__(self, in_chs, out_chs, kernel_size, stride=1, eps=1e-8):
+        super().__init__(in_chs, out_chs, kernel_size, stride=stride, padding=0, bias=False)
+        self.eps = eps
+        self._std_weight = None
+
+    def standardized_weight(self):
+        w = self.weight
+        if not self.training and self._std_weight is not None and self._std_weight.dtype == w.dtype \
+                and self._std_weight.device == w.device:
+            return self._std_weight
+        w32 = w.float()
+        flat = w32.reshape(w32.shape[0], -1)
+        mean = flat.mean(dim=1, keepdim=True)
+        var = flat.var(dim=1, unbiased=False, keepdim=True)
+        std_w = ((flat - mean) / torch.sqrt(var + self.eps)).reshape_as(w32).to(w.dtype)
+        if w.dim() == 4 and w.is_contiguous(memory_format=torch.channels_last):
+            std_w = std_w.contiguous(memory_format=torch.channels_last)
+        if not self.training:
+            self._std_weight = std_w.detach()
+        return std_w
+
+    def train(self, mode=True):
+        self._std_weight = None
+        return super().train(mode)
+
+    def _apply(self, fn, *args, **kwargs):
+        self._std_weight = None
+        return super()._apply(fn, *args, **kwargs)
+
+    def forward(self, x):
+        ih, iw = x.shape[-2:]
+        kh, kw = self.kernel_size
+        ph, pw = _same_pad(ih, kh, self.stride[0]), _same_pad(iw, kw, self.stride[1])
+        if ph > 0 or pw > 0:
+            x = F.pad(x, (pw // 2, pw - pw // 2, ph // 2, ph - ph // 2))
+        return F.conv2d(x, self.standardized_weight(), None, self.stride, 0, self.dilation, self.groups)
+
+
+class GroupNormAct(nn.GroupNorm):
+    def __init__(self, num_channels, num_groups=32, eps=1e-5, apply_act=True):
+        super().__init__(num_groups, num_channels, eps=eps)
+        self.apply_act = apply_act
+
+    def forward(self, x):
+        x = F.group_norm(x, self.num_groups, self.weight, self.bias, self.eps)
+        return F.relu(x) if self.apply_act else x
+
+
+class MaxPool2dSame(nn.Module):
+    def __init__(self, kernel_size=3, stride=2):
+        super().__init__()
+        self.k, self.s = kernel_size, stride
+
+    def forward(self, x):
+        ih, iw = x.shape[-2:]
+        ph, pw = _same_pad(ih, self.k, self.s), _same_pad(iw, self.k, self.s)
+        x = F.pad(x, (pw // 2, pw - pw // 2, ph // 2, ph - ph // 2), value=float("-inf"))
+        return F.max_pool2d(x, self.k, self.s)
+
+
+class DownsampleConv(nn.Module):
+    def __init__(self, in_chs, out_chs, stride):
+        super().__init__()
+        self.conv = StdConv2dSame(in_chs, out_chs, 1, stride=stride)
+        self.norm = GroupNormAct(out_chs, apply_act=False)
+
+    def forward(self, x):
+        return self.norm(self.conv(x))
+
+
+class Bottleneck(nn.Module):
+    """Non pre-activation bottleneck: 1x1 -> 3x3(stride) -> 1x1, GroupNorm after each conv, ReLU after the sum."""
+
+    def __init__(self, in_chs, out_chs, stride, downsample):
+        super().__init__()
+        mid = out_chs // 4
+        self.downsample = DownsampleConv(in_chs, out_chs, stride) if downsample else None
+        self.conv1 = StdConv2dSame(in_chs, mid, 1)
+        self.norm1 = GroupNormAct(mid)
+        self.conv2 = StdConv2dSame(mid, mid, 3, stride=stride)
+        self.norm2 = GroupNormAct(mid)
+        self.conv3 = StdConv2dSame(mid, out_chs, 1)
+        self.norm3 = GroupNormAct(out_chs, apply_act=False)
+
+    def forward(self, x):
+        shortcut = x if self.downsample is None else self.downsample(x)
+        x = self.norm1(self.conv1(x))
+        x = self.norm2(self.conv2(x))
+        x = self.norm3(self.conv3(x))
+        return F.relu(x + shortcut)
+
+
+class ResNetStage(nn.Module):
+    def __init__(self, in_chs, out_chs, stride, depth):
+        super().__init__()
+        self.blocks = nn.Sequential(*[Bottleneck(in_chs if i == 0 else out_chs, out_chs, stride if i == 0 else 1, i == 0)
+                                      for i in range(depth)])
+
+    def forward(self, x):
+        return self.blocks(x)
+
+
+class ResNetV2Stem(nn.Sequential):
+    def __init__(self, in_chs=3, out_chs=64):
+        super().__init__()
+        self.conv = StdConv2dSame(in_chs, out_chs, 7, stride=2)
+        self.norm = GroupNormAct(out_chs)
+        self.pool = MaxPool2dSame(3, 2)
+
+
+class ResNetV2(nn.Module):
+    def __init__(self, layers=(3, 4, 9), channels=(256, 512, 1024)):
+        super().__init__()
+        self.stem = ResNetV2Stem()
+        stages, prev = [], 64
+        for i, (depth, chs) in enumerate(zip(layers, channels)):
+            stages.append(ResNetStage(prev, chs, 1 if i == 0 else 2, depth))
+            prev = chs
+        self.stages = nn.Sequential(*stages)
+        self.norm = nn.Identity()
+        self.num_features = prev
+
+
+class HybridEmbed(nn.Module):
+    def __init__(self, embed_dim=768):
+        super().__init__()
+        self.backbone = ResNetV2()
+        self.proj = nn.Conv2d(self.backbone.num_features, embed_dim, kernel_size=1, stride=1)
+
+
+# ------------------------------------------------------------------------------------------------
+# ViT-B encoder
+class Attention(nn.Module):
+    def __init__(self, dim, num_heads):
+        super().__init__()
+        self.num_heads = num_heads
+        self.scale = (dim // num_heads) ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias=True)
+        self.proj = nn.Linear(dim, dim)
+
+    def forward(self, x):
+        B, N, C = x.shape
+        qkv = self.qkv(x).reshape(B, N, 3, self.num_heads, C // self.num_heads).permute(2, 0, 3, 1, 4)
+        q, k, v = qkv[0], qkv[1], qkv[2]
+        attn = (q @ k.transpose(-2, -1)) * self.scale
+        attn = attn.softmax(dim=-1)
+        x = (attn @ v).transpose(1, 2).reshape(B, N, C)
+        return self.proj(x)
+
+
+class Mlp(nn.Module):
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, hidden)
+        self.act = nn.GELU()
+        self.fc2 = nn.Linear(hidden, dim)
+
+    def forward(self, x):
+        return self.fc2(self.act(self.fc1(x)))
+
+
+class Block(nn.Module):
+    def __init__(self, dim, num_heads, mlp_ratio=4.0):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim, eps=1e-6)
+        self.attn = Attention(dim, num_heads)
+        self.norm2 = nn.LayerNorm(dim, eps=1e-6)
+        self.mlp = Mlp(dim, int(dim * mlp_ratio))
+
+    def forward(self, x):
+        x = x + self.attn(self.norm1(x))
+        return x + self.mlp(self.norm2(x))
+
+
+class VisionTransformerHybrid(nn.Module):
+    """``timm.vit_base_resnet50_384`` as DPT uses it (``forward_flex``: any input size that is a multiple
+    of 16, position embedding resized bilinearly from its 24 x 24 training grid)."""
+
+    def __init__(self, embed_dim=768, depth=12, num_heads=12, train_grid=24):
+        super().__init__()
+        self.embed_dim, self.num_heads = embed_dim, num_heads
+        self.patch_size = [16, 16]
+        self.patch_embed = HybridEmbed(embed_dim)
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.pos_embed = nn.Parameter(torch.zeros(1, train_grid * train_grid + 1, embed_dim))
+        self.blocks = nn.Sequential(*[Block(embed_dim, num_heads) for _ in range(depth)])
+        self.norm = nn.LayerNorm(embed_dim, eps=1e-6)
+        nn.init.trunc_normal_(self.pos_embed, std=0.02)
+        nn.init.trunc_normal_(self.cls_token, std=0.02)
+
+    def resize_pos_embed(self, gs_h, gs_w):
+        tok, grid = self.pos_embed[:, :1], self.pos_embed[0, 1:]
+        gs_old = int(math.sqrt(grid.shape[0]))
+        grid = grid.reshape(1, gs_old, gs_old, -1).permute(0, 3, 1, 2)
+        grid = F.interpolate(grid.float(), size=(gs_h, gs_w), mode="bilinear").to(tok.dtype)
+        grid = grid.permute(0, 2, 3, 1).reshape(1, gs_h * gs_w, -1)
+        return torch.cat([tok, grid], dim=1)
+
+
+# ------------------------------------------------------------------------------------------------
+# DPT decoder
+class ProjectReadout(nn.Module):
+    def __init__(self, in_features, start_index=1):
+        super().__init__()
+        self.start_index = start_index
+        self.project = nn.Sequential(nn.Linear(2 * in_features, in_features), nn.GELU())
+
+    def forward(self, x):
+        readout = x[:, 0].unsqueeze(1).expand_as(x[:, self.start_index:])
+        return self.project(torch.cat((x[:, self.start_index:], readout), -1))
+
+
+class Transpose(nn.Module):
+    def __init__(self, dim0, dim1):
+        super().__init__()
+        self.dim0, self.dim1 = dim0, dim1
+
+    def forward(self, x):
+        return x.transpose(self.dim0, self.dim1)
+
+
+class ResidualConvUnit(nn.Module):
+    def __init__(self, features):
+        super().__init__()
+        self.conv1 = nn.Conv2d(features, features, 3, 1, 1, bias=True)
+        self.conv2 = nn.Conv2d(features, features, 3, 1, 1, bias=True)
+
+    def forward(self, x):
+        out = self.conv1(F.relu(x))
+        out = self.conv2(F.relu(out))
+        return out + x
+
+
+class FeatureFusionBlock(nn.Module):
+    def __init__(self, features):
+        super().__init__()
+        self.out_conv = nn.Conv2d(features, features, 1, 1, 0, bias=True)
+        self.resConfUnit1 = ResidualConvUnit(features)
+        self.resConfUnit2 = ResidualConvUnit(features)
+
+    def forward(self, *xs):
+        output = xs[0]
+        if len(xs) == 2:
+            output = output + self.resConfUnit1(xs[1])
+        output = self.resConfUnit2(output)
+        output = F.interpolate(output, scale_factor=2, mode="bilinear", align_corners=True)
+        return self.out_conv(output)
+
+
+class Interpolate(nn.Module):
+    def __init__(self, scale_factor, mode, align_corners=False):
+        super().__init__()
+        self.scale_factor, self.mode, self.align_corners = scale_factor, mode, align_corners
+
+    def forward(self, x):
+        return F.interpolate(x, scale_factor=self.scale_factor, mode=self.mode, align_corners=self.align_corners)
+
+
+class _Pretrained(nn.Module):
+    """Backbone + reassemble stages; hooks of the reference (ResNet stage 0, stage 1, ViT block 8, 11)."""
+
+    def __init__(self, features=(256, 512, 768, 768), vit_features=768, hooks=(0, 1, 8, 11)):
+        super().__init__()
+        self.hooks = hooks
+        self.model = VisionTransformerHybrid(embed_dim=vit_features)
+        self.act_postprocess1 = nn.Sequential(nn.Identity(), nn.Identity(), nn.Identity())
+        self.act_postprocess2 = nn.Sequential(nn.Identity(), nn.Identity(), nn.Identity())
+        # index 2 (nn.Unflatten in the reference) depends on the input size and holds no parameters
+        self.act_postprocess3 = nn.Sequential(ProjectReadout(vit_features), Transpose(1, 2), nn.Identity(),
+                                              nn.Conv2d(vit_features, features[2], 1, 1, 0))
+        self.act_postprocess4 = nn.Sequential(ProjectReadout(vit_features), Transpose(1, 2), nn.Identity(),
+                                              nn.Conv2d(vit_features, features[3], 1, 1, 0),
+                                              nn.Conv2d(features[3], features[3], 3, 2, 1))
+
+
+class _Scratch(nn.Module):
+    def __init__(self, in_shape=(256, 512, 768, 768), features=256):
+        super().__init__()
+        self.layer1_rn = nn.Conv2d(in_shape[0], features, 3, 1, 1, bias=False)
+        self.layer2_rn = nn.Conv2d(in_shape[1], features, 3, 1, 1, bias=False)
+        self.layer3_rn = nn.Conv2d(in_shape[2], features, 3, 1, 1, bias=False)
+        self.layer4_rn = nn.Conv2d(in_shape[3], features, 3, 1, 1, bias=False)
+        self.refinenet1 = FeatureFusionBlock(features)
+        self.refinenet2 = FeatureFusionBlock(features)
+        self.refinenet3 = FeatureFusionBlock(features)
+        self.refinenet4 = FeatureFusionBlock(features)
+
+
+class DPT(nn.Module):
+    def __init__(self, head, features=256, engine="hip"):
+        super().__init__()
+        self.engine = engine
+        self.pretrained = _Pretrained()
+        self.scratch = _Scratch(features=features)
+        self.scratch.output_conv = head
+        self._vit_engine = None
+
+    # -- ViT encoder ---------------------------------------------------------------------------
+    def _run_blocks(self, tokens):
+        """tokens [B, N, 768] -> (output of block 8, output of block 11)."""
+        vit = self.pretrained.model
+        if self.engine == "torch":
+            taps = {}
+            x = tokens
+            for i, blk in enumerate(vit.blocks):
+                x = blk(x)
+                if i in self.pretrained.hooks[2:]:
+                    taps[i] = x
+            return taps[self.pretrained.hooks[2]], taps[self.pretrained.hooks[3]]
+        if self.engine != "hip":
+            raise ValueError(f"unknown engine {self.engine!r}")
+        if self._vit_engine is None:
+            from hive_amd.dpt.vit_engine import VitEngine  # raises if libhive_mi355x.so is missing
+            self._vit_engine = VitEngine(vit)
+        return self._vit_engine.forward(tokens, taps=self.pretrained.hooks[2:])
+
+    def forward_backbone(self, x):
+        p = self.pretrained
+        vit = p.model
+        b, _, h, w = x.shape
+        gh, gw = h // vit.patch_size[1], w // vit.patch_size[0]
+        feat = vit.patch_embed.backbone.stem(x)
+        layer_1 = vit.patch_embed.backbone.stages[0](feat)
+        layer_2 = vit.patch_embed.backbone.stages[1](layer_1)
+        feat = vit.patch_embed.backbone.stages[2](layer_2)
+        tokens = vit.patch_embed.proj(feat).flatten(2).transpose(1, 2)
+        tokens = torch.cat((vit.cls_token.expand(b, -1, -1).to(tokens.dtype), tokens), dim=1)
+        tokens = tokens + vit.resize_pos_embed(gh, gw).to(tokens.dtype)
+        tap3, tap4 = self._run_blocks(tokens)
+        layer_3 = p.act_postprocess3[1](p.act_postprocess3[0](tap3)).reshape(b, -1, gh, gw)
+        layer_4 = p.act_postprocess4[1](p.act_postprocess4[0](tap4)).reshape(b, -1, gh, gw)
+        if x.is_contiguous(memory_format=torch.channels_last):
+            layer_3 = layer_3.contiguous(memory_format=torch.channels_last)
+            layer_4 = layer_4.contiguous(memory_format=torch.channels_last)
+        layer_3 = p.act_postprocess3[3](layer_3)
+        layer_4 = p.act_postprocess4[4](p.act_postprocess4[3](layer_4))
+        return layer_1, layer_2, layer_3, layer_4
+
+    def forward_decoder(self, x):
+        layer_1, layer_2, layer_3, layer_4 = self.forward_backbone(x)
+        s = self.scratch
+        path_4 = s.refinenet4(s.layer4_rn(layer_4))
+        path_3 = s.refinenet3(path_4, s.layer3_rn(layer_3))
+        path_2 = s.refinenet2(path_3, s.layer2_rn(layer_2))
+        return s.refinenet1(path_2, s.layer1_rn(layer_1))
+
+    def forward(self, x):
+        return self.scratch.output_conv(self.forward_decoder(x))
+
+
+class DPTDepthModel(DPT):
+    """Same constructor as the reference's ``dpt.models.DPTDepthModel`` (dataset_adaptors.py:1366-1374).
+
+    ``backbone`` must be ``"vitb_rn50_384"`` (the only one the reference instantiates);
+    ``enable_attention_hooks`` must be False.  ``engine`` is this build's addition.
+    """
+
+    def __init__(self, path=None, non_negative=True, scale=1.0, shift=0.0, invert=False, backbone="vitb_rn50_384",
+                 enable_attention_hooks=False, engine="hip", **kwargs):
+        if backbone != "vitb_rn50_384":
+            raise NotImplementedError(f"backbone {backbone!r}: only 'vitb_rn50_384' (DPT-Hybrid) is implemented")
+        if enable_attention_hooks:
+            raise NotImplementedError("attention hooks (visualisation) are not part of the hot path")
+        features = kwargs.get("features", 256)
+        head = nn.Sequential(
+            nn.Conv2d(features, features // 2, kernel_size=3, stride=1, padding=1),
+            Interpolate(scale_factor=2, mode="bilinear", align_corners=True),
+            nn.Conv2d(features // 2, 32, kernel_size=3, stride=1, padding=1),
+            nn.ReLU(True),
+            nn.Conv2d(32, 1, kernel_size=1, stride=1, padding=0),
+            nn.ReLU(True) if non_negative else nn.Identity(),
+            nn.Identity(),
+        )
+        super().__init__(head, features=features, engine=engine)
+        self.scale, self.shift, self.invert = scale, shift, invert
+        if path is not None:
+            self.load(path)
+
+    def load(self, path):
+        parameters = torch.load(path, map_location=torch.device("cpu"))
+        if "optimizer" in parameters:
+            parameters = parameters["model"]
+        # the published checkpoints also carry the (unused) classification head / final norm of the ViT
+        missing, unexpected = self.load_state_dict(parameters, strict=False)
+        missing = [k for k in missing if not k.endswith("_std_weight")]
+        if missing:
+            raise RuntimeError(f"checkpoint {path} lacks parameters: {missing[:8]}{'...' if len(missing) > 8 else ''}")
+
+    def forward_head_features(self, x):
+        """Everything up to (and including) the ReLU before the last 1x1 convolution: [B, 32, h, w]."""
+        head = self.scratch.output_conv
+        return head[3](head[2](head[1](head[0](self.forward_decoder(x)))))
+
+    def forward(self, x, handoff=None):
+        """[B, 3, h, w] -> depth [B, h, w] in **float32**.
+
+        The reference returns the network's working precision (fp16 on a GPU); the last 1x1 convolution and
+        the inversion ``1 / (scale * x + shift)`` run in float32 here because bf16 cannot resolve metric depth
+        (8 significant bits: 3 cm steps at 7 m).  ``handoff=(max_depth,)`` additionally applies the
+        reference's depth hand-off on the device -- uint16 millimetres (dataset_adaptors.py:1432-1433), read
+        back as float32 metres with ``> max_depth -> 0`` (io.py:1032-1039) -- and returns (depth, depth_mm, depth_m).
+        """
+        feat = self.forward_head_features(x)
+        conv = self.scratch.output_conv[4]
+        non_negative = isinstance(self.scratch.output_conv[5], nn.ReLU)
+        b, c, h, w = feat.shape
+        if self.engine == "hip" and feat.is_cuda and feat.dtype in (torch.float16, torch.bfloat16):
+            from hive_amd import _lib
+            ctx = _lib.default_context(feat.device.index or 0)
+            feat = feat.contiguous(memory_format=torch.channels_last)
+            depth = torch.empty((b, h, w), dtype=torch.float32, device=feat.device)
+            mm = torch.empty((b, h, w), dtype=torch.int16, device=feat.device) if handoff else None
+            m = torch.empty((b, h, w), dtype=torch.float32, device=feat.device) if handoff else None
+            key = (conv.weight.data_ptr(), conv.weight._version, conv.bias._version)
+            if getattr(self, "_tail_host", (None,))[0] != key:  # one D2H per set of weights, not per forward
+                self._tail_host = (key, conv.weight.detach().float().reshape(-1).cpu().numpy(), float(conv.bias.detach().float().item()))
+            weight, bias = self._tail_host[1], self._tail_host[2]
+            ctx.check(ctx.lib.hive_dpt_head_tail(
+                ctx.handle, feat.data_ptr(), _lib.BF16 if feat.dtype == torch.bfloat16 else _lib.F16, b * h * w, c,
+                weight.ctypes.data, bias, int(non_negative), int(bool(self.invert)),
+                float(self.scale), float(self.shift), depth.data_ptr(), 1.0 / 1000.0, float(handoff[0]) if handoff else 0.0,
+                _lib.ptr(mm), _lib.ptr(m)))
+            return (depth, mm, m) if handoff else depth
+        out = F.conv2d(feat.float(), conv.weight.float(), conv.bias.float()).squeeze(dim=1)
+        if non_negative:
+            out = F.relu(out)
+        if self.invert:
+            out = 1.0 / torch.clamp(self.scale * out + self.shift, min=1e-8)  # depth[depth < 1e-8] = 1e-8
+        if handoff:
+            mm = (out * 1000.0).clamp(0, 65535).to(torch.int32)
+            m = mm.float() * (1.0 / 1000.0)
+            m = torch.where(m > handoff[0], torch.zeros_like(m), m)
+            return out, mm.to(torch.int16), m
+        return out
+
+
+def count_flops(height=480, width=640):
+    """Algorithmic FLOPs (2 x MACs) of one DPT-Hybrid forward at height x width, by component."""
+    def conv(cin, cout, k, h, w):
+        return 2 * cin * cout * k * k * h * w
+    h4, w4 = height // 4, width // 4
+    flops = {"stem": conv(3, 64, 7, height // 2, width // 2)}
+    rn = 0
+    prev = 64
+    for i, (depth, chs) in enumerate(zip((3, 4, 9), (256, 512, 1024))):
+        s = 2 ** i
+        h, w = h4 // s, w4 // s
+        mid = chs // 4
+        for b in range(depth):
+            cin = prev if b == 0 else chs
+            hin, win = (h * (2 if (i > 0 and b == 0) else 1), w * (2 if (i > 0 and b == 0) else 1))
+            rn += conv(cin, mid, 1, hin, win) + conv(mid, mid, 3, h, w) + conv(mid, chs, 1, h, w)
+            if b == 0:
+                rn += conv(cin, chs, 1, h, w)
+        prev = chs
+    flops["resnet_stages"] = rn
+    gh, gw = height // 16, width // 16
+    n, d = gh * gw + 1, 768
+    flops["patch_proj"] = conv(1024, d, 1, gh, gw)
+    flops["vit_gemm"] = 12 * (2 * n * d * 3 * d + 2 * n * d * d + 2 * 2 * n * d * 4 * d)
+    flops["vit_attention"] = 12 * (2 * 2 * n * n * d)
+    flops["readout"] = 2 * (2 * (n - 1) * 2 * d * d)
+    flops["reassemble"] = conv(d, 768, 1, gh, gw) * 2 + conv(768, 768, 3, gh // 2, gw // 2)
+    f = 256
+    flops["layer_rn"] = conv(256, f, 3, h4, w4) + conv(512, f, 3, h4 // 2, w4 // 2) + conv(768, f, 3, gh, gw) + \
+        conv(768, f, 3, gh // 2, gw // 2)
+    ref = 0
+    for i, (h, w) in enumerate(((gh // 2, gw // 2), (gh, gw), (h4 // 2, w4 // 2), (h4, w4))):
+        n_rcu = 1 if i == 0 else 2
+        ref += n_rcu * 2 * conv(f, f, 3, h, w) + conv(f, f, 1, 2 * h, 2 * w)
+    flops["refinenets"] = ref
+    flops["head"] = conv(f, f // 2, 3, 2 * h4, 2 * w4) + conv(f // 2, 32, 3, height, width) + conv(32, 1, 1, height, width)
+    flops["total"] = sum(flops.values())
+    return flops

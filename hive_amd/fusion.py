@@ -204,9 +204,9 @@ class TSDFVolume:
         self._ctx.check(self._ctx.lib.hive_tsdf_accum_finalize(self._handle, ptr(accum)))
 
     def close(self):
-        if getattr(self, "_handle", None):
+        if getattr(self, "_handle", None) and _lib.alive():
             self._ctx.lib.hive_tsdf_destroy(self._handle)
-            self._handle = None
+        self._handle = None
 
     def __del__(self):
         try:

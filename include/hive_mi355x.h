@@ -58,8 +58,11 @@ typedef struct hive_tsdf hive_tsdf;
 
 /* ---- library / context ------------------------------------------------------------ */
 int hive_abi_version(void);
-/* `stream` is a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) or NULL to let the
- * context create and own a stream of its own. */
+/* `stream` is the hipStream_t every kernel and copy of the context is issued on, e.g.
+ * torch.cuda.current_stream().cuda_stream.  NULL is HIP's default (null) stream -- which is what that
+ * expression returns for PyTorch's default stream -- and HIVE_STREAM_OWN makes the context create a
+ * non-blocking stream of its own. */
+#define HIVE_STREAM_OWN ((void *)(intptr_t)-1)
 int hive_ctx_create(int device_id, void *stream, hive_ctx **out);
 int hive_ctx_destroy(hive_ctx *ctx);
 int hive_ctx_synchronize(hive_ctx *ctx);
@@ -165,6 +168,55 @@ typedef enum hive_dtype { HIVE_F32 = 0, HIVE_F16 = 1, HIVE_BF16 = 2 } hive_dtype
 int hive_depth_quantize(hive_ctx *ctx, const void *d_depth, int dtype, int H, int W,
                         float depth_scale, float max_depth, const uint8_t *d_mask,
                         uint16_t *d_out_mm, float *d_out_m);
+
+/* ---- DPT ViT encoder blocks: replaces the transformer blocks of dpt.models.DPTDepthModel.forward
+ *      (timm vit_base_resnet50_384) -- hive/dataset_adaptors.py:1366-1374,1419 --------------------- */
+/* All pointers are device memory.  Activations / weights are bf16 ([out][in] row-major weights, as
+ * nn.Linear stores them); biases and LayerNorm affine parameters are float32. */
+typedef struct hive_vit hive_vit;
+typedef struct hive_vit_block_weights {
+    const void *ln1_g, *ln1_b;   /* f32 [D]            norm1            */
+    const void *qkv_w, *qkv_b;   /* bf16 [3D][D], f32 [3D]   attn.qkv   */
+    const void *proj_w, *proj_b; /* bf16 [D][D],  f32 [D]    attn.proj  */
+    const void *ln2_g, *ln2_b;   /* f32 [D]            norm2            */
+    const void *fc1_w, *fc1_b;   /* bf16 [F][D],  f32 [F]    mlp.fc1    */
+    const void *fc2_w, *fc2_b;   /* bf16 [D][F],  f32 [D]    mlp.fc2    */
+} hive_vit_block_weights;
+/* head dim must be 64 (D = 64 * heads), D a multiple of 256 and <= 1024, F a multiple of 128. */
+int hive_vit_create(hive_ctx *ctx, int depth, int dim, int heads, int mlp_dim, float ln_eps,
+                    const hive_vit_block_weights *blocks, hive_vit **out);
+int hive_vit_destroy(hive_vit *vit);
+/* x bf16 [B][N][D] -> runs all blocks; after block tap_blocks[t] its output is copied to tap_out[t]
+ * (bf16 [B][N][D]).  x = x + proj(attn(LN1 x)); x = x + fc2(gelu(fc1(LN2 x))). */
+int hive_vit_forward(hive_vit *vit, const void *x, int B, int N, const int *tap_blocks, int n_taps,
+                     void *const *tap_out);
+/* the individual kernels (used by hive_vit_forward; exposed for the numerics tests) */
+int hive_vit_layernorm(hive_ctx *ctx, const void *x, const float *gamma, const float *beta, void *out,
+                       int M, int D, float eps);
+/* C = epilogue(A[M][K] W[N][K]^T + bias): epilogue 0 = none, 1 = GELU (erf), 2 = + residual[M][N] */
+int hive_vit_linear(hive_ctx *ctx, const void *A, const void *W, const float *bias, const void *residual,
+                    void *C, int M, int N, int K, int epilogue);
+/* qkv projection of x [B*Np][D] (Np a multiple of 64): q|k -> qk [B*Np][2D], v -> vT [B][H][64][Np] */
+int hive_vit_qkv(hive_ctx *ctx, const void *x, const void *W, const float *bias, void *qk, void *vT,
+                 int B, int Np, int D, int H);
+/* softmax(q k^T / 8) v over the first N keys of each image -> out [B*Np][D] */
+int hive_vit_attention(hive_ctx *ctx, const void *qk, const void *vT, void *out, int B, int N, int Np,
+                       int D, int H);
+
+/* ---- DPT pre/post-processing around the network (device pointers) -------------------------------- */
+/* uint8 RGB values -> ((x / 255) - mean) / std as f16 / bf16, same element order (a [B][H][W][3] frame
+ * batch becomes the channels-last network input) -- hive/dataset_adaptors.py:1407-1417 */
+int hive_dpt_preprocess(hive_ctx *ctx, const uint8_t *d_rgb, int64_t n_values, float mean, float std,
+                        int dtype, void *d_out);
+/* Last layer of the depth head, fused, in float32: 1x1 conv C -> 1 on the channels-last f16 / bf16 map
+ * d_feat [n_px][C] (weights / bias on the host), ReLU if non_negative, depth = 1 / max(scale x + shift, 1e-8)
+ * if invert (DPTDepthModel.forward).  Optional outputs: d_depth f32 metres; and the PNG hand-off
+ * d_out_mm = uint16(depth * 1000), d_out_m = depth_scale * mm with > max_depth -> 0
+ * (hive/dataset_adaptors.py:1432-1433, hive/io.py:1032-1039). */
+int hive_dpt_head_tail(hive_ctx *ctx, const void *d_feat, int dtype, int64_t n_px, int C,
+                       const float *h_weight, float bias, int non_negative, int invert, float scale,
+                       float shift, float *d_depth, float depth_scale, float max_depth,
+                       uint16_t *d_out_mm, float *d_out_m);
 
 #ifdef __cplusplus
 }

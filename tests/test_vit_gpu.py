@@ -1,0 +1,172 @@
+"""Numerics of the hand-written HIP ViT kernels (through the C ABI) against a plain PyTorch fp32
+reference of the same op, evaluated on the same bf16-rounded inputs.
+
+Tolerance (stated, floating point): outputs are bf16 (8 significant bits, relative step 2^-8 = 3.9e-3);
+accumulation is f32.  Each comparison allows |err| <= 1.5e-2 * max|ref| + 1e-2 * |ref| elementwise, and
+a relative Frobenius error <= 6e-3."""
+import ctypes
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(out, ref, name):
+    import torch
+    out, ref = out.float(), ref.float()
+    assert torch.isfinite(out).all(), f"{name}: non-finite output"
+    scale = ref.abs().max().item()
+    err = (out - ref).abs()
+    bound = 1.5e-2 * scale + 1e-2 * ref.abs()
+    assert (err <= bound).all(), f"{name}: max err {err.max().item():.4g} vs scale {scale:.4g}"
+    rel = (out - ref).norm().item() / max(ref.norm().item(), 1e-30)
+    assert rel <= 6e-3, f"{name}: relative Frobenius error {rel:.4g}"
+
+
+@pytest.mark.parametrize("M,D", [(1216, 768), (37, 768), (130, 1024), (5, 256)])
+def test_layernorm(gpu_ctx, M, D):
+    import torch
+    torch.manual_seed(0)
+    x = (torch.randn(M, D, device="cuda") * 3 + 0.5).bfloat16()
+    g = torch.randn(D, device="cuda") * 0.5 + 1
+    b = torch.randn(D, device="cuda") * 0.1
+    out = torch.empty_like(x)
+    gpu_ctx.check(gpu_ctx.lib.hive_vit_layernorm(gpu_ctx.handle, x.data_ptr(), g.data_ptr(), b.data_ptr(), out.data_ptr(), M, D, 1e-6))
+    ref = torch.nn.functional.layer_norm(x.float(), (D,), g, b, 1e-6)
+    _close(out, ref, "layernorm")
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(1216, 768, 768, 0), (1216, 3072, 768, 1), (1216, 768, 3072, 2), (200, 128, 64, 0),
+                                        (129, 256, 128, 2), (2432, 2304, 768, 0)])
+def test_linear_epilogues(gpu_ctx, M, N, K, epi):
+    import torch
+    torch.manual_seed(1)
+    A = torch.randn(M, K, device="cuda").bfloat16()
+    W = (torch.randn(N, K, device="cuda") / K ** 0.5).bfloat16()
+    bias = torch.randn(N, device="cuda") * 0.1
+    res = torch.randn(M, N, device="cuda").bfloat16()
+    C = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    gpu_ctx.check(gpu_ctx.lib.hive_vit_linear(gpu_ctx.handle, A.data_ptr(), W.data_ptr(), bias.data_ptr(), res.data_ptr() if epi == 2 else None,
+                                              C.data_ptr(), M, N, K, epi))
+    ref = A.float() @ W.float().t() + bias
+    if epi == 1:
+        ref = torch.nn.functional.gelu(ref)
+    if epi == 2:
+        ref = ref + res.float()
+    _close(C, ref, f"linear epi={epi}")
+
+
+def test_linear_asymmetric_identity(gpu_ctx):
+    """A = I with an asymmetric W catches a transposed C write (a symmetric operand would hide it)."""
+    import torch
+    M = N = K = 128
+    A = torch.eye(M, device="cuda").bfloat16()
+    W = (torch.arange(N * K, device="cuda").reshape(N, K) % 251).float().bfloat16()
+    bias = torch.zeros(N, device="cuda")
+    C = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    gpu_ctx.check(gpu_ctx.lib.hive_vit_linear(gpu_ctx.handle, A.data_ptr(), W.data_ptr(), bias.data_ptr(), None, C.data_ptr(), M, N, K, 0))
+    assert torch.equal(C.float(), W.float().t())
+
+
+def test_linear_rejects_bad_shapes(gpu_ctx):
+    from hive_amd._lib import HiveError
+    import torch
+    t = torch.zeros(128 * 128, device="cuda", dtype=torch.bfloat16)
+    f = torch.zeros(128, device="cuda")
+    with pytest.raises(HiveError):
+        gpu_ctx.check(gpu_ctx.lib.hive_vit_linear(gpu_ctx.handle, t.data_ptr(), t.data_ptr(), f.data_ptr(), None, t.data_ptr(), 128, 100, 64, 0))
+    with pytest.raises(HiveError):
+        gpu_ctx.check(gpu_ctx.lib.hive_vit_linear(gpu_ctx.handle, t.data_ptr(), t.data_ptr(), f.data_ptr(), None, t.data_ptr(), 128, 128, 64, 2))
+
+
+@pytest.mark.parametrize("B,N", [(1, 1201), (2, 77), (1, 64), (3, 130)])
+def test_qkv_and_attention(gpu_ctx, B, N):
+    """qkv projection (q|k row-major, v transposed) + softmax(q k^T / 8) v, incl. ragged N (key masking),
+    and a spiked key row that forces the online-softmax rescale branch."""
+    import torch
+    torch.manual_seed(2)
+    D, H = 768, 12
+    Np = (N + 63) // 64 * 64
+    x = torch.zeros(B, Np, D, device="cuda")
+    x[:, :N] = torch.randn(B, N, D, device="cuda")
+    x = x.bfloat16()
+    W = (torch.randn(3 * D, D, device="cuda") / D ** 0.5).bfloat16()
+    # spike: make one late key dominate for every query of head 0 (running max jumps mid-sequence)
+    W[D:D + 64] *= 1.0
+    x[:, N - 3] *= 6.0
+    bias = torch.randn(3 * D, device="cuda") * 0.1
+    qk = torch.empty(B * Np, 2 * D, device="cuda", dtype=torch.bfloat16)
+    vT = torch.empty(B, H, 64, Np, device="cuda", dtype=torch.bfloat16)
+    gpu_ctx.check(gpu_ctx.lib.hive_vit_qkv(gpu_ctx.handle, x.data_ptr(), W.data_ptr(), bias.data_ptr(), qk.data_ptr(), vT.data_ptr(), B, Np, D, H))
+    ref_qkv = x.float().reshape(B * Np, D) @ W.float().t() + bias
+    _close(qk, ref_qkv[:, :2 * D], "q|k")
+    ref_v = ref_qkv[:, 2 * D:].reshape(B, Np, H, 64).permute(0, 2, 3, 1)
+    _close(vT, ref_v, "v^T")
+    out = torch.empty(B * Np, D, device="cuda", dtype=torch.bfloat16)
+    gpu_ctx.check(gpu_ctx.lib.hive_vit_attention(gpu_ctx.handle, qk.data_ptr(), vT.data_ptr(), out.data_ptr(), B, N, Np, D, H))
+    # reference on the kernel's own bf16 q, k, v
+    q = qk[:, :D].float().reshape(B, Np, H, 64).permute(0, 2, 1, 3)[:, :, :N]
+    k = qk[:, D:].float().reshape(B, Np, H, 64).permute(0, 2, 1, 3)[:, :, :N]
+    v = vT.float().permute(0, 1, 3, 2)[:, :, :N]
+    attn = torch.softmax(q @ k.transpose(-1, -2) * 0.125, dim=-1)
+    ref = (attn @ v).permute(0, 2, 1, 3).reshape(B, N, D)
+    _close(out.reshape(B, Np, D)[:, :N], ref, "attention")
+
+
+def test_vit_forward_matches_fp32_blocks(gpu_ctx):
+    """All 12 blocks through hive_vit_forward vs the fp32 torch blocks with the same (bf16-rounded) weights."""
+    import torch
+    from hive_amd.dpt.models import VisionTransformerHybrid
+    from hive_amd.dpt.vit_engine import VitEngine
+    torch.manual_seed(3)
+    vit = VisionTransformerHybrid().eval()
+    for p in vit.blocks.parameters():  # round the weights once so that both paths see identical values
+        p.data = p.data.bfloat16().float()
+    vit = vit.cuda()
+    eng = VitEngine(vit, ctx=gpu_ctx)
+    B, N = 2, 301
+    tokens = torch.randn(B, N, 768, device="cuda").bfloat16()
+    t8, t11 = eng.forward(tokens, taps=(8, 11))
+    with torch.no_grad():
+        x = tokens.float()
+        refs = {}
+        for i, blk in enumerate(vit.blocks):
+            x = blk(x)
+            refs[i] = x
+    # 12 blocks of bf16 activations: the error accumulates along the residual stream
+    for out, ref, name in ((t8, refs[8], "block 8"), (t11, refs[11], "block 11")):
+        rel = (out.float() - ref).norm().item() / ref.norm().item()
+        assert torch.isfinite(out).all() and rel < 2e-2, f"{name}: relative error {rel:.4g}"
+    assert t8.shape == (B, N, 768) and t8.dtype == torch.bfloat16
+
+
+def test_dpt_hip_engine_matches_torch_engine(gpu_ctx):
+    """Whole DPT-Hybrid (random weights): engine='hip' vs engine='torch' in bf16, and vs fp32."""
+    import torch
+    from hive_amd.dpt.models import DPTDepthModel
+    torch.manual_seed(4)
+    ref32 = DPTDepthModel(path=None, scale=0.000305, shift=0.1378, invert=True, engine="torch").eval().cuda()
+    hip = DPTDepthModel(path=None, scale=0.000305, shift=0.1378, invert=True, engine="hip").eval()
+    hip.load_state_dict(ref32.state_dict())
+    hip = hip.to(torch.bfloat16).cuda()
+    tor = DPTDepthModel(path=None, scale=0.000305, shift=0.1378, invert=True, engine="torch").eval()
+    tor.load_state_dict(ref32.state_dict())
+    tor = tor.to(torch.bfloat16).cuda()
+    x = torch.rand(2, 3, 96, 128, device="cuda") * 2 - 1
+    with torch.no_grad():
+        d32 = ref32(x)
+        d_hip, mm, m = hip(x.bfloat16().contiguous(memory_format=torch.channels_last), handoff=(10.0,))
+        d_tor, mm_t, m_t = tor(x.bfloat16().contiguous(memory_format=torch.channels_last), handoff=(10.0,))
+    assert d_hip.shape == (2, 96, 128) and d_hip.dtype == torch.float32 and torch.isfinite(d_hip).all()
+    # bf16 network, f32 tail: compare the inverse depth (the network's own output) relative to its range.
+    # Tolerance: 12 bf16 transformer blocks + ~60 bf16 convolutions; 5 % of the output range.
+    inv = lambda d: (1.0 / d - 0.1378) / 0.000305
+    span = (inv(d32).max() - inv(d32).min()).item() + 1e-6
+    assert (inv(d_hip) - inv(d32)).abs().max().item() / span < 0.05
+    assert (inv(d_hip) - inv(d_tor)).abs().max().item() / span < 0.05
+    # device hand-off == reference arithmetic on the same f32 depth: trunc(depth * 1000) -> uint16 -> / 1000 -> > 10 -> 0
+    exp_mm = (d_hip * 1000.0).to(torch.int32)
+    assert torch.equal(mm.to(torch.int32) & 0xFFFF, exp_mm)
+    exp_m = exp_mm.float() * (1.0 / 1000.0)
+    assert torch.equal(m, torch.where(exp_m > 10.0, torch.zeros_like(exp_m), exp_m))
