@@ -1,0 +1,133 @@
+"""Depth estimation driver: ``estimate_depth_dpt`` of /root/reference/hive/dataset_adaptors.py:1346-1435,
+and the on-device depth+fusion stream that keeps DPT -> TSDF inside HBM.
+"""
+import os
+
+import numpy as np
+import torch
+
+from hive_amd import _lib
+from hive_amd.dpt import transforms as dpt_transforms
+from hive_amd.dpt.models import DPTDepthModel
+
+NET_W, NET_H = 640, 480  # hard-coded in the reference (dataset_adaptors.py:1363-1364)
+DPT_SCALE, DPT_SHIFT = 0.000305, 0.1378  # NYU fine-tuned DPT-Hybrid (dataset_adaptors.py:1368-1369)
+
+
+def build_model(weights_path=None, device="cuda", dtype=torch.bfloat16, engine="hip"):
+    """DPT-Hybrid-NYU as the reference constructs it (dataset_adaptors.py:1366-1374, 1394-1401), in
+    channels-last 16-bit on the GPU.  ``weights_path=None`` gives a randomly initialised network."""
+    model = DPTDepthModel(path=weights_path, scale=DPT_SCALE, shift=DPT_SHIFT, invert=True, backbone="vitb_rn50_384",
+                          non_negative=True, enable_attention_hooks=False, engine=engine)
+    model.eval()
+    model = model.to(memory_format=torch.channels_last)
+    if dtype is not None:
+        model = model.to(dtype)
+    return model.to(device)
+
+
+def make_transform():
+    """Resize(640, 480, keep aspect, multiple of 32, "minimal", cubic) -> Normalize(.5, .5) -> PrepareForNet
+    (dataset_adaptors.py:1376-1392)."""
+    return dpt_transforms.Compose([
+        dpt_transforms.Resize(NET_W, NET_H, resize_target=None, keep_aspect_ratio=True, ensure_multiple_of=32,
+                              resize_method="minimal", image_interpolation_method=dpt_transforms.INTER_CUBIC),
+        dpt_transforms.NormalizeImage(mean=[0.5, 0.5, 0.5], std=[0.5, 0.5, 0.5]),
+        dpt_transforms.PrepareForNet(),
+    ])
+
+
+def preprocess_on_device(frames_u8, dtype=torch.bfloat16, ctx=None):
+    """uint8 [B, H, W, 3] on the GPU -> normalised channels-last network input [B, 3, H, W]:
+    ``((x / 255) - 0.5) / 0.5`` (dataset_adaptors.py:1407 + NormalizeImage), one fused HIP kernel."""
+    assert frames_u8.dtype == torch.uint8 and frames_u8.is_cuda and frames_u8.dim() == 4 and frames_u8.shape[-1] == 3
+    frames_u8 = frames_u8.contiguous()
+    b, h, w, _ = frames_u8.shape
+    ctx = ctx or _lib.default_context(frames_u8.device.index or 0)
+    out = torch.empty((b, 3, h, w), dtype=dtype, device=frames_u8.device).contiguous(memory_format=torch.channels_last)
+    ctx.check(ctx.lib.hive_dpt_preprocess(ctx.handle, frames_u8.data_ptr(), frames_u8.numel(), 0.5, 0.5,
+                                          _lib.BF16 if dtype == torch.bfloat16 else _lib.F16, out.data_ptr()))
+    return out
+
+
+def _write_png16(path, depth_mm_u16):
+    from PIL import Image
+    Image.fromarray(depth_mm_u16, mode="I;16").save(path)
+
+
+def estimate_depth_dpt(rgb_dataset, output_path: str, weights_filename='dpt_hybrid_nyu.pt', optimize=True, batch_size=8):
+    """Estimate a depth map for every frame of ``rgb_dataset`` and write it as ``%06d.png`` (16-bit,
+    millimetres) into ``output_path`` -- the side effect on disk is the contract
+    (dataset_adaptors.py:1346-1435).  Frames are batched on the GPU (the reference runs them one by
+    one); frames whose size is not the network's 640 x 480 go through the reference's resize rule and a
+    nearest-neighbour resize of the prediction back to the frame size (:1421-1426).
+    """
+    weights_dir = os.environ.get('WEIGHTS_PATH', 'weights')
+    model_path = os.path.join(weights_dir, weights_filename)
+    if not os.path.isfile(model_path):
+        model_path = os.path.join('weights', weights_filename)
+    if not os.path.isfile(model_path):
+        raise FileNotFoundError(f"DPT weights not found: {model_path} (set WEIGHTS_PATH)")
+    if not torch.cuda.is_available():
+        raise _lib.HiveError(_lib.ERR_DEVICE, "estimate_depth_dpt needs an MI355X; hive_amd has no CPU fallback")
+    dtype = torch.bfloat16 if optimize else None
+    model = build_model(model_path, dtype=dtype)
+    os.makedirs(output_path, exist_ok=True)
+    transform = make_transform()
+    n = len(rgb_dataset)
+    with torch.no_grad():
+        for start in range(0, n, batch_size):
+            images = [np.asarray(rgb_dataset[i]) for i in range(start, min(n, start + batch_size))]
+            same = all(im.shape == (NET_H, NET_W, 3) and im.dtype == np.uint8 for im in images)
+            if same and dtype is not None:
+                frames = torch.from_numpy(np.stack(images)).cuda()
+                sample = preprocess_on_device(frames, dtype)
+            else:
+                batch = np.stack([transform({"image": im / 255.0})["image"] for im in images])
+                sample = torch.from_numpy(batch).cuda().contiguous(memory_format=torch.channels_last)
+                if dtype is not None:
+                    sample = sample.to(dtype)
+            prediction = model(sample)
+            if prediction.shape[-2:] != images[0].shape[:2]:
+                prediction = torch.nn.functional.interpolate(prediction.unsqueeze(1), size=images[0].shape[:2], mode="nearest").squeeze(1)
+            depth_mm = (prediction * 1000.0).clamp(0, 65535).to(torch.int32).cpu().numpy().astype(np.uint16)
+            for j in range(len(images)):
+                _write_png16(os.path.join(output_path, f"{start + j:06d}.png"), depth_mm[j])
+
+
+class DepthFusionStream:
+    """The hot path as one device-resident stream: uint8 frames in HBM -> DPT-Hybrid depth -> uint16-mm
+    hand-off (same arithmetic as the PNG round trip, no file) -> TSDF integrate, batch by batch.
+
+    ``accumulate=True`` integrates into the 5 accumulator planes instead of the running-average volume, for
+    frame-sharded multi-GPU fusion (``hive_amd.distributed``).
+    """
+
+    def __init__(self, model, volume, cam_intr, max_depth=10.0, accumulate=False):
+        self.model = model
+        self.volume = volume
+        self.K = np.ascontiguousarray(cam_intr, dtype=np.float32)
+        self.max_depth = float(max_depth)
+        self.dtype = next(model.parameters()).dtype
+        self.accum = None
+        if accumulate:
+            self.accum = torch.empty(5 * volume.num_voxels, dtype=torch.float32, device="cuda")
+            volume.accum_reset(self.accum)
+
+    @torch.no_grad()
+    def depth(self, frames_u8):
+        """[B, H, W, 3] uint8 (GPU) -> (depth_m f32 [B, H, W] after the hand-off, depth_mm int16-viewed-as-uint16)."""
+        x = preprocess_on_device(frames_u8, self.dtype)
+        _, mm, m = self.model(x, handoff=(self.max_depth,))
+        return m, mm
+
+    @torch.no_grad()
+    def step(self, frames_u8, poses_c2w, obs_weight=1.0):
+        """One batch through the whole path; returns the depth maps that were integrated."""
+        depth_m, _ = self.depth(frames_u8)
+        if self.accum is None:
+            self.volume.integrate_batch(frames_u8, depth_m, self.K, poses_c2w, obs_weight=obs_weight)
+        else:
+            for i in range(frames_u8.shape[0]):
+                self.volume.accum_integrate(self.accum, frames_u8[i], depth_m[i], self.K, poses_c2w[i], obs_weight=obs_weight)
+        return depth_m
