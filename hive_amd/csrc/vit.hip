@@ -98,60 +98,74 @@ struct GemmParams {
     int n_split;         // EPI_QKV: columns >= n_split are V columns
 };
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
+constexpr int BN = 128, BK = 64;
 
 __device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
-template <int EPI>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // 2 stages x (A tile, W tile)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;  // wave -> 64 x 64 sub-tile
-    const int tiles_n = p.N / BN;
-    const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x % tiles_n;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const bool v_tile = (EPI == EPI_QKV) && n0 >= p.n_split;
+// Global -> LDS staging with LDS-DMA (global_load_lds_dwordx4): one wave instruction deposits 64 x 16 B =
+// 8 rows of 128 B, lane-linear.  The bank swizzle therefore lives on the SOURCE side: LDS slot (row, s)
+// receives global chunk s ^ ((row >> 1) & 7), and the fragment reads apply the same XOR (swz()).
+__device__ __forceinline__ void stage_group(const bf16 *__restrict__ src, int ld, int row0, int row_max, int k0,
+                                            unsigned char *tile, int grp, int lane) {
+    const int row = grp * 8 + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+    const int grow = min(row0 + row, row_max);  // clamp: rows past the end are never stored
+    const bf16 *g = src + (size_t)grow * ld + k0 + chunk * 8;
+    __builtin_amdgcn_global_load_lds((const void *)g, (__attribute__((address_space(3))) void *)(tile + grp * 1024), 16, 0, 0);
+}
 
-    // staging: 1024 16-byte chunks per operand tile, 4 per thread; chunk id -> (row, chunk-in-row)
-    int st_row[4], st_c[4];
-    const bf16 *a_src[4], *w_src[4];
-    for (int i = 0; i < 4; ++i) {
-        const int id = tid + 256 * i;
-        st_row[i] = id >> 3;
-        st_c[i] = id & 7;
-        const int am = min(m0 + st_row[i], p.M - 1);  // clamp: rows >= M are never stored
-        a_src[i] = p.A + (size_t)am * p.K + st_c[i] * 8;
-        w_src[i] = p.W + (size_t)(n0 + st_row[i]) * p.K + st_c[i] * 8;
-    }
-    uint4 a_reg[4], w_reg[4];
-    auto load_global = [&](int kt) {
-        for (int i = 0; i < 4; ++i) {
-            a_reg[i] = *reinterpret_cast<const uint4 *>(a_src[i] + kt * BK);
-            w_reg[i] = *reinterpret_cast<const uint4 *>(w_src[i] + kt * BK);
-        }
-    };
-    auto store_lds = [&](int stage) {
-        unsigned char *a_t = lds + stage * 2 * TILE_BYTES, *w_t = a_t + TILE_BYTES;
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<uint4 *>(a_t + swz(st_row[i], st_c[i])) = a_reg[i];
-            *reinterpret_cast<uint4 *>(w_t + swz(st_row[i], st_c[i])) = w_reg[i];
+// C tile = TM x 128, K-step 64, TM/32 waves (each a 64 x 64 sub-tile = 4 x 4 MFMA 16x16x32 accumulators).
+// 3-stage LDS ring: while stage kt is multiplied, stages kt+1 and kt+2 are in flight as LDS-DMA; per K-step
+// ONE raw s_barrier behind a counted s_waitcnt vmcnt (never 0 inside the loop), so the loads span barriers.
+// EPI_QKV here means "v^T tile": orientation A.W^T and the transposed store; q|k columns use EPI_BIAS.
+template <int EPI, int TM>
+__global__ __launch_bounds__(TM * 2, 1) void gemm_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // 3 stages x (A tile TM x 64, W tile 128 x 64)
+    constexpr int NWAVES = TM / 32;
+    constexpr int A_GROUPS = TM / 8, GROUPS = A_GROUPS + 16, PER_WAVE = GROUPS / NWAVES;
+    constexpr int STAGE_BYTES = GROUPS * 1024;
+    constexpr bool VT = (EPI == EPI_QKV);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so give each XCD a contiguous
+    // run of tiles (n fastest) -- neighbours then share their A panel in that XCD's L2 (bijective remap)
+    const int nwg = gridDim.x, xcd = blockIdx.x & 7, q = nwg >> 3, r = nwg & 7;
+    const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+    const int tiles_n = p.N / BN;
+    const int m0 = (tile / tiles_n) * TM, n0 = (tile % tiles_n) * BN;
+
+    auto issue_stage = [&](int kt) {
+        unsigned char *st = lds + (kt % 3) * STAGE_BYTES;
+#pragma unroll
+        for (int j = 0; j < PER_WAVE; ++j) {
+            const int g = wave + j * NWAVES;
+            if (g < A_GROUPS)
+                stage_group(p.A, p.K, m0, p.M - 1, kt * BK, st, g, lane);
+            else
+                stage_group(p.W, p.K, n0, p.N - 1, kt * BK, st + A_GROUPS * 1024, g - A_GROUPS, lane);
         }
     };
 
     f32x4 acc[4][4];
+#pragma unroll
     for (int i = 0; i < 4; ++i)
+#pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int KT = p.K / BK;
-    load_global(0);
-    store_lds(0);
-    __syncthreads();
+    issue_stage(0);
+    if (KT > 1) issue_stage(1);
     const int fr = lane & 15, fq = lane >> 4;
     for (int kt = 0; kt < KT; ++kt) {
-        const int stage = kt & 1;
-        if (kt + 1 < KT) load_global(kt + 1);
-        const unsigned char *a_t = lds + stage * 2 * TILE_BYTES, *w_t = a_t + TILE_BYTES;
+        // my stage-kt loads have landed once at most one younger stage (PER_WAVE instructions) is outstanding
+        if (kt + 1 < KT)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_WAVE) : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // everyone's stage kt landed; everyone finished reading stage kt-1
+        if (kt + 2 < KT) issue_stage(kt + 2);  // overwrites the buffer of stage kt-1
+        const unsigned char *a_t = lds + (kt % 3) * STAGE_BYTES, *w_t = a_t + A_GROUPS * 1024;
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             bf16x8 af[4], wf[4];
@@ -160,28 +174,20 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
                 af[t] = *reinterpret_cast<const bf16x8 *>(a_t + swz(wr * 64 + t * 16 + fr, sub * 4 + fq));
                 wf[t] = *reinterpret_cast<const bf16x8 *>(w_t + swz(wc * 64 + t * 16 + fr, sub * 4 + fq));
             }
-            if (!v_tile) {
-                // acc[nt][mt] = W_frag . A_frag^T : rows = n, cols = m
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt)
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int mt = 0; mt < 4; ++mt)
-                        acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], af[mt], acc[nt][mt], 0, 0, 0);
-            } else {
-                // acc[mt][nt] = A_frag . W_frag^T : rows = m, cols = n
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < 4; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mt], wf[nt], acc[mt][nt], 0, 0, 0);
-            }
+                for (int j = 0; j < 4; ++j) {
+                    if (VT)  // acc[mt][nt] = A_frag . W_frag^T : rows = m, cols = n
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], wf[j], acc[i][j], 0, 0, 0);
+                    else     // acc[nt][mt] = W_frag . A_frag^T : rows = n, cols = m
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+                }
         }
-        if (kt + 1 < KT) store_lds(stage ^ 1);
-        __syncthreads();
     }
 
     // epilogue
-    if (!v_tile) {
+    if (!VT) {
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             const int n = n0 + wc * 64 + nt * 16 + fq * 4;
@@ -189,35 +195,41 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
                 const int m = m0 + wr * 64 + mt * 16 + fr;
-                if (m >= p.M) continue;
-                float o[4] = {acc[nt][mt][0] + b.x, acc[nt][mt][1] + b.y, acc[nt][mt][2] + b.z, acc[nt][mt][3] + b.w};
-                if (EPI == EPI_BIAS_GELU)
-                    for (int j = 0; j < 4; ++j) o[j] = gelu_exact(o[j]);
-                bf16 *dst = p.C + (size_t)m * p.ldc + n;
-                if (EPI == EPI_BIAS_RESIDUAL) {
-                    const bf16x4 r = *reinterpret_cast<const bf16x4 *>(p.residual + (size_t)m * p.ldc + n);
-                    for (int j = 0; j < 4; ++j) o[j] += (float)r[j];
+                if (m < p.M) {
+                    float o[4] = {acc[nt][mt][0] + b.x, acc[nt][mt][1] + b.y, acc[nt][mt][2] + b.z, acc[nt][mt][3] + b.w};
+                    if (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) o[j] = gelu_exact(o[j]);
+                    }
+                    if (EPI == EPI_BIAS_RESIDUAL) {
+                        const bf16x4 rs = *reinterpret_cast<const bf16x4 *>(p.residual + (size_t)m * p.ldc + n);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) o[j] += (float)rs[j];
+                    }
+                    bf16x4 ov;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) ov[j] = (bf16)o[j];
+                    *reinterpret_cast<bf16x4 *>(p.C + (size_t)m * p.ldc + n) = ov;
                 }
-                bf16x4 ov;
-                for (int j = 0; j < 4; ++j) ov[j] = (bf16)o[j];
-                *reinterpret_cast<bf16x4 *>(dst) = ov;
             }
         }
     } else {
         // v^T[b][h][c][token]: a lane owns 4 consecutive tokens (rows m) of one channel (col n)
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
-            const int n = n0 + wc * 64 + nt * 16 + fr;
+            const int n = n0 + wc * 64 + nt * 16 + fr;  // column of the V block
             const float b = p.bias[n];
-            const int vc = n - p.n_split, head = vc >> 6, ch = vc & 63;
+            const int head = n >> 6, ch = n & 63;
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
                 const int m = m0 + wr * 64 + mt * 16 + fq * 4;  // multiple of 4; Np is a multiple of 64
-                if (m >= p.M) continue;
-                const int img = m / p.Np, tok = m % p.Np;
-                bf16x4 ov;
-                for (int j = 0; j < 4; ++j) ov[j] = (bf16)(acc[mt][nt][j] + b);
-                *reinterpret_cast<bf16x4 *>(p.vT + (((size_t)img * p.H + head) * 64 + ch) * p.Np + tok) = ov;
+                if (m < p.M) {
+                    const int img = m / p.Np, tok = m % p.Np;
+                    bf16x4 ov;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) ov[j] = (bf16)(acc[mt][nt][j] + b);
+                    *reinterpret_cast<bf16x4 *>(p.vT + (((size_t)img * p.H + head) * 64 + ch) * p.Np + tok) = ov;
+                }
             }
         }
     }
@@ -460,18 +472,26 @@ static int launch_layernorm(hive_ctx *ctx, const bf16 *x, const float *g, const 
     return HIVE_OK;
 }
 
-static int launch_gemm(hive_ctx *ctx, int epi, const GemmParams &p) {
-    const dim3 grid((unsigned)(((p.M + BM - 1) / BM) * (p.N / BN))), block(256);
-    const size_t lds_bytes = 4 * TILE_BYTES;
+template <int TM>
+static int launch_gemm_tm(hive_ctx *ctx, int epi, const GemmParams &p) {
+    const dim3 grid((unsigned)(((p.M + TM - 1) / TM) * (p.N / BN))), block(TM * 2);
+    const size_t lds_bytes = 3 * (TM / 8 + 16) * 1024;
     switch (epi) {
-        case EPI_BIAS: hipLaunchKernelGGL(gemm_kernel<EPI_BIAS>, grid, block, lds_bytes, ctx->stream, p); break;
-        case EPI_BIAS_GELU: hipLaunchKernelGGL(gemm_kernel<EPI_BIAS_GELU>, grid, block, lds_bytes, ctx->stream, p); break;
-        case EPI_BIAS_RESIDUAL: hipLaunchKernelGGL(gemm_kernel<EPI_BIAS_RESIDUAL>, grid, block, lds_bytes, ctx->stream, p); break;
-        case EPI_QKV: hipLaunchKernelGGL(gemm_kernel<EPI_QKV>, grid, block, lds_bytes, ctx->stream, p); break;
+        case EPI_BIAS: hipLaunchKernelGGL((gemm_kernel<EPI_BIAS, TM>), grid, block, lds_bytes, ctx->stream, p); break;
+        case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm_kernel<EPI_BIAS_GELU, TM>), grid, block, lds_bytes, ctx->stream, p); break;
+        case EPI_BIAS_RESIDUAL: hipLaunchKernelGGL((gemm_kernel<EPI_BIAS_RESIDUAL, TM>), grid, block, lds_bytes, ctx->stream, p); break;
+        case EPI_QKV: hipLaunchKernelGGL((gemm_kernel<EPI_QKV, TM>), grid, block, lds_bytes, ctx->stream, p); break;
         default: return hive_fail(ctx, HIVE_ERR_INVALID, "gemm: unknown epilogue %d", epi);
     }
     HIVE_CHECK_HIP(ctx, hipGetLastError());
     return HIVE_OK;
+}
+
+static int launch_gemm(hive_ctx *ctx, int epi, const GemmParams &p) {
+    // 256-row tiles halve the operand traffic per flop; use them once they still fill the chip
+    const long long tiles256 = (long long)((p.M + 255) / 256) * (p.N / BN);
+    if (tiles256 >= (long long)ctx->num_cus * 3 / 4) return launch_gemm_tm<256>(ctx, epi, p);
+    return launch_gemm_tm<128>(ctx, epi, p);
 }
 
 static int launch_attention(hive_ctx *ctx, const AttnParams &p) {
@@ -483,13 +503,21 @@ static int launch_attention(hive_ctx *ctx, const AttnParams &p) {
 
 static bool g_gemm_attr_set[64] = {false};
 
+template <int EPI, int TM>
+static hipError_t set_gemm_lds() {
+    return hipFuncSetAttribute((const void *)gemm_kernel<EPI, TM>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (TM / 8 + 16) * 1024);
+}
+
 static int ensure_gemm_attrs(hive_ctx *ctx) {
     if (ctx->device < 64 && g_gemm_attr_set[ctx->device]) return HIVE_OK;
-    const int bytes = 4 * TILE_BYTES;
-    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)gemm_kernel<EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)gemm_kernel<EPI_BIAS_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)gemm_kernel<EPI_BIAS_RESIDUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)gemm_kernel<EPI_QKV>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    HIVE_CHECK_HIP(ctx, (set_gemm_lds<EPI_BIAS, 128>()));
+    HIVE_CHECK_HIP(ctx, (set_gemm_lds<EPI_BIAS_GELU, 128>()));
+    HIVE_CHECK_HIP(ctx, (set_gemm_lds<EPI_BIAS_RESIDUAL, 128>()));
+    HIVE_CHECK_HIP(ctx, (set_gemm_lds<EPI_QKV, 128>()));
+    HIVE_CHECK_HIP(ctx, (set_gemm_lds<EPI_BIAS, 256>()));
+    HIVE_CHECK_HIP(ctx, (set_gemm_lds<EPI_BIAS_GELU, 256>()));
+    HIVE_CHECK_HIP(ctx, (set_gemm_lds<EPI_BIAS_RESIDUAL, 256>()));
+    HIVE_CHECK_HIP(ctx, (set_gemm_lds<EPI_QKV, 256>()));
     if (ctx->device < 64) g_gemm_attr_set[ctx->device] = true;
     return HIVE_OK;
 }
@@ -533,20 +561,30 @@ int hive_vit_qkv(hive_ctx *ctx, const void *x, const void *W, const float *bias,
     HIVE_REQUIRE(ctx, B > 0 && Np > 0 && Np % 64 == 0 && D == H * 64 && D % 128 == 0, "qkv: need Np %% 64 == 0, D == 64 H, D %% 128 == 0");
     int rc = ensure_gemm_attrs(ctx);
     if (rc) return rc;
+    // q | k columns: plain bias epilogue into qk [M][2D]
     GemmParams p{};
     p.A = (const bf16 *)x;
     p.W = (const bf16 *)W;
     p.bias = bias;
     p.C = (bf16 *)qk;
-    p.vT = (bf16 *)vT;
     p.M = B * Np;
-    p.N = 3 * D;
+    p.N = 2 * D;
     p.K = D;
     p.ldc = 2 * D;
-    p.Np = Np;
-    p.H = H;
-    p.n_split = 2 * D;
-    return launch_gemm(ctx, EPI_QKV, p);
+    if ((rc = launch_gemm(ctx, EPI_BIAS, p))) return rc;
+    // v columns: transposed store into vT [B][H][64][Np]
+    GemmParams pv{};
+    pv.A = (const bf16 *)x;
+    pv.W = (const bf16 *)W + (size_t)2 * D * D;
+    pv.bias = bias + 2 * D;
+    pv.vT = (bf16 *)vT;
+    pv.M = B * Np;
+    pv.N = D;
+    pv.K = D;
+    pv.ldc = D;
+    pv.Np = Np;
+    pv.H = H;
+    return launch_gemm(ctx, EPI_QKV, pv);
 }
 
 int hive_vit_attention(hive_ctx *ctx, const void *qk, const void *vT, void *out, int B, int N, int Np, int D, int H) {
