@@ -432,19 +432,27 @@ __global__ __launch_bounds__(256) void head_tail_kernel(const T *__restrict__ fe
     }
 }
 
-// uint8 RGB [n] -> network input, channels-last: ((x / 255) - mean) / std per element (dataset_adaptors.py:1407-1417)
+// uint8 RGB [n] -> network input, channels-last.  The reference evaluates ((x / 255.0) - mean) / std in float64
+// (numpy), casts to float32 (PrepareForNet) and then to the 16-bit network type (dataset_adaptors.py:1407-1417);
+// with only 256 possible inputs that is a table, built on the host in float64.
+struct PreprocessLut {
+    float v[256];
+};
+
 template <typename T>
-__global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t *__restrict__ rgb, long long n, float mean, float std,
+__global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t *__restrict__ rgb, long long n, PreprocessLut lut,
                                                          T *__restrict__ out) {
+    __shared__ float tab[256];
+    tab[threadIdx.x] = lut.v[threadIdx.x];
+    __syncthreads();
     const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i >= n) return;
     if (i + 4 <= n) {
         const uchar4 v = *reinterpret_cast<const uchar4 *>(rgb + i);
-        T o[4] = {(T)(((float)v.x / 255.0f - mean) / std), (T)(((float)v.y / 255.0f - mean) / std),
-                  (T)(((float)v.z / 255.0f - mean) / std), (T)(((float)v.w / 255.0f - mean) / std)};
+        T o[4] = {(T)tab[v.x], (T)tab[v.y], (T)tab[v.z], (T)tab[v.w]};
         *reinterpret_cast<uint2 *>(out + i) = *reinterpret_cast<const uint2 *>(o);
     } else {
-        for (long long j = i; j < n; ++j) out[j] = (T)(((float)rgb[j] / 255.0f - mean) / std);
+        for (long long j = i; j < n; ++j) out[j] = (T)tab[rgb[j]];
     }
 }
 
@@ -609,10 +617,12 @@ int hive_dpt_preprocess(hive_ctx *ctx, const uint8_t *d_rgb, int64_t n_values, f
     HIVE_REQUIRE(ctx, d_rgb && d_out && n_values > 0 && std != 0.f, "dpt_preprocess: bad arguments");
     HIVE_REQUIRE(ctx, ((uintptr_t)d_rgb % 4 == 0) && ((uintptr_t)d_out % 8 == 0), "dpt_preprocess: unaligned buffers");
     const dim3 grid((unsigned)((n_values / 4 + 256) / 256));
+    PreprocessLut lut;
+    for (int i = 0; i < 256; ++i) lut.v[i] = (float)(((double)i / 255.0 - (double)mean) / (double)std);
     if (dtype == HIVE_BF16)
-        hipLaunchKernelGGL(preprocess_kernel<bf16>, grid, dim3(256), 0, ctx->stream, d_rgb, (long long)n_values, mean, std, (bf16 *)d_out);
+        hipLaunchKernelGGL(preprocess_kernel<bf16>, grid, dim3(256), 0, ctx->stream, d_rgb, (long long)n_values, lut, (bf16 *)d_out);
     else if (dtype == HIVE_F16)
-        hipLaunchKernelGGL(preprocess_kernel<_Float16>, grid, dim3(256), 0, ctx->stream, d_rgb, (long long)n_values, mean, std, (_Float16 *)d_out);
+        hipLaunchKernelGGL(preprocess_kernel<_Float16>, grid, dim3(256), 0, ctx->stream, d_rgb, (long long)n_values, lut, (_Float16 *)d_out);
     else
         return hive_fail(ctx, HIVE_ERR_INVALID, "dpt_preprocess: dtype must be HIVE_F16 or HIVE_BF16");
     HIVE_CHECK_HIP(ctx, hipGetLastError());
