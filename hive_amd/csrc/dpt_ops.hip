@@ -1,0 +1,230 @@
+// Memory-bound glue of the DPT-Hybrid convolutional parts, fused for channels-last 16-bit tensors on gfx950:
+//   hive_nhwc_group_norm   GroupNorm(32) [+ residual add] [+ ReLU] of the ResNetV2 stem / bottlenecks
+//   hive_nhwc_upsample2x   bilinear x2, align_corners=True, of the RefineNet fusion blocks and the depth head
+// (timm 0.5.4 `GroupNormAct`, isl-org/DPT `FeatureFusionBlock_custom` / `Interpolate`, reached from
+// dpt.models.DPTDepthModel.forward -- /root/reference/hive/dataset_adaptors.py:1419).  The convolutions
+// themselves stay with MIOpen this round.
+//
+// Both are HBM-bound: every lane moves 16 bytes (8 channels) per access, channels fastest.
+//   group norm: 2 reads + 1 write of the tensor (statistics pass, apply pass) + 1 read of the residual;
+//   upsample  : 1 read (mostly L2 hits, each input pixel feeds 4 outputs) + 1 write of 4x the input.
+#include "hive_internal.hpp"
+
+#include <algorithm>
+
+typedef __bf16 bf16;
+
+template <typename T>
+struct Vec8 {
+    T v[8];
+};
+
+template <typename T>
+__device__ __forceinline__ void load8(const T *p, float (&f)[8]) {
+    const uint4 raw = *reinterpret_cast<const uint4 *>(p);
+    const T *t = reinterpret_cast<const T *>(&raw);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = (float)t[j];
+}
+
+template <typename T>
+__device__ __forceinline__ void store8(T *p, const float (&f)[8]) {
+    Vec8<T> o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o.v[j] = (T)f[j];
+    *reinterpret_cast<uint4 *>(p) = *reinterpret_cast<const uint4 *>(&o);
+}
+
+// ------------------------------------------------------------------------------------------------
+// GroupNorm statistics, stage 1: per (sample, slab of pixels, channel) sum and sum of squares.
+// grid (slabs, N); 256 threads = (256 / VC) pixels x VC channel vectors, VC = C / 8 (a power of two <= 256).
+template <typename T>
+__global__ __launch_bounds__(256) void gn_partial_kernel(const T *__restrict__ x, int HW, int C, int slabs, float *__restrict__ partial) {
+    __shared__ float red[256 * 16];
+    const int VC = C >> 3, PP = 256 / VC;
+    const int n = blockIdx.y, slab = blockIdx.x;
+    const int v = threadIdx.x % VC, pp = threadIdx.x / VC;
+    const int per = (HW + slabs - 1) / slabs;
+    const int p0 = slab * per, p1 = min(p0 + per, HW);
+    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const T *base = x + (size_t)n * HW * C + v * 8;
+    for (int p = p0 + pp; p < p1; p += PP) {
+        float f[8];
+        load8(base + (size_t)p * C, f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            s[j] += f[j];
+            q[j] += f[j] * f[j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        red[threadIdx.x * 16 + j] = s[j];
+        red[threadIdx.x * 16 + 8 + j] = q[j];
+    }
+    __syncthreads();
+    // thread t < 2 * C: t -> (which = sum / sumsq, channel c); add the PP pixel lanes in a fixed order
+    for (int t = threadIdx.x; t < 2 * C; t += 256) {
+        const int which = t / C, c = t % C, vv = c >> 3, j = c & 7;
+        float acc = 0.f;
+        for (int r = 0; r < PP; ++r) acc += red[(r * VC + vv) * 16 + which * 8 + j];
+        partial[(((size_t)n * slabs + slab) * 2 + which) * C + c] = acc;
+    }
+}
+
+// stage 2: per (sample, group) mean and rstd from the slab partials, summed in a fixed order (deterministic)
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const float *__restrict__ partial, int C, int G, int slabs, int HW, float eps,
+                                                         float *__restrict__ stats, int total) {
+    // one wave per (sample, group): lanes stride over the slabs x channels-of-the-group partials, then a
+    // fixed butterfly -- the summation order depends only on the shapes
+    const int i = blockIdx.x;  // i = n * G + g
+    if (i >= total) return;
+    const int n = i / G, g = i % G, cpg = C / G;
+    double s = 0.0, q = 0.0;
+    for (int e = threadIdx.x; e < slabs * cpg; e += 64) {
+        const int sl = e / cpg, c = e % cpg;
+        const float *ps = partial + (((size_t)n * slabs + sl) * 2) * C + g * cpg + c;
+        s += (double)ps[0];
+        q += (double)ps[C];
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        s += __shfl_xor(s, off);
+        q += __shfl_xor(q, off);
+    }
+    if (threadIdx.x == 0) {
+        const double cnt = (double)HW * cpg;
+        const double mean = s / cnt;
+        const double var = fmax(q / cnt - mean * mean, 0.0);
+        stats[2 * i] = (float)mean;
+        stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
+
+// stage 3: y = (x - mean) * rstd * gamma + beta  [+ residual]  [ReLU].  grid (blocks, N)
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T *__restrict__ x, const T *__restrict__ gamma, const T *__restrict__ beta,
+                                                       const float *__restrict__ stats, const T *__restrict__ residual, T *__restrict__ out,
+                                                       int HW, int C, int G, int relu) {
+    const int VC = C >> 3, PP = 256 / VC;
+    const int n = blockIdx.y;
+    const int v = threadIdx.x % VC, pp = threadIdx.x / VC;
+    const int cpg = C / G;
+    float a[8], b[8];
+    {
+        float gm[8], bt[8];
+        load8(gamma + v * 8, gm);
+        load8(beta + v * 8, bt);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int g = (v * 8 + j) / cpg;
+            const float mean = stats[2 * (n * G + g)], rstd = stats[2 * (n * G + g) + 1];
+            a[j] = rstd * gm[j];
+            b[j] = bt[j] - mean * a[j];
+        }
+    }
+    const size_t off = (size_t)n * HW * C + v * 8;
+    for (int p = blockIdx.x * PP + pp; p < HW; p += gridDim.x * PP) {
+        float f[8];
+        load8(x + off + (size_t)p * C, f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = f[j] * a[j] + b[j];
+        if (residual) {
+            // the reference rounds the normalised value to the tensor type before the add (separate ops)
+            float r[8];
+            load8(residual + off + (size_t)p * C, r);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = (float)(T)f[j] + r[j];
+        }
+        if (relu) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = fmaxf(f[j], 0.f);
+        }
+        store8(out + off + (size_t)p * C, f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// bilinear x2 upsampling, align_corners=True (PyTorch's formula, evaluated in float):
+//   src = dst * (in - 1) / (out - 1);  i0 = floor(src), i1 = min(i0 + 1, in - 1), l1 = src - i0, l0 = 1 - l1
+//   y = h0 * (w0 * v00 + w1 * v01) + h1 * (w0 * v10 + w1 * v11)
+template <typename T>
+__global__ __launch_bounds__(256) void upsample2x_kernel(const T *__restrict__ in, T *__restrict__ out, int N, int H, int W, int C) {
+    const int VC = C >> 3;
+    const int OH = 2 * H, OW = 2 * W;
+    const size_t total = (size_t)N * OH * OW * VC;
+    const float sh = OH > 1 ? (float)(H - 1) / (float)(OH - 1) : 0.f;
+    const float sw = OW > 1 ? (float)(W - 1) / (float)(OW - 1) : 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int v = (int)(i % VC);
+        size_t r = i / VC;
+        const int ox = (int)(r % OW);
+        r /= OW;
+        const int oy = (int)(r % OH);
+        const int n = (int)(r / OH);
+        const float fy = sh * (float)oy, fx = sw * (float)ox;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+        const float h1 = fy - (float)y0, h0 = 1.f - h1, w1 = fx - (float)x0, w0 = 1.f - w1;
+        const T *b = in + (size_t)n * H * W * C + v * 8;
+        float v00[8], v01[8], v10[8], v11[8], o[8];
+        load8(b + ((size_t)y0 * W + x0) * C, v00);
+        load8(b + ((size_t)y0 * W + x1) * C, v01);
+        load8(b + ((size_t)y1 * W + x0) * C, v10);
+        load8(b + ((size_t)y1 * W + x1) * C, v11);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = h0 * (w0 * v00[j] + w1 * v01[j]) + h1 * (w0 * v10[j] + w1 * v11[j]);
+        store8(out + i * 8, o);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+static bool pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
+
+extern "C" {
+
+int hive_nhwc_group_norm(hive_ctx *ctx, const void *d_x, int dtype, int N, int HW, int C, int G, const void *d_gamma,
+                         const void *d_beta, float eps, const void *d_residual, int relu, void *d_out) {
+    if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
+    HIVE_REQUIRE(ctx, d_x && d_gamma && d_beta && d_out, "group_norm: NULL argument");
+    HIVE_REQUIRE(ctx, N > 0 && HW > 0 && C >= 8 && C <= 2048 && pow2(C) && G > 0 && C % G == 0,
+                 "group_norm: need C a power of two in [8, 2048] and C %% G == 0 (N=%d HW=%d C=%d G=%d)", N, HW, C, G);
+    HIVE_REQUIRE(ctx, dtype == HIVE_BF16 || dtype == HIVE_F16, "group_norm: dtype must be HIVE_F16 or HIVE_BF16");
+    const int VC = C / 8, PP = 256 / VC;
+    const int slabs = std::max(1, std::min(64, std::min(HW / (4 * PP) + 1, (ctx->num_cus * 8 + N - 1) / N)));
+    const size_t partial_floats = (size_t)N * slabs * 2 * C, stats_floats = (size_t)N * G * 2;
+    int rc = hive_reserve_device(ctx, &ctx->d_scratch, &ctx->scratch_bytes, (partial_floats + stats_floats) * sizeof(float));
+    if (rc) return rc;
+    float *partial = (float *)ctx->d_scratch, *stats = partial + partial_floats;
+    const dim3 g1(slabs, N), g3(std::max(1, std::min((HW + PP - 1) / PP, (ctx->num_cus * 8 + N - 1) / N)), N);
+    if (dtype == HIVE_BF16) {
+        hipLaunchKernelGGL(gn_partial_kernel<bf16>, g1, dim3(256), 0, ctx->stream, (const bf16 *)d_x, HW, C, slabs, partial);
+        hipLaunchKernelGGL(gn_finalize_kernel, dim3(N * G), dim3(64), 0, ctx->stream, partial, C, G, slabs, HW, eps, stats, N * G);
+        hipLaunchKernelGGL(gn_apply_kernel<bf16>, g3, dim3(256), 0, ctx->stream, (const bf16 *)d_x, (const bf16 *)d_gamma, (const bf16 *)d_beta,
+                           stats, (const bf16 *)d_residual, (bf16 *)d_out, HW, C, G, relu);
+    } else {
+        hipLaunchKernelGGL(gn_partial_kernel<_Float16>, g1, dim3(256), 0, ctx->stream, (const _Float16 *)d_x, HW, C, slabs, partial);
+        hipLaunchKernelGGL(gn_finalize_kernel, dim3(N * G), dim3(64), 0, ctx->stream, partial, C, G, slabs, HW, eps, stats, N * G);
+        hipLaunchKernelGGL(gn_apply_kernel<_Float16>, g3, dim3(256), 0, ctx->stream, (const _Float16 *)d_x, (const _Float16 *)d_gamma,
+                           (const _Float16 *)d_beta, stats, (const _Float16 *)d_residual, (_Float16 *)d_out, HW, C, G, relu);
+    }
+    HIVE_CHECK_HIP(ctx, hipGetLastError());
+    return HIVE_OK;
+}
+
+int hive_nhwc_upsample2x(hive_ctx *ctx, const void *d_in, int dtype, int N, int H, int W, int C, void *d_out) {
+    if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
+    HIVE_REQUIRE(ctx, d_in && d_out, "upsample2x: NULL argument");
+    HIVE_REQUIRE(ctx, N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "upsample2x: need C %% 8 == 0 (N=%d H=%d W=%d C=%d)", N, H, W, C);
+    const size_t total = (size_t)N * 4 * H * W * (C / 8);
+    const dim3 grid((unsigned)std::min<size_t>((total + 255) / 256, (size_t)ctx->num_cus * 32));
+    if (dtype == HIVE_BF16)
+        hipLaunchKernelGGL(upsample2x_kernel<bf16>, grid, dim3(256), 0, ctx->stream, (const bf16 *)d_in, (bf16 *)d_out, N, H, W, C);
+    else if (dtype == HIVE_F16)
+        hipLaunchKernelGGL(upsample2x_kernel<_Float16>, grid, dim3(256), 0, ctx->stream, (const _Float16 *)d_in, (_Float16 *)d_out, N, H, W, C);
+    else
+        return hive_fail(ctx, HIVE_ERR_INVALID, "upsample2x: dtype must be HIVE_F16 or HIVE_BF16");
+    HIVE_CHECK_HIP(ctx, hipGetLastError());
+    return HIVE_OK;
+}
+
+}  // extern "C"

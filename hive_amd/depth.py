@@ -44,7 +44,7 @@ def preprocess_on_device(frames_u8, dtype=torch.bfloat16, ctx=None):
     frames_u8 = frames_u8.contiguous()
     b, h, w, _ = frames_u8.shape
     ctx = ctx or _lib.default_context(frames_u8.device.index or 0)
-    out = torch.empty((b, 3, h, w), dtype=dtype, device=frames_u8.device).contiguous(memory_format=torch.channels_last)
+    out = torch.empty((b, 3, h, w), dtype=dtype, device=frames_u8.device, memory_format=torch.channels_last)
     ctx.check(ctx.lib.hive_dpt_preprocess(ctx.handle, frames_u8.data_ptr(), frames_u8.numel(), 0.5, 0.5,
                                           _lib.BF16 if dtype == torch.bfloat16 else _lib.F16, out.data_ptr()))
     return out

@@ -1,0 +1,47 @@
+"""Fused channels-last glue ops of DPT-Hybrid's convolutional parts (``csrc/dpt_ops.hip``): GroupNorm
+[+ residual] [+ ReLU] and bilinear x2 upsampling.  ``engine="hip"`` uses the HIP kernels for 16-bit
+channels-last CUDA tensors; ``engine="torch"`` is the plain PyTorch formulation the numerics tests
+compare against (and what fp32 / CPU reference runs use)."""
+import torch
+import torch.nn.functional as F
+
+from hive_amd import _lib
+
+
+def _hip_eligible(x):
+    return (x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and x.dim() == 4 and x.shape[1] % 8 == 0
+            and x.is_contiguous(memory_format=torch.channels_last))
+
+
+def _code(dtype):
+    return _lib.BF16 if dtype == torch.bfloat16 else _lib.F16
+
+
+def group_norm_act(x, num_groups, weight, bias, eps, relu=True, residual=None, engine="torch"):
+    """relu?(group_norm(x) (+ residual)).  x: [N, C, H, W]."""
+    c = x.shape[1]
+    if engine == "hip" and _hip_eligible(x) and (c & (c - 1)) == 0 and c <= 2048 and weight.dtype == x.dtype:
+        if residual is not None:
+            assert residual.shape == x.shape and residual.dtype == x.dtype
+            residual = residual.contiguous(memory_format=torch.channels_last)
+        n, _, h, w = x.shape
+        out = torch.empty_like(x)  # preserves channels_last
+        ctx = _lib.default_context(x.device.index or 0)
+        ctx.check(ctx.lib.hive_nhwc_group_norm(ctx.handle, x.data_ptr(), _code(x.dtype), n, h * w, c, num_groups, weight.data_ptr(),
+                                               bias.data_ptr(), float(eps), _lib.ptr(residual), int(bool(relu)), out.data_ptr()))
+        return out
+    y = F.group_norm(x, num_groups, weight, bias, eps)
+    if residual is not None:
+        y = y + residual
+    return F.relu(y) if relu else y
+
+
+def upsample2x(x, engine="torch"):
+    """interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)."""
+    if engine == "hip" and _hip_eligible(x):
+        n, c, h, w = x.shape
+        out = torch.empty((n, c, 2 * h, 2 * w), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        ctx = _lib.default_context(x.device.index or 0)
+        ctx.check(ctx.lib.hive_nhwc_upsample2x(ctx.handle, x.data_ptr(), _code(x.dtype), n, h, w, c, out.data_ptr()))
+        return out
+    return F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)

@@ -218,6 +218,17 @@ int hive_dpt_head_tail(hive_ctx *ctx, const void *d_feat, int dtype, int64_t n_p
                        float shift, float *d_depth, float depth_scale, float max_depth,
                        uint16_t *d_out_mm, float *d_out_m);
 
+/* ---- fused channels-last glue of the DPT convolutional parts (device pointers, f16 / bf16) ----------- */
+/* GroupNorm over [N][HW][C] (C a power of two, 8..2048) with G groups, affine gamma / beta [C] in the tensor
+ * dtype, optional residual add (same shape) and ReLU:  out = relu?( gn(x) (+ residual) ).  timm GroupNormAct +
+ * the bottleneck's `relu(norm3(x) + shortcut)`, reached from DPTDepthModel.forward (dataset_adaptors.py:1419). */
+int hive_nhwc_group_norm(hive_ctx *ctx, const void *d_x, int dtype, int N, int HW, int C, int G,
+                         const void *d_gamma, const void *d_beta, float eps, const void *d_residual,
+                         int relu, void *d_out);
+/* bilinear x2, align_corners=True: [N][H][W][C] -> [N][2H][2W][C] (C % 8 == 0): the RefineNet fusion blocks'
+ * and the depth head's `interpolate(scale_factor=2, mode="bilinear", align_corners=True)` */
+int hive_nhwc_upsample2x(hive_ctx *ctx, const void *d_in, int dtype, int N, int H, int W, int C, void *d_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -76,6 +76,39 @@ def test_integrate_random_poses_weights_and_ragged_images(gpu_ctx, oracle_lib, s
     _volumes_equal(vol, ora)
 
 
+def test_full_size_512_vga(gpu_ctx, oracle_lib):
+    """BASELINE.json's full size (640 x 480 into 512^3): one frame bit-exact against the C oracle, then
+    size-independent properties -- integrating the same observation again leaves tsdf and colour unchanged
+    and doubles the weights (running average of equal values), N_upd is the number of weighted voxels,
+    and a checksum of the volume is reproducible across an independent second volume."""
+    from hive_amd import fusion, synthetic
+    seq = synthetic.make_sequence(num_frames=2, yaw_step_deg=40.0)
+    vol = fusion.TSDFVolume(synthetic.room_bounds(), 0.01, ctx=gpu_ctx)
+    assert tuple(vol.vol_dim) == (512, 512, 512)
+    n1 = vol.integrate(seq["color"][0], seq["depth"][0], seq["K"], seq["poses"][0], return_n_updated=True)
+    tsdf, color, weight = vol.get_volume(with_weight=True)
+    ora = oracle_lib.TSDFVolume(synthetic.room_bounds(), 0.01)
+    ora.integrate(seq["color"][0], seq["depth"][0], seq["K"], seq["poses"][0])
+    assert n1 == ora.last_n_updated == int(np.count_nonzero(weight))
+    assert np.array_equal(weight, ora._weight) and np.array_equal(tsdf, ora._tsdf) and np.array_equal(color, ora._color)
+    del ora
+    n2 = vol.integrate(seq["color"][0], seq["depth"][0], seq["K"], seq["poses"][0], return_n_updated=True)
+    tsdf2, color2, weight2 = vol.get_volume(with_weight=True)
+    assert n2 == n1
+    assert np.array_equal(tsdf2, tsdf) and np.array_equal(color2, color) and np.array_equal(weight2, 2 * weight)
+    # second frame into two independent volumes (one via the batch entry point): identical bits
+    vol.integrate(seq["color"][1], seq["depth"][1], seq["K"], seq["poses"][1])
+    other = fusion.TSDFVolume(synthetic.room_bounds(), 0.01, ctx=gpu_ctx)
+    idx = [0, 0, 1]
+    other.integrate_batch(seq["color"][idx], seq["depth"][idx], seq["K"], seq["poses"][idx])
+    a, b = vol.get_volume(with_weight=True), other.get_volume(with_weight=True)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    verts, faces, norms, colors = vol.get_mesh()
+    assert len(verts) > 10000 and faces.max() == len(verts) - 1 and faces.min() == 0
+    assert np.isfinite(verts).all() and np.abs(np.linalg.norm(norms, axis=1) - 1).max() < 1e-4
+
+
 def test_integrate_batch_and_device_inputs(gpu_ctx, oracle_lib, small_sequence):
     import torch
     from hive_amd import fusion, synthetic

@@ -114,6 +114,45 @@ def test_qkv_and_attention(gpu_ctx, B, N):
     _close(out.reshape(B, Np, D)[:, :N], ref, "attention")
 
 
+@pytest.mark.parametrize("N,C,H,W,relu,res", [(2, 64, 24, 32, True, False), (1, 256, 30, 40, False, True), (3, 1024, 6, 8, True, False),
+                                               (2, 512, 15, 20, False, False), (1, 128, 33, 17, True, True)])
+def test_group_norm_fused_matches_torch(gpu_ctx, N, C, H, W, relu, res):
+    """GroupNorm(32) [+ residual] [+ ReLU] on channels-last bf16 vs F.group_norm in fp32 on the same values."""
+    import torch
+    from hive_amd.dpt import ops
+    torch.manual_seed(5)
+    cl = torch.channels_last
+    x = (torch.randn(N, C, H, W, device="cuda") * 2 + 0.3).bfloat16().contiguous(memory_format=cl)
+    g = (torch.randn(C, device="cuda") * 0.5 + 1).bfloat16()
+    b = (torch.randn(C, device="cuda") * 0.2).bfloat16()
+    r = torch.randn(N, C, H, W, device="cuda").bfloat16().contiguous(memory_format=cl) if res else None
+    out = ops.group_norm_act(x, 32, g, b, 1e-5, relu=relu, residual=r, engine="hip")
+    assert out.is_contiguous(memory_format=cl) and out.dtype == torch.bfloat16
+    ref = torch.nn.functional.group_norm(x.float(), 32, g.float(), b.float(), 1e-5)
+    if res:
+        ref = ref.bfloat16().float() + r.float()
+    if relu:
+        ref = torch.relu(ref)
+    _close(out, ref, "group_norm")
+    # and bit-for-bit deterministic
+    assert torch.equal(out, ops.group_norm_act(x, 32, g, b, 1e-5, relu=relu, residual=r, engine="hip"))
+
+
+@pytest.mark.parametrize("N,C,H,W", [(2, 256, 15, 20), (1, 128, 24, 32), (1, 8, 1, 1), (2, 32, 7, 5)])
+def test_upsample2x_matches_torch(gpu_ctx, N, C, H, W):
+    import torch
+    from hive_amd.dpt import ops
+    torch.manual_seed(6)
+    x = torch.randn(N, C, H, W, device="cuda").bfloat16().contiguous(memory_format=torch.channels_last)
+    out = ops.upsample2x(x, engine="hip")
+    ref = torch.nn.functional.interpolate(x.float(), scale_factor=2, mode="bilinear", align_corners=True)
+    assert out.shape == ref.shape and out.is_contiguous(memory_format=torch.channels_last)
+    # same formula evaluated in float: only the final bf16 rounding differs from the fp32 reference
+    assert (out.float() - ref).abs().max().item() <= 2 ** -8 * ref.abs().max().item() + 1e-6
+    ref16 = torch.nn.functional.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)
+    assert (out.float() - ref16.float()).abs().max().item() <= 2 ** -7 * ref.abs().max().item() + 1e-6
+
+
 def test_vit_forward_matches_fp32_blocks(gpu_ctx):
     """All 12 blocks through hive_vit_forward vs the fp32 torch blocks with the same (bf16-rounded) weights."""
     import torch
