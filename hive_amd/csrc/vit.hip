@@ -100,7 +100,16 @@ struct GemmParams {
 
 constexpr int BN = 128, BK = 64;
 
-__device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// erf-GELU (nn.GELU default): 0.5 x (1 + erf(x / sqrt 2)).  erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7,
+// three orders of magnitude below the bf16 output step) on the hardware rcp / exp2: ~14 instructions
+// instead of libm erff's ~45 -- the GELU epilogue was 28 us of the 100 us fc1 GEMM.
+__device__ __forceinline__ float gelu_exact(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+    const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
+    const float erf_abs = 1.0f - poly * __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);
+    return 0.5f * x * (1.0f + copysignf(erf_abs, x));
+}
 
 // Global -> LDS staging with LDS-DMA (global_load_lds_dwordx4): one wave instruction deposits 64 x 16 B =
 // 8 rows of 128 B, lane-linear.  The bank swizzle therefore lives on the SOURCE side: LDS slot (row, s)
@@ -245,6 +254,7 @@ struct AttnParams {
 };
 
 constexpr int ATT_KV = 64;  // keys per tile
+constexpr float ATT_DEFER = 8.0f / (0.125f * 1.44269504088896340736f);  // raw-score margin = 8 in the log2 domain
 
 __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * ATT_KV * 128];  // 2 stages x (K tile, V^T tile)
@@ -310,38 +320,46 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
                 const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(k_t + swz(kb * 32 + lq, ks * 2 + hh));
                 sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[kb], 0, 0, 0);
             }
-        // online softmax (base 2); key row of register i: 32 kb + (i & 3) + 8 (i >> 2) + 4 hh
-        float m_tile = -INFINITY;
-        const int key0 = t * ATT_KV + 4 * hh;
+        // online softmax in base 2 on the raw scores: p = exp2(c * (s - m)), c = log2(e) / 8.
+        // key row of register i: 32 kb + (i & 3) + 8 (i >> 2) + 4 hh.  Keys >= N exist only in the last tile.
+        if (t == n_tiles - 1) {
+            const int key0 = t * ATT_KV + 4 * hh;
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if (key0 + kb * 32 + (i & 3) + 8 * (i >> 2) >= p.N) sacc[kb][i] = -INFINITY;
+        }
+        float m_tile = fmaxf(sacc[0][0], sacc[1][0]);
+#pragma unroll
+        for (int i = 1; i < 16; ++i) m_tile = fmaxf(m_tile, fmaxf(sacc[0][i], sacc[1][i]));
+        m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32));
+        // deferred maximum: the running maximum m_run only moves when some query of the wave exceeds it by
+        // more than ATT_DEFER (probabilities then stay below 2^(c * ATT_DEFER) = 2^8 -- harmless in f32 / bf16),
+        // so the rescale of the O accumulators is skipped for almost every tile.  Any m gives the same softmax.
+        if (__any(m_tile > m_run + ATT_DEFER)) {
+            const float m_new = fmaxf(m_run, m_tile);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.scale_log2e);  // 0 for the first tile
+            m_run = m_new;
+            l_run *= alpha;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const int key = key0 + kb * 32 + (i & 3) + 8 * (i >> 2);
-                const float s = key < p.N ? sacc[kb][i] * p.scale_log2e : -INFINITY;
-                sacc[kb][i] = s;
-                m_tile = fmaxf(m_tile, s);
+                oacc[0][i] *= alpha;
+                oacc[1][i] *= alpha;
             }
-        m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32));
-        const float m_new = fmaxf(m_run, m_tile);  // finite: every tile holds at least one valid key for t = 0
-        const float alpha = exp2f(m_run - m_new);
-        m_run = m_new;
+        }
+        const float mc = m_run * p.scale_log2e;
         float l_tile = 0.f;
         bf16x8 pf[2][2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const float e = exp2f(sacc[kb][i] - m_new);
+                const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[kb][i], p.scale_log2e, -mc));
                 l_tile += e;
                 pf[kb][i >> 3][i & 7] = (bf16)e;
             }
-        l_run = l_run * alpha + l_tile;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            oacc[0][i] *= alpha;
-            oacc[1][i] *= alpha;
-        }
+        l_run += l_tile;
         // O^T[ch][q] += V^T[ch][key] P^T[key][q]; k index j of half hh <-> key 32 kb + 16 s + 8 (j >> 2) + 4 hh + (j & 3)
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
