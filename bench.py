@@ -75,8 +75,9 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback); the CPU baseline is only the comparison leg")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    dev_index = local_rank % torch.cuda.device_count()  # one GPU per rank on a node; wraps only in 1-GPU rehearsals
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     torch.backends.cudnn.benchmark = True
 
     H, W = 480, 640
@@ -89,7 +90,7 @@ def main():
     frames_dev = torch.from_numpy(seq["color"]).to(device)  # uint8 [T, H, W, 3] resident in HBM
     poses = seq["poses"]
 
-    ctx = _lib.default_context(local_rank)
+    ctx = _lib.default_context(dev_index)
     model = depth_mod.build_model(None, device=device, dtype=torch.bfloat16, engine=args.engine)
     volume = fusion.TSDFVolume(synthetic.room_bounds(), args.voxel, ctx=ctx)
     stream = depth_mod.DepthFusionStream(model, volume, K, accumulate=(world > 1))

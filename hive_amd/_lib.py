@@ -12,7 +12,7 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libhive_mi355x.so")
+LIB_PATH = os.environ.get("HIVE_AMD_LIB") or os.path.join(_HERE, "lib", "libhive_mi355x.so")  # override: kernel experiments
 
 OK, ERR_INVALID, ERR_DEVICE, ERR_NOMEM, ERR_EMPTY, ERR_STATE = 0, -1, -2, -3, -4, -5
 MEM_HOST, MEM_DEVICE = 0, 1

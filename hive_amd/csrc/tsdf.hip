@@ -18,6 +18,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <type_traits>
 
 struct FrameParams {
     float R[9];  // cam_pose[r][c] for r,c < 3, row-major (camera-to-world rotation)
@@ -175,73 +176,172 @@ __global__ __launch_bounds__(1024) void build_worklist_kernel(FrameParams p, Wor
 }
 
 // ---------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------
+// Per-voxel arithmetic, written once for V = float and V = f2 (two consecutive z voxels in one 64-bit
+// register pair).  On gfx950 a wave64 f32 VALU instruction occupies its SIMD for 4 cycles and the packed
+// forms (v_pk_mul/add/fma_f32) produce two results in the same 4 -- the kernel was VALU-issue bound (PMC:
+// 4.08 SIMD cycles per VALU instruction, 53 % of the kernel), so every mul/add/fma below is 2-wide.
+// Element-wise, the operation order is exactly the contract's: packed instructions are IEEE per element.
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float v_splat(float x, float) { return x; }
+__device__ __forceinline__ f2 v_splat(float x, f2) { return f2{x, x}; }
+__device__ __forceinline__ float v_rcp(float d) { return __builtin_amdgcn_rcpf(d); }
+__device__ __forceinline__ f2 v_rcp(f2 d) { return f2{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)}; }
+__device__ __forceinline__ float v_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ f2 v_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ float v_min(float a, float b) { return fminf(a, b); }
+__device__ __forceinline__ f2 v_min(f2 a, f2 b) { return f2{fminf(a.x, b.x), fminf(a.y, b.y)}; }
+template <int RM>
+__device__ __forceinline__ float v_round(float x) { return hive_round<RM>(x); }
+template <int RM>
+__device__ __forceinline__ f2 v_round(f2 x) { return f2{hive_round<RM>(x.x), hive_round<RM>(x.y)}; }
+__device__ __forceinline__ float v_get(float v, int) { return v; }
+__device__ __forceinline__ float v_get(f2 v, int i) { return i ? v.y : v.x; }
+__device__ __forceinline__ void v_set(float &v, int, float x) { v = x; }
+__device__ __forceinline__ void v_set(f2 &v, int i, float x) {
+    if (i) v.y = x; else v.x = x;
+}
+
 // IEEE-exact float division with a shared, refined reciprocal of the denominator.  This is the
 // sequence hipcc itself emits for a correctly rounded a/d (rcp, one Newton step on the reciprocal,
 // two on the quotient) minus the range scaling / special-case fix-up, which cannot trigger for the
 // operands used here (|d| and |a/d| within 2^+-60); sharing y between quotients of one denominator
 // removes a third of the instructions of the update.  Checked bit-for-bit against the CPU oracle.
-__device__ __forceinline__ float refined_rcp(float d) {
-    const float r0 = __builtin_amdgcn_rcpf(d);
-    const float e = __builtin_fmaf(-d, r0, 1.0f);
-    return __builtin_fmaf(e, r0, r0);
+template <typename V>
+__device__ __forceinline__ V refined_rcp(V d) {
+    const V r0 = v_rcp(d);
+    const V e = v_fma(-d, r0, v_splat(1.0f, d));
+    return v_fma(e, r0, r0);
 }
 
-__device__ __forceinline__ float div_exact(float a, float d, float y) {
-    const float q0 = a * y;
-    const float e0 = __builtin_fmaf(-d, q0, a);
-    const float q1 = __builtin_fmaf(e0, y, q0);
-    const float e1 = __builtin_fmaf(-d, q1, a);
-    return __builtin_fmaf(e1, y, q1);
+template <typename V>
+__device__ __forceinline__ V div_exact(V a, V d, V y) {
+    const V q0 = a * y;
+    const V e0 = v_fma(-d, q0, a);
+    const V q1 = v_fma(e0, y, q0);
+    const V e1 = v_fma(-d, q1, a);
+    return v_fma(e1, y, q1);
 }
 
-// per-voxel inclusion tests + sample fetch; returns false when the voxel is not updated
-template <int RM>
-__device__ __forceinline__ bool sample_voxel(const FrameParams &p, float ax, float ay, float az, int z, float trunc_rcp,
-                                             float &dist, unsigned &rgb) {
-    const float pt_z = p.oz + (float)z * p.vs;
-    const float tz = pt_z - p.T[2];
-    const float cam_x = ax + p.R[6] * tz;
-    const float cam_y = ay + p.R[7] * tz;
-    const float cam_z = az + p.R[8] * tz;
-    bool ok = cam_z > 0.0f;
-    float qx, qy;
-    if (__builtin_expect(ok && cam_z < 1.0e-18f, 0)) {  // outside div_exact's domain (never in practice): full division
-        qx = cam_x / cam_z;
-        qy = cam_y / cam_z;
+// Geometry half of the per-voxel work (no memory access) for NV consecutive z voxels starting at z:
+// camera depth and the pixel each voxel centre rounds to, or -1 (behind the camera / outside the image).
+template <int RM, typename V, int NV>
+__device__ __forceinline__ void voxel_pixels(const FrameParams &p, float ax, float ay, float az, int z, V &cam_z, int (&pix)[NV]) {
+    V zf;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v_set(zf, i, (float)(z + i));
+    const V pt_z = v_splat(p.oz, zf) + zf * v_splat(p.vs, zf);
+    const V tz = pt_z - v_splat(p.T[2], zf);
+    const V cam_x = v_splat(ax, zf) + v_splat(p.R[6], zf) * tz;
+    const V cam_y = v_splat(ay, zf) + v_splat(p.R[7], zf) * tz;
+    cam_z = v_splat(az, zf) + v_splat(p.R[8], zf) * tz;
+    bool tiny = false;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) tiny = tiny || (v_get(cam_z, i) > 0.0f && v_get(cam_z, i) < 1.0e-18f);
+    V qx, qy;
+    if (__builtin_expect(__any(tiny), 0)) {  // outside div_exact's domain (never in practice): full divisions, wave-uniform branch
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            v_set(qx, i, v_get(cam_x, i) / v_get(cam_z, i));
+            v_set(qy, i, v_get(cam_y, i) / v_get(cam_z, i));
+        }
     } else {
-        const float zr = refined_rcp(cam_z);
+        const V zr = refined_rcp(cam_z);
         qx = div_exact(cam_x, cam_z, zr);
         qy = div_exact(cam_y, cam_z, zr);
     }
-    const float px = hive_round<RM>(p.fx * qx + p.cx);
-    const float py = hive_round<RM>(p.fy * qy + p.cy);
-    ok = ok && (px >= 0.0f) && (px < (float)p.W) && (py >= 0.0f) && (py < (float)p.H);
-    const int pix = ok ? ((int)py * p.W + (int)px) : 0;
-    const uint2 s = p.frame[pix];
-    const float depth = __uint_as_float(s.x);
-    const float diff = depth - cam_z;
-    ok = ok && (depth != 0.0f) && !(diff < -p.trunc);
-    dist = fminf(1.0f, div_exact(diff, p.trunc, trunc_rcp));
-    rgb = s.y;
-    return ok;
+    const V px = v_round<RM>(v_splat(p.fx, zf) * qx + v_splat(p.cx, zf));
+    const V py = v_round<RM>(v_splat(p.fy, zf) * qy + v_splat(p.cy, zf));
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const float fx_ = v_get(px, i), fy_ = v_get(py, i);
+        const bool ok = v_get(cam_z, i) > 0.0f && (fx_ >= 0.0f) && (fx_ < (float)p.W) && (fy_ >= 0.0f) && (fy_ < (float)p.H);
+        pix[i] = ok ? (__mul24((int)fy_, p.W) + (int)fx_) : -1;  // H, W < 2^23 (checked on the host)
+    }
 }
 
-template <int RM>
-__device__ __forceinline__ void update_voxel(float &t, float &w, float &c, float dist, unsigned rgb, float ow) {
-    const float w_old = w;
-    const float w_new = w_old + ow;
-    const float wr = refined_rcp(w_new);
-    w = w_new;
-    t = div_exact(t * w_old + ow * dist, w_new, wr);
-    const unsigned oc = (unsigned)c;  // exact: packed colour is an integer < 2^24
-    const float r = fminf(hive_round<RM>(div_exact((float)(oc & 255u) * w_old + ow * (float)(rgb & 255u), w_new, wr)), 255.0f);
-    const float g = fminf(hive_round<RM>(div_exact((float)((oc >> 8) & 255u) * w_old + ow * (float)((rgb >> 8) & 255u), w_new, wr)), 255.0f);
-    const float b = fminf(hive_round<RM>(div_exact((float)(oc >> 16) * w_old + ow * (float)((rgb >> 16) & 255u), w_new, wr)), 255.0f);
-    c = (float)(((unsigned)b << 16) | ((unsigned)g << 8) | (unsigned)r);
+// Running-average update of NV voxels; lanes / elements with ok == false keep their values.
+template <int RM, typename V, int NV>
+__device__ __forceinline__ void update_voxels(V &t, V &w, V &c, V dist, const unsigned (&rgb)[NV], const bool (&ok)[NV], float ow) {
+    const V w_old = w;
+    const V vow = v_splat(ow, w);
+    const V w_new = w_old + vow;
+    const V wr = refined_rcp(w_new);
+    const V t_new = div_exact(t * w_old + vow * dist, w_new, wr);
+    V or_, og, ob, nr, ng, nb;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const unsigned oc = (unsigned)v_get(c, i);  // exact: packed colour is an integer < 2^24
+        v_set(or_, i, (float)(oc & 255u));
+        v_set(og, i, (float)((oc >> 8) & 255u));
+        v_set(ob, i, (float)(oc >> 16));
+        v_set(nr, i, (float)(rgb[i] & 255u));
+        v_set(ng, i, (float)((rgb[i] >> 8) & 255u));
+        v_set(nb, i, (float)((rgb[i] >> 16) & 255u));
+    }
+    const V lim = v_splat(255.0f, w);
+    const V r = v_min(v_round<RM>(div_exact(or_ * w_old + vow * nr, w_new, wr)), lim);
+    const V g = v_min(v_round<RM>(div_exact(og * w_old + vow * ng, w_new, wr)), lim);
+    const V b = v_min(v_round<RM>(div_exact(ob * w_old + vow * nb, w_new, wr)), lim);
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        if (ok[i]) {
+            v_set(t, i, v_get(t_new, i));
+            v_set(w, i, v_get(w_new, i));
+            v_set(c, i, (float)(((unsigned)v_get(b, i) << 16) | ((unsigned)v_get(g, i) << 8) | (unsigned)v_get(r, i)));
+        }
 }
 
-// Persistent grid-stride sweep over the work list: one wave per item (= 64*VPT consecutive z voxels
-// of one (x,y) row; VPT = 4 needs Z % 4 == 0), 16-byte accesses per lane and volume.
+// One work item (64 * VPT consecutive z voxels of one row) in flight: geometry done, texel gathers issued.
+// The VPT voxels of a lane are NG groups of NV (= 2 packed, or 1 for the scalar kernel).
+template <int VPT>
+struct ItemShape {
+    static constexpr int NV = VPT >= 2 ? 2 : 1;
+    static constexpr int NG = VPT / NV;
+    typedef typename std::conditional<NV == 2, f2, float>::type V;
+};
+
+template <int VPT>
+struct ItemState {
+    int x, y, zb;
+    bool live;          // this lane has voxels inside the item's clipped interval
+    int pix[VPT];       // pixel index or -1
+    typename ItemShape<VPT>::V cam_z[ItemShape<VPT>::NG];
+    uint2 tex[VPT];     // {depth bits, rgb} of the voxel's pixel (gather result)
+};
+
+template <int VPT, int RM>
+__device__ __forceinline__ void issue_item(const FrameParams &p, const WorkItem item, int lane, ItemState<VPT> &s) {
+    typedef ItemShape<VPT> Sh;
+    s.x = (int)(item.xy & 0xffffu);
+    s.y = (int)(item.xy >> 16);
+    s.zb = (int)(item.zz & 0xffffu) + lane * VPT;
+    s.live = s.zb < (int)(item.zz >> 16);
+    // row constants, in the contract's operation order
+    const float tx = (p.ox + (float)s.x * p.vs) - p.T[0];
+    const float ty = (p.oy + (float)s.y * p.vs) - p.T[1];
+    const float ax = p.R[0] * tx + p.R[3] * ty;
+    const float ay = p.R[1] * tx + p.R[4] * ty;
+    const float az = p.R[2] * tx + p.R[5] * ty;
+#pragma unroll
+    for (int g = 0; g < Sh::NG; ++g) {
+        int pix[Sh::NV];
+        voxel_pixels<RM, typename Sh::V, Sh::NV>(p, ax, ay, az, s.zb + g * Sh::NV, s.cam_z[g], pix);
+#pragma unroll
+        for (int i = 0; i < Sh::NV; ++i) {
+            s.pix[g * Sh::NV + i] = pix[i];
+            s.tex[g * Sh::NV + i] = p.frame[max(pix[i], 0)];  // issued here, consumed one pipeline stage later
+        }
+    }
+}
+
+// Grid-stride sweep over the work list, one wave per item (= 64*VPT consecutive z voxels of one (x,y) row;
+// VPT = 4 needs Z % 4 == 0), 16-byte accesses per lane and volume.  The item loop is software-pipelined so
+// that a wave always has memory in flight: while the volume loads of item i are outstanding the wave computes
+// the geometry of item i+1 and issues its texel gathers, and those gathers land while item i is updated
+// and stored.  (Unpipelined, the chain gather -> volume load -> update of each item was exposed: 110 us at
+// 512^3 although VALU and HBM each needed < 60 us.)
 // ACCUM = false: running-average update of (tsdf, weight, colour) -- the reference semantics.
 // ACCUM = true : add into the 5 accumulator planes [num, w, r, g, b] (frame-sharded fusion).
 template <int VPT, int RM, bool COUNT, bool ACCUM>
@@ -253,82 +353,135 @@ __global__ __launch_bounds__(256) void integrate_kernel(FrameParams p, const Wor
     const unsigned stride = gridDim.x * 4;
     const float trunc_rcp = refined_rcp(p.trunc);
     unsigned n_upd = 0;
-    for (unsigned it = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)); it < n_items; it += stride) {
-        const WorkItem item = items[it];
-        const int x = (int)(item.xy & 0xffffu), y = (int)(item.xy >> 16);
-        const int zb = (int)(item.zz & 0xffffu) + lane * VPT, z1 = (int)(item.zz >> 16);
-        if (zb >= z1) continue;
-        // row constants, in the contract's operation order
-        const float tx = (p.ox + (float)x * p.vs) - p.T[0];
-        const float ty = (p.oy + (float)y * p.vs) - p.T[1];
-        const float ax = p.R[0] * tx + p.R[3] * ty;
-        const float ay = p.R[1] * tx + p.R[4] * ty;
-        const float az = p.R[2] * tx + p.R[5] * ty;
-        float dist[VPT];
+    unsigned it = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (it >= n_items) return;
+    ItemState<VPT> cur;
+    issue_item<VPT, RM>(p, items[it], lane, cur);
+    while (true) {
+        const unsigned it_next = it + stride;
+        const bool has_next = it_next < n_items;
+        WorkItem next_item;
+        next_item.xy = next_item.zz = 0u;
+        if (has_next) next_item = items[it_next];  // scalar load, needed only after the volume loads are issued
+        // finish the inclusion tests of the current item (waits for its gathers)
+        typedef ItemShape<VPT> Sh;
+        typedef typename Sh::V V;
+        V dist[Sh::NG];
         unsigned rgb[VPT];
         bool ok[VPT];
         bool any = false;
 #pragma unroll
-        for (int j = 0; j < VPT; ++j) {
-            ok[j] = sample_voxel<RM>(p, ax, ay, az, zb + j, trunc_rcp, dist[j], rgb[j]);
-            any = any || ok[j];
+        for (int g = 0; g < Sh::NG; ++g) {
+            V depth;
+#pragma unroll
+            for (int i = 0; i < Sh::NV; ++i) v_set(depth, i, __uint_as_float(cur.tex[g * Sh::NV + i].x));
+            const V diff = depth - cur.cam_z[g];
+            dist[g] = v_min(v_splat(1.0f, diff), div_exact(diff, v_splat(p.trunc, diff), v_splat(trunc_rcp, diff)));
+#pragma unroll
+            for (int i = 0; i < Sh::NV; ++i) {
+                const int j = g * Sh::NV + i;
+                ok[j] = cur.live && cur.pix[j] >= 0 && (v_get(depth, i) != 0.0f) && !(v_get(diff, i) < -p.trunc);
+                rgb[j] = cur.tex[j].y;
+                any = any || ok[j];
+            }
         }
-        if (!any) continue;
-        const long long idx = ((long long)x * p.Y + y) * p.Z + zb;
-        if (!ACCUM) {
-            float t[VPT], w[VPT], c[VPT];
+        const long long idx = ((long long)cur.x * p.Y + cur.y) * p.Z + cur.zb;
+        float t[VPT], w[VPT], c[VPT];  // ACCUM: planes 0..2
+        float c3[VPT], c4[VPT];        // ACCUM: planes 3..4
+        if (any) {
             if (VPT == 4) {
                 *reinterpret_cast<float4 *>(t) = *reinterpret_cast<const float4 *>(v0 + idx);
-                *reinterpret_cast<float4 *>(w) = *reinterpret_cast<const float4 *>(v1 + idx);
-                *reinterpret_cast<float4 *>(c) = *reinterpret_cast<const float4 *>(v2 + idx);
+                if (!ACCUM) {
+                    *reinterpret_cast<float4 *>(w) = *reinterpret_cast<const float4 *>(v1 + idx);
+                    *reinterpret_cast<float4 *>(c) = *reinterpret_cast<const float4 *>(v2 + idx);
+                } else {
+                    *reinterpret_cast<float4 *>(w) = *reinterpret_cast<const float4 *>(v0 + plane + idx);
+                    *reinterpret_cast<float4 *>(c) = *reinterpret_cast<const float4 *>(v0 + 2 * plane + idx);
+                    *reinterpret_cast<float4 *>(c3) = *reinterpret_cast<const float4 *>(v0 + 3 * plane + idx);
+                    *reinterpret_cast<float4 *>(c4) = *reinterpret_cast<const float4 *>(v0 + 4 * plane + idx);
+                }
             } else {
                 t[0] = v0[idx];
-                w[0] = v1[idx];
-                c[0] = v2[idx];
-            }
-#pragma unroll
-            for (int j = 0; j < VPT; ++j)
-                if (ok[j]) {
-                    update_voxel<RM>(t[j], w[j], c[j], dist[j], rgb[j], p.obs_w);
-                    if (COUNT) ++n_upd;
+                if (!ACCUM) {
+                    w[0] = v1[idx];
+                    c[0] = v2[idx];
+                } else {
+                    w[0] = v0[plane + idx];
+                    c[0] = v0[2 * plane + idx];
+                    c3[0] = v0[3 * plane + idx];
+                    c4[0] = v0[4 * plane + idx];
                 }
-            if (VPT == 4) {
-                *reinterpret_cast<float4 *>(v0 + idx) = *reinterpret_cast<float4 *>(t);
-                *reinterpret_cast<float4 *>(v1 + idx) = *reinterpret_cast<float4 *>(w);
-                *reinterpret_cast<float4 *>(v2 + idx) = *reinterpret_cast<float4 *>(c);
-            } else {
-                v0[idx] = t[0];
-                v1[idx] = w[0];
-                v2[idx] = c[0];
-            }
-        } else {
-            // v0 = accumulator base, 5 planes of `plane` floats
-            float a[5][VPT];
-#pragma unroll
-            for (int k = 0; k < 5; ++k) {
-                if (VPT == 4)
-                    *reinterpret_cast<float4 *>(a[k]) = *reinterpret_cast<const float4 *>(v0 + k * plane + idx);
-                else
-                    a[k][0] = v0[k * plane + idx];
-            }
-#pragma unroll
-            for (int j = 0; j < VPT; ++j)
-                if (ok[j]) {
-                    a[0][j] = a[0][j] + p.obs_w * dist[j];
-                    a[1][j] = a[1][j] + p.obs_w;
-                    a[2][j] = a[2][j] + p.obs_w * (float)(rgb[j] & 255u);
-                    a[3][j] = a[3][j] + p.obs_w * (float)((rgb[j] >> 8) & 255u);
-                    a[4][j] = a[4][j] + p.obs_w * (float)((rgb[j] >> 16) & 255u);
-                    if (COUNT) ++n_upd;
-                }
-#pragma unroll
-            for (int k = 0; k < 5; ++k) {
-                if (VPT == 4)
-                    *reinterpret_cast<float4 *>(v0 + k * plane + idx) = *reinterpret_cast<float4 *>(a[k]);
-                else
-                    v0[k * plane + idx] = a[k][0];
             }
         }
+        // next item's geometry + gathers, overlapping the volume loads above
+        ItemState<VPT> nxt;
+        if (has_next) issue_item<VPT, RM>(p, next_item, lane, nxt);
+        if (any) {
+            if (!ACCUM) {
+#pragma unroll
+                for (int g = 0; g < Sh::NG; ++g) {
+                    V tv, wv, cv;
+                    unsigned rg[Sh::NV];
+                    bool okg[Sh::NV];
+#pragma unroll
+                    for (int i = 0; i < Sh::NV; ++i) {
+                        const int j = g * Sh::NV + i;
+                        v_set(tv, i, t[j]);
+                        v_set(wv, i, w[j]);
+                        v_set(cv, i, c[j]);
+                        rg[i] = rgb[j];
+                        okg[i] = ok[j];
+                    }
+                    update_voxels<RM, V, Sh::NV>(tv, wv, cv, dist[g], rg, okg, p.obs_w);
+#pragma unroll
+                    for (int i = 0; i < Sh::NV; ++i) {
+                        const int j = g * Sh::NV + i;
+                        t[j] = v_get(tv, i);
+                        w[j] = v_get(wv, i);
+                        c[j] = v_get(cv, i);
+                        if (COUNT && ok[j]) ++n_upd;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < VPT; ++j)
+                    if (ok[j]) {
+                        const float d = v_get(dist[j / Sh::NV], j % Sh::NV);
+                        t[j] = t[j] + p.obs_w * d;
+                        w[j] = w[j] + p.obs_w;
+                        c[j] = c[j] + p.obs_w * (float)(rgb[j] & 255u);
+                        c3[j] = c3[j] + p.obs_w * (float)((rgb[j] >> 8) & 255u);
+                        c4[j] = c4[j] + p.obs_w * (float)((rgb[j] >> 16) & 255u);
+                        if (COUNT) ++n_upd;
+                    }
+            }
+            if (VPT == 4) {
+                *reinterpret_cast<float4 *>(v0 + idx) = *reinterpret_cast<float4 *>(t);
+                if (!ACCUM) {
+                    *reinterpret_cast<float4 *>(v1 + idx) = *reinterpret_cast<float4 *>(w);
+                    *reinterpret_cast<float4 *>(v2 + idx) = *reinterpret_cast<float4 *>(c);
+                } else {
+                    *reinterpret_cast<float4 *>(v0 + plane + idx) = *reinterpret_cast<float4 *>(w);
+                    *reinterpret_cast<float4 *>(v0 + 2 * plane + idx) = *reinterpret_cast<float4 *>(c);
+                    *reinterpret_cast<float4 *>(v0 + 3 * plane + idx) = *reinterpret_cast<float4 *>(c3);
+                    *reinterpret_cast<float4 *>(v0 + 4 * plane + idx) = *reinterpret_cast<float4 *>(c4);
+                }
+            } else {
+                v0[idx] = t[0];
+                if (!ACCUM) {
+                    v1[idx] = w[0];
+                    v2[idx] = c[0];
+                } else {
+                    v0[plane + idx] = w[0];
+                    v0[2 * plane + idx] = c[0];
+                    v0[3 * plane + idx] = c3[0];
+                    v0[4 * plane + idx] = c4[0];
+                }
+            }
+        }
+        if (!has_next) break;
+        cur = nxt;
+        it = it_next;
     }
     if (COUNT) {
         for (int off = 32; off > 0; off >>= 1) n_upd += __shfl_xor((int)n_upd, off);
@@ -486,7 +639,7 @@ static int check_frame_args(hive_tsdf *vol, const void *color, const void *depth
     if (!vol) return hive_fail(nullptr, HIVE_ERR_INVALID, "vol is NULL");
     hive_ctx *ctx = vol->ctx;
     HIVE_REQUIRE(ctx, color && depth && K && pose, "integrate: NULL argument");
-    HIVE_REQUIRE(ctx, H > 0 && W > 0 && (long long)H * W < (1ll << 30), "integrate: bad image size %dx%d", H, W);
+    HIVE_REQUIRE(ctx, H > 0 && W > 0 && H < (1 << 23) && W < (1 << 23) && (long long)H * W < (1ll << 30), "integrate: bad image size %dx%d", H, W);
     HIVE_REQUIRE(ctx, mem == HIVE_MEM_HOST || mem == HIVE_MEM_DEVICE, "integrate: bad mem kind %d", mem);
     HIVE_REQUIRE(ctx, K[0] != 0.f && K[4] != 0.f, "integrate: singular intrinsics");
     return HIVE_OK;
