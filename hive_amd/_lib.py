@@ -58,6 +58,7 @@ SIGNATURES = {
     "hive_image2world": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_double, c_int, c_void_p]),
     "hive_project": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_double, c_int, c_void_p, c_void_p,
                              c_void_p]),
+    "hive_project_bbox": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "hive_dilate_mask": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "hive_vit_create": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, P(c_void_p)]),
     "hive_vit_destroy": (c_int, [c_void_p]),

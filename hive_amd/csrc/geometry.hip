@@ -154,6 +154,42 @@ __global__ __launch_bounds__(256) void project_kernel(const double *__restrict__
     }
 }
 
+// world2image + the visibility reduction of HiveDataset.select_key_frames (hive/io.py:1161-1175): project,
+// round (np.round), keep pixels inside [0, W) x [0, H), and reduce them to (min u, max u, min v, max v, count).
+// out[0..4] must be initialised to {INT_MAX, INT_MIN, INT_MAX, INT_MIN, 0}.
+__global__ __launch_bounds__(256) void project_bbox_kernel(const double *__restrict__ pts, long long n, ProjectParams p, int W, int H,
+                                                           int *__restrict__ out) {
+    int mn_u = 0x7fffffff, mx_u = (int)0x80000000, mn_v = 0x7fffffff, mx_v = (int)0x80000000, cnt = 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const double X[3] = {pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]};
+        double cam[3], c[3];
+        for (int r = 0; r < 3; ++r) cam[r] = p.R[3 * r + 0] * X[0] + p.R[3 * r + 1] * X[1] + p.R[3 * r + 2] * X[2] + p.t[r];
+        for (int r = 0; r < 3; ++r) c[r] = p.K[3 * r + 0] * cam[0] + p.K[3 * r + 1] * cam[1] + p.K[3 * r + 2] * cam[2];
+        const int u = (int)rint(c[0] / c[2] / p.scale), v = (int)rint(c[1] / c[2] / p.scale);
+        if (u >= 0 && u < W && v >= 0 && v < H) {
+            mn_u = min(mn_u, u);
+            mx_u = max(mx_u, u);
+            mn_v = min(mn_v, v);
+            mx_v = max(mx_v, v);
+            ++cnt;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        mn_u = min(mn_u, __shfl_xor(mn_u, off));
+        mx_u = max(mx_u, __shfl_xor(mx_u, off));
+        mn_v = min(mn_v, __shfl_xor(mn_v, off));
+        mx_v = max(mx_v, __shfl_xor(mx_v, off));
+        cnt += __shfl_xor(cnt, off);
+    }
+    if ((threadIdx.x & 63) == 0 && cnt) {
+        atomicMin(out + 0, mn_u);
+        atomicMax(out + 1, mx_u);
+        atomicMin(out + 2, mn_v);
+        atomicMax(out + 3, mx_v);
+        atomicAdd(out + 4, cnt);
+    }
+}
+
 // image2world for an explicit list of pixel coordinates (hive/geometric.py:183-206)
 __global__ __launch_bounds__(256) void image2world_kernel(const double *__restrict__ uv, const double *__restrict__ depth, long long n,
                                                           UnprojectParams p, double scale, double *__restrict__ out_xyz) {
@@ -390,6 +426,33 @@ int hive_project(hive_ctx *ctx, const double *points, int64_t n, const double K[
         if (out_uv_f64) HIVE_CHECK_HIP(ctx, hipMemcpy(out_uv_f64, d_uvf, (size_t)n * 16, hipMemcpyDeviceToHost));
         if (out_depth) HIVE_CHECK_HIP(ctx, hipMemcpy(out_depth, d_depth, (size_t)n * 8, hipMemcpyDeviceToHost));
     }
+    return HIVE_OK;
+}
+
+int hive_project_bbox(hive_ctx *ctx, const double *points, int64_t n, const double K[9], const double R[9], const double t[3],
+                      int W, int H, int mem, int32_t out[5]) {
+    if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
+    HIVE_REQUIRE(ctx, K && R && t && out && W > 0 && H > 0, "project_bbox: bad arguments");
+    HIVE_REQUIRE(ctx, n >= 0 && (n == 0 || points), "project_bbox: bad points");
+    int32_t init[5] = {0x7fffffff, (int32_t)0x80000000, 0x7fffffff, (int32_t)0x80000000, 0};
+    memcpy(out, init, sizeof(init));
+    if (n == 0) return HIVE_OK;
+    int rc;
+    const void *d_pts;
+    if (mem == HIVE_MEM_HOST && (rc = hive_reserve_device(ctx, &ctx->d_in, &ctx->in_bytes, (size_t)n * 24))) return rc;
+    if ((rc = to_device(ctx, points, (size_t)n * 24, 0, mem, &d_pts))) return rc;
+    int *d_out = (int *)(ctx->d_scalars + 24);
+    HIVE_CHECK_HIP(ctx, hipMemcpyAsync(d_out, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
+    ProjectParams p;
+    memcpy(p.K, K, sizeof(p.K));
+    memcpy(p.R, R, sizeof(p.R));
+    memcpy(p.t, t, sizeof(p.t));
+    p.scale = 1.0;
+    const dim3 grid((unsigned)std::min<long long>((n + 255) / 256, (long long)ctx->num_cus * 4));
+    hipLaunchKernelGGL(project_bbox_kernel, grid, dim3(256), 0, ctx->stream, (const double *)d_pts, (long long)n, p, W, H, d_out);
+    HIVE_CHECK_HIP(ctx, hipGetLastError());
+    HIVE_CHECK_HIP(ctx, hipMemcpyAsync(out, d_out, sizeof(init), hipMemcpyDeviceToHost, ctx->stream));
+    HIVE_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return HIVE_OK;
 }
 

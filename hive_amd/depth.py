@@ -52,7 +52,7 @@ def preprocess_on_device(frames_u8, dtype=torch.bfloat16, ctx=None):
 
 def _write_png16(path, depth_mm_u16):
     from PIL import Image
-    Image.fromarray(depth_mm_u16, mode="I;16").save(path)
+    Image.fromarray(np.ascontiguousarray(depth_mm_u16, dtype=np.uint16)).save(path)  # uint16 -> 16-bit PNG
 
 
 def estimate_depth_dpt(rgb_dataset, output_path: str, weights_filename='dpt_hybrid_nyu.pt', optimize=True, batch_size=8):

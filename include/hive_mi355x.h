@@ -154,6 +154,12 @@ int hive_project(hive_ctx *ctx, const double *points, int64_t n, const double K[
                  const double t[3], double scale_factor, int mem,
                  int32_t *out_uv_i32, double *out_uv_f64, double *out_depth);
 
+/* world2image + the visibility reduction of HiveDataset.select_key_frames -- hive/io.py:1161-1175:
+ * project points (f64 [n][3]), round half-to-even, keep pixels inside [0,W) x [0,H) and return
+ * out = {min u, max u, min v, max v, count} (count == 0: the extrema are INT_MAX / INT_MIN). */
+int hive_project_bbox(hive_ctx *ctx, const double *points, int64_t n, const double K[9], const double R[9],
+                      const double t[3], int W, int H, int mem, int32_t out[5]);
+
 /* ---- dilate_mask(mask, MaskDilationOptions(num_iterations)) -- hive/image_processing.py:30-45 */
 /* 3x3 rectangular structuring element applied `iterations` times == one (2*it+1)^2 box max
  * (cv2.dilate border = no contribution from outside).  mask/out u8 [H][W], non-zero = set. */
