@@ -68,10 +68,11 @@ SIGNATURES = {
     "hive_vit_qkv": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int]),
     "hive_vit_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int]),
     "hive_dpt_preprocess": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_float, c_int, c_void_p]),
-    "hive_dpt_head_tail": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p, c_float, c_int, c_int, c_float, c_float,
-                                   c_void_p, c_float, c_float, c_void_p, c_void_p]),
+    "hive_dpt_head_tail": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p, c_int, c_void_p, c_float, c_int, c_int, c_float,
+                                   c_float, c_void_p, c_float, c_float, c_void_p, c_void_p]),
     "hive_nhwc_group_norm": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_int,
                                      c_void_p]),
+    "hive_nhwc_bias_act": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "hive_nhwc_upsample2x": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "hive_depth_quantize": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p]),
 }

@@ -178,6 +178,39 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const T *__restrict__ i
 }
 
 // ------------------------------------------------------------------------------------------------
+// out = relu?( (x + bias[c]) (+ residual) ) on [n_px][C]: the convolution bias, the ReLU between the two convs of a
+// RefineNet residual unit and its skip add, as one pass (PyTorch runs them as 2-3 elementwise kernels after MIOpen's
+// bias-less convolution).  Rounding follows the separate ops: x + bias is rounded to the tensor type first.
+template <typename T>
+__global__ __launch_bounds__(256) void bias_act_kernel(const T *__restrict__ x, const T *__restrict__ bias, const T *__restrict__ residual,
+                                                       const T *__restrict__ residual2, T *__restrict__ out, size_t n_vec, int VC, int relu) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n_vec; i += (size_t)gridDim.x * 256) {
+        const int v = (int)(i % VC);
+        float f[8], b[8];
+        load8(x + i * 8, f);
+        load8(bias + v * 8, b);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = (float)(T)(f[j] + b[j]);
+        if (residual) {
+            float r[8];
+            load8(residual + i * 8, r);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] += r[j];
+        }
+        if (residual2) {  // second skip (fusion block: output + rcu(x)); the first sum is rounded first, as separate ops would
+            float r[8];
+            load8(residual2 + i * 8, r);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = (float)(T)f[j] + r[j];
+        }
+        if (relu) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = fmaxf(f[j], 0.f);
+        }
+        store8(out + i * 8, f);
+    }
+}
+
 static bool pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
 
 extern "C" {
@@ -207,6 +240,25 @@ int hive_nhwc_group_norm(hive_ctx *ctx, const void *d_x, int dtype, int N, int H
         hipLaunchKernelGGL(gn_apply_kernel<_Float16>, g3, dim3(256), 0, ctx->stream, (const _Float16 *)d_x, (const _Float16 *)d_gamma,
                            (const _Float16 *)d_beta, stats, (const _Float16 *)d_residual, (_Float16 *)d_out, HW, C, G, relu);
     }
+    HIVE_CHECK_HIP(ctx, hipGetLastError());
+    return HIVE_OK;
+}
+
+int hive_nhwc_bias_act(hive_ctx *ctx, const void *d_x, int dtype, int64_t n_px, int C, const void *d_bias, int relu,
+                       const void *d_residual, const void *d_residual2, void *d_out) {
+    if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
+    HIVE_REQUIRE(ctx, d_x && d_bias && d_out, "bias_act: NULL argument");
+    HIVE_REQUIRE(ctx, n_px > 0 && C > 0 && C % 8 == 0, "bias_act: need C %% 8 == 0 (n_px=%lld C=%d)", (long long)n_px, C);
+    const size_t n_vec = (size_t)n_px * (C / 8);
+    const dim3 grid((unsigned)std::min<size_t>((n_vec + 255) / 256, (size_t)ctx->num_cus * 32));
+    if (dtype == HIVE_BF16)
+        hipLaunchKernelGGL(bias_act_kernel<bf16>, grid, dim3(256), 0, ctx->stream, (const bf16 *)d_x, (const bf16 *)d_bias, (const bf16 *)d_residual,
+                           (const bf16 *)d_residual2, (bf16 *)d_out, n_vec, C / 8, relu);
+    else if (dtype == HIVE_F16)
+        hipLaunchKernelGGL(bias_act_kernel<_Float16>, grid, dim3(256), 0, ctx->stream, (const _Float16 *)d_x, (const _Float16 *)d_bias,
+                           (const _Float16 *)d_residual, (const _Float16 *)d_residual2, (_Float16 *)d_out, n_vec, C / 8, relu);
+    else
+        return hive_fail(ctx, HIVE_ERR_INVALID, "bias_act: dtype must be HIVE_F16 or HIVE_BF16");
     HIVE_CHECK_HIP(ctx, hipGetLastError());
     return HIVE_OK;
 }

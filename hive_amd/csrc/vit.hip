@@ -418,6 +418,8 @@ __global__ __launch_bounds__(256) void pad_tokens_kernel(const bf16 *__restrict_
 // optionally the uint16-millimetre hand-off of dataset_adaptors.py:1432-1433 + io.py:1032-1039.
 struct HeadTailParams {
     float w[64];
+    float pre_bias[64];  // bias of the preceding convolution (all zero when it was already applied)
+    int pre_relu;        // ReLU between that convolution and this one (head: conv 128->32, ReLU, conv 32->1)
     float bias, scale, shift;
     int C, non_negative, invert;
     long long n_px;
@@ -435,7 +437,11 @@ __global__ __launch_bounds__(256) void head_tail_kernel(const T *__restrict__ fe
         const uint4 raw = *reinterpret_cast<const uint4 *>(f + c);
         const T *v = reinterpret_cast<const T *>(&raw);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc += (float)v[j] * p.w[c + j];
+        for (int j = 0; j < 8; ++j) {
+            float x = (float)v[j] + p.pre_bias[c + j];
+            if (p.pre_relu) x = fmaxf(x, 0.0f);
+            acc += x * p.w[c + j];
+        }
     }
     if (p.non_negative) acc = fmaxf(acc, 0.0f);
     float depth = acc;
@@ -647,15 +653,17 @@ int hive_dpt_preprocess(hive_ctx *ctx, const uint8_t *d_rgb, int64_t n_values, f
     return HIVE_OK;
 }
 
-int hive_dpt_head_tail(hive_ctx *ctx, const void *d_feat, int dtype, int64_t n_px, int C, const float *h_weight, float bias,
-                       int non_negative, int invert, float scale, float shift, float *d_depth, float depth_scale, float max_depth,
-                       uint16_t *d_out_mm, float *d_out_m) {
+int hive_dpt_head_tail(hive_ctx *ctx, const void *d_feat, int dtype, int64_t n_px, int C, const float *h_pre_bias, int pre_relu,
+                       const float *h_weight, float bias, int non_negative, int invert, float scale, float shift, float *d_depth,
+                       float depth_scale, float max_depth, uint16_t *d_out_mm, float *d_out_m) {
     if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
     HIVE_REQUIRE(ctx, d_feat && h_weight && n_px > 0, "dpt_head_tail: bad arguments");
     HIVE_REQUIRE(ctx, C > 0 && C <= 64 && C % 8 == 0, "dpt_head_tail: C must be a multiple of 8 and <= 64, got %d", C);
     HIVE_REQUIRE(ctx, d_depth || d_out_mm || d_out_m, "dpt_head_tail: no output requested");
     HeadTailParams p{};
     memcpy(p.w, h_weight, sizeof(float) * C);
+    if (h_pre_bias) memcpy(p.pre_bias, h_pre_bias, sizeof(float) * C);
+    p.pre_relu = pre_relu;
     p.bias = bias;
     p.scale = scale;
     p.shift = shift;

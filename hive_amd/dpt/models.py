@@ -261,15 +261,17 @@ class Transpose(nn.Module):
 
 
 class ResidualConvUnit(nn.Module):
+    engine = "torch"
+
     def __init__(self, features):
         super().__init__()
         self.conv1 = nn.Conv2d(features, features, 3, 1, 1, bias=True)
         self.conv2 = nn.Conv2d(features, features, 3, 1, 1, bias=True)
 
-    def forward(self, x):
-        out = self.conv1(F.relu(x))
-        out = self.conv2(F.relu(out))
-        return out + x
+    def forward(self, x, skip=None):
+        # out = conv2(relu(conv1(relu(x)))) + x (+ skip), with bias / ReLU / skip adds fused behind each convolution
+        out = dpt_ops.conv_bias_act(F.relu(x), self.conv1, relu=True, engine=self.engine)
+        return dpt_ops.conv_bias_act(out, self.conv2, relu=False, residual=x, residual2=skip, engine=self.engine)
 
 
 class FeatureFusionBlock(nn.Module):
@@ -284,7 +286,7 @@ class FeatureFusionBlock(nn.Module):
     def forward(self, *xs):
         output = xs[0]
         if len(xs) == 2:
-            output = output + self.resConfUnit1(xs[1])
+            output = self.resConfUnit1(xs[1], skip=output)  # output + resConfUnit1(xs[1])
         output = self.resConfUnit2(output)
         output = dpt_ops.upsample2x(output, engine=self.engine)  # bilinear, align_corners=True
         return self.out_conv(output)
@@ -342,7 +344,7 @@ class DPT(nn.Module):
         self.scratch.output_conv = head
         self._vit_engine = None
         for m in self.modules():  # the fused channels-last glue kernels follow the engine choice
-            if isinstance(m, (GroupNormAct, FeatureFusionBlock, Interpolate)):
+            if isinstance(m, (GroupNormAct, FeatureFusionBlock, Interpolate, ResidualConvUnit)):
                 m.engine = engine
 
     # -- ViT encoder ---------------------------------------------------------------------------
@@ -450,27 +452,32 @@ class DPTDepthModel(DPT):
         reference's depth hand-off on the device -- uint16 millimetres (dataset_adaptors.py:1432-1433), read
         back as float32 metres with ``> max_depth -> 0`` (io.py:1032-1039) -- and returns (depth, depth_mm, depth_m).
         """
-        feat = self.forward_head_features(x)
-        conv = self.scratch.output_conv[4]
-        non_negative = isinstance(self.scratch.output_conv[5], nn.ReLU)
-        b, c, h, w = feat.shape
-        if self.engine == "hip" and feat.is_cuda and feat.dtype in (torch.float16, torch.bfloat16):
+        head = self.scratch.output_conv
+        conv = head[4]
+        non_negative = isinstance(head[5], nn.ReLU)
+        if self.engine == "hip" and x.is_cuda and x.dtype in (torch.float16, torch.bfloat16):
             from hive_amd import _lib
-            ctx = _lib.default_context(feat.device.index or 0)
+            ctx = _lib.default_context(x.device.index or 0)
+            # conv 128 -> 32 without its bias (MIOpen); bias + ReLU + conv 32 -> 1 + inversion + hand-off in one HIP kernel
+            pre = head[2]
+            feat = F.conv2d(head[1](head[0](self.forward_decoder(x))), pre.weight, None, pre.stride, pre.padding)
             feat = feat.contiguous(memory_format=torch.channels_last)
+            b, c, h, w = feat.shape
             depth = torch.empty((b, h, w), dtype=torch.float32, device=feat.device)
             mm = torch.empty((b, h, w), dtype=torch.int16, device=feat.device) if handoff else None
             m = torch.empty((b, h, w), dtype=torch.float32, device=feat.device) if handoff else None
-            key = (conv.weight.data_ptr(), conv.weight._version, conv.bias._version)
+            key = (conv.weight.data_ptr(), conv.weight._version, conv.bias._version, pre.bias._version)
             if getattr(self, "_tail_host", (None,))[0] != key:  # one D2H per set of weights, not per forward
-                self._tail_host = (key, conv.weight.detach().float().reshape(-1).cpu().numpy(), float(conv.bias.detach().float().item()))
-            weight, bias = self._tail_host[1], self._tail_host[2]
+                self._tail_host = (key, conv.weight.detach().float().reshape(-1).cpu().numpy(), float(conv.bias.detach().float().item()),
+                                   pre.bias.detach().float().cpu().numpy())
+            weight, bias, pre_bias = self._tail_host[1], self._tail_host[2], self._tail_host[3]
             ctx.check(ctx.lib.hive_dpt_head_tail(
                 ctx.handle, feat.data_ptr(), _lib.BF16 if feat.dtype == torch.bfloat16 else _lib.F16, b * h * w, c,
-                weight.ctypes.data, bias, int(non_negative), int(bool(self.invert)),
+                pre_bias.ctypes.data, 1, weight.ctypes.data, bias, int(non_negative), int(bool(self.invert)),
                 float(self.scale), float(self.shift), depth.data_ptr(), 1.0 / 1000.0, float(handoff[0]) if handoff else 0.0,
                 _lib.ptr(mm), _lib.ptr(m)))
             return (depth, mm, m) if handoff else depth
+        feat = self.forward_head_features(x)
         out = F.conv2d(feat.float(), conv.weight.float(), conv.bias.float()).squeeze(dim=1)
         if non_negative:
             out = F.relu(out)

@@ -36,6 +36,33 @@ def group_norm_act(x, num_groups, weight, bias, eps, relu=True, residual=None, e
     return F.relu(y) if relu else y
 
 
+def conv_bias_act(x, conv, relu=False, residual=None, residual2=None, engine="torch"):
+    """relu?(conv(x) (+ residual) (+ residual2)) for an ``nn.Conv2d`` with bias.  With the HIP engine the convolution runs
+    without its bias (MIOpen) and one fused kernel adds bias, skip connection and ReLU."""
+    if engine == "hip" and conv.bias is not None and _hip_eligible(x) and conv.out_channels % 8 == 0 and conv.bias.dtype == x.dtype:
+        y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+        if _hip_eligible(y):
+            if residual is not None:
+                assert residual.shape == y.shape and residual.dtype == y.dtype
+                residual = residual.contiguous(memory_format=torch.channels_last)
+            if residual2 is not None:
+                assert residual2.shape == y.shape and residual2.dtype == y.dtype
+                residual2 = residual2.contiguous(memory_format=torch.channels_last)
+            n, c, h, w = y.shape
+            ctx = _lib.default_context(y.device.index or 0)
+            ctx.check(ctx.lib.hive_nhwc_bias_act(ctx.handle, y.data_ptr(), _code(y.dtype), n * h * w, c, conv.bias.data_ptr(), int(bool(relu)),
+                                                 _lib.ptr(residual), _lib.ptr(residual2), y.data_ptr()))  # in place
+            return y
+        y = y + conv.bias.view(1, -1, 1, 1)
+    else:
+        y = conv(x)
+    if residual is not None:
+        y = y + residual
+    if residual2 is not None:
+        y = y + residual2
+    return F.relu(y) if relu else y
+
+
 def upsample2x(x, engine="torch"):
     """interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)."""
     if engine == "hip" and _hip_eligible(x):

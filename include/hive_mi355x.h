@@ -216,13 +216,15 @@ int hive_dpt_preprocess(hive_ctx *ctx, const uint8_t *d_rgb, int64_t n_values, f
                         int dtype, void *d_out);
 /* Last layer of the depth head, fused, in float32: 1x1 conv C -> 1 on the channels-last f16 / bf16 map
  * d_feat [n_px][C] (weights / bias on the host), ReLU if non_negative, depth = 1 / max(scale x + shift, 1e-8)
- * if invert (DPTDepthModel.forward).  Optional outputs: d_depth f32 metres; and the PNG hand-off
+ * if invert (DPTDepthModel.forward).  h_pre_bias (optional, host, [C]) and pre_relu apply the bias and ReLU of the
+ * convolution that produced d_feat on the fly (head: conv 128->32 + bias, ReLU, conv 32->1), saving two passes over
+ * the largest activation of the network.  Optional outputs: d_depth f32 metres; and the PNG hand-off
  * d_out_mm = uint16(depth * 1000), d_out_m = depth_scale * mm with > max_depth -> 0
  * (hive/dataset_adaptors.py:1432-1433, hive/io.py:1032-1039). */
 int hive_dpt_head_tail(hive_ctx *ctx, const void *d_feat, int dtype, int64_t n_px, int C,
-                       const float *h_weight, float bias, int non_negative, int invert, float scale,
-                       float shift, float *d_depth, float depth_scale, float max_depth,
-                       uint16_t *d_out_mm, float *d_out_m);
+                       const float *h_pre_bias, int pre_relu, const float *h_weight, float bias,
+                       int non_negative, int invert, float scale, float shift, float *d_depth,
+                       float depth_scale, float max_depth, uint16_t *d_out_mm, float *d_out_m);
 
 /* ---- fused channels-last glue of the DPT convolutional parts (device pointers, f16 / bf16) ----------- */
 /* GroupNorm over [N][HW][C] (C a power of two, 8..2048) with G groups, affine gamma / beta [C] in the tensor
@@ -231,6 +233,11 @@ int hive_dpt_head_tail(hive_ctx *ctx, const void *d_feat, int dtype, int64_t n_p
 int hive_nhwc_group_norm(hive_ctx *ctx, const void *d_x, int dtype, int N, int HW, int C, int G,
                          const void *d_gamma, const void *d_beta, float eps, const void *d_residual,
                          int relu, void *d_out);
+/* out = relu?( (x + bias[c]) (+ residual) (+ residual2) ) over [n_px][C] (C % 8 == 0; bias in the tensor dtype; out may
+ * alias x): convolution bias + ReLU + skip adds of the RefineNet residual units / fusion blocks (isl-org/DPT
+ * ResidualConvUnit_custom, FeatureFusionBlock_custom) in one pass */
+int hive_nhwc_bias_act(hive_ctx *ctx, const void *d_x, int dtype, int64_t n_px, int C, const void *d_bias,
+                       int relu, const void *d_residual, const void *d_residual2, void *d_out);
 /* bilinear x2, align_corners=True: [N][H][W][C] -> [N][2H][2W][C] (C % 8 == 0): the RefineNet fusion blocks'
  * and the depth head's `interpolate(scale_factor=2, mode="bilinear", align_corners=True)` */
 int hive_nhwc_upsample2x(hive_ctx *ctx, const void *d_in, int dtype, int N, int H, int W, int C, void *d_out);
