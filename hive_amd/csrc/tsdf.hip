@@ -9,11 +9,12 @@
 //   dist = min(1, diff/trunc) ; w' = w + ow ; tsdf' = (tsdf*w + ow*dist)/w' ;
 //   c' = min(255, round((c*w + ow*c_new)/w')) per channel.
 //
-// Kernel shape: HBM-bound voxel sweep.  The volume is [X][Y][Z] with z fastest, so one wave owns one
-// (x,y) row and sweeps z with 16-byte accesses per lane (1 KiB per wave instruction and volume).
-// Each row is clipped analytically against the view frustum first (the camera-space position is
-// affine in z), so voxels that cannot pass the inclusion tests cost nothing; the clip is padded and
-// every surviving voxel still runs the exact tests above, so results do not depend on it.
+// Kernel shape: voxel sweep over the part of the volume a frame can touch.  The volume is [X][Y][Z] with
+// z fastest.  pack_frame fuses depth + colour into 8-byte texels and reduces max(depth); build_worklist clips
+// every (x,y) row analytically against the view frustum (the camera-space position is affine in z; one LANE
+// per row) and emits 256-voxel chunks; integrate gives one wave to a chunk, 4 consecutive z voxels (16 bytes
+// per volume) per lane, with packed-f32 arithmetic and a software-pipelined chunk loop.  The clip is padded
+// and every voxel of a chunk still runs the exact tests above, so results do not depend on it.
 #include "hive_internal.hpp"
 
 #include <algorithm>

@@ -12,15 +12,17 @@
 //                                      over a contiguous axis and the attention needs no transposed reads
 //   weights            [out][in] row-major (nn.Linear), bias / LayerNorm affine in f32
 //
-// GEMM: C[M][N] = A[M][K] W[N][K]^T.  128 x 128 x 64 tiles, 4 waves (2 x 2), 16 MFMA 16x16x32 per wave and
-// 32-deep k-step, operands staged global -> registers -> LDS (XOR-swizzled 128-byte rows, conflict-free
-// ds_read_b128), double-buffered with the next tile's global loads issued before the MFMAs of the current.
-// The MFMA is issued as W.A^T so that a lane owns 4 consecutive output columns (8-byte stores); v^T tiles
-// use A.W^T so that a lane owns 4 consecutive tokens.
+// GEMM: C[M][N] = A[M][K] W[N][K]^T.  TM x 128 x 64 tiles (TM = 256, 8 waves, when that still fills the chip, else
+// 128, 4 waves); each wave a 64 x 64 sub-tile = 4 x 4 accumulators of v_mfma_f32_16x16x32_bf16.  Operands go
+// global -> LDS by LDS-DMA (global_load_lds_dwordx4) into a 3-stage ring; the bank swizzle is applied on the
+// SOURCE address and again on the ds_read_b128 (conflict-free); one raw s_barrier per K-step behind a counted
+// s_waitcnt vmcnt so that two stages stay in flight across the barrier; XCD-aware tile order.
+// The MFMA is issued as W.A^T so that a lane owns 4 consecutive output columns (8-byte stores); the v^T
+// kernel variant issues A.W^T so that a lane owns 4 consecutive tokens.  Epilogues: bias, erf-GELU, residual.
 //
 // Attention: one workgroup = 128 queries of one (image, head); each wave 32 queries.  S^T = K Q^T puts the
-// query on the lane and the keys in the accumulator registers, so softmax is in-register (one cross-half
-// shuffle) and the probabilities are already the B operand of O^T += V^T P^T.
+// query on the lane and the keys in the accumulator registers, so the online softmax (base 2, deferred maximum)
+// is in-register with one cross-half shuffle, and the probabilities are already the B operand of O^T += V^T P^T.
 #include "hive_internal.hpp"
 
 #include <algorithm>

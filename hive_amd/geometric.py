@@ -145,6 +145,60 @@ def get_identity_pose():
     return np.asarray([0., 0., 0., 1., 0., 0., 0.])
 
 
+class Quaternion:
+    """Batched scalar-last quaternions as a (4, N) torch tensor with rows x, y, z, w -- the small algebra the
+    reference's pose optimiser uses and its only unit tests cover (/root/reference/hive/geometric.py:209-299,
+    tests/quaternion.py).  Host-side helper, not part of the dense-compute path."""
+
+    def __init__(self, values):
+        if len(values.shape) != 2 or values.shape[0] != 4:
+            raise ValueError(f"Invalid shape. Expected shape (4, N) but got {values.shape}.")
+        self.values = values
+
+    x = property(lambda self: self.values[0])
+    y = property(lambda self: self.values[1])
+    z = property(lambda self: self.values[2])
+    w = property(lambda self: self.values[3])
+
+    def conjugate(self) -> 'Quaternion':
+        import torch
+        return Quaternion(torch.vstack((-self.x, -self.y, -self.z, self.w)))
+
+    inverse = conjugate  # for unit quaternions
+
+    def normalise(self) -> 'Quaternion':
+        import torch
+        return Quaternion(self.values / torch.linalg.norm(self.values, ord=2, dim=0))
+
+    @staticmethod
+    def multiply(q1: 'Quaternion', q2: 'Quaternion') -> 'Quaternion':
+        """Hamilton product q1 q2, component-wise over the batch."""
+        import torch
+        x1, y1, z1, w1 = q1.values
+        x2, y2, z2, w2 = q2.values
+        return Quaternion(torch.vstack((w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2,
+                                        w1 * y2 + y1 * w2 + z1 * x2 - x1 * z2,
+                                        w1 * z2 + z1 * w2 + x1 * y2 - y1 * x2,
+                                        w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2)))
+
+    def __mul__(self, other):
+        if not isinstance(other, Quaternion):
+            raise TypeError(f"Cannot multiply a {self.__class__.__name__} with a {type(other)}")
+        return Quaternion.multiply(self, other)
+
+    __rmul__ = __mul__
+
+    def apply(self, v):
+        """Rotate the (3, N) vectors: q (v, 0) q*."""
+        import torch
+        assert len(v.shape) == 2 and v.shape[0] == 3
+        pure = Quaternion(torch.vstack((v, torch.zeros(v.shape[1], dtype=v.dtype, device=v.device))))
+        return (self * pure * self.conjugate()).values[:3, :]
+
+    def __repr__(self):
+        return f"{self.__class__.__name__}({repr(self.values)})"
+
+
 class Trajectory:
     """A sequence of camera poses, N x 7 rows of [scalar-last quaternion, xyz position]
     (/root/reference/hive/geometric.py:302-648)."""
