@@ -74,12 +74,16 @@ __global__ __launch_bounds__(256) void pack_frame_kernel(const float *__restrict
 
 // ---------------------------------------------------------------------------------------------
 // Work list.  One lane per (x,y) row clips the row analytically against the padded view frustum (the
-// camera-space position is affine in z) and emits one item per 64*VPT-voxel chunk of the surviving
-// z interval.  Only chunks on the list are ever touched by the integrate kernel; every voxel of a
-// chunk still runs the exact inclusion tests, so the (conservative) clip cannot change a result.
+// camera-space position is affine in z) and emits one item per SEG_LANES*VPT-voxel segment of the
+// surviving z interval.  Only segments on the list are ever touched by the integrate kernel; every voxel
+// of a segment still runs the exact inclusion tests, so the (conservative) clip cannot change a result.
+// A wave sweeps 64 / SEG_LANES segments at once (one per 16-lane group): the clipped intervals are short
+// (mean 120-190 voxels at 512^3), so with one 256-voxel item per wave 59 % of the lanes were padding --
+// 16-lane segments (64 voxels, 256 contiguous bytes per volume) cut the wave count by 40 %.
+constexpr int SEG_LANES = 16;
 struct WorkItem {
     unsigned xy;  // x | y << 16
-    unsigned zz;  // chunk start z | interval end z << 16
+    unsigned zz;  // segment start z | interval end z << 16
 };
 
 struct RowClip {
@@ -128,7 +132,7 @@ template <int VPT>
 __global__ __launch_bounds__(1024) void build_worklist_kernel(FrameParams p, WorkItem *__restrict__ items, unsigned *n_items) {
     __shared__ unsigned wave_sum[16];
     __shared__ unsigned block_base;
-    constexpr int CHUNK = 64 * VPT;
+    constexpr int CHUNK = SEG_LANES * VPT;
     const long long row = (long long)blockIdx.x * 1024 + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned n_chunks = 0;
@@ -294,8 +298,21 @@ __device__ __forceinline__ void update_voxels(V &t, V &w, V &c, V dist, const un
         }
 }
 
-// One work item (64 * VPT consecutive z voxels of one row) in flight: geometry done, texel gathers issued.
-// The VPT voxels of a lane are NG groups of NV (= 2 packed, or 1 for the scalar kernel).
+// Volume accesses: one 16-byte access per lane and volume.  Default cache policy -- the non-temporal forms
+// measured 6 % faster on a frame that updates every voxel and 3 % slower on the room scene (A/B in one
+// process group, tools/ab_integrate.py), so they are not used.
+typedef float f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void vol_load4(float *dst, const float *src) {
+    *reinterpret_cast<f4 *>(dst) = *reinterpret_cast<const f4 *>(src);
+}
+__device__ __forceinline__ void vol_store4(float *dst, const float *src) {
+    *reinterpret_cast<f4 *>(dst) = *reinterpret_cast<const f4 *>(src);
+}
+__device__ __forceinline__ float vol_load1(const float *src) { return *src; }
+__device__ __forceinline__ void vol_store1(float *dst, float v) { *dst = v; }
+
+// One lane's share of a work item (VPT consecutive z voxels of one segment): geometry done, texel gathers
+// issued.  The VPT voxels are NG groups of NV (= 2 packed, or 1 for the scalar kernel).
 template <int VPT>
 struct ItemShape {
     static constexpr int NV = VPT >= 2 ? 2 : 1;
@@ -313,11 +330,11 @@ struct ItemState {
 };
 
 template <int VPT, int RM>
-__device__ __forceinline__ void issue_item(const FrameParams &p, const WorkItem item, int lane, ItemState<VPT> &s) {
+__device__ __forceinline__ void issue_item(const FrameParams &p, const WorkItem item, int seg_lane, ItemState<VPT> &s) {
     typedef ItemShape<VPT> Sh;
     s.x = (int)(item.xy & 0xffffu);
     s.y = (int)(item.xy >> 16);
-    s.zb = (int)(item.zz & 0xffffu) + lane * VPT;
+    s.zb = (int)(item.zz & 0xffffu) + seg_lane * VPT;
     s.live = s.zb < (int)(item.zz >> 16);
     // row constants, in the contract's operation order
     const float tx = (p.ox + (float)s.x * p.vs) - p.T[0];
@@ -332,38 +349,44 @@ __device__ __forceinline__ void issue_item(const FrameParams &p, const WorkItem 
 #pragma unroll
         for (int i = 0; i < Sh::NV; ++i) {
             s.pix[g * Sh::NV + i] = pix[i];
-            s.tex[g * Sh::NV + i] = p.frame[max(pix[i], 0)];  // issued here, consumed one pipeline stage later
+            s.tex[g * Sh::NV + i] = p.frame[max(pix[i], 0)];
         }
     }
 }
 
-// Grid-stride sweep over the work list, one wave per item (= 64*VPT consecutive z voxels of one (x,y) row;
-// VPT = 4 needs Z % 4 == 0), 16-byte accesses per lane and volume.  The item loop is software-pipelined so
-// that a wave always has memory in flight: while the volume loads of item i are outstanding the wave computes
-// the geometry of item i+1 and issues its texel gathers, and those gathers land while item i is updated
-// and stored.  (Unpipelined, the chain gather -> volume load -> update of each item was exposed: 110 us at
-// 512^3 although VALU and HBM each needed < 60 us.)
+// Grid-stride sweep over the work list: a wave takes 64 / SEG_LANES consecutive segments per trip (16 lanes
+// x VPT voxels each; VPT = 4 needs Z % 4 == 0), 16-byte accesses per lane and volume.  Lanes past the end of
+// the list or of their row's clipped interval are dead (no volume access).
+//
+// What bounds it (512^3, room scene, ~100 us / frame; experiments in DESIGN.md section 5): the CU's vector
+// memory pipeline, per INSTRUCTION.  A trip issues 4 texel gathers (8 B / lane) + 3 volume loads + 3 volume
+// stores (16 B / lane); each costs the pipeline about 70-100 cycles whatever its lanes do (the dwordx4 stream
+// ceiling of ~10 B / cycle / CU is the same figure).  Removing the gathers (a scalar broadcast read instead)
+// gives 61 us, one gather instead of four 76 us, four 98 us -- 7.5 us per gather instruction, = 65 k trips x
+// ~73 cycles / 256 CUs.  Coalescing the gathers, masking dead lanes, reusing texels between voxels of one
+// pixel, software pipelining, speculative volume loads, non-temporal policies, 2 x / 8 x the grid and 4- or
+// 8-lane segments all measured within +-3 % of this kernel; what does pay is fewer instructions per updated
+// voxel: denser waves (the 16-lane segments: 40 % fewer trips than one 256-voxel item per wave).
 // ACCUM = false: running-average update of (tsdf, weight, colour) -- the reference semantics.
 // ACCUM = true : add into the 5 accumulator planes [num, w, r, g, b] (frame-sharded fusion).
 template <int VPT, int RM, bool COUNT, bool ACCUM>
 __global__ __launch_bounds__(256) void integrate_kernel(FrameParams p, const WorkItem *__restrict__ items,
                                                         const unsigned *__restrict__ n_items_ptr, float *__restrict__ v0,
                                                         float *__restrict__ v1, float *__restrict__ v2, long long plane) {
+    constexpr int PER_WAVE = 64 / SEG_LANES;
     const int lane = threadIdx.x & 63;
     const unsigned n_items = *n_items_ptr;
+    const unsigned n_trips = (n_items + PER_WAVE - 1) / PER_WAVE;
     const unsigned stride = gridDim.x * 4;
     const float trunc_rcp = refined_rcp(p.trunc);
     unsigned n_upd = 0;
-    unsigned it = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
-    if (it >= n_items) return;
-    ItemState<VPT> cur;
-    issue_item<VPT, RM>(p, items[it], lane, cur);
-    while (true) {
-        const unsigned it_next = it + stride;
-        const bool has_next = it_next < n_items;
-        WorkItem next_item;
-        next_item.xy = next_item.zz = 0u;
-        if (has_next) next_item = items[it_next];  // scalar load, needed only after the volume loads are issued
+    for (unsigned trip = blockIdx.x * 4 + (threadIdx.x >> 6); trip < n_trips; trip += stride) {
+        const unsigned ii = trip * PER_WAVE + (unsigned)(lane / SEG_LANES);
+        WorkItem item;
+        item.xy = item.zz = 0u;  // interval end 0: dead lanes
+        if (ii < n_items) item = items[ii];
+        ItemState<VPT> cur;
+        issue_item<VPT, RM>(p, item, lane % SEG_LANES, cur);
         // finish the inclusion tests of the current item (waits for its gathers)
         typedef ItemShape<VPT> Sh;
         typedef typename Sh::V V;
@@ -391,32 +414,29 @@ __global__ __launch_bounds__(256) void integrate_kernel(FrameParams p, const Wor
         float c3[VPT], c4[VPT];        // ACCUM: planes 3..4
         if (any) {
             if (VPT == 4) {
-                *reinterpret_cast<float4 *>(t) = *reinterpret_cast<const float4 *>(v0 + idx);
+                vol_load4(t, v0 + idx);
                 if (!ACCUM) {
-                    *reinterpret_cast<float4 *>(w) = *reinterpret_cast<const float4 *>(v1 + idx);
-                    *reinterpret_cast<float4 *>(c) = *reinterpret_cast<const float4 *>(v2 + idx);
+                    vol_load4(w, v1 + idx);
+                    vol_load4(c, v2 + idx);
                 } else {
-                    *reinterpret_cast<float4 *>(w) = *reinterpret_cast<const float4 *>(v0 + plane + idx);
-                    *reinterpret_cast<float4 *>(c) = *reinterpret_cast<const float4 *>(v0 + 2 * plane + idx);
-                    *reinterpret_cast<float4 *>(c3) = *reinterpret_cast<const float4 *>(v0 + 3 * plane + idx);
-                    *reinterpret_cast<float4 *>(c4) = *reinterpret_cast<const float4 *>(v0 + 4 * plane + idx);
+                    vol_load4(w, v0 + plane + idx);
+                    vol_load4(c, v0 + 2 * plane + idx);
+                    vol_load4(c3, v0 + 3 * plane + idx);
+                    vol_load4(c4, v0 + 4 * plane + idx);
                 }
             } else {
-                t[0] = v0[idx];
+                t[0] = vol_load1(v0 + idx);
                 if (!ACCUM) {
-                    w[0] = v1[idx];
-                    c[0] = v2[idx];
+                    w[0] = vol_load1(v1 + idx);
+                    c[0] = vol_load1(v2 + idx);
                 } else {
-                    w[0] = v0[plane + idx];
-                    c[0] = v0[2 * plane + idx];
-                    c3[0] = v0[3 * plane + idx];
-                    c4[0] = v0[4 * plane + idx];
+                    w[0] = vol_load1(v0 + plane + idx);
+                    c[0] = vol_load1(v0 + 2 * plane + idx);
+                    c3[0] = vol_load1(v0 + 3 * plane + idx);
+                    c4[0] = vol_load1(v0 + 4 * plane + idx);
                 }
             }
         }
-        // next item's geometry + gathers, overlapping the volume loads above
-        ItemState<VPT> nxt;
-        if (has_next) issue_item<VPT, RM>(p, next_item, lane, nxt);
         if (any) {
             if (!ACCUM) {
 #pragma unroll
@@ -457,32 +477,29 @@ __global__ __launch_bounds__(256) void integrate_kernel(FrameParams p, const Wor
                     }
             }
             if (VPT == 4) {
-                *reinterpret_cast<float4 *>(v0 + idx) = *reinterpret_cast<float4 *>(t);
+                vol_store4(v0 + idx, t);
                 if (!ACCUM) {
-                    *reinterpret_cast<float4 *>(v1 + idx) = *reinterpret_cast<float4 *>(w);
-                    *reinterpret_cast<float4 *>(v2 + idx) = *reinterpret_cast<float4 *>(c);
+                    vol_store4(v1 + idx, w);
+                    vol_store4(v2 + idx, c);
                 } else {
-                    *reinterpret_cast<float4 *>(v0 + plane + idx) = *reinterpret_cast<float4 *>(w);
-                    *reinterpret_cast<float4 *>(v0 + 2 * plane + idx) = *reinterpret_cast<float4 *>(c);
-                    *reinterpret_cast<float4 *>(v0 + 3 * plane + idx) = *reinterpret_cast<float4 *>(c3);
-                    *reinterpret_cast<float4 *>(v0 + 4 * plane + idx) = *reinterpret_cast<float4 *>(c4);
+                    vol_store4(v0 + plane + idx, w);
+                    vol_store4(v0 + 2 * plane + idx, c);
+                    vol_store4(v0 + 3 * plane + idx, c3);
+                    vol_store4(v0 + 4 * plane + idx, c4);
                 }
             } else {
-                v0[idx] = t[0];
+                vol_store1(v0 + idx, t[0]);
                 if (!ACCUM) {
-                    v1[idx] = w[0];
-                    v2[idx] = c[0];
+                    vol_store1(v1 + idx, w[0]);
+                    vol_store1(v2 + idx, c[0]);
                 } else {
-                    v0[plane + idx] = w[0];
-                    v0[2 * plane + idx] = c[0];
-                    v0[3 * plane + idx] = c3[0];
-                    v0[4 * plane + idx] = c4[0];
+                    vol_store1(v0 + plane + idx, w[0]);
+                    vol_store1(v0 + 2 * plane + idx, c[0]);
+                    vol_store1(v0 + 3 * plane + idx, c3[0]);
+                    vol_store1(v0 + 4 * plane + idx, c4[0]);
                 }
             }
         }
-        if (!has_next) break;
-        cur = nxt;
-        it = it_next;
     }
     if (COUNT) {
         for (int off = 32; off > 0; off >>= 1) n_upd += __shfl_xor((int)n_upd, off);
@@ -600,9 +617,9 @@ static int launch_integrate(hive_tsdf *v, float *accum, int H, int W, const floa
     const long long rows = (long long)p.X * p.Y;
     float *a0 = ACCUM ? accum : v->d_tsdf;
     const bool vec = (p.Z % 4 == 0) && (((uintptr_t)a0 | (uintptr_t)v->d_weight | (uintptr_t)v->d_color) % 16 == 0);
-    // work list: at most ceil(Z / chunk) items per row
-    const long long chunk = vec ? 256 : 64;
-    const size_t max_items = (size_t)rows * (size_t)((p.Z + chunk - 1) / chunk);
+    // work list: at most ceil(Z / segment) items per row
+    const long long seg = SEG_LANES * (vec ? 4 : 1);
+    const size_t max_items = (size_t)rows * (size_t)((p.Z + seg - 1) / seg);
     int rc = hive_reserve_device(ctx, &ctx->d_scratch, &ctx->scratch_bytes, max_items * sizeof(WorkItem));
     if (rc) return rc;
     WorkItem *items = (WorkItem *)ctx->d_scratch;
@@ -612,9 +629,10 @@ static int launch_integrate(hive_tsdf *v, float *accum, int H, int W, const floa
         hipLaunchKernelGGL(build_worklist_kernel<4>, wl_grid, dim3(1024), 0, ctx->stream, p, items, n_items);
     else
         hipLaunchKernelGGL(build_worklist_kernel<1>, wl_grid, dim3(1024), 0, ctx->stream, p, items, n_items);
-    // grid-stride sweep: 4 x the resident wave count (8 workgroups of 4 waves per CU = 8 waves per SIMD at
-    // <= 64 VGPRs), so that the dispatcher evens out items of unequal cost (measured: 120 -> 110 us at 512^3)
-    const dim3 grid((unsigned)std::min<long long>((long long)ctx->num_cus * 8 * 4, (long long)((max_items + 3) / 4))), block(256);
+    // grid-stride sweep: 4 x the resident wave count (8 workgroups of 4 waves per CU), so that the dispatcher
+    // evens out trips of unequal cost (measured: 120 -> 110 us at 512^3); a wave takes 64 / SEG_LANES items per trip
+    const long long max_trips = (long long)((max_items + 64 / SEG_LANES - 1) / (64 / SEG_LANES));
+    const dim3 grid((unsigned)std::min<long long>((long long)ctx->num_cus * 8 * 4, (max_trips + 3) / 4)), block(256);
     if ((rc = hive_time_begin(ctx))) return rc;
 #define HIVE_LAUNCH(VPT, RM, CNT)                                                                                      \
     hipLaunchKernelGGL((integrate_kernel<VPT, RM, CNT, ACCUM>), grid, block, 0, ctx->stream, p, items, n_items, a0, \
