@@ -10,6 +10,11 @@ from hive_amd import _lib
 from hive_amd.dpt import transforms as dpt_transforms
 from hive_amd.dpt.models import DPTDepthModel
 
+# The ResNet stem / RefineNet convolutions run on MIOpen.  Its find step times every applicable solver the
+# first time a shape is seen, including its naive reference convolution -- 0.1-1.4 s per call at 640 x 480
+# (30 s of a cold start).  That solver can never win, so it is taken out of the search.
+os.environ.setdefault("MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_FWD", "0")
+
 NET_W, NET_H = 640, 480  # hard-coded in the reference (dataset_adaptors.py:1363-1364)
 DPT_SCALE, DPT_SHIFT = 0.000305, 0.1378  # NYU fine-tuned DPT-Hybrid (dataset_adaptors.py:1368-1369)
 

@@ -14,12 +14,16 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
-stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)
+def newest(sub, pattern):
+    """gpurun merges every call's files into the same directory: only the latest run counts"""
+    files = glob.glob(os.path.join(src, sub, "**", pattern), recursive=True)
+    return [max(files, key=os.path.getmtime)] if files else []
+stats = newest("trace", "*kernel_stats.csv")
 if stats:
     shutil.copy(stats[0], os.path.join(dst, f"{tag}_kernel_stats.csv"))
 def mean_counter(sub, counter, pat):
     vals = []
-    for f in glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True):
+    for f in newest(sub, "*counter_collection.csv"):
         for row in csv.DictReader(open(f)):
             if row["Counter_Name"] == counter and pat in row["Kernel_Name"] and "true" not in row["Kernel_Name"].split(">")[0].split(",")[2]:
                 vals.append(float(row["Counter_Value"]))
