@@ -1,9 +1,14 @@
 #!/bin/bash
-# kernel-level steady-state profile of the bench step: 43 steps so that per-step kernels have >= 40 calls
+# Steady-state kernel profile of the bench step: two rocprofv3 --kernel-trace --stats runs that differ only in
+# --steps (S1 < S2); tools/steady_diff.py subtracts them, which removes MIOpen's find step and every other
+# one-off of the warm-up.  Usage (GPU box): tools/steady_profile.sh <tag> [batch]
 set -e
 OUT=$GRAFT_REPO_ROOT/gpurun_out/steady_$1
-mkdir -p $OUT
+rm -rf $OUT && mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --steps 40 --warmup 3 --batch ${2:-8} > $OUT/trace.log 2>&1
-find $OUT/trace -name "*kernel_trace.csv" -delete
-tail -1 $OUT/trace.log | cut -c1-200
+python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --steps 4 --warmup 2 --batch ${2:-16} > $OUT/warm.log 2>&1
+for S in 10 30; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/s$S -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --steps $S --warmup 2 --batch ${2:-16} > $OUT/s$S.log 2>&1
+  find $OUT/s$S -name "*kernel_trace.csv" -delete
+done
+tail -1 $OUT/s30.log | cut -c1-200
