@@ -1,0 +1,266 @@
+// Depth head of DPT, second half, as ONE kernel (isl-org/DPT `DPTDepthModel.scratch.output_conv[1:]`, reached from
+// dpt.models.DPTDepthModel.forward -- /root/reference/hive/dataset_adaptors.py:1419):
+//
+//   Interpolate(x2, bilinear, align_corners=True) -> Conv3x3(128 -> 32) + bias -> ReLU -> Conv1x1(32 -> 1) + bias
+//   -> ReLU -> depth = 1 / max(scale * x + shift, 1e-8) -> uint16-mm hand-off
+//
+// Unfused this is the largest activation of the network: the upsampled [B][480][640][128] map (1.26 GB at
+// B = 16) written once and read once, a 362-GFLOP convolution with only 32 output channels (MIOpen: 1.08 ms,
+// 335 TFLOP/s) and a pass over its output.  Fused, the kernel reads the [B][240][320][128] input (79 MB) and
+// writes 6 bytes per pixel; it is bound by MFMA issue / LDS operand bandwidth:
+//
+//   * workgroup = 8 x 16 output pixels, 4 waves, persistent over the tile list;
+//   * the low-resolution patch (7 x 11 pixels) is staged in LDS with coalesced 16-byte loads, the 10 x 18
+//     upsampled patch (halo for the 3x3 taps, zero outside the image) is built from it once, rounded to bf16
+//     exactly as the stand-alone upsampling kernel rounds its output;
+//   * D^T[oc][px] = sum_tap W_tap[oc][ic] X_tap[ic][px] on v_mfma_f32_32x32x16_bf16: output channels are the rows
+//     (A operand), pixels the columns (B operand), so a lane ends up with 16 of the 32 channels of ONE pixel and
+//     the 1x1 convolution is a register sum plus one cross-half shuffle;
+//   * the 128 input channels are split over the 4 waves (32 each): a wave keeps its 18 weight fragments (9 taps
+//     x 2 k-steps) in registers for the whole kernel and reads only pixel operands from LDS -- 1 KiB per MFMA,
+//     which is the LDS bandwidth of a CU at full MFMA rate, so weights must not come from LDS as well;
+//     the 4 partial sums per pixel tile are exchanged through LDS once per tile;
+//   * pixel stride in LDS is 272 bytes (256 + 16): 8 consecutive pixels x 16 bytes then cover 32 distinct banks.
+#include "hive_internal.hpp"
+
+#include <algorithm>
+
+typedef __bf16 bf16;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int TH = 8, TW = 16;                 // output tile
+constexpr int UP_H = TH + 2, UP_W = TW + 2;    // upsampled patch with the 3x3 halo
+constexpr int LO_H = 7, LO_W = 11;             // low-resolution patch that feeds it (scale < 0.5)
+constexpr int CIN = 128, COUT = 32;
+constexpr int PIX = 272;                       // bytes per pixel in LDS
+constexpr int UP_BYTES = 49152;                // >= UP_H * UP_W * PIX (48960) and >= the partial-sum exchange (4*3*16*64*4)
+constexpr int LO_BYTES = LO_H * LO_W * PIX;    // 20944
+static_assert(UP_H * UP_W * PIX <= UP_BYTES, "upsampled patch does not fit");
+
+struct HeadParams {
+    const bf16 *x;      // [N][H][W][128]
+    const bf16 *w3;     // [9][32][128]  (tap = ky * 3 + kx, output channel, input channel)
+    float b3[COUT];     // bias of the 3x3 convolution
+    float w1[COUT];     // 1x1 convolution
+    float b1, scale, shift;
+    int non_negative, invert;
+    int N, H, W;        // low-resolution input; output is 2H x 2W
+    float depth_scale, max_depth;
+    float *out_depth;   // [N][2H][2W] or null
+    uint16_t *out_mm;   // or null
+    float *out_m;       // or null
+};
+
+__device__ __forceinline__ bf16x8 lds_read8(const unsigned char *base, int byte_off) {
+    return *reinterpret_cast<const bf16x8 *>(base + byte_off);
+}
+
+__global__ __launch_bounds__(256, 2) void head_conv_kernel(HeadParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char *up = smem;             // upsampled patch, later the partial-sum exchange
+    unsigned char *lo = smem + UP_BYTES;  // low-resolution patch
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nn = lane & 31, hh = lane >> 5;
+    const int OH = 2 * p.H, OW = 2 * p.W;
+    const int tiles_x = (OW + TW - 1) / TW, tiles_y = (OH + TH - 1) / TH;
+    const int n_tiles = p.N * tiles_y * tiles_x;  // < 2^31: checked on the host
+    const float sh = OH > 1 ? (float)(p.H - 1) / (float)(OH - 1) : 0.f;
+    const float sw = OW > 1 ? (float)(p.W - 1) / (float)(OW - 1) : 0.f;
+
+    // this wave's weight fragments: input channels [32 * wave, 32 * wave + 32), lane = (output channel nn, k half hh)
+    bf16x8 wf[9][2];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            wf[t][ks] = *reinterpret_cast<const bf16x8 *>(p.w3 + ((size_t)(t * COUT + nn) * CIN + 32 * wave + 16 * ks + 8 * hh));
+    // epilogue constants (bias of the 3x3 convolution, 1x1 weights) live in LDS: 32 registers less in the MFMA loop
+    float *tab = reinterpret_cast<float *>(smem + UP_BYTES + LO_BYTES);
+    if (tid < COUT) {
+        tab[tid] = p.b3[tid];
+        tab[COUT + tid] = p.w1[tid];
+    }
+
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int tx = tile % tiles_x;
+        const int ty = (tile / tiles_x) % tiles_y;
+        const int n = tile / (tiles_x * tiles_y);
+        const int R0 = ty * TH - 1, C0 = tx * TW - 1;  // output coordinates of the patch origin
+        const int lo_y0 = (int)(sh * (float)max(R0, 0)), lo_x0 = (int)(sw * (float)max(C0, 0));
+        // (a) low-resolution patch -> LDS (rows / columns past the image edge are clamped duplicates: exactly what
+        // align_corners' i1 = min(i0 + 1, size - 1) reads).  Prefetching it a tile ahead through registers was
+        // measured slower (20 more live VGPRs spill in the MFMA phase); the second workgroup of the CU covers the latency.
+        const bf16 *img = p.x + (size_t)n * p.H * p.W * CIN;
+        for (int item = tid; item < LO_H * LO_W * 16; item += 256) {
+            const int v = item & 15, q = item >> 4;
+            const int gy = min(lo_y0 + q / LO_W, p.H - 1), gx = min(lo_x0 + q % LO_W, p.W - 1);
+            const uint4 raw = *reinterpret_cast<const uint4 *>(img + ((size_t)gy * p.W + gx) * CIN + v * 8);
+            *reinterpret_cast<uint4 *>(lo + q * PIX + v * 16) = raw;
+        }
+        __syncthreads();
+        // (b) upsampled patch: PyTorch's align_corners=True formula in float, evaluated as upsample2x_kernel does,
+        //   y = h0 * (w0 * v00 + w1 * v01) + h1 * (w0 * v10 + w1 * v11),
+        // but a thread owns one (patch column, 8-channel vector) and walks down the rows, so the horizontal terms
+        // t(r) = w0 * v(r, x0) + w1 * v(r, x1) of a low-resolution row r are computed once and kept in registers for
+        // the two or three output rows that use them (same values, 43 % fewer flops and LDS reads than per pixel)
+        const int rt = (tid + 64 * (tile & 3)) & 255;  // the 32 left-over pairs rotate over the waves
+        for (int pr = rt; pr < UP_W * 16; pr += 256) {
+            const int v = pr & 15, ux = pr >> 4, ox = C0 + ux;
+            const bool col_ok = ox >= 0 && ox < OW;
+            const float fx = sw * (float)ox;
+            const int x0 = (int)fx, x1 = min(x0 + 1, p.W - 1);
+            const float w1 = fx - (float)x0, w0 = 1.f - w1;
+            const int c0 = col_ok ? (x0 - lo_x0) * PIX + v * 16 : 0, c1 = col_ok ? (x1 - lo_x0) * PIX + v * 16 : 0;
+            unsigned char *dst = up + ux * PIX + v * 16;
+            const uint4 zero = make_uint4(0u, 0u, 0u, 0u);  // zero padding of the convolution
+            int uy = 0;                                      // patch row to emit next (uniform over the workgroup)
+            while (uy < UP_H && R0 + uy < 0) {               // rows above the image
+                *reinterpret_cast<uint4 *>(dst + uy * UP_W * PIX) = zero;
+                ++uy;
+            }
+            float ta[8], tb[8];
+            {
+                const bf16x8 a0 = lds_read8(lo, c0), a1 = lds_read8(lo, c1);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ta[j] = w0 * (float)a0[j] + w1 * (float)a1[j];
+            }
+#pragma unroll
+            for (int r = 0; r < LO_H - 1; ++r) {  // low-resolution rows r, r + 1 (clamped duplicates past the image edge)
+                const bf16x8 a0 = lds_read8(lo, (r + 1) * LO_W * PIX + c0), a1 = lds_read8(lo, (r + 1) * LO_W * PIX + c1);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) tb[j] = w0 * (float)a0[j] + w1 * (float)a1[j];
+                while (uy < UP_H && R0 + uy < OH) {  // the output rows whose upper source row is r: at most three
+                    const float fy = sh * (float)(R0 + uy);
+                    const int y0 = (int)fy;
+                    if (__builtin_amdgcn_readfirstlane(y0 - lo_y0) != r) break;
+                    const float h1 = fy - (float)y0, h0 = 1.f - h1;
+                    uint4 packed = zero;
+                    if (col_ok) {
+                        bf16x8 o;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) o[j] = (bf16)(h0 * ta[j] + h1 * tb[j]);
+                        packed = *reinterpret_cast<const uint4 *>(&o);
+                    }
+                    *reinterpret_cast<uint4 *>(dst + uy * UP_W * PIX) = packed;
+                    ++uy;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ta[j] = tb[j];
+            }
+            while (uy < UP_H) {  // rows below the image
+                *reinterpret_cast<uint4 *>(dst + uy * UP_W * PIX) = zero;
+                ++uy;
+            }
+        }
+        __syncthreads();
+        // (c) 9 taps x 2 k-steps x 4 pixel tiles of 32 (tile m = output rows 2m, 2m+1 of the 8 x 16 patch)
+        f32x16 acc[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[m][v] = 0.f;
+        const int pix_base = ((nn >> 4) * UP_W + (nn & 15)) * PIX + (32 * wave + 8 * hh) * 2;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int tap_off = ((t / 3) * UP_W + (t % 3)) * PIX;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const bf16x8 xf = lds_read8(up, pix_base + tap_off + 2 * m * UP_W * PIX + ks * 32);
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[t][ks], xf, acc[m], 0, 0, 0);
+                }
+        }
+        __syncthreads();  // every wave is done reading the patch: its space becomes the exchange buffer
+        // (d) wave w owns pixel tile w: the other three waves hand it their channel-partial sums
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        f32x4 *part = reinterpret_cast<f32x4 *>(up);
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+            if (wave != m) {
+                const int slot = wave < m ? wave : wave - 1;
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    part[((m * 3 + slot) * 4 + g) * 64 + lane] = f32x4{acc[m][4 * g], acc[m][4 * g + 1], acc[m][4 * g + 2], acc[m][4 * g + 3]};
+            }
+        __syncthreads();
+        f32x16 mine = wave == 0 ? acc[0] : wave == 1 ? acc[1] : wave == 2 ? acc[2] : acc[3];
+        float s = 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {  // registers 4g .. 4g+3 = output channels 8g + 4hh .. + 3 of pixel nn
+            f32x4 sum = f32x4{mine[4 * g], mine[4 * g + 1], mine[4 * g + 2], mine[4 * g + 3]};
+#pragma unroll
+            for (int slot = 0; slot < 3; ++slot) sum += part[((wave * 3 + slot) * 4 + g) * 64 + lane];
+            const f32x4 b3q = *reinterpret_cast<const f32x4 *>(tab + 8 * g + 4 * hh);
+            const f32x4 w1q = *reinterpret_cast<const f32x4 *>(tab + COUT + 8 * g + 4 * hh);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s += fmaxf(sum[e] + b3q[e], 0.f) * w1q[e];
+        }
+        s += __shfl_xor(s, 32);
+        const int oy = ty * TH + 2 * wave + (nn >> 4), ox = tx * TW + (nn & 15);
+        if (hh == 0 && oy < OH && ox < OW) {
+            float acc1 = s + p.b1;
+            if (p.non_negative) acc1 = fmaxf(acc1, 0.f);
+            float depth = acc1;
+            if (p.invert) depth = 1.0f / fmaxf(p.scale * acc1 + p.shift, 1e-8f);
+            const size_t o = ((size_t)n * OH + oy) * OW + ox;
+            if (p.out_depth) p.out_depth[o] = depth;
+            if (p.out_mm || p.out_m) {
+                const uint16_t mm = (uint16_t)(int)fminf(fmaxf(depth * 1000.0f, 0.0f), 65535.0f);
+                float m = p.depth_scale * (float)mm;
+                if (m > p.max_depth) m = 0.0f;
+                if (p.out_mm) p.out_mm[o] = mm;
+                if (p.out_m) p.out_m[o] = m;
+            }
+        }
+        __syncthreads();  // exchange buffer and low-resolution patch are free again
+    }
+}
+
+}  // namespace
+
+extern "C" int hive_dpt_head_fused(hive_ctx *ctx, const void *d_x, int dtype, int N, int H, int W, int C_in, int C_mid,
+                                   const void *d_w3, const float *h_b3, const float *h_w1, float b1, int non_negative, int invert,
+                                   float scale, float shift, float *d_depth, float depth_scale, float max_depth,
+                                   uint16_t *d_out_mm, float *d_out_m) {
+    if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
+    HIVE_REQUIRE(ctx, d_x && d_w3 && h_b3 && h_w1, "dpt_head_fused: NULL argument");
+    HIVE_REQUIRE(ctx, dtype == HIVE_BF16, "dpt_head_fused: bf16 only (use hive_dpt_head_tail behind a library convolution for f16)");
+    HIVE_REQUIRE(ctx, C_in == CIN && C_mid == COUT, "dpt_head_fused: built for 128 -> 32 channels, got %d -> %d", C_in, C_mid);
+    HIVE_REQUIRE(ctx, N > 0 && H > 1 && W > 1 && (long long)N * H * W < (1ll << 28), "dpt_head_fused: bad shape N=%d H=%d W=%d", N, H, W);
+    HIVE_REQUIRE(ctx, d_depth || d_out_mm || d_out_m, "dpt_head_fused: no output requested");
+    HeadParams p;
+    p.x = (const bf16 *)d_x;
+    p.w3 = (const bf16 *)d_w3;
+    for (int i = 0; i < COUT; ++i) {
+        p.b3[i] = h_b3[i];
+        p.w1[i] = h_w1[i];
+    }
+    p.b1 = b1;
+    p.scale = scale;
+    p.shift = shift;
+    p.non_negative = non_negative;
+    p.invert = invert;
+    p.N = N;
+    p.H = H;
+    p.W = W;
+    p.depth_scale = depth_scale;
+    p.max_depth = max_depth;
+    p.out_depth = d_depth;
+    p.out_mm = d_out_mm;
+    p.out_m = d_out_m;
+    static bool attr_set[64] = {};
+    const int lds = UP_BYTES + LO_BYTES + 2 * COUT * (int)sizeof(float);
+    if (ctx->device >= 64 || !attr_set[ctx->device]) {
+        HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)head_conv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        if (ctx->device < 64) attr_set[ctx->device] = true;
+    }
+    const long long tiles = (long long)N * ((2 * H + TH - 1) / TH) * ((2 * W + TW - 1) / TW);
+    const dim3 grid((unsigned)std::min<long long>(tiles, (long long)ctx->num_cus * 2));
+    hipLaunchKernelGGL(head_conv_kernel, grid, dim3(256), lds, ctx->stream, p);
+    HIVE_CHECK_HIP(ctx, hipGetLastError());
+    return HIVE_OK;
+}

@@ -431,6 +431,7 @@ class DPTDepthModel(DPT):
         )
         super().__init__(head, features=features, engine=engine)
         self.scale, self.shift, self.invert = scale, shift, invert
+        self.fused_head = True  # HIP engine, bf16: output_conv[1:] + the depth tail as one kernel (csrc/dpt_head.hip)
         if path is not None:
             self.load(path)
 
@@ -464,19 +465,35 @@ class DPTDepthModel(DPT):
         if self.engine == "hip" and x.is_cuda and x.dtype in (torch.float16, torch.bfloat16):
             from hive_amd import _lib
             ctx = _lib.default_context(x.device.index or 0)
-            # conv 128 -> 32 without its bias (MIOpen); bias + ReLU + conv 32 -> 1 + inversion + hand-off in one HIP kernel
             pre = head[2]
+            key = (conv.weight.data_ptr(), conv.weight._version, conv.bias._version, pre.bias._version, pre.weight._version)
+            if getattr(self, "_tail_host", (None,))[0] != key:  # one D2H per set of weights, not per forward
+                self._tail_host = (key, conv.weight.detach().float().reshape(-1).cpu().numpy(), float(conv.bias.detach().float().item()),
+                                   pre.bias.detach().float().cpu().numpy(),
+                                   pre.weight.detach().permute(2, 3, 0, 1).contiguous())  # [ky][kx][out][in] for the fused head
+            weight, bias, pre_bias, w3 = self._tail_host[1:5]
+            fused = (self.fused_head and x.dtype == torch.bfloat16 and isinstance(head[1], Interpolate) and head[1].scale_factor == 2
+                     and head[1].mode == "bilinear" and head[1].align_corners and isinstance(head[3], nn.ReLU)
+                     and tuple(pre.weight.shape) == (32, 128, 3, 3) and pre.stride == (1, 1) and pre.padding == (1, 1))
+            if fused:
+                # Interpolate + conv 128 -> 32 + ReLU + conv 32 -> 1 + inversion + hand-off: one HIP kernel (csrc/dpt_head.hip)
+                lo = head[0](self.forward_decoder(x)).contiguous(memory_format=torch.channels_last)
+                b, c, h, w = lo.shape
+                depth = torch.empty((b, 2 * h, 2 * w), dtype=torch.float32, device=lo.device)
+                mm = torch.empty((b, 2 * h, 2 * w), dtype=torch.int16, device=lo.device) if handoff else None
+                m = torch.empty((b, 2 * h, 2 * w), dtype=torch.float32, device=lo.device) if handoff else None
+                ctx.check(ctx.lib.hive_dpt_head_fused(
+                    ctx.handle, lo.data_ptr(), _lib.BF16, b, h, w, c, 32, w3.data_ptr(), pre_bias.ctypes.data, weight.ctypes.data, bias,
+                    int(non_negative), int(bool(self.invert)), float(self.scale), float(self.shift), depth.data_ptr(), 1.0 / 1000.0,
+                    float(handoff[0]) if handoff else 0.0, _lib.ptr(mm), _lib.ptr(m)))
+                return (depth, mm, m) if handoff else depth
+            # conv 128 -> 32 without its bias (MIOpen); bias + ReLU + conv 32 -> 1 + inversion + hand-off in one HIP kernel
             feat = F.conv2d(head[1](head[0](self.forward_decoder(x))), pre.weight, None, pre.stride, pre.padding)
             feat = feat.contiguous(memory_format=torch.channels_last)
             b, c, h, w = feat.shape
             depth = torch.empty((b, h, w), dtype=torch.float32, device=feat.device)
             mm = torch.empty((b, h, w), dtype=torch.int16, device=feat.device) if handoff else None
             m = torch.empty((b, h, w), dtype=torch.float32, device=feat.device) if handoff else None
-            key = (conv.weight.data_ptr(), conv.weight._version, conv.bias._version, pre.bias._version)
-            if getattr(self, "_tail_host", (None,))[0] != key:  # one D2H per set of weights, not per forward
-                self._tail_host = (key, conv.weight.detach().float().reshape(-1).cpu().numpy(), float(conv.bias.detach().float().item()),
-                                   pre.bias.detach().float().cpu().numpy())
-            weight, bias, pre_bias = self._tail_host[1], self._tail_host[2], self._tail_host[3]
             ctx.check(ctx.lib.hive_dpt_head_tail(
                 ctx.handle, feat.data_ptr(), _lib.BF16 if feat.dtype == torch.bfloat16 else _lib.F16, b * h * w, c,
                 pre_bias.ctypes.data, 1, weight.ctypes.data, bias, int(non_negative), int(bool(self.invert)),
