@@ -70,7 +70,7 @@ SIGNATURES = {
     "hive_dpt_preprocess": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_float, c_int, c_void_p]),
     "hive_dpt_head_tail": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p, c_int, c_void_p, c_float, c_int, c_int, c_float,
                                    c_float, c_void_p, c_float, c_float, c_void_p, c_void_p]),
-    "hive_dpt_head_fused": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float,
+    "hive_dpt_head_fused": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float,
                                     c_int, c_int, c_float, c_float, c_void_p, c_float, c_float, c_void_p, c_void_p]),
     "hive_nhwc_group_norm": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_int,
                                      c_void_p]),

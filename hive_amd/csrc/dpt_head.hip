@@ -45,6 +45,7 @@ struct HeadParams {
     const bf16 *w3;     // [9][32][128]  (tap = ky * 3 + kx, output channel, input channel)
     float b3[COUT];     // bias of the 3x3 convolution
     float w1[COUT];     // 1x1 convolution
+    const float *b0;    // device, [128]: bias of the convolution that produced x, added on load (or null)
     float b1, scale, shift;
     int non_negative, invert;
     int N, H, W;        // low-resolution input; output is 2H x 2W
@@ -97,7 +98,15 @@ __global__ __launch_bounds__(256, 2) void head_conv_kernel(HeadParams p) {
         for (int item = tid; item < LO_H * LO_W * 16; item += 256) {
             const int v = item & 15, q = item >> 4;
             const int gy = min(lo_y0 + q / LO_W, p.H - 1), gx = min(lo_x0 + q % LO_W, p.W - 1);
-            const uint4 raw = *reinterpret_cast<const uint4 *>(img + ((size_t)gy * p.W + gx) * CIN + v * 8);
+            uint4 raw = *reinterpret_cast<const uint4 *>(img + ((size_t)gy * p.W + gx) * CIN + v * 8);
+            if (p.b0) {  // x + bias rounded to bf16, as the separate bias add of the unfused network rounds it
+                bf16x8 xv = *reinterpret_cast<const bf16x8 *>(&raw);
+                const float4 ba = *reinterpret_cast<const float4 *>(p.b0 + v * 8), bb = *reinterpret_cast<const float4 *>(p.b0 + v * 8 + 4);
+                const float bias8[8] = {ba.x, ba.y, ba.z, ba.w, bb.x, bb.y, bb.z, bb.w};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) xv[j] = (bf16)((float)xv[j] + bias8[j]);
+                raw = *reinterpret_cast<const uint4 *>(&xv);
+            }
             *reinterpret_cast<uint4 *>(lo + q * PIX + v * 16) = raw;
         }
         __syncthreads();
@@ -222,7 +231,7 @@ __global__ __launch_bounds__(256, 2) void head_conv_kernel(HeadParams p) {
 
 }  // namespace
 
-extern "C" int hive_dpt_head_fused(hive_ctx *ctx, const void *d_x, int dtype, int N, int H, int W, int C_in, int C_mid,
+extern "C" int hive_dpt_head_fused(hive_ctx *ctx, const void *d_x, const float *d_b0, int dtype, int N, int H, int W, int C_in, int C_mid,
                                    const void *d_w3, const float *h_b3, const float *h_w1, float b1, int non_negative, int invert,
                                    float scale, float shift, float *d_depth, float depth_scale, float max_depth,
                                    uint16_t *d_out_mm, float *d_out_m) {
@@ -235,6 +244,7 @@ extern "C" int hive_dpt_head_fused(hive_ctx *ctx, const void *d_x, int dtype, in
     HeadParams p;
     p.x = (const bf16 *)d_x;
     p.w3 = (const bf16 *)d_w3;
+    p.b0 = d_b0;
     for (int i = 0; i < COUT; ++i) {
         p.b3[i] = h_b3[i];
         p.w1[i] = h_w1[i];

@@ -229,9 +229,11 @@ int hive_dpt_head_tail(hive_ctx *ctx, const void *d_feat, int dtype, int64_t n_p
  * Conv3x3(C_in=128 -> C_mid=32) + bias -> ReLU -> Conv1x1(32 -> 1) + bias -> [ReLU] -> [1 / max(scale x + shift, 1e-8)]
  * -> optional uint16-mm hand-off, i.e. scratch.output_conv[1:] of DPTDepthModel plus the tail above
  * (hive/dataset_adaptors.py:1419, 1432-1433).  d_x: channels-last [N][H][W][C_in] (output of output_conv[0]);
+ * d_b0 (optional, device, f32 [C_in]): bias of output_conv[0], added to d_x on load (x + b rounded to bf16 first, as the
+ * separate bias add rounds it), so that convolution can run without its bias pass;
  * d_w3: the 3x3 weights on the device as [ky][kx][C_mid][C_in]; h_b3 [C_mid], h_w1 [C_mid] on the host.
  * Outputs are [N][2H][2W]; any of them may be NULL (not all). */
-int hive_dpt_head_fused(hive_ctx *ctx, const void *d_x, int dtype, int N, int H, int W, int C_in, int C_mid,
+int hive_dpt_head_fused(hive_ctx *ctx, const void *d_x, const float *d_b0, int dtype, int N, int H, int W, int C_in, int C_mid,
                         const void *d_w3, const float *h_b3, const float *h_w1, float b1, int non_negative, int invert,
                         float scale, float shift, float *d_depth, float depth_scale, float max_depth,
                         uint16_t *d_out_mm, float *d_out_m);

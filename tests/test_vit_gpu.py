@@ -229,7 +229,9 @@ def test_fused_head_matches_torch(gpu_ctx, N, H, W):
     # the stand-alone HIP upsampling kernel (itself tested against F.interpolate to one bf16 ulp) gives the bf16
     # map that the fused kernel builds tile by tile: same expression, same rounding
     from hive_amd.dpt import ops as dpt_ops
-    up = dpt_ops.upsample2x(x, engine="hip").float()
+    b0 = torch.randn(128, device="cuda") * 0.2  # bias of the producing convolution, folded into the kernel's load
+    xb = (x.float() + b0.reshape(1, 128, 1, 1)).bfloat16().contiguous(memory_format=torch.channels_last)
+    up = dpt_ops.upsample2x(xb, engine="hip").float()
     feat = F.relu(F.conv2d(up, w3.float(), b3.cuda(), padding=1))
     pre = F.relu(F.conv2d(feat, w1.cuda().reshape(1, 32, 1, 1), torch.tensor([b1], device="cuda"))).squeeze(1)
     ref = 1.0 / torch.clamp(scale * pre + shift, min=1e-8)
@@ -239,7 +241,7 @@ def test_fused_head_matches_torch(gpu_ctx, N, H, W):
     w3_dev = w3.permute(2, 3, 0, 1).contiguous()
     b3_np, w1_np = b3.numpy().astype("float32"), w1.numpy().astype("float32")
     ctx = gpu_ctx
-    ctx.check(ctx.lib.hive_dpt_head_fused(ctx.handle, x.data_ptr(), _lib.BF16, N, H, W, 128, 32, w3_dev.data_ptr(), b3_np.ctypes.data,
+    ctx.check(ctx.lib.hive_dpt_head_fused(ctx.handle, x.data_ptr(), b0.data_ptr(), _lib.BF16, N, H, W, 128, 32, w3_dev.data_ptr(), b3_np.ctypes.data,
                                           w1_np.ctypes.data, b1, 1, 1, scale, shift, depth.data_ptr(), 1.0 / 1000.0, 10.0,
                                           mm.data_ptr(), m.data_ptr()))
     torch.cuda.synchronize()
