@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""hive_vit_linear at the ViT shapes of the bench (B = 16 and 8): current tile choice vs HIVE_GEMM_TILE=big/std (set
+in the environment of the process), against torch (hipBLASLt).  Also checks the result against torch."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from hive_amd import _lib
+ctx = _lib.default_context(0); lib = ctx.lib
+def timed(fn, reps=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e-3
+print("HIVE_GEMM_TILE =", os.environ.get("HIVE_GEMM_TILE"))
+for (M, N, K, epi) in [(19456, 1536, 768, 0), (19456, 768, 768, 2), (19456, 3072, 768, 1), (19456, 768, 3072, 2), (9728, 3072, 768, 1), (9728, 768, 3072, 2), (4096, 4096, 4096, 0), (19456 - 100, 768, 768, 0)]:
+    A = torch.randn(M, K, device="cuda").bfloat16(); W = (torch.randn(N, K, device="cuda") / K ** 0.5).bfloat16(); b = torch.randn(N, device="cuda") * 0.1
+    R = torch.randn(M, N, device="cuda").bfloat16()
+    C = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    run = lambda: ctx.check(lib.hive_vit_linear(ctx.handle, A.data_ptr(), W.data_ptr(), b.data_ptr(), R.data_ptr() if epi == 2 else None, C.data_ptr(), M, N, K, epi))
+    dt = timed(run)
+    ref = A.float() @ W.float().t() + b
+    if epi == 1: ref = torch.nn.functional.gelu(ref)
+    if epi == 2: ref = ref + R.float()
+    err = (C.float() - ref).norm().item() / ref.norm().item()
+    dtt = timed(lambda: torch.nn.functional.linear(A, W))
+    print(f"M={M} N={N} K={K} epi={epi}: hive {dt*1e6:8.1f} us {2*M*N*K/dt/1e12:7.1f} TF/s (rel err {err:.2e}) | torch {dtt*1e6:8.1f} us {2*M*N*K/dtt/1e12:7.1f} TF/s")
