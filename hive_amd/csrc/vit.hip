@@ -125,13 +125,20 @@ __device__ __forceinline__ void stage_group(const bf16 *__restrict__ src, int ld
     __builtin_amdgcn_global_load_lds((const void *)g, (__attribute__((address_space(3))) void *)(tile + grp * 1024), 16, 0, 0);
 }
 
-// C tile = TM x 128, K-step 64, TM/32 waves (each a 64 x 64 sub-tile = 4 x 4 MFMA 16x16x32 accumulators).
-// 3-stage LDS ring: while stage kt is multiplied, stages kt+1 and kt+2 are in flight as LDS-DMA; per K-step
-// ONE raw s_barrier behind a counted s_waitcnt vmcnt (never 0 inside the loop), so the loads span barriers.
+// C tile = TM x 128, K-step 64, TM/32 waves (each a 64 x 64 sub-tile = 4 x 4 MFMA 16x16x32 accumulators), an
+// NST-stage LDS ring filled by LDS-DMA, ONE raw s_barrier per K-step.
+//   NST = 3: stages kt+1 and kt+2 in flight while kt is multiplied, counted s_waitcnt vmcnt (never 0 in the loop);
+//            144 KiB at TM = 256: one workgroup per CU.
+//   NST = 2 (used): 64 KiB at TM = 128, so TWO workgroups share a CU and one's prologue (first stage in flight) and
+//            epilogue (GELU, stores) overlap the other's K loop -- at K = 768 a tile is only 12 K-steps long and those
+//            ends were a third of its time.  Measured at M = 19456: 640 -> 664 (qkv), 491 -> 529 (proj), 689 -> 730
+//            (fc2) TFLOP/s against TM = 256 / NST = 3.  Also measured and not kept: 256 x 256 tiles with 128 x 128 per
+//            wave (half the LDS bytes per flop, one wave per SIMD: 570-680 TFLOP/s, register-staged variant spills),
+//            LDS-DMA pieces interleaved between the MFMAs (no change).
 // EPI_QKV here means "v^T tile": orientation A.W^T and the transposed store; q|k columns use EPI_BIAS.
-template <int EPI, int TM>
+template <int EPI, int TM, int NST>
 __global__ __launch_bounds__(TM * 2, 1) void gemm_kernel(GemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // 3 stages x (A tile TM x 64, W tile 128 x 64)
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // NST stages x (A tile TM x 64, W tile 128 x 64)
     constexpr int NWAVES = TM / 32;
     constexpr int A_GROUPS = TM / 8, GROUPS = A_GROUPS + 16, PER_WAVE = GROUPS / NWAVES;
     constexpr int STAGE_BYTES = GROUPS * 1024;
@@ -147,7 +154,7 @@ __global__ __launch_bounds__(TM * 2, 1) void gemm_kernel(GemmParams p) {
     const int m0 = (tile / tiles_n) * TM, n0 = (tile % tiles_n) * BN;
 
     auto issue_stage = [&](int kt) {
-        unsigned char *st = lds + (kt % 3) * STAGE_BYTES;
+        unsigned char *st = lds + (kt % NST) * STAGE_BYTES;
 #pragma unroll
         for (int j = 0; j < PER_WAVE; ++j) {
             const int g = wave + j * NWAVES;
@@ -166,17 +173,17 @@ __global__ __launch_bounds__(TM * 2, 1) void gemm_kernel(GemmParams p) {
 
     const int KT = p.K / BK;
     issue_stage(0);
-    if (KT > 1) issue_stage(1);
+    if (NST == 3 && KT > 1) issue_stage(1);
     const int fr = lane & 15, fq = lane >> 4;
     for (int kt = 0; kt < KT; ++kt) {
-        // my stage-kt loads have landed once at most one younger stage (PER_WAVE instructions) is outstanding
-        if (kt + 1 < KT)
+        // NST = 3: my stage-kt loads have landed once at most one younger stage (PER_WAVE instructions) is outstanding
+        if (NST == 3 && kt + 1 < KT)
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_WAVE) : "memory");
         else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();  // everyone's stage kt landed; everyone finished reading stage kt-1
-        if (kt + 2 < KT) issue_stage(kt + 2);  // overwrites the buffer of stage kt-1
-        const unsigned char *a_t = lds + (kt % 3) * STAGE_BYTES, *w_t = a_t + A_GROUPS * 1024;
+        if (kt + NST - 1 < KT) issue_stage(kt + NST - 1);  // overwrites the buffer of stage kt-1
+        const unsigned char *a_t = lds + (kt % NST) * STAGE_BYTES, *w_t = a_t + A_GROUPS * 1024;
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             bf16x8 af[4], wf[4];
@@ -506,26 +513,20 @@ static int launch_layernorm(hive_ctx *ctx, const bf16 *x, const float *g, const 
     return HIVE_OK;
 }
 
-template <int TM>
-static int launch_gemm_tm(hive_ctx *ctx, int epi, const GemmParams &p) {
-    const dim3 grid((unsigned)(((p.M + TM - 1) / TM) * (p.N / BN))), block(TM * 2);
-    const size_t lds_bytes = 3 * (TM / 8 + 16) * 1024;
+constexpr int GEMM_TM = 128, GEMM_NST = 2;
+constexpr size_t GEMM_LDS = (size_t)GEMM_NST * (GEMM_TM / 8 + 16) * 1024;
+
+static int launch_gemm(hive_ctx *ctx, int epi, const GemmParams &p) {
+    const dim3 grid((unsigned)(((p.M + GEMM_TM - 1) / GEMM_TM) * (p.N / BN))), block(GEMM_TM * 2);
     switch (epi) {
-        case EPI_BIAS: hipLaunchKernelGGL((gemm_kernel<EPI_BIAS, TM>), grid, block, lds_bytes, ctx->stream, p); break;
-        case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm_kernel<EPI_BIAS_GELU, TM>), grid, block, lds_bytes, ctx->stream, p); break;
-        case EPI_BIAS_RESIDUAL: hipLaunchKernelGGL((gemm_kernel<EPI_BIAS_RESIDUAL, TM>), grid, block, lds_bytes, ctx->stream, p); break;
-        case EPI_QKV: hipLaunchKernelGGL((gemm_kernel<EPI_QKV, TM>), grid, block, lds_bytes, ctx->stream, p); break;
+        case EPI_BIAS: hipLaunchKernelGGL((gemm_kernel<EPI_BIAS, GEMM_TM, GEMM_NST>), grid, block, GEMM_LDS, ctx->stream, p); break;
+        case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm_kernel<EPI_BIAS_GELU, GEMM_TM, GEMM_NST>), grid, block, GEMM_LDS, ctx->stream, p); break;
+        case EPI_BIAS_RESIDUAL: hipLaunchKernelGGL((gemm_kernel<EPI_BIAS_RESIDUAL, GEMM_TM, GEMM_NST>), grid, block, GEMM_LDS, ctx->stream, p); break;
+        case EPI_QKV: hipLaunchKernelGGL((gemm_kernel<EPI_QKV, GEMM_TM, GEMM_NST>), grid, block, GEMM_LDS, ctx->stream, p); break;
         default: return hive_fail(ctx, HIVE_ERR_INVALID, "gemm: unknown epilogue %d", epi);
     }
     HIVE_CHECK_HIP(ctx, hipGetLastError());
     return HIVE_OK;
-}
-
-static int launch_gemm(hive_ctx *ctx, int epi, const GemmParams &p) {
-    // 256-row tiles halve the operand traffic per flop; use them once they still fill the chip
-    const long long tiles256 = (long long)((p.M + 255) / 256) * (p.N / BN);
-    if (tiles256 >= (long long)ctx->num_cus * 3 / 4) return launch_gemm_tm<256>(ctx, epi, p);
-    return launch_gemm_tm<128>(ctx, epi, p);
 }
 
 static int launch_attention(hive_ctx *ctx, const AttnParams &p) {
@@ -537,21 +538,17 @@ static int launch_attention(hive_ctx *ctx, const AttnParams &p) {
 
 static bool g_gemm_attr_set[64] = {false};
 
-template <int EPI, int TM>
+template <int EPI>
 static hipError_t set_gemm_lds() {
-    return hipFuncSetAttribute((const void *)gemm_kernel<EPI, TM>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (TM / 8 + 16) * 1024);
+    return hipFuncSetAttribute((const void *)gemm_kernel<EPI, GEMM_TM, GEMM_NST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS);
 }
 
 static int ensure_gemm_attrs(hive_ctx *ctx) {
     if (ctx->device < 64 && g_gemm_attr_set[ctx->device]) return HIVE_OK;
-    HIVE_CHECK_HIP(ctx, (set_gemm_lds<EPI_BIAS, 128>()));
-    HIVE_CHECK_HIP(ctx, (set_gemm_lds<EPI_BIAS_GELU, 128>()));
-    HIVE_CHECK_HIP(ctx, (set_gemm_lds<EPI_BIAS_RESIDUAL, 128>()));
-    HIVE_CHECK_HIP(ctx, (set_gemm_lds<EPI_QKV, 128>()));
-    HIVE_CHECK_HIP(ctx, (set_gemm_lds<EPI_BIAS, 256>()));
-    HIVE_CHECK_HIP(ctx, (set_gemm_lds<EPI_BIAS_GELU, 256>()));
-    HIVE_CHECK_HIP(ctx, (set_gemm_lds<EPI_BIAS_RESIDUAL, 256>()));
-    HIVE_CHECK_HIP(ctx, (set_gemm_lds<EPI_QKV, 256>()));
+    HIVE_CHECK_HIP(ctx, (set_gemm_lds<EPI_BIAS>()));
+    HIVE_CHECK_HIP(ctx, (set_gemm_lds<EPI_BIAS_GELU>()));
+    HIVE_CHECK_HIP(ctx, (set_gemm_lds<EPI_BIAS_RESIDUAL>()));
+    HIVE_CHECK_HIP(ctx, (set_gemm_lds<EPI_QKV>()));
     if (ctx->device < 64) g_gemm_attr_set[ctx->device] = true;
     return HIVE_OK;
 }
