@@ -1,0 +1,60 @@
+"""The RCCL leg of the frame-sharded path on the one GPU a test box has: a single-rank ``nccl`` process group
+(``backend="nccl"`` is RCCL on ROCm) runs the very collectives ``bench.py --gpus N`` issues -- the chunked in-place
+all-reduce over views of the accumulator planes, the float64 MAX all-reduce of the timing and the barrier -- on
+device memory, and the accumulate -> all-reduce -> finalize path must reproduce the sequential volume within the
+tolerance stated in hive_amd/distributed.py.  (World size 2 is covered on CPU with gloo, tests/test_distributed_cpu.py.)"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def nccl_group():
+    import torch
+    import torch.distributed as dist
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29531")
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend="nccl", rank=0, world_size=1)
+    yield dist
+    dist.destroy_process_group()
+
+
+def test_rccl_collectives_on_accumulator_views(gpu_ctx, nccl_group):
+    import torch
+    from hive_amd import distributed as hdist, fusion, synthetic
+    dist = nccl_group
+    seq = synthetic.make_sequence(num_frames=4, height=120, width=160, yaw_step_deg=20.0)
+    bounds = synthetic.room_bounds()
+    ref = fusion.TSDFVolume(bounds, 0.04, ctx=gpu_ctx)
+    vol = fusion.TSDFVolume(bounds, 0.04, ctx=gpu_ctx)
+    accum = torch.empty(5 * vol.num_voxels, dtype=torch.float32, device="cuda")  # as DepthFusionStream(accumulate=True) allocates it
+    vol.accum_reset(accum)
+    for i in range(4):
+        ref.integrate(seq["color"][i], seq["depth"][i], seq["K"], seq["poses"][i])
+        vol.accum_integrate(accum, seq["color"][i], seq["depth"][i], seq["K"], seq["poses"][i])
+    before = accum.clone()
+    # the exact calls of allreduce_accumulators (it returns early for one rank): in-place SUM over chunk views
+    flat = accum.view(-1)
+    chunk = 1 << 20
+    for start in range(0, flat.numel(), chunk):
+        dist.all_reduce(flat[start:start + chunk], op=dist.ReduceOp.SUM)
+    torch.cuda.synchronize()
+    assert torch.equal(accum, before)  # one rank: the sum is the identity, bit for bit
+    hdist.barrier()
+    assert hdist.max_over_ranks(1.25, device=torch.device("cuda", 0)) == 1.25
+    hdist.fuse_sharded(vol, accum)
+    t_ref, c_ref = ref.get_volume()
+    t_acc, c_acc = vol.get_volume()
+    assert np.abs(t_ref - t_acc).max() <= 1e-5
+    observed = t_ref != 1.0
+    assert observed.any() and np.array_equal(observed, t_acc != 1.0)
+    for sh in (0, 8, 16):
+        a = (c_ref.astype(np.int64) >> sh) & 255
+        b = (c_acc.astype(np.int64) >> sh) & 255
+        assert np.abs(a - b).max() <= 2
