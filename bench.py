@@ -9,8 +9,8 @@
 A step = one batch of `--batch` synthetic frames, already resident in HBM as uint8, through
 preprocess -> DPT-Hybrid (random-init weights of the real architecture, bf16, HIP ViT engine) -> f32 head
 tail + uint16-mm hand-off -> TSDF integrate.  N > 1: frames are sharded over the ranks (weak scaling:
-fixed work per GPU), every rank accumulates into its own planes, and ONE all-reduce + finalize merges the
-shared static-scene volume inside the timed region.  Rank 0 prints one JSON line.
+fixed work per GPU), every rank fuses its shard into its own volume, and ONE all-reduce of the 5 accumulator planes
++ finalize merges the shared static-scene volume inside the timed region.  Rank 0 prints one JSON line.
 """
 import argparse
 import json
@@ -93,7 +93,7 @@ def main():
     ctx = _lib.default_context(dev_index)
     model = depth_mod.build_model(None, device=device, dtype=torch.bfloat16, engine=args.engine)
     volume = fusion.TSDFVolume(synthetic.room_bounds(), args.voxel, ctx=ctx)
-    stream = depth_mod.DepthFusionStream(model, volume, K, accumulate=(world > 1))
+    stream = depth_mod.DepthFusionStream(model, volume, K)  # every rank fuses its shard with the same kernels as one GPU
 
     def batch_indices(step):
         return [(step * B + j) % T for j in range(B)]
@@ -109,9 +109,7 @@ def main():
     for s in range(args.warmup):
         run_step(s)
     torch.cuda.synchronize()
-    # reset the volume / accumulators so that the timed job starts from an empty scene
-    if stream.accum is not None:
-        volume.accum_reset(stream.accum)
+    # reset the volume so that the timed job starts from an empty scene
     volume.reset()
     ctx.set_timing(True)
     hdist.barrier()
@@ -120,7 +118,7 @@ def main():
     for s in range(args.steps):
         run_step(args.warmup + s)
     if world > 1:
-        hdist.fuse_sharded(volume, stream)
+        hdist.fuse_sharded(volume)  # volumes -> sums, one all-reduce of the 5 planes, finalize
     torch.cuda.synchronize()
     hdist.barrier()
     elapsed = time.perf_counter() - t0
@@ -137,7 +135,7 @@ def main():
             for j, i in enumerate(idx):
                 n_upd.append(volume.integrate(frames_dev[i], depth_m[j], K, poses[i], return_n_updated=True))
     n_upd_mean = float(np.mean(n_upd))
-    bytes_per_voxel = 24 if world == 1 else 40  # 3 volumes r+w, or 5 accumulator planes r+w
+    bytes_per_voxel = 24  # 3 volumes read + written
     alg_bytes = bytes_per_voxel * n_upd_mean + 8.0 * H * W
     avg_kernel_s = kernel_ms / max(n_launch, 1) * 1e-3
     achieved = alg_bytes / avg_kernel_s / 1e9

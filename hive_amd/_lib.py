@@ -52,6 +52,7 @@ SIGNATURES = {
     "hive_tsdf_accum_integrate": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_float,
                                           c_int]),
     "hive_tsdf_accum_finalize": (c_int, [c_void_p, c_void_p]),
+    "hive_tsdf_accum_from_volume": (c_int, [c_void_p, c_void_p]),
     "hive_view_frustum": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "hive_unproject": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                c_void_p, c_void_p, c_int64, P(c_int64)]),

@@ -545,6 +545,22 @@ __global__ __launch_bounds__(256) void finalize_kernel(const float *__restrict__
     }
 }
 
+// running-average volumes -> accumulator planes [num, w, r, g, b] = [tsdf * w, w, r * w, g * w, b * w]: a rank that fused
+// its own frames with the ordinary integrate kernel contributes exactly these sums to the all-reduce
+__global__ __launch_bounds__(256) void to_accum_kernel(const float *__restrict__ tsdf, const float *__restrict__ weight,
+                                                       const float *__restrict__ color, long long n, float *__restrict__ acc) {
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const float w = weight[i];
+        const unsigned c = (unsigned)color[i];
+        acc[0 * n + i] = tsdf[i] * w;  // w == 0 (never observed): tsdf is 1, the sum is 0
+        acc[1 * n + i] = w;
+        acc[2 * n + i] = (float)(c & 255u) * w;
+        acc[3 * n + i] = (float)((c >> 8) & 255u) * w;
+        acc[4 * n + i] = (float)(c >> 16) * w;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 static int fill_volume(hive_tsdf *v) {
     hive_ctx *ctx = v->ctx;
@@ -837,6 +853,16 @@ int hive_tsdf_accum_integrate(hive_tsdf *vol, float *d_accum, const uint8_t *col
     const float *d_depth;
     if ((rc = prepare_frame(vol, color, depth, H, W, mem, &d_color, &d_depth))) return rc;
     return launch_integrate<true>(vol, d_accum, H, W, K, cam_pose, obs_weight, false);
+}
+
+int hive_tsdf_accum_from_volume(hive_tsdf *v, float *d_accum) {
+    if (!v) return hive_fail(nullptr, HIVE_ERR_INVALID, "vol is NULL");
+    hive_ctx *ctx = v->ctx;
+    HIVE_REQUIRE(ctx, d_accum, "accum_from_volume: d_accum is NULL");
+    const int blocks = (int)std::min<long long>((v->n + 255) / 256, 256 * 32);
+    hipLaunchKernelGGL(to_accum_kernel, dim3(blocks), dim3(256), 0, ctx->stream, v->d_tsdf, v->d_weight, v->d_color, (long long)v->n, d_accum);
+    HIVE_CHECK_HIP(ctx, hipGetLastError());
+    return HIVE_OK;
 }
 
 int hive_tsdf_accum_finalize(hive_tsdf *v, const float *d_accum) {

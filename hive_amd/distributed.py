@@ -2,8 +2,9 @@
 
 One process per GPU.  Frames are independent units for DPT, so rank r takes the contiguous block
 ``[r * T / W, (r + 1) * T / W)`` with no communication.  For the shared static-scene TSDF each rank
-integrates its frames into private accumulator planes ``[num, w, r, g, b]`` (sums, not running
-averages, so they commute); ONE all-reduce (RCCL over xGMI; ``backend="nccl"`` is RCCL on ROCm) over
+fuses its frames into its own volume and contributes the sums ``[num, w, r, g, b]`` (they commute, unlike
+running averages): either converted from its volumes at the end (``fuse_sharded(volume)``) or accumulated
+directly (``accum_integrate``); ONE all-reduce (RCCL over xGMI; ``backend="nccl"`` is RCCL on ROCm) over
 the 5 N floats merges them, after which every rank folds the sums into its volume.
 
 Parity (stated): the merged tsdf equals the sequential running average up to float32 re-association
@@ -66,10 +67,18 @@ def max_over_ranks(value, device="cpu"):
     return float(t.item())
 
 
-def fuse_sharded(volume, stream_or_accum):
-    """All-reduce the accumulators of a ``DepthFusionStream(accumulate=True)`` (or a raw accumulator tensor)
-    and fold them into ``volume`` on every rank."""
-    accum = stream_or_accum.accum if hasattr(stream_or_accum, "accum") else stream_or_accum
+def fuse_sharded(volume, stream_or_accum=None):
+    """Merge the per-rank fusions into the shared static-scene volume, on every rank: ONE all-reduce of the
+    accumulator planes, then ``finalize``.
+
+    ``stream_or_accum=None`` (what ``bench.py --gpus N`` does): every rank fused its own frames with the ordinary
+    ``integrate`` (same kernel and cost as on one GPU); its volumes are converted to the sums
+    ``[tsdf * w, w, r * w, g * w, b * w]`` here.  Otherwise: the accumulators of a ``DepthFusionStream(accumulate=True)``
+    or a raw accumulator tensor filled with ``accum_integrate`` (sums of the raw observations, 40 B / voxel / frame)."""
+    accum = getattr(stream_or_accum, "accum", stream_or_accum)
+    if accum is None:
+        accum = torch.empty(5 * volume.num_voxels, dtype=torch.float32, device="cuda")
+        volume.accum_from_volume(accum)
     allreduce_accumulators(accum)
     volume.accum_finalize(accum)
     return volume

@@ -200,6 +200,10 @@ class TSDFVolume:
         self._ctx.check(self._ctx.lib.hive_tsdf_accum_integrate(self._handle, ptr(accum), ptr(color), ptr(depth), depth.shape[0],
                                                                 depth.shape[1], ptr(K), ptr(pose), float(obs_weight), mem))
 
+    def accum_from_volume(self, accum):
+        """planes = [tsdf * w, w, r * w, g * w, b * w] of this volume (a rank's contribution to the all-reduce)."""
+        self._ctx.check(self._ctx.lib.hive_tsdf_accum_from_volume(self._handle, ptr(accum)))
+
     def accum_finalize(self, accum):
         self._ctx.check(self._ctx.lib.hive_tsdf_accum_finalize(self._handle, ptr(accum)))
 

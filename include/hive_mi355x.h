@@ -118,6 +118,11 @@ int hive_tsdf_copy_mesh(hive_tsdf *vol, float *verts, int32_t *faces, float *nor
 /* vertices of the same extraction in voxel units (before x voxel_size + origin), f32 [nv][3] */
 int hive_tsdf_copy_mesh_voxel_coords(hive_tsdf *vol, float *verts_vox);
 
+/* Alternative to accum_integrate for a rank that fused its own frames with hive_tsdf_integrate: convert its
+ * running-average volumes into the same sums, planes = [tsdf * w, w, r * w, g * w, b * w], ready for the all-reduce.
+ * (The per-rank colours are already rounded per frame, so the merged colour can differ from the sequential one by the
+ * same +-2 levels as with accum_integrate; tsdf and weight merge exactly up to float re-association.) */
+int hive_tsdf_accum_from_volume(hive_tsdf *vol, float *d_accum);
 /* Frame-sharded fusion (BASELINE.json north_star): a rank accumulates
  * num = sum(w_i*dist_i), w = sum(w_i), rgb = sum(w_i*c_i) for its frames into 5 float planes
  * [5][X][Y][Z]; planes are summed across ranks (RCCL all-reduce by the caller), then folded

@@ -176,6 +176,15 @@ class AccumVolume:
             _p(_c(cam_intr, np.float32).reshape(9)), _p(_c(cam_pose, np.float64).reshape(16)),
             ctypes.c_float(obs_weight), v.round_mode)
 
+    @staticmethod
+    def planes_from_volume(vol):
+        """[tsdf * w, w, r * w, g * w, b * w] of a running-average oracle volume, float32 products (what
+        ``hive_tsdf_accum_from_volume`` computes): a rank's contribution when it fused its frames the ordinary way."""
+        w = vol._weight.astype(np.float32)
+        c = vol._color.astype(np.uint32)
+        return np.stack([vol._tsdf * w, w, (c & 255).astype(np.float32) * w, ((c >> 8) & 255).astype(np.float32) * w,
+                         (c >> 16).astype(np.float32) * w]).astype(np.float32)
+
     def finalize(self, accum=None):
         v = self.vol
         a = _c(self.accum if accum is None else accum, np.float32)

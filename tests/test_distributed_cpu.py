@@ -18,7 +18,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, out_path):
+def _worker(rank, world, port, out_path, mode="accumulate"):
     sys.path.insert(0, ROOT)
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import torch
@@ -29,8 +29,14 @@ def _worker(rank, world, port, out_path):
     seq = synthetic.make_sequence(num_frames=8, height=60, width=80, yaw_step_deg=45.0)
     lo, hi = hdist.shard_range(8, rank, world)
     acc = oracle.AccumVolume(synthetic.room_bounds(), 0.16)
-    for i in range(lo, hi):
-        acc.integrate(seq["color"][i], seq["depth"][i], seq["K"], seq["poses"][i])
+    if mode == "accumulate":  # sums of the raw observations (accum_integrate)
+        for i in range(lo, hi):
+            acc.integrate(seq["color"][i], seq["depth"][i], seq["K"], seq["poses"][i])
+    else:  # "volume": the rank fuses its shard the ordinary way, then converts its volumes to sums (fuse_sharded(volume))
+        own = oracle.TSDFVolume(synthetic.room_bounds(), 0.16)
+        for i in range(lo, hi):
+            own.integrate(seq["color"][i], seq["depth"][i], seq["K"], seq["poses"][i])
+        acc.accum[...] = oracle.AccumVolume.planes_from_volume(own)
     t = torch.from_numpy(acc.accum)
     hdist.allreduce_accumulators(t, chunk_elems=10_000)  # several chunks on purpose
     hdist.barrier()
@@ -53,11 +59,12 @@ def test_shard_range_partitions():
             assert max(sizes) - min(sizes) <= 1
 
 
-def test_two_rank_frame_sharded_fusion_matches_sequential(tmp_path, oracle_lib):
+@pytest.mark.parametrize("mode", ["accumulate", "volume"])
+def test_two_rank_frame_sharded_fusion_matches_sequential(tmp_path, oracle_lib, mode):
     import torch.multiprocessing as mp
     from hive_amd import synthetic
     out = str(tmp_path / "rank0.npz")
-    mp.start_processes(_worker, args=(2, _free_port(), out), nprocs=2, join=True, start_method="spawn")
+    mp.start_processes(_worker, args=(2, _free_port(), out, mode), nprocs=2, join=True, start_method="spawn")
     got = np.load(out)
     seq = synthetic.make_sequence(num_frames=8, height=60, width=80, yaw_step_deg=45.0)
     ref = oracle_lib.TSDFVolume(synthetic.room_bounds(), 0.16)

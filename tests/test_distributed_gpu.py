@@ -58,3 +58,16 @@ def test_rccl_collectives_on_accumulator_views(gpu_ctx, nccl_group):
         a = (c_ref.astype(np.int64) >> sh) & 255
         b = (c_acc.astype(np.int64) >> sh) & 255
         assert np.abs(a - b).max() <= 2
+    # the other contribution mode (bench.py --gpus N): volumes -> sums on the device, bit-exact against the numpy
+    # statement of the same products, and with one rank fuse_sharded(volume) must give the volume back
+    import oracle
+    planes = torch.empty(5 * ref.num_voxels, dtype=torch.float32, device="cuda")
+    ref.accum_from_volume(planes)
+    ora = oracle.TSDFVolume(bounds, 0.04)
+    for i in range(4):
+        ora.integrate(seq["color"][i], seq["depth"][i], seq["K"], seq["poses"][i])
+    assert np.array_equal(ora._tsdf, t_ref) and np.array_equal(ora._color, c_ref)
+    assert np.array_equal(planes.cpu().numpy().reshape(5, *t_ref.shape), oracle.AccumVolume.planes_from_volume(ora))
+    hdist.fuse_sharded(ref)
+    t2, c2 = ref.get_volume()
+    assert np.abs(t2 - t_ref).max() <= 1e-6 and np.array_equal(c2, c_ref)
