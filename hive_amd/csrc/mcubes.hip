@@ -5,12 +5,18 @@
 // (call site /root/reference/hive/fusion.py:127), which wraps scikit-image's Lewiner marching cubes.
 // Table conventions and ordering: tools/gen_mc_tables.py and include/hive_mi355x.h.
 //
-// Passes (each a coalesced sweep over the float32 tsdf volume, 4 voxels per lane):
-//   count   per-block number of owned-edge vertices and of triangles
+// Passes:
+//   signs   ONE coalesced sweep over the float32 tsdf volume -> 1 bit per voxel (tsdf < 0), 32 consecutive z per word
+//   count   per word (lane): the sign words of the 4 rows (x, y), (x+1, y), (x, y+1), (x+1, y+1) and their successors give
+//           every owned sign-changing edge and every non-uniform cell of 32 voxels with a few XOR / popcount
+//           instructions; the triangle count loops over the (rare) active cells only
 //   scan    exclusive scan of the per-block counts (one workgroup)
-//   verts   per-block wave scan -> vertex id; writes position / normal / colour and, per voxel,
-//           vbase = first vertex id | owned-axis mask << 29 (only where the mask is non-zero)
-//   faces   per-block wave scan -> triangle id; vertex ids looked up through vbase
+//   verts   per-block scan -> vertex id; writes position / normal / colour and, per voxel, vbase = first vertex id |
+//           owned-axis mask << 29 (only where the mask is non-zero)
+//   faces   per-block scan -> triangle id; vertex ids looked up through vbase
+// Only `signs` reads the whole volume (4 N bytes); the other passes read the N / 8-byte bitmap and touch tsdf / colour
+// for surface voxels only.  (The first version classified every voxel from 8 scalar float loads in each of the three
+// passes: 0.8-1.0 ms per pass at 512^3, bound by the CU's vector-memory instruction rate, not by bytes.)
 #include "hive_internal.hpp"
 #include "../../include/hive_mc_tables.h"
 
@@ -23,47 +29,103 @@ __constant__ unsigned char c_edge_owner[12][4];
 struct McParams {
     const float *tsdf;
     const float *color;
+    const unsigned *sign;  // 1 bit per voxel (tsdf < 0), rows padded to WZ words
+    int WZ;
     int X, Y, Z;
     long long n;
     float ox, oy, oz, vs;
 };
 
-constexpr int MC_VPT = 4;
 constexpr int MC_BLOCK = 256;
-constexpr int MC_TILE = MC_VPT * MC_BLOCK;
 
-struct VoxClass {
-    unsigned axis_mask;  // bit a set: the edge from this voxel towards +axis a carries a vertex
-    int cs;              // marching-cubes case of the cell whose corner 0 is this voxel, -1 if no cell
-};
-
-__device__ __forceinline__ VoxClass classify(const McParams &p, long long idx, int x, int y, int z) {
-    const long long sx = (long long)p.Y * p.Z, sy = p.Z;
-    const bool hx = x + 1 < p.X, hy = y + 1 < p.Y, hz = z + 1 < p.Z;
-    const float v0 = p.tsdf[idx];
-    const bool n0 = v0 < 0.0f;
-    const bool n1 = hx ? p.tsdf[idx + sx] < 0.0f : n0;
-    const bool n3 = hy ? p.tsdf[idx + sy] < 0.0f : n0;
-    const bool n4 = hz ? p.tsdf[idx + 1] < 0.0f : n0;
-    VoxClass c;
-    c.axis_mask = (unsigned)(n1 != n0) | ((unsigned)(n3 != n0) << 1) | ((unsigned)(n4 != n0) << 2);
-    c.cs = -1;
-    if (hx && hy && hz) {
-        const bool n2 = p.tsdf[idx + sx + sy] < 0.0f;
-        const bool n5 = p.tsdf[idx + sx + 1] < 0.0f;
-        const bool n6 = p.tsdf[idx + sx + sy + 1] < 0.0f;
-        const bool n7 = p.tsdf[idx + sy + 1] < 0.0f;
-        c.cs = (int)n0 | ((int)n1 << 1) | ((int)n2 << 2) | ((int)n3 << 3) | ((int)n4 << 4) | ((int)n5 << 5) | ((int)n6 << 6) |
-               ((int)n7 << 7);
+// ---- sign bitmap ---------------------------------------------------------------------------------
+// fast path (Z % 32 == 0): a lane loads 4 consecutive voxels (16 B, coalesced), 8 lanes assemble one word
+__global__ __launch_bounds__(256) void mc_signs_vec_kernel(const float *__restrict__ tsdf, long long n, unsigned *__restrict__ sign) {
+    const long long i4 = (long long)blockIdx.x * 256 + threadIdx.x;  // group of 4 voxels
+    unsigned v = 0;
+    if (i4 * 4 < n) {
+        const float4 t = *reinterpret_cast<const float4 *>(tsdf + i4 * 4);
+        v = (unsigned)(t.x < 0.f) | ((unsigned)(t.y < 0.f) << 1) | ((unsigned)(t.z < 0.f) << 2) | ((unsigned)(t.w < 0.f) << 3);
     }
-    return c;
+    v <<= 4 * (threadIdx.x & 7);
+    v |= (unsigned)__shfl_xor((int)v, 1);
+    v |= (unsigned)__shfl_xor((int)v, 2);
+    v |= (unsigned)__shfl_xor((int)v, 4);
+    if ((threadIdx.x & 7) == 0 && i4 * 4 < n) sign[i4 >> 3] = v;
 }
 
-__device__ __forceinline__ void decode(const McParams &p, long long idx, int &x, int &y, int &z) {
-    z = (int)(idx % p.Z);
-    const long long r = idx / p.Z;
-    y = (int)(r % p.Y);
-    x = (int)(r / p.Y);
+// general path: one lane per word, rows padded to whole words (bits past Z are 0)
+__global__ __launch_bounds__(256) void mc_signs_row_kernel(const float *__restrict__ tsdf, int Z, int WZ, long long n_words,
+                                                           unsigned *__restrict__ sign) {
+    const long long w = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (w >= n_words) return;
+    const long long row = w / WZ;
+    const int z0 = (int)(w % WZ) * 32;
+    const float *src = tsdf + row * Z + z0;
+    unsigned v = 0;
+    for (int b = 0; b < 32 && z0 + b < Z; ++b) v |= (unsigned)(src[b] < 0.f) << b;
+    sign[w] = v;
+}
+
+// ---- per-word classification ----------------------------------------------------------------------
+struct WordClass {
+    unsigned xe, ye, ze;  // bit b set: voxel z0 + b owns a sign-changing edge towards +x / +y / +z
+    unsigned act;         // bit b set: the cell whose corner 0 is voxel z0 + b is cut by the surface
+    unsigned c[8];        // sign words of the 8 cell corners (marching-cubes corner order), aligned to corner 0
+    int x, y, z0;
+    long long row;        // x * Y + y
+};
+
+__device__ __forceinline__ WordClass classify_word(const McParams &p, long long w, bool need_cells) {
+    WordClass k;
+    k.row = w / p.WZ;
+    const int wz = (int)(w % p.WZ);
+    k.z0 = wz * 32;
+    k.y = (int)(k.row % p.Y);
+    k.x = (int)(k.row / p.Y);
+    const bool hx = k.x + 1 < p.X, hy = k.y + 1 < p.Y, hw = wz + 1 < p.WZ;
+    const long long sx = (long long)p.Y * p.WZ, sy = p.WZ;
+    const int left = p.Z - k.z0;  // voxels of the row from z0 on (>= 1)
+    const unsigned in_mask = left >= 32 ? 0xffffffffu : (1u << left) - 1u;                    // z < Z
+    const unsigned vz_mask = left - 1 >= 32 ? 0xffffffffu : (1u << max(left - 1, 0)) - 1u;    // z + 1 < Z
+    const unsigned w00 = p.sign[w];
+    const unsigned w10 = hx ? p.sign[w + sx] : w00;
+    const unsigned w01 = hy ? p.sign[w + sy] : w00;
+    const unsigned n00 = hw ? p.sign[w + 1] : 0u;
+    const unsigned s00 = (w00 >> 1) | (n00 << 31);
+    k.xe = (w00 ^ w10) & in_mask;
+    k.ye = (w00 ^ w01) & in_mask;
+    k.ze = (w00 ^ s00) & vz_mask;
+    k.act = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) k.c[i] = 0;
+    if (need_cells && hx && hy) {
+        const unsigned w11 = p.sign[w + sx + sy];
+        const unsigned n10 = hw ? p.sign[w + sx + 1] : 0u, n01 = hw ? p.sign[w + sy + 1] : 0u, n11 = hw ? p.sign[w + sx + sy + 1] : 0u;
+        k.c[0] = w00;
+        k.c[1] = w10;
+        k.c[2] = w11;
+        k.c[3] = w01;
+        k.c[4] = s00;
+        k.c[5] = (w10 >> 1) | (n10 << 31);
+        k.c[6] = (w11 >> 1) | (n11 << 31);
+        k.c[7] = (w01 >> 1) | (n01 << 31);
+        unsigned any = 0u, all = 0xffffffffu;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            any |= k.c[i];
+            all &= k.c[i];
+        }
+        k.act = any & ~all & vz_mask;
+    }
+    return k;
+}
+
+__device__ __forceinline__ int cell_case(const WordClass &k, int b) {
+    int cs = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) cs |= (int)((k.c[i] >> b) & 1u) << i;
+    return cs;
 }
 
 // exclusive scan of one unsigned per thread over the 256-thread block; returns the block total in `total`
@@ -86,18 +148,15 @@ __device__ __forceinline__ unsigned block_exclusive_scan(unsigned v, unsigned *l
     return before + inc - v;
 }
 
-__global__ __launch_bounds__(MC_BLOCK) void mc_count_kernel(McParams p, unsigned *__restrict__ blk_v, unsigned *__restrict__ blk_t) {
+__global__ __launch_bounds__(MC_BLOCK) void mc_count_kernel(McParams p, long long n_words, unsigned *__restrict__ blk_v,
+                                                            unsigned *__restrict__ blk_t) {
     __shared__ unsigned lds[8];
-    const long long base = (long long)blockIdx.x * MC_TILE + (long long)threadIdx.x * MC_VPT;
+    const long long w = (long long)blockIdx.x * MC_BLOCK + threadIdx.x;
     unsigned nv = 0, nt = 0;
-    for (int j = 0; j < MC_VPT; ++j) {
-        const long long idx = base + j;
-        if (idx >= p.n) break;
-        int x, y, z;
-        decode(p, idx, x, y, z);
-        const VoxClass c = classify(p, idx, x, y, z);
-        nv += __popc(c.axis_mask);
-        if (c.cs >= 0) nt += c_num_tris[c.cs];
+    if (w < n_words) {
+        const WordClass k = classify_word(p, w, true);
+        nv = __popc(k.xe) + __popc(k.ye) + __popc(k.ze);
+        for (unsigned m = k.act; m; m &= m - 1u) nt += c_num_tris[cell_case(k, __ffs((int)m) - 1)];
     }
     for (int off = 32; off > 0; off >>= 1) {
         nv += (unsigned)__shfl_xor((int)nv, off);
@@ -165,38 +224,28 @@ __device__ __forceinline__ float grad_axis(const McParams &p, int x, int y, int 
     return span > 0.0f ? (a - b) / span : 0.0f;
 }
 
-__global__ __launch_bounds__(MC_BLOCK) void mc_verts_kernel(McParams p, const unsigned *__restrict__ blk_v,
+__global__ __launch_bounds__(MC_BLOCK) void mc_verts_kernel(McParams p, long long n_words, const unsigned *__restrict__ blk_v,
                                                             unsigned *__restrict__ vbase, float *__restrict__ verts,
                                                             float *__restrict__ verts_vox, float *__restrict__ norms,
                                                             uint8_t *__restrict__ colors) {
     __shared__ unsigned lds[4];
-    const long long base = (long long)blockIdx.x * MC_TILE + (long long)threadIdx.x * MC_VPT;
-    unsigned mask[MC_VPT];
-    unsigned cnt = 0;
-#pragma unroll
-    for (int j = 0; j < MC_VPT; ++j) {
-        mask[j] = 0;
-        const long long idx = base + j;
-        if (idx < p.n) {
-            int x, y, z;
-            decode(p, idx, x, y, z);
-            mask[j] = classify(p, idx, x, y, z).axis_mask;
-        }
-        cnt += __popc(mask[j]);
-    }
+    const long long w = (long long)blockIdx.x * MC_BLOCK + threadIdx.x;
+    WordClass k;
+    k.xe = k.ye = k.ze = 0;
+    if (w < n_words) k = classify_word(p, w, false);
+    const unsigned cnt = __popc(k.xe) + __popc(k.ye) + __popc(k.ze);
     unsigned total;
     unsigned id = blk_v[blockIdx.x] + block_exclusive_scan(cnt, lds, total);
-#pragma unroll
-    for (int j = 0; j < MC_VPT; ++j) {
-        if (!mask[j]) continue;
-        const long long idx = base + j;
-        int x, y, z;
-        decode(p, idx, x, y, z);
-        vbase[idx] = id | (mask[j] << 29);
+    for (unsigned m = k.xe | k.ye | k.ze; m; m &= m - 1u) {  // voxels in ascending z, axes in x, y, z order
+        const int b = __ffs((int)m) - 1;
+        const unsigned mask = ((k.xe >> b) & 1u) | (((k.ye >> b) & 1u) << 1) | (((k.ze >> b) & 1u) << 2);
+        const int x = k.x, y = k.y, z = k.z0 + b;
+        const long long idx = k.row * p.Z + z;
+        vbase[idx] = id | (mask << 29);
         const float v0 = p.tsdf[idx];
         const long long stride[3] = {(long long)p.Y * p.Z, p.Z, 1};
         for (int a = 0; a < 3; ++a) {
-            if (!((mask[j] >> a) & 1u)) continue;
+            if (!((mask >> a) & 1u)) continue;
             const float v1 = p.tsdf[idx + stride[a]];
             const float t = v0 / (v0 - v1);
             float pos[3] = {(float)x, (float)y, (float)z};
@@ -228,38 +277,30 @@ __global__ __launch_bounds__(MC_BLOCK) void mc_verts_kernel(McParams p, const un
     }
 }
 
-__global__ __launch_bounds__(MC_BLOCK) void mc_faces_kernel(McParams p, const unsigned *__restrict__ blk_t,
+__global__ __launch_bounds__(MC_BLOCK) void mc_faces_kernel(McParams p, long long n_words, const unsigned *__restrict__ blk_t,
                                                             const unsigned *__restrict__ vbase, int32_t *__restrict__ faces) {
     __shared__ unsigned lds[4];
-    const long long base = (long long)blockIdx.x * MC_TILE + (long long)threadIdx.x * MC_VPT;
-    int cs[MC_VPT];
+    const long long w = (long long)blockIdx.x * MC_BLOCK + threadIdx.x;
+    WordClass k;
+    k.act = 0;
+    if (w < n_words) k = classify_word(p, w, true);
     unsigned cnt = 0;
-#pragma unroll
-    for (int j = 0; j < MC_VPT; ++j) {
-        cs[j] = -1;
-        const long long idx = base + j;
-        if (idx < p.n) {
-            int x, y, z;
-            decode(p, idx, x, y, z);
-            cs[j] = classify(p, idx, x, y, z).cs;
-        }
-        if (cs[j] >= 0) cnt += c_num_tris[cs[j]];
-    }
+    for (unsigned m = k.act; m; m &= m - 1u) cnt += c_num_tris[cell_case(k, __ffs((int)m) - 1)];
     unsigned total;
     unsigned long long fid = blk_t[blockIdx.x] + block_exclusive_scan(cnt, lds, total);
-#pragma unroll
-    for (int j = 0; j < MC_VPT; ++j) {
-        if (cs[j] < 0) continue;
-        const int nt = c_num_tris[cs[j]];
-        const long long idx = base + j;
-        for (int k = 0; k < nt; ++k) {
-            for (int m = 0; m < 3; ++m) {
-                const int e = c_tri_table[cs[j]][3 * k + m];
+    for (unsigned m = k.act; m; m &= m - 1u) {  // cells in ascending z
+        const int b = __ffs((int)m) - 1;
+        const int cs = cell_case(k, b);
+        const int nt = c_num_tris[cs];
+        const long long idx = k.row * p.Z + k.z0 + b;
+        for (int t = 0; t < nt; ++t) {
+            for (int v = 0; v < 3; ++v) {
+                const int e = c_tri_table[cs][3 * t + v];
                 const long long oi = idx + ((long long)c_edge_owner[e][0] * p.Y + c_edge_owner[e][1]) * p.Z + c_edge_owner[e][2];
                 const unsigned vb = vbase[oi];
                 const unsigned am = vb >> 29;
                 const int a = c_edge_owner[e][3];
-                faces[3 * fid + m] = (int32_t)((vb & 0x1fffffffu) + __popc(am & ((1u << a) - 1u)));
+                faces[3 * fid + v] = (int32_t)((vb & 0x1fffffffu) + __popc(am & ((1u << a) - 1u)));
             }
             ++fid;
         }
@@ -309,12 +350,21 @@ int hive_tsdf_extract_mesh(hive_tsdf *v, int64_t *n_verts, int64_t *n_faces) {
     p.oy = v->origin[1];
     p.oz = v->origin[2];
     p.vs = v->voxel_size;
-    const long long nb = (v->n + MC_TILE - 1) / MC_TILE;
+    p.WZ = (p.Z + 31) / 32;
+    const long long n_words = (long long)p.X * p.Y * p.WZ;
+    const long long nb = (n_words + MC_BLOCK - 1) / MC_BLOCK;
     HIVE_REQUIRE(ctx, nb < (1ll << 31), "volume too large for mesh extraction");
+    if ((rc = hive_reserve_device(ctx, &ctx->d_scratch, &ctx->scratch_bytes, (size_t)n_words * sizeof(unsigned)))) return rc;
+    unsigned *d_sign = (unsigned *)ctx->d_scratch;
+    p.sign = d_sign;
+    if (p.Z % 32 == 0 && ((uintptr_t)v->d_tsdf % 16) == 0)
+        hipLaunchKernelGGL(mc_signs_vec_kernel, dim3((unsigned)((v->n / 4 + 255) / 256)), dim3(256), 0, ctx->stream, v->d_tsdf, (long long)v->n, d_sign);
+    else
+        hipLaunchKernelGGL(mc_signs_row_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, ctx->stream, v->d_tsdf, p.Z, p.WZ, n_words, d_sign);
     if ((rc = hive_reserve_device(ctx, (void **)&v->d_blk, &v->blk_bytes, 2 * (size_t)nb * sizeof(unsigned)))) return rc;
     unsigned *blk_v = v->d_blk, *blk_t = v->d_blk + nb;
     unsigned long long *d_tot = (unsigned long long *)(ctx->d_scalars + 8);
-    hipLaunchKernelGGL(mc_count_kernel, dim3((unsigned)nb), dim3(MC_BLOCK), 0, ctx->stream, p, blk_v, blk_t);
+    hipLaunchKernelGGL(mc_count_kernel, dim3((unsigned)nb), dim3(MC_BLOCK), 0, ctx->stream, p, n_words, blk_v, blk_t);
     hipLaunchKernelGGL(mc_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, blk_v, blk_t, (int)nb, d_tot);
     HIVE_CHECK_HIP(ctx, hipGetLastError());
     unsigned long long tot[2] = {0, 0};
@@ -333,9 +383,9 @@ int hive_tsdf_extract_mesh(hive_tsdf *v, int64_t *n_verts, int64_t *n_faces) {
     HIVE_CHECK_HIP(ctx, hipMalloc((void **)&v->d_norms, nv * 3 * sizeof(float)));
     HIVE_CHECK_HIP(ctx, hipMalloc((void **)&v->d_vcolors, nv * 3));
     HIVE_CHECK_HIP(ctx, hipMalloc((void **)&v->d_faces, std::max<size_t>(nf, 1) * 3 * sizeof(int32_t)));
-    hipLaunchKernelGGL(mc_verts_kernel, dim3((unsigned)nb), dim3(MC_BLOCK), 0, ctx->stream, p, blk_v, v->d_vbase, v->d_verts,
+    hipLaunchKernelGGL(mc_verts_kernel, dim3((unsigned)nb), dim3(MC_BLOCK), 0, ctx->stream, p, n_words, blk_v, v->d_vbase, v->d_verts,
                        v->d_verts_vox, v->d_norms, v->d_vcolors);
-    hipLaunchKernelGGL(mc_faces_kernel, dim3((unsigned)nb), dim3(MC_BLOCK), 0, ctx->stream, p, blk_t, v->d_vbase, v->d_faces);
+    hipLaunchKernelGGL(mc_faces_kernel, dim3((unsigned)nb), dim3(MC_BLOCK), 0, ctx->stream, p, n_words, blk_t, v->d_vbase, v->d_faces);
     HIVE_CHECK_HIP(ctx, hipGetLastError());
     v->n_verts = (int64_t)nv;
     v->n_faces = (int64_t)nf;
