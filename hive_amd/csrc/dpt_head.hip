@@ -20,7 +20,10 @@
 //     x 2 k-steps) in registers for the whole kernel and reads only pixel operands from LDS -- 1 KiB per MFMA,
 //     which is the LDS bandwidth of a CU at full MFMA rate, so weights must not come from LDS as well;
 //     the 4 partial sums per pixel tile are exchanged through LDS once per tile;
-//   * pixel stride in LDS is 272 bytes (256 + 16): 8 consecutive pixels x 16 bytes then cover 32 distinct banks.
+//   * LDS layout of the upsampled patch: 272 bytes per pixel (256 + 16) and a row pitch that is a multiple of 256 bytes,
+//     so the 16-byte bank slot of a pixel depends on its column only; the lane groups in which ds_read_b128 is serviced
+//     ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ...) each hold 16 different columns of the 2 x 16 pixel block: conflict-free
+//     (with the natural pitch 18 x 272 the two rows of a group overlapped: SQ_LDS_BANK_CONFLICT 26 % of the LDS cycles).
 #include "hive_internal.hpp"
 
 #include <algorithm>
@@ -36,9 +39,10 @@ constexpr int UP_H = TH + 2, UP_W = TW + 2;    // upsampled patch with the 3x3 h
 constexpr int LO_H = 7, LO_W = 11;             // low-resolution patch that feeds it (scale < 0.5)
 constexpr int CIN = 128, COUT = 32;
 constexpr int PIX = 272;                       // bytes per pixel in LDS
-constexpr int UP_BYTES = 49152;                // >= UP_H * UP_W * PIX (48960) and >= the partial-sum exchange (4*3*16*64*4)
+constexpr int UP_PITCH = 5120;                 // bytes per row of the upsampled patch: >= UP_W * PIX (4896) and a multiple of 256
+constexpr int UP_BYTES = UP_H * UP_PITCH;      // 51200, also >= the partial-sum exchange (4*3*16*64*4 = 49152)
 constexpr int LO_BYTES = LO_H * LO_W * PIX;    // 20944
-static_assert(UP_H * UP_W * PIX <= UP_BYTES, "upsampled patch does not fit");
+static_assert(UP_W * PIX <= UP_PITCH && UP_PITCH % 256 == 0 && UP_BYTES >= 49152, "upsampled patch layout");
 
 struct HeadParams {
     const bf16 *x;      // [N][H][W][128]
@@ -123,11 +127,11 @@ __global__ __launch_bounds__(256, 2) void head_conv_kernel(HeadParams p) {
             const int x0 = (int)fx, x1 = min(x0 + 1, p.W - 1);
             const float w1 = fx - (float)x0, w0 = 1.f - w1;
             const int c0 = col_ok ? (x0 - lo_x0) * PIX + v * 16 : 0, c1 = col_ok ? (x1 - lo_x0) * PIX + v * 16 : 0;
-            unsigned char *dst = up + ux * PIX + v * 16;
+            unsigned char *dst = up + ux * PIX + v * 16;  // + uy * UP_PITCH
             const uint4 zero = make_uint4(0u, 0u, 0u, 0u);  // zero padding of the convolution
             int uy = 0;                                      // patch row to emit next (uniform over the workgroup)
             while (uy < UP_H && R0 + uy < 0) {               // rows above the image
-                *reinterpret_cast<uint4 *>(dst + uy * UP_W * PIX) = zero;
+                *reinterpret_cast<uint4 *>(dst + uy * UP_PITCH) = zero;
                 ++uy;
             }
             float ta[8], tb[8];
@@ -153,14 +157,14 @@ __global__ __launch_bounds__(256, 2) void head_conv_kernel(HeadParams p) {
                         for (int j = 0; j < 8; ++j) o[j] = (bf16)(h0 * ta[j] + h1 * tb[j]);
                         packed = *reinterpret_cast<const uint4 *>(&o);
                     }
-                    *reinterpret_cast<uint4 *>(dst + uy * UP_W * PIX) = packed;
+                    *reinterpret_cast<uint4 *>(dst + uy * UP_PITCH) = packed;
                     ++uy;
                 }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) ta[j] = tb[j];
             }
             while (uy < UP_H) {  // rows below the image
-                *reinterpret_cast<uint4 *>(dst + uy * UP_W * PIX) = zero;
+                *reinterpret_cast<uint4 *>(dst + uy * UP_PITCH) = zero;
                 ++uy;
             }
         }
@@ -171,15 +175,15 @@ __global__ __launch_bounds__(256, 2) void head_conv_kernel(HeadParams p) {
         for (int m = 0; m < 4; ++m)
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[m][v] = 0.f;
-        const int pix_base = ((nn >> 4) * UP_W + (nn & 15)) * PIX + (32 * wave + 8 * hh) * 2;
+        const int pix_base = (nn >> 4) * UP_PITCH + (nn & 15) * PIX + (32 * wave + 8 * hh) * 2;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-            const int tap_off = ((t / 3) * UP_W + (t % 3)) * PIX;
+            const int tap_off = (t / 3) * UP_PITCH + (t % 3) * PIX;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
-                    const bf16x8 xf = lds_read8(up, pix_base + tap_off + 2 * m * UP_W * PIX + ks * 32);
+                    const bf16x8 xf = lds_read8(up, pix_base + tap_off + 2 * m * UP_PITCH + ks * 32);
                     acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[t][ks], xf, acc[m], 0, 0, 0);
                 }
         }
