@@ -72,16 +72,17 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const T *__restrict__ x
     }
 }
 
-// stage 2: per (sample, group) mean and rstd from the slab partials, summed in a fixed order (deterministic)
-__global__ __launch_bounds__(64) void gn_finalize_kernel(const float *__restrict__ partial, int C, int G, int slabs, int HW, float eps,
-                                                         float *__restrict__ stats, int total) {
-    // one wave per (sample, group): lanes stride over the slabs x channels-of-the-group partials, then a
-    // fixed butterfly -- the summation order depends only on the shapes
+// stage 2: per (sample, group) mean and rstd from the slab partials, summed in a fixed order (deterministic):
+// one 256-thread workgroup per (sample, group) -- threads stride over the slabs x channels-of-the-group partials (two
+// dependent-load rounds instead of eight with one wave), fixed butterfly per wave, the four wave sums added in order
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float *__restrict__ partial, int C, int G, int slabs, int HW, float eps,
+                                                          float *__restrict__ stats, int total) {
+    __shared__ double red[8];
     const int i = blockIdx.x;  // i = n * G + g
     if (i >= total) return;
     const int n = i / G, g = i % G, cpg = C / G;
     double s = 0.0, q = 0.0;
-    for (int e = threadIdx.x; e < slabs * cpg; e += 64) {
+    for (int e = threadIdx.x; e < slabs * cpg; e += 256) {
         const int sl = e / cpg, c = e % cpg;
         const float *ps = partial + (((size_t)n * slabs + sl) * 2) * C + g * cpg + c;
         s += (double)ps[0];
@@ -91,7 +92,14 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float *__restrict
         s += __shfl_xor(s, off);
         q += __shfl_xor(q, off);
     }
+    if ((threadIdx.x & 63) == 0) {
+        red[threadIdx.x >> 6] = s;
+        red[4 + (threadIdx.x >> 6)] = q;
+    }
+    __syncthreads();
     if (threadIdx.x == 0) {
+        s = ((red[0] + red[1]) + red[2]) + red[3];
+        q = ((red[4] + red[5]) + red[6]) + red[7];
         const double cnt = (double)HW * cpg;
         const double mean = s / cnt;
         const double var = fmax(q / cnt - mean * mean, 0.0);
@@ -231,12 +239,12 @@ int hive_nhwc_group_norm(hive_ctx *ctx, const void *d_x, int dtype, int N, int H
     const dim3 g1(slabs, N), g3(std::max(1, std::min((HW + PP - 1) / PP, (ctx->num_cus * 8 + N - 1) / N)), N);
     if (dtype == HIVE_BF16) {
         hipLaunchKernelGGL(gn_partial_kernel<bf16>, g1, dim3(256), 0, ctx->stream, (const bf16 *)d_x, HW, C, slabs, partial);
-        hipLaunchKernelGGL(gn_finalize_kernel, dim3(N * G), dim3(64), 0, ctx->stream, partial, C, G, slabs, HW, eps, stats, N * G);
+        hipLaunchKernelGGL(gn_finalize_kernel, dim3(N * G), dim3(256), 0, ctx->stream, partial, C, G, slabs, HW, eps, stats, N * G);
         hipLaunchKernelGGL(gn_apply_kernel<bf16>, g3, dim3(256), 0, ctx->stream, (const bf16 *)d_x, (const bf16 *)d_gamma, (const bf16 *)d_beta,
                            stats, (const bf16 *)d_residual, (bf16 *)d_out, HW, C, G, relu);
     } else {
         hipLaunchKernelGGL(gn_partial_kernel<_Float16>, g1, dim3(256), 0, ctx->stream, (const _Float16 *)d_x, HW, C, slabs, partial);
-        hipLaunchKernelGGL(gn_finalize_kernel, dim3(N * G), dim3(64), 0, ctx->stream, partial, C, G, slabs, HW, eps, stats, N * G);
+        hipLaunchKernelGGL(gn_finalize_kernel, dim3(N * G), dim3(256), 0, ctx->stream, partial, C, G, slabs, HW, eps, stats, N * G);
         hipLaunchKernelGGL(gn_apply_kernel<_Float16>, g3, dim3(256), 0, ctx->stream, (const _Float16 *)d_x, (const _Float16 *)d_gamma,
                            (const _Float16 *)d_beta, stats, (const _Float16 *)d_residual, (_Float16 *)d_out, HW, C, G, relu);
     }
