@@ -26,6 +26,7 @@
 #include "hive_internal.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cmath>
 
 typedef __bf16 bf16;
@@ -248,6 +249,92 @@ __global__ __launch_bounds__(TM * 2, 1) void gemm_kernel(GemmParams p) {
                     for (int j = 0; j < 4; ++j) ov[j] = (bf16)(acc[mt][nt][j] + b);
                     *reinterpret_cast<bf16x4 *>(p.vT + (((size_t)img * p.H + head) * 64 + ch) * p.Np + tok) = ov;
                 }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Large-M variant: C tile 256 x 256, K-step 64, EIGHT waves as 2 (M) x 4 (N), each a 128 x 64 sub-tile (8 x 4 MFMA
+// 16x16x32 accumulators, 128 VGPRs: two waves per SIMD).  Half the L2 operand bytes per flop of the 128 x 128 tile
+// (the operand stream, not the MFMAs or LDS, bounds that one: DESIGN.md section 5.3).  Two 64-KiB LDS-DMA stages.
+constexpr int T256 = 256, T256_STAGE = 2 * T256 / 8 * 1024;
+
+template <int EPI>
+__global__ __launch_bounds__(512, 1) void gemm256_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // 2 stages x (A tile 256 x 64, W tile 256 x 64)
+    constexpr int A_GROUPS = T256 / 8, GROUPS = 2 * A_GROUPS, PER_WAVE = GROUPS / 8;
+    static_assert(EPI != EPI_QKV, "the transposed v^T store stays with the 128-row kernel (N = 768)");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;  // 128 rows x 64 columns per wave
+    const int nwg = gridDim.x, xcd = blockIdx.x & 7, q = nwg >> 3, r = nwg & 7;
+    const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+    const int tiles_n = p.N / T256;
+    const int m0 = (tile / tiles_n) * T256, n0 = (tile % tiles_n) * T256;
+
+    auto issue_stage = [&](int kt) {
+        unsigned char *st = lds + (kt & 1) * T256_STAGE;
+#pragma unroll
+        for (int j = 0; j < PER_WAVE; ++j) {
+            const int g = wave + j * 8;
+            if (g < A_GROUPS)
+                stage_group(p.A, p.K, m0, p.M - 1, kt * BK, st, g, lane);
+            else
+                stage_group(p.W, p.K, n0, p.N - 1, kt * BK, st + A_GROUPS * 1024, g - A_GROUPS, lane);
+        }
+    };
+
+    f32x4 acc[4][8];  // acc[nt][mt] = W_frag . A_frag^T : rows = n, cols = m
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int KT = p.K / BK;
+    issue_stage(0);
+    const int fr = lane & 15, fq = lane >> 4;
+    for (int kt = 0; kt < KT; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // everyone's stage kt landed; everyone finished reading stage kt-1
+        if (kt + 1 < KT) issue_stage(kt + 1);  // overwrites the buffer of stage kt-1
+        const unsigned char *a_t = lds + (kt & 1) * T256_STAGE, *w_t = a_t + A_GROUPS * 1024;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            bf16x8 af[8], wf[4];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) af[t] = *reinterpret_cast<const bf16x8 *>(a_t + swz(wr * 128 + t * 16 + fr, sub * 4 + fq));
+#pragma unroll
+            for (int t = 0; t < 4; ++t) wf[t] = *reinterpret_cast<const bf16x8 *>(w_t + swz(wc * 64 + t * 16 + fr, sub * 4 + fq));
+#pragma unroll
+            for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], af[mt], acc[nt][mt], 0, 0, 0);
+        }
+    }
+
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int n = n0 + wc * 64 + nt * 16 + fq * 4;
+        const float4 b = *reinterpret_cast<const float4 *>(p.bias + n);
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+            const int m = m0 + wr * 128 + mt * 16 + fr;
+            if (m < p.M) {
+                float o[4] = {acc[nt][mt][0] + b.x, acc[nt][mt][1] + b.y, acc[nt][mt][2] + b.z, acc[nt][mt][3] + b.w};
+                if (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = gelu_exact(o[j]);
+                }
+                if (EPI == EPI_BIAS_RESIDUAL) {
+                    const bf16x4 rs = *reinterpret_cast<const bf16x4 *>(p.residual + (size_t)m * p.ldc + n);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] += (float)rs[j];
+                }
+                bf16x4 ov;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ov[j] = (bf16)o[j];
+                *reinterpret_cast<bf16x4 *>(p.C + (size_t)m * p.ldc + n) = ov;
             }
         }
     }
@@ -516,7 +603,25 @@ static int launch_layernorm(hive_ctx *ctx, const bf16 *x, const float *g, const 
 constexpr int GEMM_TM = 128, GEMM_NST = 2;
 constexpr size_t GEMM_LDS = (size_t)GEMM_NST * (GEMM_TM / 8 + 16) * 1024;
 
+static int launch_gemm256(hive_ctx *ctx, int epi, const GemmParams &p) {
+    const dim3 grid((unsigned)(((p.M + T256 - 1) / T256) * (p.N / T256))), block(512);
+    const size_t lds_bytes = 2 * T256_STAGE;
+    switch (epi) {
+        case EPI_BIAS: hipLaunchKernelGGL((gemm256_kernel<EPI_BIAS>), grid, block, lds_bytes, ctx->stream, p); break;
+        case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm256_kernel<EPI_BIAS_GELU>), grid, block, lds_bytes, ctx->stream, p); break;
+        case EPI_BIAS_RESIDUAL: hipLaunchKernelGGL((gemm256_kernel<EPI_BIAS_RESIDUAL>), grid, block, lds_bytes, ctx->stream, p); break;
+        default: return hive_fail(ctx, HIVE_ERR_INVALID, "gemm: unknown epilogue %d", epi);
+    }
+    HIVE_CHECK_HIP(ctx, hipGetLastError());
+    return HIVE_OK;
+}
+
 static int launch_gemm(hive_ctx *ctx, int epi, const GemmParams &p) {
+    // 256 x 256 tiles where there are plenty of them and N is wide (fc1, N = 3072: 563 -> 621 TFLOP/s at M = 29184; 4096^3:
+    // 881 -> 1031); with N = 768 / 1536 the 128-row tiles with two workgroups per CU are as fast or faster
+    static const char *force = getenv("HIVE_GEMM_TILE");  // "256" / "128": tuning override
+    const long long tiles256 = (long long)((p.M + T256 - 1) / T256) * (p.N / T256);
+    if (epi != EPI_QKV && p.N % T256 == 0 && ((force && force[0] == '2') || (!force && p.N >= 2048 && tiles256 >= ctx->num_cus))) return launch_gemm256(ctx, epi, p);
     const dim3 grid((unsigned)(((p.M + GEMM_TM - 1) / GEMM_TM) * (p.N / BN))), block(GEMM_TM * 2);
     switch (epi) {
         case EPI_BIAS: hipLaunchKernelGGL((gemm_kernel<EPI_BIAS, GEMM_TM, GEMM_NST>), grid, block, GEMM_LDS, ctx->stream, p); break;
@@ -549,6 +654,9 @@ static int ensure_gemm_attrs(hive_ctx *ctx) {
     HIVE_CHECK_HIP(ctx, (set_gemm_lds<EPI_BIAS_GELU>()));
     HIVE_CHECK_HIP(ctx, (set_gemm_lds<EPI_BIAS_RESIDUAL>()));
     HIVE_CHECK_HIP(ctx, (set_gemm_lds<EPI_QKV>()));
+    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)gemm256_kernel<EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * T256_STAGE));
+    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)gemm256_kernel<EPI_BIAS_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * T256_STAGE));
+    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)gemm256_kernel<EPI_BIAS_RESIDUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * T256_STAGE));
     if (ctx->device < 64) g_gemm_attr_set[ctx->device] = true;
     return HIVE_OK;
 }

@@ -38,7 +38,9 @@ def test_layernorm(gpu_ctx, M, D):
 
 
 @pytest.mark.parametrize("M,N,K,epi", [(1216, 768, 768, 0), (1216, 3072, 768, 1), (1216, 768, 3072, 2), (200, 128, 64, 0),
-                                        (129, 256, 128, 2), (2432, 2304, 768, 0)])
+                                        (129, 256, 128, 2), (2432, 2304, 768, 0),
+                                        # wide N with >= 256 tiles of 256 x 256: the 8-wave 256-tile kernel, incl. a ragged last row tile
+                                        (5632, 3072, 768, 1), (7300, 2304, 768, 2), (5600, 3072, 128, 0)])
 def test_linear_epilogues(gpu_ctx, M, N, K, epi):
     import torch
     torch.manual_seed(1)

@@ -14,7 +14,7 @@ def timed(fn, reps=20):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e-3
 print("HIVE_GEMM_TILE =", os.environ.get("HIVE_GEMM_TILE"))
-for (M, N, K, epi) in [(19456, 1536, 768, 0), (19456, 768, 768, 2), (19456, 3072, 768, 1), (19456, 768, 3072, 2), (9728, 3072, 768, 1), (9728, 768, 3072, 2), (4096, 4096, 4096, 0), (19456 - 100, 768, 768, 0)]:
+for (M, N, K, epi) in [(29184, 1536, 768, 0), (29184, 768, 768, 2), (29184, 3072, 768, 1), (29184, 768, 3072, 2), (19456, 1536, 768, 0), (19456, 768, 768, 2), (19456, 3072, 768, 1), (19456, 768, 3072, 2), (9728, 3072, 768, 1), (9728, 768, 3072, 2), (4096, 4096, 4096, 0), (19456 - 100, 768, 768, 0)]:
     A = torch.randn(M, K, device="cuda").bfloat16(); W = (torch.randn(N, K, device="cuda") / K ** 0.5).bfloat16(); b = torch.randn(N, device="cuda") * 0.1
     R = torch.randn(M, N, device="cuda").bfloat16()
     C = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
