@@ -75,8 +75,8 @@ SIGNATURES = {
                                     c_int, c_int, c_float, c_float, c_void_p, c_float, c_float, c_void_p, c_void_p]),
     "hive_nhwc_group_norm": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_int,
                                      c_void_p]),
-    "hive_nhwc_bias_act": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
-    "hive_nhwc_upsample2x": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "hive_nhwc_bias_act": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "hive_nhwc_upsample2x": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "hive_depth_quantize": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p]),
 }
 

@@ -155,8 +155,11 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T *__restrict__ x, 
 // bilinear x2 upsampling, align_corners=True (PyTorch's formula, evaluated in float):
 //   src = dst * (in - 1) / (out - 1);  i0 = floor(src), i1 = min(i0 + 1, in - 1), l1 = src - i0, l0 = 1 - l1
 //   y = h0 * (w0 * v00 + w1 * v01) + h1 * (w0 * v10 + w1 * v11)
+// `bias` (optional, [C]): added to every input value on load and rounded to T first -- the bias pass of the
+// convolution that produced `in`, folded in (x + b rounded to the tensor type, as the separate add rounds it).
 template <typename T>
-__global__ __launch_bounds__(256) void upsample2x_kernel(const T *__restrict__ in, T *__restrict__ out, int N, int H, int W, int C) {
+__global__ __launch_bounds__(256) void upsample2x_kernel(const T *__restrict__ in, const T *__restrict__ bias, T *__restrict__ out, int N, int H,
+                                                         int W, int C) {
     const int VC = C >> 3;
     const int OH = 2 * H, OW = 2 * W;
     const size_t total = (size_t)N * OH * OW * VC;
@@ -179,6 +182,17 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const T *__restrict__ i
         load8(b + ((size_t)y0 * W + x1) * C, v01);
         load8(b + ((size_t)y1 * W + x0) * C, v10);
         load8(b + ((size_t)y1 * W + x1) * C, v11);
+        if (bias) {
+            float bb[8];
+            load8(bias + v * 8, bb);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                v00[j] = (float)(T)(v00[j] + bb[j]);
+                v01[j] = (float)(T)(v01[j] + bb[j]);
+                v10[j] = (float)(T)(v10[j] + bb[j]);
+                v11[j] = (float)(T)(v11[j] + bb[j]);
+            }
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] = h0 * (w0 * v00[j] + w1 * v01[j]) + h1 * (w0 * v10[j] + w1 * v11[j]);
         store8(out + i * 8, o);
@@ -189,9 +203,12 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const T *__restrict__ i
 // out = relu?( (x + bias[c]) (+ residual) ) on [n_px][C]: the convolution bias, the ReLU between the two convs of a
 // RefineNet residual unit and its skip add, as one pass (PyTorch runs them as 2-3 elementwise kernels after MIOpen's
 // bias-less convolution).  Rounding follows the separate ops: x + bias is rounded to the tensor type first.
+// `out_relu` (optional): additionally relu(out), the input of the next residual unit's first convolution, so that
+// unit does not need its own ReLU pass.
 template <typename T>
 __global__ __launch_bounds__(256) void bias_act_kernel(const T *__restrict__ x, const T *__restrict__ bias, const T *__restrict__ residual,
-                                                       const T *__restrict__ residual2, T *__restrict__ out, size_t n_vec, int VC, int relu) {
+                                                       const T *__restrict__ residual2, T *__restrict__ out, T *__restrict__ out_relu, size_t n_vec,
+                                                       int VC, int relu) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n_vec; i += (size_t)gridDim.x * 256) {
         const int v = (int)(i % VC);
         float f[8], b[8];
@@ -216,6 +233,11 @@ __global__ __launch_bounds__(256) void bias_act_kernel(const T *__restrict__ x, 
             for (int j = 0; j < 8; ++j) f[j] = fmaxf(f[j], 0.f);
         }
         store8(out + i * 8, f);
+        if (out_relu) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = fmaxf((float)(T)f[j], 0.f);
+            store8(out_relu + i * 8, f);
+        }
     }
 }
 
@@ -253,7 +275,7 @@ int hive_nhwc_group_norm(hive_ctx *ctx, const void *d_x, int dtype, int N, int H
 }
 
 int hive_nhwc_bias_act(hive_ctx *ctx, const void *d_x, int dtype, int64_t n_px, int C, const void *d_bias, int relu,
-                       const void *d_residual, const void *d_residual2, void *d_out) {
+                       const void *d_residual, const void *d_residual2, void *d_out, void *d_out_relu) {
     if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
     HIVE_REQUIRE(ctx, d_x && d_bias && d_out, "bias_act: NULL argument");
     HIVE_REQUIRE(ctx, n_px > 0 && C > 0 && C % 8 == 0, "bias_act: need C %% 8 == 0 (n_px=%lld C=%d)", (long long)n_px, C);
@@ -261,26 +283,26 @@ int hive_nhwc_bias_act(hive_ctx *ctx, const void *d_x, int dtype, int64_t n_px, 
     const dim3 grid((unsigned)std::min<size_t>((n_vec + 255) / 256, (size_t)ctx->num_cus * 32));
     if (dtype == HIVE_BF16)
         hipLaunchKernelGGL(bias_act_kernel<bf16>, grid, dim3(256), 0, ctx->stream, (const bf16 *)d_x, (const bf16 *)d_bias, (const bf16 *)d_residual,
-                           (const bf16 *)d_residual2, (bf16 *)d_out, n_vec, C / 8, relu);
+                           (const bf16 *)d_residual2, (bf16 *)d_out, (bf16 *)d_out_relu, n_vec, C / 8, relu);
     else if (dtype == HIVE_F16)
         hipLaunchKernelGGL(bias_act_kernel<_Float16>, grid, dim3(256), 0, ctx->stream, (const _Float16 *)d_x, (const _Float16 *)d_bias,
-                           (const _Float16 *)d_residual, (const _Float16 *)d_residual2, (_Float16 *)d_out, n_vec, C / 8, relu);
+                           (const _Float16 *)d_residual, (const _Float16 *)d_residual2, (_Float16 *)d_out, (_Float16 *)d_out_relu, n_vec, C / 8, relu);
     else
         return hive_fail(ctx, HIVE_ERR_INVALID, "bias_act: dtype must be HIVE_F16 or HIVE_BF16");
     HIVE_CHECK_HIP(ctx, hipGetLastError());
     return HIVE_OK;
 }
 
-int hive_nhwc_upsample2x(hive_ctx *ctx, const void *d_in, int dtype, int N, int H, int W, int C, void *d_out) {
+int hive_nhwc_upsample2x(hive_ctx *ctx, const void *d_in, const void *d_bias, int dtype, int N, int H, int W, int C, void *d_out) {
     if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
     HIVE_REQUIRE(ctx, d_in && d_out, "upsample2x: NULL argument");
     HIVE_REQUIRE(ctx, N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "upsample2x: need C %% 8 == 0 (N=%d H=%d W=%d C=%d)", N, H, W, C);
     const size_t total = (size_t)N * 4 * H * W * (C / 8);
     const dim3 grid((unsigned)std::min<size_t>((total + 255) / 256, (size_t)ctx->num_cus * 32));
     if (dtype == HIVE_BF16)
-        hipLaunchKernelGGL(upsample2x_kernel<bf16>, grid, dim3(256), 0, ctx->stream, (const bf16 *)d_in, (bf16 *)d_out, N, H, W, C);
+        hipLaunchKernelGGL(upsample2x_kernel<bf16>, grid, dim3(256), 0, ctx->stream, (const bf16 *)d_in, (const bf16 *)d_bias, (bf16 *)d_out, N, H, W, C);
     else if (dtype == HIVE_F16)
-        hipLaunchKernelGGL(upsample2x_kernel<_Float16>, grid, dim3(256), 0, ctx->stream, (const _Float16 *)d_in, (_Float16 *)d_out, N, H, W, C);
+        hipLaunchKernelGGL(upsample2x_kernel<_Float16>, grid, dim3(256), 0, ctx->stream, (const _Float16 *)d_in, (const _Float16 *)d_bias, (_Float16 *)d_out, N, H, W, C);
     else
         return hive_fail(ctx, HIVE_ERR_INVALID, "upsample2x: dtype must be HIVE_F16 or HIVE_BF16");
     HIVE_CHECK_HIP(ctx, hipGetLastError());

@@ -268,10 +268,11 @@ class ResidualConvUnit(nn.Module):
         self.conv1 = nn.Conv2d(features, features, 3, 1, 1, bias=True)
         self.conv2 = nn.Conv2d(features, features, 3, 1, 1, bias=True)
 
-    def forward(self, x, skip=None):
-        # out = conv2(relu(conv1(relu(x)))) + x (+ skip), with bias / ReLU / skip adds fused behind each convolution
-        out = dpt_ops.conv_bias_act(F.relu(x), self.conv1, relu=True, engine=self.engine)
-        return dpt_ops.conv_bias_act(out, self.conv2, relu=False, residual=x, residual2=skip, engine=self.engine)
+    def forward(self, x, skip=None, x_relu=None, also_relu=False):
+        # out = conv2(relu(conv1(relu(x)))) + x (+ skip), with bias / ReLU / skip adds fused behind each convolution.
+        # x_relu: relu(x) if the producer of x already wrote it; also_relu: return (out, relu(out)) for the next unit.
+        out = dpt_ops.conv_bias_act(F.relu(x) if x_relu is None else x_relu, self.conv1, relu=True, engine=self.engine)
+        return dpt_ops.conv_bias_act(out, self.conv2, relu=False, residual=x, residual2=skip, engine=self.engine, also_relu=also_relu)
 
 
 class FeatureFusionBlock(nn.Module):
@@ -284,16 +285,18 @@ class FeatureFusionBlock(nn.Module):
         self.resConfUnit2 = ResidualConvUnit(features)
 
     def forward(self, *xs):
-        output = xs[0]
-        if len(xs) == 2:
-            output = self.resConfUnit1(xs[1], skip=output)  # output + resConfUnit1(xs[1])
-        output = self.resConfUnit2(output)
+        output, output_relu = xs[0], None
+        if len(xs) == 2:  # output + resConfUnit1(xs[1]), and its ReLU for resConfUnit2 from the same kernel
+            output, output_relu = self.resConfUnit1(xs[1], skip=output, also_relu=True)
+        output = self.resConfUnit2(output, x_relu=output_relu)
         if self.engine == "hip":
             # The reference interpolates, then applies the 1x1 out_conv.  A 1x1 convolution (per-pixel, with
             # bias) and bilinear interpolation (per-channel, weights summing to 1) commute exactly in real
             # arithmetic, so the projection runs on a quarter of the pixels; the results differ only by bf16
             # rounding order (covered by the tolerance of tests/test_vit_gpu.py against the torch engine).
-            return dpt_ops.upsample2x(self.out_conv(output), engine=self.engine)
+            # (and its bias is added by the upsampling kernel while loading)
+            oc = self.out_conv
+            return dpt_ops.upsample2x(F.conv2d(output, oc.weight, None, oc.stride, oc.padding), engine=self.engine, bias=oc.bias)
         output = dpt_ops.upsample2x(output, engine=self.engine)  # bilinear, align_corners=True
         return self.out_conv(output)
 

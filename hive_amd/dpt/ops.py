@@ -36,9 +36,10 @@ def group_norm_act(x, num_groups, weight, bias, eps, relu=True, residual=None, e
     return F.relu(y) if relu else y
 
 
-def conv_bias_act(x, conv, relu=False, residual=None, residual2=None, engine="torch"):
+def conv_bias_act(x, conv, relu=False, residual=None, residual2=None, engine="torch", also_relu=False):
     """relu?(conv(x) (+ residual) (+ residual2)) for an ``nn.Conv2d`` with bias.  With the HIP engine the convolution runs
-    without its bias (MIOpen) and one fused kernel adds bias, skip connection and ReLU."""
+    without its bias (MIOpen) and one fused kernel adds bias, skip connection and ReLU.  ``also_relu=True`` returns
+    ``(y, relu(y))``: the second tensor is what the next residual unit feeds to its first convolution."""
     if engine == "hip" and conv.bias is not None and _hip_eligible(x) and conv.out_channels % 8 == 0 and conv.bias.dtype == x.dtype:
         y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
         if _hip_eligible(y):
@@ -49,10 +50,11 @@ def conv_bias_act(x, conv, relu=False, residual=None, residual2=None, engine="to
                 assert residual2.shape == y.shape and residual2.dtype == y.dtype
                 residual2 = residual2.contiguous(memory_format=torch.channels_last)
             n, c, h, w = y.shape
+            y_relu = torch.empty_like(y) if also_relu else None
             ctx = _lib.default_context(y.device.index or 0)
             ctx.check(ctx.lib.hive_nhwc_bias_act(ctx.handle, y.data_ptr(), _code(y.dtype), n * h * w, c, conv.bias.data_ptr(), int(bool(relu)),
-                                                 _lib.ptr(residual), _lib.ptr(residual2), y.data_ptr()))  # in place
-            return y
+                                                 _lib.ptr(residual), _lib.ptr(residual2), y.data_ptr(), _lib.ptr(y_relu)))  # y in place
+            return (y, y_relu) if also_relu else y
         y = y + conv.bias.view(1, -1, 1, 1)
     else:
         y = conv(x)
@@ -60,15 +62,20 @@ def conv_bias_act(x, conv, relu=False, residual=None, residual2=None, engine="to
         y = y + residual
     if residual2 is not None:
         y = y + residual2
-    return F.relu(y) if relu else y
+    y = F.relu(y) if relu else y
+    return (y, F.relu(y)) if also_relu else y
 
 
-def upsample2x(x, engine="torch"):
-    """interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)."""
-    if engine == "hip" and _hip_eligible(x):
+def upsample2x(x, engine="torch", bias=None):
+    """interpolate(x (+ bias per channel), scale_factor=2, mode="bilinear", align_corners=True).  ``bias`` folds the bias
+    pass of the convolution that produced ``x`` into the load (x + b is rounded to the tensor dtype first, as a separate
+    add would round it)."""
+    if engine == "hip" and _hip_eligible(x) and (bias is None or bias.dtype == x.dtype):
         n, c, h, w = x.shape
         out = torch.empty((n, c, 2 * h, 2 * w), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
         ctx = _lib.default_context(x.device.index or 0)
-        ctx.check(ctx.lib.hive_nhwc_upsample2x(ctx.handle, x.data_ptr(), _code(x.dtype), n, h, w, c, out.data_ptr()))
+        ctx.check(ctx.lib.hive_nhwc_upsample2x(ctx.handle, x.data_ptr(), _lib.ptr(bias), _code(x.dtype), n, h, w, c, out.data_ptr()))
         return out
+    if bias is not None:
+        x = x + bias.view(1, -1, 1, 1)
     return F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)

@@ -252,12 +252,14 @@ int hive_nhwc_group_norm(hive_ctx *ctx, const void *d_x, int dtype, int N, int H
                          int relu, void *d_out);
 /* out = relu?( (x + bias[c]) (+ residual) (+ residual2) ) over [n_px][C] (C % 8 == 0; bias in the tensor dtype; out may
  * alias x): convolution bias + ReLU + skip adds of the RefineNet residual units / fusion blocks (isl-org/DPT
- * ResidualConvUnit_custom, FeatureFusionBlock_custom) in one pass */
-int hive_nhwc_bias_act(hive_ctx *ctx, const void *d_x, int dtype, int64_t n_px, int C, const void *d_bias,
-                       int relu, const void *d_residual, const void *d_residual2, void *d_out);
+ * ResidualConvUnit_custom, FeatureFusionBlock_custom) in one pass.  d_out_relu (optional) additionally receives
+ * relu(out): the input of the next residual unit's first convolution (its `relu(x)`), saving that unit a pass. */
+int hive_nhwc_bias_act(hive_ctx *ctx, const void *d_x, int dtype, int64_t n_px, int C, const void *d_bias, int relu,
+                       const void *d_residual, const void *d_residual2, void *d_out, void *d_out_relu);
 /* bilinear x2, align_corners=True: [N][H][W][C] -> [N][2H][2W][C] (C % 8 == 0): the RefineNet fusion blocks'
- * and the depth head's `interpolate(scale_factor=2, mode="bilinear", align_corners=True)` */
-int hive_nhwc_upsample2x(hive_ctx *ctx, const void *d_in, int dtype, int N, int H, int W, int C, void *d_out);
+ * and the depth head's `interpolate(scale_factor=2, mode="bilinear", align_corners=True)`.  d_bias (optional, [C], tensor
+ * dtype) is added to the input on load, rounded to the tensor dtype first: the bias pass of the producing convolution. */
+int hive_nhwc_upsample2x(hive_ctx *ctx, const void *d_in, const void *d_bias, int dtype, int N, int H, int W, int C, void *d_out);
 
 #ifdef __cplusplus
 }

@@ -148,6 +148,10 @@ def test_upsample2x_matches_torch(gpu_ctx, N, C, H, W):
     x = torch.randn(N, C, H, W, device="cuda").bfloat16().contiguous(memory_format=torch.channels_last)
     out = ops.upsample2x(x, engine="hip")
     ref = torch.nn.functional.interpolate(x.float(), scale_factor=2, mode="bilinear", align_corners=True)
+    # bias folded into the load == bias added (and rounded to bf16) first, bit for bit
+    b = torch.randn(C, device="cuda").bfloat16()
+    xb = (x + b.view(1, -1, 1, 1)).contiguous(memory_format=torch.channels_last)
+    assert torch.equal(ops.upsample2x(x, engine="hip", bias=b), ops.upsample2x(xb, engine="hip"))
     assert out.shape == ref.shape and out.is_contiguous(memory_format=torch.channels_last)
     # same formula evaluated in float: only the final bf16 rounding differs from the fp32 reference
     assert (out.float() - ref).abs().max().item() <= 2 ** -8 * ref.abs().max().item() + 1e-6
