@@ -106,13 +106,23 @@ constexpr int BN = 128, BK = 64;
 // erf-GELU (nn.GELU default): 0.5 x (1 + erf(x / sqrt 2)).  erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7,
 // three orders of magnitude below the bf16 output step) on the hardware rcp / exp2: ~14 instructions
 // instead of libm erff's ~45 -- the GELU epilogue was 28 us of the 100 us fc1 GEMM.
-__device__ __forceinline__ float gelu_exact(float x) {
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
-    const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
-    const float erf_abs = 1.0f - poly * __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);
-    return 0.5f * x * (1.0f + copysignf(erf_abs, x));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// evaluated for two values at once on the packed f32 pipe (v_pk_mul / v_pk_fma, IEEE per element): the fc1 epilogue is as
+// long as the 12-step K loop of its tile, and the packed form is 5 % faster end to end (222 -> 210 us at M = 29184)
+__device__ __forceinline__ f32x2 gelu_exact2(f32x2 x) {
+    const f32x2 ax = f32x2{fabsf(x.x), fabsf(x.y)};
+    const f32x2 z = ax * 0.70710678118654752440f;
+    const f32x2 d = 1.0f + 0.3275911f * z;
+    const f32x2 t = f32x2{__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+    const f32x2 poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
+    const f32x2 a = -z * z * 1.44269504088896340736f;
+    const f32x2 e = f32x2{__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)};
+    const f32x2 erf_abs = 1.0f - poly * e;
+    const f32x2 s = f32x2{copysignf(erf_abs.x, x.x), copysignf(erf_abs.y, x.y)};
+    return 0.5f * x * (1.0f + s);
 }
+
 
 // Global -> LDS staging with LDS-DMA (global_load_lds_dwordx4): one wave instruction deposits 64 x 16 B =
 // 8 rows of 128 B, lane-linear.  The bank swizzle therefore lives on the SOURCE side: LDS slot (row, s)
@@ -218,7 +228,11 @@ __global__ __launch_bounds__(TM * 2, 1) void gemm_kernel(GemmParams p) {
                     float o[4] = {acc[nt][mt][0] + b.x, acc[nt][mt][1] + b.y, acc[nt][mt][2] + b.z, acc[nt][mt][3] + b.w};
                     if (EPI == EPI_BIAS_GELU) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) o[j] = gelu_exact(o[j]);
+                        for (int j = 0; j < 4; j += 2) {
+                            const f32x2 g = gelu_exact2(f32x2{o[j], o[j + 1]});
+                            o[j] = g.x;
+                            o[j + 1] = g.y;
+                        }
                     }
                     if (EPI == EPI_BIAS_RESIDUAL) {
                         const bf16x4 rs = *reinterpret_cast<const bf16x4 *>(p.residual + (size_t)m * p.ldc + n);
@@ -324,7 +338,11 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(GemmParams p) {
                 float o[4] = {acc[nt][mt][0] + b.x, acc[nt][mt][1] + b.y, acc[nt][mt][2] + b.z, acc[nt][mt][3] + b.w};
                 if (EPI == EPI_BIAS_GELU) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] = gelu_exact(o[j]);
+                    for (int j = 0; j < 4; j += 2) {
+                        const f32x2 g = gelu_exact2(f32x2{o[j], o[j + 1]});
+                        o[j] = g.x;
+                        o[j + 1] = g.y;
+                    }
                 }
                 if (EPI == EPI_BIAS_RESIDUAL) {
                     const bf16x4 rs = *reinterpret_cast<const bf16x4 *>(p.residual + (size_t)m * p.ldc + n);
