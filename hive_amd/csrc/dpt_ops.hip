@@ -3,7 +3,7 @@
 //   hive_nhwc_upsample2x   bilinear x2, align_corners=True, of the RefineNet fusion blocks and the depth head
 // (timm 0.5.4 `GroupNormAct`, isl-org/DPT `FeatureFusionBlock_custom` / `Interpolate`, reached from
 // dpt.models.DPTDepthModel.forward -- /root/reference/hive/dataset_adaptors.py:1419).  The convolutions
-// themselves stay with MIOpen this round.
+// themselves stay with MIOpen this round; the second half of the depth head is dpt_head.hip.
 //
 // Both are HBM-bound: every lane moves 16 bytes (8 channels) per access, channels fastest.
 //   group norm: 2 reads + 1 write of the tensor (statistics pass, apply pass) + 1 read of the residual;

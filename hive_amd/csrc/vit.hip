@@ -12,11 +12,10 @@
 //                                      over a contiguous axis and the attention needs no transposed reads
 //   weights            [out][in] row-major (nn.Linear), bias / LayerNorm affine in f32
 //
-// GEMM: C[M][N] = A[M][K] W[N][K]^T.  TM x 128 x 64 tiles (TM = 256, 8 waves, when that still fills the chip, else
-// 128, 4 waves); each wave a 64 x 64 sub-tile = 4 x 4 accumulators of v_mfma_f32_16x16x32_bf16.  Operands go
-// global -> LDS by LDS-DMA (global_load_lds_dwordx4) into a 3-stage ring; the bank swizzle is applied on the
-// SOURCE address and again on the ds_read_b128 (conflict-free); one raw s_barrier per K-step behind a counted
-// s_waitcnt vmcnt so that two stages stay in flight across the barrier; XCD-aware tile order.
+// GEMM: C[M][N] = A[M][K] W[N][K]^T on v_mfma_f32_16x16x32_bf16, K-step 64.  Two tilings: 128 x 128 (4 waves of 64 x 64,
+// 2-stage ring of 64 KiB so that two workgroups share a CU) and, for wide N with plenty of tiles, 256 x 256 (8 waves of
+// 128 x 64).  Operands go global -> LDS by LDS-DMA (global_load_lds_dwordx4); the bank swizzle is applied on the
+// SOURCE address and again on the ds_read_b128 (conflict-free); one raw s_barrier per K-step; XCD-aware tile order.
 // The MFMA is issued as W.A^T so that a lane owns 4 consecutive output columns (8-byte stores); the v^T
 // kernel variant issues A.W^T so that a lane owns 4 consecutive tokens.  Epilogues: bias, erf-GELU, residual.
 //
