@@ -10,8 +10,11 @@ checkpoint (``path=None``) the network is randomly initialised -- parity unpinne
 What runs where:
   * ViT encoder blocks (LayerNorm, QKV / proj / MLP GEMMs, attention): hand-written HIP kernels for
     gfx950 (bf16 MFMA, LDS-tiled QK^T) behind the C ABI -- ``hive_amd/csrc/vit.hip``.  ``engine="hip"``.
-  * convolutions (ResNetV2 stem, reassemble, RefineNet fusion, head), GroupNorm, bilinear resize:
-    PyTorch-ROCm ops (MIOpen / hipBLASLt), as SURVEY.md §7 step 7 plans for the first rounds.
+  * convolutions (ResNetV2 stem, reassemble, RefineNet fusion, first head convolution): MIOpen through
+    PyTorch-ROCm, as SURVEY.md §7 step 7 plans for the first rounds.
+  * GroupNorm(+residual+ReLU), bias / ReLU / skip adds, x2 bilinear upsampling and the rest of the depth head
+    (upsample + conv 128->32 + ReLU + conv 32->1 + inversion + mm hand-off): HIP kernels on channels-last bf16
+    -- ``hive_amd/csrc/dpt_ops.hip``, ``hive_amd/csrc/dpt_head.hip``.
   * ``engine="torch"`` runs the ViT blocks with plain PyTorch ops too: it is the fp32 reference that
     the numerics tests compare the HIP engine against, not a fallback -- ``engine="hip"`` raises if
     the extension is missing.
