@@ -19,7 +19,8 @@
 // The MFMA is issued as W.A^T so that a lane owns 4 consecutive output columns (8-byte stores); the v^T
 // kernel variant issues A.W^T so that a lane owns 4 consecutive tokens.  Epilogues: bias, erf-GELU, residual.
 //
-// Attention: one workgroup = 128 queries of one (image, head); each wave 32 queries.  S^T = K Q^T puts the
+// Attention: one workgroup = 128 queries of one (image, head); each wave 32 queries; K / V^T tiles of 64 keys staged by
+// LDS-DMA into a 2-stage ring.  S^T = K Q^T puts the
 // query on the lane and the keys in the accumulator registers, so the online softmax (base 2, deferred maximum)
 // is in-register with one cross-half shuffle, and the probabilities are already the B operand of O^T += V^T P^T.
 #include "hive_internal.hpp"
@@ -387,27 +388,19 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
     for (int ks = 0; ks < 4; ++ks)
         qf[ks] = *reinterpret_cast<const bf16x8 *>(p.qk + (row0 + q_tok) * ld + head * 64 + ks * 16 + hh * 8);
 
-    // staging of one K tile [64 keys][64 ch] and one V^T tile [64 ch][64 keys]: 512 chunks each, 2 per thread
+    // staging of one K tile [64 keys][64 ch] and one V^T tile [64 ch][64 keys] by LDS-DMA: 8 + 8 groups of 8 rows x 128 B,
+    // 4 per wave, with the GEMM's source-side chunk swizzle (slot = chunk ^ ((row >> 1) & 7))
     const bf16 *k_base = p.qk + row0 * ld + p.D + head * 64;
     const bf16 *v_base = p.vT + ((size_t)img * p.H + head) * 64 * p.Np;
-    uint4 k_reg[2], v_reg[2];
-    auto load_global = [&](int t) {
-        for (int i = 0; i < 2; ++i) {
-            const int id = tid + 256 * i, r = id >> 3, c = id & 7;
-            k_reg[i] = *reinterpret_cast<const uint4 *>(k_base + (size_t)(t * ATT_KV + r) * ld + c * 8);
-            v_reg[i] = *reinterpret_cast<const uint4 *>(v_base + (size_t)r * p.Np + t * ATT_KV + c * 8);
-        }
-    };
-    auto store_lds = [&](int stage) {
+    auto issue_tile = [&](int t, int stage) {
         unsigned char *k_t = lds + stage * 2 * ATT_KV * 128, *v_t = k_t + ATT_KV * 128;
-        for (int i = 0; i < 2; ++i) {
-            const int id = tid + 256 * i, r = id >> 3, c = id & 7;
-            *reinterpret_cast<uint4 *>(k_t + swz(r, c)) = k_reg[i];
-            // V^T rows are read 8 bytes at a time with 32 different rows per access: swizzle the 8-byte unit
-            // index with (r >> 1) & 15 so that 32 consecutive rows cover the 32 slots of a bank row
-            const int u0 = (2 * c) ^ ((r >> 1) & 15), u1 = (2 * c + 1) ^ ((r >> 1) & 15);
-            *reinterpret_cast<uint2 *>(v_t + r * 128 + u0 * 8) = make_uint2(v_reg[i].x, v_reg[i].y);
-            *reinterpret_cast<uint2 *>(v_t + r * 128 + u1 * 8) = make_uint2(v_reg[i].z, v_reg[i].w);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int g = wave + 4 * j;  // 0..15
+            if (g < 8)
+                stage_group(k_base, ld, t * ATT_KV, p.Np - 1, 0, k_t, g, lane);
+            else
+                stage_group(v_base + t * ATT_KV, p.Np, 0, 63, 0, v_t, g - 8, lane);
         }
     };
 
@@ -416,12 +409,12 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
     float m_run = -INFINITY, l_run = 0.f;
 
     const int n_tiles = p.Np / ATT_KV;
-    load_global(0);
-    store_lds(0);
+    issue_tile(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int t = 0; t < n_tiles; ++t) {
         const int stage = t & 1;
-        if (t + 1 < n_tiles) load_global(t + 1);
+        if (t + 1 < n_tiles) issue_tile(t + 1, stage ^ 1);  // that buffer was last read in tile t-1, before its barrier
         const unsigned char *k_t = lds + stage * 2 * ATT_KV * 128, *v_t = k_t + ATT_KV * 128;
         // S^T[key][q] for 64 keys x 32 queries: rows (keys) in registers, query on the lane
         f32x16 sacc[2];
@@ -482,13 +475,17 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
                 for (int db = 0; db < 2; ++db) {
                     const int r = db * 32 + lq;
                     const int u = (kb * 32 + s * 16 + 4 * hh) >> 2;  // 8-byte unit of the first 4 keys; second group is u + 2
-                    const uint2 lo = *reinterpret_cast<const uint2 *>(v_t + r * 128 + ((u ^ ((r >> 1) & 15)) << 3));
-                    const uint2 hi = *reinterpret_cast<const uint2 *>(v_t + r * 128 + (((u + 2) ^ ((r >> 1) & 15)) << 3));
+                    // V^T rows are read 8 bytes at a time (two groups of 4 keys); with the 16-byte chunk swizzle of the DMA
+                    // image rows r and r + 16 of a 32-lane read share a bank slot (2-way, +2 LDS cycles per read: cheap
+                    // next to the 49 us per call that register staging + ds_write cost)
+                    const int sw = (r >> 1) & 7;
+                    const uint2 lo = *reinterpret_cast<const uint2 *>(v_t + r * 128 + ((((u >> 1) ^ sw) << 4) | ((u & 1) << 3)));
+                    const uint2 hi = *reinterpret_cast<const uint2 *>(v_t + r * 128 + (((((u >> 1) + 1) ^ sw) << 4) | ((u & 1) << 3)));
                     uint4 raw = make_uint4(lo.x, lo.y, hi.x, hi.y);
                     const bf16x8 vf = *reinterpret_cast<const bf16x8 *>(&raw);
                     oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kb][s], oacc[db], 0, 0, 0);
                 }
-        if (t + 1 < n_tiles) store_lds(stage ^ 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my pieces of tile t+1 have landed
         __syncthreads();
     }
     const float l_tot = l_run + __shfl_xor(l_run, 32);
