@@ -13,7 +13,7 @@ pass C SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INST_CYCLES_VM
 python3 - <<PY
 import csv, glob, collections, json
 kernels = {"gemm_kernel<0": "gemm q|k / v^T (bias)", "gemm_kernel<1": "gemm fc1 + GELU", "gemm_kernel<2": "gemm proj / fc2 + residual",
-           "gemm_kernel<3": "gemm v^T", "attention_kernel": "attention", "head_conv_kernel": "fused depth head"}
+           "gemm_kernel<3": "gemm v^T", "gemm256_kernel<1": "gemm fc1 + GELU (256 x 256 tiles)", "attention_kernel": "attention", "head_conv_kernel": "fused depth head"}
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("$OUT/p?/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
