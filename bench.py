@@ -108,6 +108,8 @@ def main():
 
     for s in range(args.warmup):
         run_step(s)
+    if world > 1 and args.warmup > 0:
+        hdist.fuse_sharded(volume)  # warm-up of the collective too (RCCL sets up its channels on the first large all-reduce)
     torch.cuda.synchronize()
     # reset the volume so that the timed job starts from an empty scene
     volume.reset()
