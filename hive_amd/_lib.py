@@ -29,6 +29,7 @@ SIGNATURES = {
     "hive_ctx_destroy": (c_int, [c_void_p]),
     "hive_ctx_synchronize": (c_int, [c_void_p]),
     "hive_last_error": (ctypes.c_char_p, [c_void_p]),
+    "hive_ctx_set_stream": (c_int, [c_void_p, c_void_p]),
     "hive_ctx_set_round_mode": (c_int, [c_void_p, c_int]),
     "hive_ctx_set_timing": (c_int, [c_void_p, c_int]),
     "hive_ctx_last_kernel_ms": (c_int, [c_void_p, P(c_float)]),
@@ -36,6 +37,7 @@ SIGNATURES = {
     "hive_tsdf_dims": (c_int, [c_void_p, c_double, c_void_p]),
     "hive_tsdf_create": (c_int, [c_void_p, c_void_p, c_double, c_void_p, c_void_p, c_void_p, P(c_void_p)]),
     "hive_tsdf_destroy": (c_int, [c_void_p]),
+    "hive_tsdf_set_round_mode": (c_int, [c_void_p, c_int]),
     "hive_tsdf_reset": (c_int, [c_void_p]),
     "hive_tsdf_info": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, P(c_float), P(c_float)]),
     "hive_tsdf_device_ptrs": (c_int, [c_void_p, P(c_void_p), P(c_void_p), P(c_void_p)]),
@@ -157,11 +159,14 @@ class Context:
         lib = load()
         self.device = int(device)
         handle = c_void_p()
+        self._follow_torch = stream == "torch"
+        self._stream = None
         if stream == "torch":
             import torch
             if not torch.cuda.is_available():
                 raise HiveError(ERR_DEVICE, "no HIP device visible to torch; hive_amd needs an MI355X (no CPU fallback)")
-            stream_ptr = c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+            self._stream = int(torch.cuda.current_stream(self.device).cuda_stream)
+            stream_ptr = c_void_p(self._stream)
         elif stream == "own":
             stream_ptr = c_void_p(-1)  # HIVE_STREAM_OWN
         else:
@@ -172,6 +177,18 @@ class Context:
 
     def check(self, rc):
         check(rc, self.handle)
+
+    def follow_torch_stream(self):
+        """Re-bind to torch's *current* stream of the device if it changed since the last call (``with
+        torch.cuda.stream(s)``): hive kernels must queue on the stream the surrounding torch ops use, or the
+        two are unordered.  A no-op for contexts created with an explicit or private stream."""
+        if self._follow_torch:
+            import torch
+            cur = int(torch.cuda.current_stream(self.device).cuda_stream)
+            if cur != self._stream:
+                self.check(self.lib.hive_ctx_set_stream(self.handle, c_void_p(cur)))
+                self._stream = cur
+        return self
 
     def synchronize(self):
         self.check(self.lib.hive_ctx_synchronize(self.handle))
@@ -214,4 +231,4 @@ def default_context(device=None):
         cache = _tls.ctx = {}
     if device not in cache:
         cache[device] = Context(device)
-    return cache[device]
+    return cache[device].follow_torch_stream()

@@ -103,7 +103,10 @@ int hive_ctx_create(int device_id, void *stream, hive_ctx **out) {
     hive_ctx *ctx = new hive_ctx();
     ctx->device = device_id;
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    e = hipSetDevice(device_id);
+    HIVE_ENTER(ctx);  // device_id current for the allocations below; the caller's device is restored on return
+    int current = -1;
+    e = hipGetDevice(&current);
+    if (e == hipSuccess && current != device_id) e = hipErrorInvalidDevice;  // the guard could not switch
     if (e == hipSuccess) {
         if (stream == HIVE_STREAM_OWN) {
             e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
@@ -124,8 +127,9 @@ int hive_ctx_create(int device_id, void *stream, hive_ctx **out) {
 
 int hive_ctx_destroy(hive_ctx *ctx) {
     if (!ctx) return HIVE_OK;
-    (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
+    {
+        HIVE_ENTER(ctx);
+        (void)hipStreamSynchronize(ctx->stream);
     for (auto &s : ctx->slots) {
         if (s.pinned) (void)hipHostFree(s.pinned);
         if (s.done) (void)hipEventDestroy(s.done);
@@ -135,12 +139,36 @@ int hive_ctx_destroy(hive_ctx *ctx) {
     if (ctx->d_frame) (void)hipFree(ctx->d_frame);
     if (ctx->d_in) (void)hipFree(ctx->d_in);
     if (ctx->d_scalars) (void)hipFree(ctx->d_scalars);
-    if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
+        if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
+    }
     delete ctx;
     return HIVE_OK;
 }
 
+int hive_ctx_set_stream(hive_ctx *ctx, void *stream) {
+    HIVE_ENTER(ctx);
+    if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
+    HIVE_REQUIRE(ctx, stream != HIVE_STREAM_OWN, "hive_ctx_set_stream: pass a hipStream_t (NULL = the default stream)");
+    hipStream_t next = (hipStream_t)stream;
+    if (next == ctx->stream) return HIVE_OK;
+    // work already queued on the old stream may still use the context's scratch buffers: order the new stream behind it
+    hipEvent_t ev;
+    HIVE_CHECK_HIP(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    hipError_t e = hipEventRecord(ev, ctx->stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(next, ev, 0);
+    (void)hipEventDestroy(ev);
+    HIVE_CHECK_HIP(ctx, e);
+    if (ctx->owns_stream) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipStreamDestroy(ctx->stream);
+        ctx->owns_stream = false;
+    }
+    ctx->stream = next;
+    return HIVE_OK;
+}
+
 int hive_ctx_synchronize(hive_ctx *ctx) {
+    HIVE_ENTER(ctx);
     if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
     HIVE_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return HIVE_OK;
@@ -149,6 +177,7 @@ int hive_ctx_synchronize(hive_ctx *ctx) {
 const char *hive_last_error(hive_ctx *ctx) { return ctx ? ctx->last_error.c_str() : g_global_error.c_str(); }
 
 int hive_ctx_set_round_mode(hive_ctx *ctx, int mode) {
+    HIVE_ENTER(ctx);
     if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
     HIVE_REQUIRE(ctx, mode == HIVE_ROUND_HALF_EVEN || mode == HIVE_ROUND_HALF_AWAY, "round mode must be 0 or 1, got %d", mode);
     ctx->round_mode = mode;
@@ -156,6 +185,7 @@ int hive_ctx_set_round_mode(hive_ctx *ctx, int mode) {
 }
 
 int hive_ctx_set_timing(hive_ctx *ctx, int enabled) {
+    HIVE_ENTER(ctx);
     if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
     ctx->timing = enabled != 0;
     ctx->ev_used = 0;
@@ -164,6 +194,7 @@ int hive_ctx_set_timing(hive_ctx *ctx, int enabled) {
 }
 
 int hive_ctx_last_kernel_ms(hive_ctx *ctx, float *ms) {
+    HIVE_ENTER(ctx);
     if (!ctx || !ms) return hive_fail(ctx, HIVE_ERR_INVALID, "NULL argument");
     HIVE_REQUIRE(ctx, ctx->last_start && ctx->last_stop, "no timed kernel has been launched on this context");
     HIVE_CHECK_HIP(ctx, hipEventSynchronize(ctx->last_stop));
@@ -172,6 +203,7 @@ int hive_ctx_last_kernel_ms(hive_ctx *ctx, float *ms) {
 }
 
 int hive_ctx_kernel_time_total(hive_ctx *ctx, int *n_launches, float *total_ms) {
+    HIVE_ENTER(ctx);
     if (!ctx || !n_launches || !total_ms) return hive_fail(ctx, HIVE_ERR_INVALID, "NULL argument");
     HIVE_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     float total = 0.f;

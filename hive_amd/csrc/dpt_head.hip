@@ -239,6 +239,7 @@ extern "C" int hive_dpt_head_fused(hive_ctx *ctx, const void *d_x, const float *
                                    const void *d_w3, const float *h_b3, const float *h_w1, float b1, int non_negative, int invert,
                                    float scale, float shift, float *d_depth, float depth_scale, float max_depth,
                                    uint16_t *d_out_mm, float *d_out_m) {
+    HIVE_ENTER(ctx);
     if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
     HIVE_REQUIRE(ctx, d_x && d_w3 && h_b3 && h_w1, "dpt_head_fused: NULL argument");
     HIVE_REQUIRE(ctx, dtype == HIVE_BF16, "dpt_head_fused: bf16 only (use hive_dpt_head_tail behind a library convolution for f16)");

@@ -247,6 +247,7 @@ extern "C" {
 
 int hive_nhwc_group_norm(hive_ctx *ctx, const void *d_x, int dtype, int N, int HW, int C, int G, const void *d_gamma,
                          const void *d_beta, float eps, const void *d_residual, int relu, void *d_out) {
+    HIVE_ENTER(ctx);
     if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
     HIVE_REQUIRE(ctx, d_x && d_gamma && d_beta && d_out, "group_norm: NULL argument");
     HIVE_REQUIRE(ctx, N > 0 && HW > 0 && C >= 8 && C <= 2048 && pow2(C) && G > 0 && C % G == 0,
@@ -276,6 +277,7 @@ int hive_nhwc_group_norm(hive_ctx *ctx, const void *d_x, int dtype, int N, int H
 
 int hive_nhwc_bias_act(hive_ctx *ctx, const void *d_x, int dtype, int64_t n_px, int C, const void *d_bias, int relu,
                        const void *d_residual, const void *d_residual2, void *d_out, void *d_out_relu) {
+    HIVE_ENTER(ctx);
     if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
     HIVE_REQUIRE(ctx, d_x && d_bias && d_out, "bias_act: NULL argument");
     HIVE_REQUIRE(ctx, n_px > 0 && C > 0 && C % 8 == 0, "bias_act: need C %% 8 == 0 (n_px=%lld C=%d)", (long long)n_px, C);
@@ -294,6 +296,7 @@ int hive_nhwc_bias_act(hive_ctx *ctx, const void *d_x, int dtype, int64_t n_px, 
 }
 
 int hive_nhwc_upsample2x(hive_ctx *ctx, const void *d_in, const void *d_bias, int dtype, int N, int H, int W, int C, void *d_out) {
+    HIVE_ENTER(ctx);
     if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
     HIVE_REQUIRE(ctx, d_in && d_out, "upsample2x: NULL argument");
     HIVE_REQUIRE(ctx, N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "upsample2x: need C %% 8 == 0 (N=%d H=%d W=%d C=%d)", N, H, W, C);

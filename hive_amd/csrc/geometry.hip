@@ -273,6 +273,7 @@ extern "C" {
 
 int hive_view_frustum(hive_ctx *ctx, const float *depth, int H, int W, const float K[9], const double cam_pose[16], int mem,
                       double out[15]) {
+    HIVE_ENTER(ctx);
     if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
     HIVE_REQUIRE(ctx, depth && K && cam_pose && out, "view_frustum: NULL argument");
     HIVE_REQUIRE(ctx, H > 0 && W > 0, "view_frustum: bad image size %dx%d", H, W);
@@ -308,6 +309,7 @@ int hive_view_frustum(hive_ctx *ctx, const float *depth, int H, int W, const flo
 int hive_unproject(hive_ctx *ctx, const float *depth, const uint8_t *mask, const uint8_t *rgb, int H, int W,
                    const double Kinv[9], const double R[9], const double t[3], int mem, double *out_xyz, uint8_t *out_rgba,
                    int64_t capacity, int64_t *n_out) {
+    HIVE_ENTER(ctx);
     if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
     HIVE_REQUIRE(ctx, depth && Kinv && R && t && n_out, "unproject: NULL argument");
     HIVE_REQUIRE(ctx, H > 0 && W > 0 && (long long)H * W < (1ll << 30), "unproject: bad image size %dx%d", H, W);
@@ -360,6 +362,7 @@ int hive_unproject(hive_ctx *ctx, const float *depth, const uint8_t *mask, const
 
 int hive_image2world(hive_ctx *ctx, const double *uv, const double *depth, int64_t n, const double Kinv[9], const double R[9],
                      const double t[3], double scale_factor, int mem, double *out_xyz) {
+    HIVE_ENTER(ctx);
     if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
     HIVE_REQUIRE(ctx, Kinv && R && t, "image2world: NULL argument");
     HIVE_REQUIRE(ctx, n >= 0 && (n == 0 || (uv && depth && out_xyz)), "image2world: bad arguments");
@@ -392,6 +395,7 @@ int hive_image2world(hive_ctx *ctx, const double *uv, const double *depth, int64
 
 int hive_project(hive_ctx *ctx, const double *points, int64_t n, const double K[9], const double R[9], const double t[3],
                  double scale_factor, int mem, int32_t *out_uv_i32, double *out_uv_f64, double *out_depth) {
+    HIVE_ENTER(ctx);
     if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
     HIVE_REQUIRE(ctx, K && R && t, "project: NULL argument");
     HIVE_REQUIRE(ctx, n >= 0 && (n == 0 || points), "project: bad points");
@@ -431,6 +435,7 @@ int hive_project(hive_ctx *ctx, const double *points, int64_t n, const double K[
 
 int hive_project_bbox(hive_ctx *ctx, const double *points, int64_t n, const double K[9], const double R[9], const double t[3],
                       int W, int H, int mem, int32_t out[5]) {
+    HIVE_ENTER(ctx);
     if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
     HIVE_REQUIRE(ctx, K && R && t && out && W > 0 && H > 0, "project_bbox: bad arguments");
     HIVE_REQUIRE(ctx, n >= 0 && (n == 0 || points), "project_bbox: bad points");
@@ -457,6 +462,7 @@ int hive_project_bbox(hive_ctx *ctx, const double *points, int64_t n, const doub
 }
 
 int hive_dilate_mask(hive_ctx *ctx, const uint8_t *mask, int H, int W, int iterations, int mem, uint8_t *out) {
+    HIVE_ENTER(ctx);
     if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
     HIVE_REQUIRE(ctx, mask && out, "dilate_mask: NULL argument");
     HIVE_REQUIRE(ctx, H > 0 && W > 0 && iterations >= 0, "dilate_mask: bad arguments %dx%d, %d iterations", H, W, iterations);
@@ -489,6 +495,7 @@ int hive_dilate_mask(hive_ctx *ctx, const uint8_t *mask, int H, int W, int itera
 
 int hive_depth_quantize(hive_ctx *ctx, const void *d_depth, int dtype, int H, int W, float depth_scale, float max_depth,
                         const uint8_t *d_mask, uint16_t *d_out_mm, float *d_out_m) {
+    HIVE_ENTER(ctx);
     if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
     HIVE_REQUIRE(ctx, d_depth && (d_out_mm || d_out_m), "depth_quantize: NULL argument");
     HIVE_REQUIRE(ctx, H > 0 && W > 0, "depth_quantize: bad image size");

@@ -51,6 +51,25 @@ struct hive_ctx {
 };
 
 int hive_fail(hive_ctx *ctx, int code, const char *fmt, ...);
+
+// Every extern "C" entry point runs with its context's device current and puts the caller's device back on
+// return: a context (or a volume / ViT engine built on it) may belong to a GPU other than the calling
+// thread's current one -- kernels, copies and allocations must land on the context's GPU, and the caller's
+// (PyTorch's) current device must not change behind its back.
+struct hive_device_guard {
+    int prev = -1;
+    bool switched = false;
+    explicit hive_device_guard(const hive_ctx *ctx) {
+        if (!ctx) return;
+        if (hipGetDevice(&prev) == hipSuccess && prev != ctx->device) switched = hipSetDevice(ctx->device) == hipSuccess;
+    }
+    ~hive_device_guard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+    hive_device_guard(const hive_device_guard &) = delete;
+    hive_device_guard &operator=(const hive_device_guard &) = delete;
+};
+#define HIVE_ENTER(ctx) hive_device_guard _hive_device_guard(ctx)
 void hive_set_global_error(const char *msg);
 
 #define HIVE_CHECK_HIP(ctx, expr)                                                                        \
@@ -85,6 +104,9 @@ struct hive_tsdf {
     float trunc = 0.f;
     float *d_tsdf = nullptr, *d_weight = nullptr, *d_color = nullptr;
     bool owns = false;
+    // pixel / colour rounding of integrate, finalize and the mesh colour lookup of THIS volume (hive_round_mode):
+    // a property of the volume, not of the context, so that two volumes of one thread may differ
+    int round_mode = HIVE_ROUND_HALF_EVEN;
     // mesh extraction results (device)
     int64_t n_verts = -1, n_faces = -1;
     float *d_verts = nullptr, *d_norms = nullptr, *d_verts_vox = nullptr;

@@ -333,6 +333,7 @@ static int upload_tables(hive_ctx *ctx) {
 extern "C" {
 
 int hive_tsdf_extract_mesh(hive_tsdf *v, int64_t *n_verts, int64_t *n_faces) {
+    HIVE_ENTER(v ? v->ctx : nullptr);
     if (!v) return hive_fail(nullptr, HIVE_ERR_INVALID, "vol is NULL");
     hive_ctx *ctx = v->ctx;
     HIVE_CHECK_HIP(ctx, hipSetDevice(ctx->device));
@@ -395,6 +396,7 @@ int hive_tsdf_extract_mesh(hive_tsdf *v, int64_t *n_verts, int64_t *n_faces) {
 }
 
 int hive_tsdf_copy_mesh(hive_tsdf *v, float *verts, int32_t *faces, float *norms, uint8_t *colors) {
+    HIVE_ENTER(v ? v->ctx : nullptr);
     if (!v) return hive_fail(nullptr, HIVE_ERR_INVALID, "vol is NULL");
     hive_ctx *ctx = v->ctx;
     if (v->n_verts < 0) return hive_fail(ctx, HIVE_ERR_STATE, "copy_mesh: call hive_tsdf_extract_mesh first");
@@ -408,6 +410,7 @@ int hive_tsdf_copy_mesh(hive_tsdf *v, float *verts, int32_t *faces, float *norms
 }
 
 int hive_tsdf_copy_mesh_voxel_coords(hive_tsdf *v, float *verts_vox) {
+    HIVE_ENTER(v ? v->ctx : nullptr);
     if (!v) return hive_fail(nullptr, HIVE_ERR_INVALID, "vol is NULL");
     hive_ctx *ctx = v->ctx;
     if (v->n_verts < 0) return hive_fail(ctx, HIVE_ERR_STATE, "copy_mesh_voxel_coords: call hive_tsdf_extract_mesh first");

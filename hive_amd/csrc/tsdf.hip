@@ -12,9 +12,10 @@
 // Kernel shape: voxel sweep over the part of the volume a frame can touch.  The volume is [X][Y][Z] with
 // z fastest.  pack_frame fuses depth + colour into 8-byte texels and reduces max(depth); build_worklist clips
 // every (x,y) row analytically against the view frustum (the camera-space position is affine in z; one LANE
-// per row) and emits 256-voxel chunks; integrate gives one wave to a chunk, 4 consecutive z voxels (16 bytes
-// per volume) per lane, with packed-f32 arithmetic and a software-pipelined chunk loop.  The clip is padded
-// and every voxel of a chunk still runs the exact tests above, so results do not depend on it.
+// per row) and emits one item per 64-voxel segment of the surviving z interval; integrate is a grid-stride
+// sweep over that list: a wave takes 4 segments per trip (16 lanes x 4 consecutive z voxels = 16 bytes per
+// lane and volume), packed-f32 arithmetic.  The clip is padded and every voxel of a segment still runs the
+// exact tests above, so results do not depend on it.
 #include "hive_internal.hpp"
 
 #include <algorithm>
@@ -653,7 +654,7 @@ static int launch_integrate(hive_tsdf *v, float *accum, int H, int W, const floa
 #define HIVE_LAUNCH(VPT, RM, CNT)                                                                                      \
     hipLaunchKernelGGL((integrate_kernel<VPT, RM, CNT, ACCUM>), grid, block, 0, ctx->stream, p, items, n_items, a0, \
                        v->d_weight, v->d_color, (long long)v->n)
-    const int sel = (vec ? 4 : 0) | (ctx->round_mode ? 2 : 0) | (count ? 1 : 0);
+    const int sel = (vec ? 4 : 0) | (v->round_mode ? 2 : 0) | (count ? 1 : 0);
     switch (sel) {
         case 0: HIVE_LAUNCH(1, 0, false); break;
         case 1: HIVE_LAUNCH(1, 0, true); break;
@@ -690,6 +691,7 @@ int hive_tsdf_dims(const double vol_bnds[6], double voxel_size, int64_t vol_dim[
 
 int hive_tsdf_create(hive_ctx *ctx, const double vol_bnds[6], double voxel_size, float *d_tsdf, float *d_weight,
                      float *d_color, hive_tsdf **out) {
+    HIVE_ENTER(ctx);
     if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
     HIVE_REQUIRE(ctx, out && vol_bnds, "hive_tsdf_create: NULL argument");
     HIVE_REQUIRE(ctx, voxel_size > 0, "hive_tsdf_create: voxel_size must be positive, got %g", voxel_size);
@@ -712,6 +714,7 @@ int hive_tsdf_create(hive_ctx *ctx, const double vol_bnds[6], double voxel_size,
     v->n = dim[0] * dim[1] * dim[2];
     v->voxel_size = (float)voxel_size;
     v->trunc = (float)(5.0 * voxel_size);
+    v->round_mode = ctx->round_mode;  // inherited at creation; hive_tsdf_set_round_mode changes it for this volume only
     if (external) {
         v->d_tsdf = d_tsdf;
         v->d_weight = d_weight;
@@ -739,6 +742,7 @@ int hive_tsdf_create(hive_ctx *ctx, const double vol_bnds[6], double voxel_size,
 }
 
 int hive_tsdf_destroy(hive_tsdf *v) {
+    HIVE_ENTER(v ? v->ctx : nullptr);
     if (!v) return HIVE_OK;
     (void)hipStreamSynchronize(v->ctx->stream);
     hive_tsdf_free_mesh(v);
@@ -753,13 +757,22 @@ int hive_tsdf_destroy(hive_tsdf *v) {
     return HIVE_OK;
 }
 
+int hive_tsdf_set_round_mode(hive_tsdf *v, int mode) {
+    if (!v) return hive_fail(nullptr, HIVE_ERR_INVALID, "vol is NULL");
+    HIVE_REQUIRE(v->ctx, mode == HIVE_ROUND_HALF_EVEN || mode == HIVE_ROUND_HALF_AWAY, "round mode must be 0 or 1, got %d", mode);
+    v->round_mode = mode;
+    return HIVE_OK;
+}
+
 int hive_tsdf_reset(hive_tsdf *v) {
+    HIVE_ENTER(v ? v->ctx : nullptr);
     if (!v) return hive_fail(nullptr, HIVE_ERR_INVALID, "vol is NULL");
     return fill_volume(v);
 }
 
 int hive_tsdf_info(hive_tsdf *v, int64_t vol_dim[3], float origin[3], double vol_bnds[6], float *voxel_size,
                    float *trunc_margin) {
+    HIVE_ENTER(v ? v->ctx : nullptr);
     if (!v) return hive_fail(nullptr, HIVE_ERR_INVALID, "vol is NULL");
     for (int a = 0; a < 3; ++a) {
         if (vol_dim) vol_dim[a] = v->dim[a];
@@ -772,6 +785,7 @@ int hive_tsdf_info(hive_tsdf *v, int64_t vol_dim[3], float origin[3], double vol
 }
 
 int hive_tsdf_device_ptrs(hive_tsdf *v, float **d_tsdf, float **d_weight, float **d_color) {
+    HIVE_ENTER(v ? v->ctx : nullptr);
     if (!v) return hive_fail(nullptr, HIVE_ERR_INVALID, "vol is NULL");
     if (d_tsdf) *d_tsdf = v->d_tsdf;
     if (d_weight) *d_weight = v->d_weight;
@@ -781,6 +795,7 @@ int hive_tsdf_device_ptrs(hive_tsdf *v, float **d_tsdf, float **d_weight, float 
 
 int hive_tsdf_integrate(hive_tsdf *vol, const uint8_t *color, const float *depth, int H, int W, const float K[9],
                         const double cam_pose[16], float obs_weight, int mem, uint64_t *n_updated) {
+    HIVE_ENTER(vol ? vol->ctx : nullptr);
     int rc = check_frame_args(vol, color, depth, H, W, K, cam_pose, mem);
     if (rc) return rc;
     hive_ctx *ctx = vol->ctx;
@@ -800,6 +815,7 @@ int hive_tsdf_integrate(hive_tsdf *vol, const uint8_t *color, const float *depth
 
 int hive_tsdf_integrate_batch(hive_tsdf *vol, int n, const uint8_t *color, const float *depth, int H, int W,
                               const float K[9], const double *cam_poses, float obs_weight, int mem) {
+    HIVE_ENTER(vol ? vol->ctx : nullptr);
     int rc = check_frame_args(vol, color, depth, H, W, K, cam_poses, mem);
     if (rc) return rc;
     HIVE_REQUIRE(vol->ctx, n >= 0, "integrate_batch: n must be >= 0");
@@ -815,6 +831,7 @@ int hive_tsdf_integrate_batch(hive_tsdf *vol, int n, const uint8_t *color, const
 }
 
 int hive_tsdf_get_volume(hive_tsdf *v, float *h_tsdf, float *h_color, float *h_weight) {
+    HIVE_ENTER(v ? v->ctx : nullptr);
     if (!v) return hive_fail(nullptr, HIVE_ERR_INVALID, "vol is NULL");
     hive_ctx *ctx = v->ctx;
     const size_t bytes = (size_t)v->n * sizeof(float);
@@ -826,6 +843,7 @@ int hive_tsdf_get_volume(hive_tsdf *v, float *h_tsdf, float *h_color, float *h_w
 }
 
 int hive_tsdf_set_volume(hive_tsdf *v, const float *h_tsdf, const float *h_color, const float *h_weight) {
+    HIVE_ENTER(v ? v->ctx : nullptr);
     if (!v) return hive_fail(nullptr, HIVE_ERR_INVALID, "vol is NULL");
     hive_ctx *ctx = v->ctx;
     const size_t bytes = (size_t)v->n * sizeof(float);
@@ -838,6 +856,7 @@ int hive_tsdf_set_volume(hive_tsdf *v, const float *h_tsdf, const float *h_color
 }
 
 int hive_tsdf_accum_reset(hive_tsdf *v, float *d_accum) {
+    HIVE_ENTER(v ? v->ctx : nullptr);
     if (!v) return hive_fail(nullptr, HIVE_ERR_INVALID, "vol is NULL");
     HIVE_REQUIRE(v->ctx, d_accum, "accum_reset: d_accum is NULL");
     HIVE_CHECK_HIP(v->ctx, hipMemsetAsync(d_accum, 0, 5 * (size_t)v->n * sizeof(float), v->ctx->stream));
@@ -846,6 +865,7 @@ int hive_tsdf_accum_reset(hive_tsdf *v, float *d_accum) {
 
 int hive_tsdf_accum_integrate(hive_tsdf *vol, float *d_accum, const uint8_t *color, const float *depth, int H, int W,
                               const float K[9], const double cam_pose[16], float obs_weight, int mem) {
+    HIVE_ENTER(vol ? vol->ctx : nullptr);
     int rc = check_frame_args(vol, color, depth, H, W, K, cam_pose, mem);
     if (rc) return rc;
     HIVE_REQUIRE(vol->ctx, d_accum, "accum_integrate: d_accum is NULL");
@@ -856,6 +876,7 @@ int hive_tsdf_accum_integrate(hive_tsdf *vol, float *d_accum, const uint8_t *col
 }
 
 int hive_tsdf_accum_from_volume(hive_tsdf *v, float *d_accum) {
+    HIVE_ENTER(v ? v->ctx : nullptr);
     if (!v) return hive_fail(nullptr, HIVE_ERR_INVALID, "vol is NULL");
     hive_ctx *ctx = v->ctx;
     HIVE_REQUIRE(ctx, d_accum, "accum_from_volume: d_accum is NULL");
@@ -866,11 +887,12 @@ int hive_tsdf_accum_from_volume(hive_tsdf *v, float *d_accum) {
 }
 
 int hive_tsdf_accum_finalize(hive_tsdf *v, const float *d_accum) {
+    HIVE_ENTER(v ? v->ctx : nullptr);
     if (!v) return hive_fail(nullptr, HIVE_ERR_INVALID, "vol is NULL");
     hive_ctx *ctx = v->ctx;
     HIVE_REQUIRE(ctx, d_accum, "accum_finalize: d_accum is NULL");
     const int blocks = (int)std::min<long long>((v->n + 255) / 256, 256 * 32);
-    if (ctx->round_mode)
+    if (v->round_mode)
         hipLaunchKernelGGL(finalize_kernel<1>, dim3(blocks), dim3(256), 0, ctx->stream, d_accum, (long long)v->n, v->d_tsdf,
                            v->d_weight, v->d_color);
     else

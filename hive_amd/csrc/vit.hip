@@ -680,6 +680,7 @@ static inline int pad64(int n) { return (n + 63) / 64 * 64; }
 extern "C" {
 
 int hive_vit_layernorm(hive_ctx *ctx, const void *x, const float *gamma, const float *beta, void *out, int M, int D, float eps) {
+    HIVE_ENTER(ctx);
     if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
     HIVE_REQUIRE(ctx, x && gamma && beta && out, "layernorm: NULL argument");
     HIVE_REQUIRE(ctx, M > 0 && D > 0 && D % 256 == 0 && D <= 1024, "layernorm: D must be a multiple of 256 and <= 1024, got %d", D);
@@ -688,6 +689,7 @@ int hive_vit_layernorm(hive_ctx *ctx, const void *x, const float *gamma, const f
 
 int hive_vit_linear(hive_ctx *ctx, const void *A, const void *W, const float *bias, const void *residual, void *C, int M, int N,
                     int K, int epilogue) {
+    HIVE_ENTER(ctx);
     if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
     HIVE_REQUIRE(ctx, A && W && bias && C, "linear: NULL argument");
     HIVE_REQUIRE(ctx, M > 0 && N > 0 && K > 0 && N % BN == 0 && K % BK == 0, "linear: need N %% 128 == 0 and K %% 64 == 0 (M=%d N=%d K=%d)", M, N, K);
@@ -709,6 +711,7 @@ int hive_vit_linear(hive_ctx *ctx, const void *A, const void *W, const float *bi
 }
 
 int hive_vit_qkv(hive_ctx *ctx, const void *x, const void *W, const float *bias, void *qk, void *vT, int B, int Np, int D, int H) {
+    HIVE_ENTER(ctx);
     if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
     HIVE_REQUIRE(ctx, x && W && bias && qk && vT, "qkv: NULL argument");
     HIVE_REQUIRE(ctx, B > 0 && Np > 0 && Np % 64 == 0 && D == H * 64 && D % 128 == 0, "qkv: need Np %% 64 == 0, D == 64 H, D %% 128 == 0");
@@ -741,9 +744,12 @@ int hive_vit_qkv(hive_ctx *ctx, const void *x, const void *W, const float *bias,
 }
 
 int hive_vit_attention(hive_ctx *ctx, const void *qk, const void *vT, void *out, int B, int N, int Np, int D, int H) {
+    HIVE_ENTER(ctx);
     if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
     HIVE_REQUIRE(ctx, qk && vT && out, "attention: NULL argument");
     HIVE_REQUIRE(ctx, B > 0 && N > 0 && N <= Np && Np % 64 == 0 && D == H * 64, "attention: need N <= Np, Np %% 64 == 0, head dim 64");
+    // the kernel masks pad keys in the LAST 64-key tile only: Np must be N rounded up to a multiple of 64
+    HIVE_REQUIRE(ctx, Np - N < 64, "attention: Np (%d) must be N (%d) rounded up to a multiple of 64", Np, N);
     AttnParams p{};
     p.qk = (const bf16 *)qk;
     p.vT = (const bf16 *)vT;
@@ -758,6 +764,7 @@ int hive_vit_attention(hive_ctx *ctx, const void *qk, const void *vT, void *out,
 }
 
 int hive_dpt_preprocess(hive_ctx *ctx, const uint8_t *d_rgb, int64_t n_values, float mean, float std, int dtype, void *d_out) {
+    HIVE_ENTER(ctx);
     if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
     HIVE_REQUIRE(ctx, d_rgb && d_out && n_values > 0 && std != 0.f, "dpt_preprocess: bad arguments");
     HIVE_REQUIRE(ctx, ((uintptr_t)d_rgb % 4 == 0) && ((uintptr_t)d_out % 8 == 0), "dpt_preprocess: unaligned buffers");
@@ -777,6 +784,7 @@ int hive_dpt_preprocess(hive_ctx *ctx, const uint8_t *d_rgb, int64_t n_values, f
 int hive_dpt_head_tail(hive_ctx *ctx, const void *d_feat, int dtype, int64_t n_px, int C, const float *h_pre_bias, int pre_relu,
                        const float *h_weight, float bias, int non_negative, int invert, float scale, float shift, float *d_depth,
                        float depth_scale, float max_depth, uint16_t *d_out_mm, float *d_out_m) {
+    HIVE_ENTER(ctx);
     if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
     HIVE_REQUIRE(ctx, d_feat && h_weight && n_px > 0, "dpt_head_tail: bad arguments");
     HIVE_REQUIRE(ctx, C > 0 && C <= 64 && C % 8 == 0, "dpt_head_tail: C must be a multiple of 8 and <= 64, got %d", C);
@@ -807,6 +815,7 @@ int hive_dpt_head_tail(hive_ctx *ctx, const void *d_feat, int dtype, int64_t n_p
 
 int hive_vit_create(hive_ctx *ctx, int depth, int dim, int heads, int mlp_dim, float ln_eps, const hive_vit_block_weights *blocks,
                     hive_vit **out) {
+    HIVE_ENTER(ctx);
     if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
     HIVE_REQUIRE(ctx, out && blocks && depth > 0, "vit_create: NULL argument");
     HIVE_REQUIRE(ctx, dim == heads * 64 && dim % 256 == 0 && dim <= 1024 && mlp_dim % 128 == 0,
@@ -829,6 +838,7 @@ int hive_vit_create(hive_ctx *ctx, int depth, int dim, int heads, int mlp_dim, f
 }
 
 int hive_vit_destroy(hive_vit *v) {
+    HIVE_ENTER(v ? v->ctx : nullptr);
     if (!v) return HIVE_OK;
     (void)hipStreamSynchronize(v->ctx->stream);
     if (v->ws) (void)hipFree(v->ws);
@@ -837,6 +847,7 @@ int hive_vit_destroy(hive_vit *v) {
 }
 
 int hive_vit_forward(hive_vit *v, const void *x, int B, int N, const int *tap_blocks, int n_taps, void *const *tap_out) {
+    HIVE_ENTER(v ? v->ctx : nullptr);
     if (!v) return hive_fail(nullptr, HIVE_ERR_INVALID, "vit is NULL");
     hive_ctx *ctx = v->ctx;
     HIVE_REQUIRE(ctx, x && B > 0 && N > 0, "vit_forward: bad arguments");

@@ -85,6 +85,13 @@ class TUMAdaptor:
                                depth_mask_dilation_iterations=BackgroundMeshOptions().depth_mask_dilation_iterations,
                                depth_scale=HiveDataset.depth_scaling_factor)
 
+    def depth_to_mm(self, raw):
+        """TUM depth PNG values -> uint16 millimetres, in the reference's operation order (dataset_adaptors.py:762-764:
+        metres first, then x 1000, then truncation) -- dividing by the two scale factors in one step rounds differently
+        and is off by one millimetre for 41 of the 65536 raw values."""
+        depth_map = np.asarray(raw) * self.depth_scale_factor  # convert to metres from non-standard scale & units.
+        return (1000 * depth_map).astype(np.uint16)  # convert to mm from metres.
+
     def convert(self, estimate_pose=False, estimate_depth=False, no_cache=False) -> HiveDataset:
         """Write the HIVE-format folder and return it as a ``HiveDataset`` (dataset_adaptors.py:176-266).
         Instance masks need detectron2 (out of scope): empty masks are written, i.e. a static scene.
@@ -105,7 +112,7 @@ class TUMAdaptor:
             Image.fromarray(np.zeros((self.height, self.width), np.uint8)).save(pjoin(out, "mask", name))
             if not estimate_depth:
                 raw = np.asarray(Image.open(pjoin(self.base_path, self.depth_folder, self.depth_filenames[i])))
-                depth_mm = (raw.astype(np.float64) * self.depth_scale_factor / HiveDataset.depth_scaling_factor).astype(np.uint16)
+                depth_mm = self.depth_to_mm(raw)
                 Image.fromarray(depth_mm).save(pjoin(out, "depth", name))  # uint16 -> 16-bit PNG
         if estimate_depth:
             estimate_depth_dpt(ImageFolderDataset(pjoin(out, "rgb")), pjoin(out, "depth"))

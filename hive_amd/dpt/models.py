@@ -355,6 +355,7 @@ class DPT(nn.Module):
         self.scratch = _Scratch(features=features)
         self.scratch.output_conv = head
         self._vit_engine = None
+        self._vit_stamp = None
         for m in self.modules():  # the fused channels-last glue kernels follow the engine choice
             if isinstance(m, (GroupNormAct, FeatureFusionBlock, Interpolate, ResidualConvUnit)):
                 m.engine = engine
@@ -373,9 +374,25 @@ class DPT(nn.Module):
             return taps[self.pretrained.hooks[2]], taps[self.pretrained.hooks[3]]
         if self.engine != "hip":
             raise ValueError(f"unknown engine {self.engine!r}")
-        if self._vit_engine is None:
+        if tokens.dtype == torch.float32:
+            # optimize=False in the reference = the network in float32 (dataset_adaptors.py:1396-1399 only halves it when
+            # optimising).  The HIP engine computes in bf16; running a float32 model through it would be a silent
+            # precision downgrade, so float32 blocks run as float32 PyTorch ops, like the reference's.
+            x, taps = tokens, {}
+            for i, blk in enumerate(vit.blocks):
+                x = blk(x)
+                if i in self.pretrained.hooks[2:]:
+                    taps[i] = x
+            return taps[self.pretrained.hooks[2]], taps[self.pretrained.hooks[3]]
+        # The engine packs private f32 copies of the biases / LayerNorm parameters (and bf16 copies of matrices that are not
+        # bf16 already): rebuild it when any parameter was replaced or written (load_state_dict, .to(), optimiser step).
+        stamp = tuple((p.data_ptr(), p._version) for p in vit.blocks.parameters())
+        if self._vit_engine is None or self._vit_stamp != stamp:
             from hive_amd.dpt.vit_engine import VitEngine  # raises if libhive_mi355x.so is missing
+            if self._vit_engine is not None:
+                self._vit_engine.close()
             self._vit_engine = VitEngine(vit)
+            self._vit_stamp = stamp
         return self._vit_engine.forward(tokens, taps=self.pretrained.hooks[2:])
 
     def forward_backbone(self, x):

@@ -57,6 +57,12 @@ class TSDFVolume:
         """
         :param vol_bnds: (3, 2) array of the xyz bounds (min/max) in metres.
         :param voxel_size: The volume discretisation in metres.
+        :param use_gpu: everything runs on the MI355X either way; the flag selects WHICH of the reference
+            library's two arithmetic paths is reproduced.  ``True`` (the reference's default, and what its
+            Docker image runs: pycuda==2021.1, requirements.txt:14) = the CUDA kernel's ``roundf`` (ties away
+            from zero) for the pixel projection and the colour average; ``False`` = the numpy path's
+            ``np.round`` (ties to even; BASELINE config 1).  They differ only on exact ``.5`` ties.
+        :param round_mode: explicit ``hive_amd._lib.ROUND_HALF_EVEN / ROUND_HALF_AWAY``; overrides ``use_gpu``.
         :param storage: optional 3-tuple of float32 torch tensors (tsdf, weight, colour), each with
             prod(vol_dim) elements, to keep the volume in caller-owned device memory.
         """
@@ -64,8 +70,9 @@ class TSDFVolume:
         assert vol_bnds.shape == (3, 2), "[!] `vol_bnds` should be of shape (3, 2)."
         self._ctx = ctx or _lib.default_context()
         lib = self._ctx.lib
-        if round_mode is not None:
-            self._ctx.set_round_mode(round_mode)
+        if round_mode is None:
+            round_mode = _lib.ROUND_HALF_AWAY if use_gpu else _lib.ROUND_HALF_EVEN
+        self.round_mode = int(round_mode)
         self._voxel_size = float(voxel_size)
         self._trunc_margin = 5 * self._voxel_size  # truncation on SDF
         self._color_const = 256 * 256
@@ -76,6 +83,7 @@ class TSDFVolume:
         self._ctx.check(lib.hive_tsdf_create(self._ctx.handle, ptr(bnds), self._voxel_size, ptr(s[0]), ptr(s[1]), ptr(s[2]),
                                              ctypes.byref(handle)))
         self._handle = handle
+        self._ctx.check(lib.hive_tsdf_set_round_mode(handle, self.round_mode))  # per volume, not per context
         dim = np.zeros(3, np.int64)
         origin = np.zeros(3, np.float32)
         adj = np.zeros(6, np.float64)

@@ -67,6 +67,11 @@ int hive_ctx_create(int device_id, void *stream, hive_ctx **out);
 int hive_ctx_destroy(hive_ctx *ctx);
 int hive_ctx_synchronize(hive_ctx *ctx);
 const char *hive_last_error(hive_ctx *ctx);
+/* Re-binds the context to another hipStream_t (NULL = the default stream).  The new stream is ordered behind
+ * everything already queued on the old one.  The Python binding calls this when torch's current stream changes
+ * (e.g. inside `with torch.cuda.stream(s)`), so that hive kernels stay ordered with the surrounding torch ops. */
+int hive_ctx_set_stream(hive_ctx *ctx, void *stream);
+/* Rounding used by hive_project / hive_project_bbox, and the mode a volume created afterwards on this context starts with. */
 int hive_ctx_set_round_mode(hive_ctx *ctx, int mode);
 /* HIP-event timing of the most recent kernel launched by a *_timed call on this context. */
 int hive_ctx_set_timing(hive_ctx *ctx, int enabled);
@@ -86,6 +91,11 @@ int hive_tsdf_dims(const double vol_bnds[6], double voxel_size, int64_t vol_dim[
 int hive_tsdf_create(hive_ctx *ctx, const double vol_bnds[6], double voxel_size,
                      float *d_tsdf, float *d_weight, float *d_color, hive_tsdf **out);
 int hive_tsdf_destroy(hive_tsdf *vol);
+/* Rounding of THIS volume's pixel projection and colour average (integrate, accum_finalize): the reference library has two
+ * arithmetic paths -- its CUDA kernel rounds with roundf (HIVE_ROUND_HALF_AWAY; what `TSDFVolume(..., use_gpu=True)` runs when
+ * pycuda is installed, as in the reference's Docker image, requirements.txt:14) and its numpy path with np.round
+ * (HIVE_ROUND_HALF_EVEN; `use_gpu=False`, BASELINE config 1). */
+int hive_tsdf_set_round_mode(hive_tsdf *vol, int mode);
 int hive_tsdf_reset(hive_tsdf *vol);
 int hive_tsdf_info(hive_tsdf *vol, int64_t vol_dim[3], float origin[3], double vol_bnds[6],
                    float *voxel_size, float *trunc_margin);
@@ -210,7 +220,7 @@ int hive_vit_linear(hive_ctx *ctx, const void *A, const void *W, const float *bi
 /* qkv projection of x [B*Np][D] (Np a multiple of 64): q|k -> qk [B*Np][2D], v -> vT [B][H][64][Np] */
 int hive_vit_qkv(hive_ctx *ctx, const void *x, const void *W, const float *bias, void *qk, void *vT,
                  int B, int Np, int D, int H);
-/* softmax(q k^T / 8) v over the first N keys of each image -> out [B*Np][D] */
+/* softmax(q k^T / 8) v over the first N keys of each image -> out [B*Np][D]; Np = N rounded up to a multiple of 64 */
 int hive_vit_attention(hive_ctx *ctx, const void *qk, const void *vT, void *out, int B, int N, int Np,
                        int D, int H);
 

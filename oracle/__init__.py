@@ -111,7 +111,11 @@ class TSDFVolume:
     """CPU oracle with the call signatures of the reference library's ``fusion.TSDFVolume``
     (call sites /root/reference/hive/fusion.py:104,124,127)."""
 
-    def __init__(self, vol_bnds, voxel_size, round_mode=ROUND_HALF_EVEN):
+    def __init__(self, vol_bnds, voxel_size, round_mode=None, use_gpu=True):
+        # use_gpu selects which arithmetic path of the reference library is restated: True (its default) = the
+        # CUDA kernel (roundf), False = the numpy path (np.round); an explicit round_mode overrides it
+        if round_mode is None:
+            round_mode = ROUND_HALF_AWAY if use_gpu else ROUND_HALF_EVEN
         vol_bnds = np.asarray(vol_bnds, dtype=np.float64)
         assert vol_bnds.shape == (3, 2), "[!] `vol_bnds` should be of shape (3, 2)."
         self._voxel_size = float(voxel_size)
@@ -162,8 +166,8 @@ class TSDFVolume:
 class AccumVolume:
     """Oracle for the frame-sharded accumulate -> (sum over ranks) -> finalize path."""
 
-    def __init__(self, vol_bnds, voxel_size, round_mode=ROUND_HALF_EVEN):
-        self.vol = TSDFVolume(vol_bnds, voxel_size, round_mode)
+    def __init__(self, vol_bnds, voxel_size, round_mode=None, use_gpu=True):
+        self.vol = TSDFVolume(vol_bnds, voxel_size, round_mode, use_gpu)
         self.accum = np.zeros((5,) + self.vol._tsdf.shape, np.float32)
 
     def integrate(self, color_im, depth_im, cam_intr, cam_pose, obs_weight=1.):

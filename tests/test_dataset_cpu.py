@@ -28,7 +28,7 @@ def test_tum_to_hive_conversion(tmp_path):
     d = ds.depth_dataset[1]
     assert d.dtype == np.float32 and d.shape == (480, 640)
     raw = np.round(seq["depth"][1].astype(np.float64) * 5000.0).astype(np.uint16)
-    expect = (np.float32(1. / 1000.) * (raw.astype(np.float64) / 5000.0 * 1000.0).astype(np.uint16).astype(np.float32))
+    expect = np.float32(1. / 1000.) * (1000 * (raw * (1.0 / 5000.0))).astype(np.uint16).astype(np.float32)  # dataset_adaptors.py:762-764
     assert np.array_equal(d, expect)
     assert (ds.mask_dataset[0] == 0).all() and not ds.has_inpainted_frame_data
     assert ds.bg_depth_dataset is ds.depth_dataset
@@ -44,6 +44,23 @@ def test_tum_to_hive_conversion(tmp_path):
     assert get_dataset(tum, str(tmp_path / "hive2"), num_frames=2).num_frames == 2
     with pytest.raises(RuntimeError):
         get_dataset(str(tmp_path), str(tmp_path / "x"))
+
+
+def test_tum_depth_to_mm_all_uint16_values():
+    """The TUM adaptor's raw -> millimetre conversion over every uint16 value, in the reference's operation order
+    (/root/reference/hive/dataset_adaptors.py:762-764): `(1000 * (raw * (1 / 5000))).astype(uint16)`.  The one-step form
+    `raw / 5000 * 1000` differs for 41 raw values (e.g. 10005 -> 2000 instead of 2001)."""
+    from hive_amd.dataset_adaptors import TUMAdaptor
+    adaptor = TUMAdaptor.__new__(TUMAdaptor)
+    adaptor.depth_scale_factor = 1.0 / 5000.0
+    raw = np.arange(65536, dtype=np.uint16).reshape(256, 256)
+    got = adaptor.depth_to_mm(raw)
+    scale = 1.0 / 5000.0
+    expect = np.array([int(1000 * (float(r) * scale)) for r in range(65536)], np.uint16).reshape(256, 256)  # scalar restatement
+    assert got.dtype == np.uint16 and np.array_equal(got, expect)
+    assert got.reshape(-1)[10005] == 2001
+    one_step = (raw.astype(np.float64) * scale / (1.0 / 1000.0)).astype(np.uint16)
+    assert 0 < int((one_step != got).sum()) < 100, "the sweep must cover the values where the operation order matters"
 
 
 def test_hive_dataset_validation_and_depth_contract(tmp_path):

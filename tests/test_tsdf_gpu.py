@@ -17,19 +17,15 @@ def _volumes_equal(vol, ora):
 def test_integrate_bit_exact(gpu_ctx, oracle_lib, small_sequence, round_mode, voxel):
     from hive_amd import fusion, synthetic
     seq = small_sequence
-    gpu_ctx.set_round_mode(round_mode)
-    try:
-        vol = fusion.TSDFVolume(synthetic.room_bounds(), voxel, ctx=gpu_ctx)
-        ora = oracle_lib.TSDFVolume(synthetic.room_bounds(), voxel, round_mode=round_mode)
-        assert np.array_equal(vol._vol_dim, ora._vol_dim)
-        assert np.array_equal(vol._vol_origin, ora._vol_origin)
-        for i in range(seq["depth"].shape[0]):
-            n = vol.integrate(seq["color"][i], seq["depth"][i], seq["K"], seq["poses"][i], return_n_updated=True)
-            ora.integrate(seq["color"][i], seq["depth"][i], seq["K"], seq["poses"][i])
-            assert n == ora.last_n_updated, f"frame {i}: N_upd {n} != oracle {ora.last_n_updated}"
-        _volumes_equal(vol, ora)
-    finally:
-        gpu_ctx.set_round_mode(0)
+    vol = fusion.TSDFVolume(synthetic.room_bounds(), voxel, ctx=gpu_ctx, round_mode=round_mode)
+    ora = oracle_lib.TSDFVolume(synthetic.room_bounds(), voxel, round_mode=round_mode)
+    assert np.array_equal(vol._vol_dim, ora._vol_dim)
+    assert np.array_equal(vol._vol_origin, ora._vol_origin)
+    for i in range(seq["depth"].shape[0]):
+        n = vol.integrate(seq["color"][i], seq["depth"][i], seq["K"], seq["poses"][i], return_n_updated=True)
+        ora.integrate(seq["color"][i], seq["depth"][i], seq["K"], seq["poses"][i])
+        assert n == ora.last_n_updated, f"frame {i}: N_upd {n} != oracle {ora.last_n_updated}"
+    _volumes_equal(vol, ora)
 
 
 def test_integrate_odd_dims_scalar_path(gpu_ctx, oracle_lib, small_sequence):
@@ -169,20 +165,18 @@ def test_pixel_ties_round_modes(gpu_ctx, oracle_lib):
     depth = np.full((H, W), 2.0, np.float32) + rng.integers(0, 3, (H, W)).astype(np.float32) * 0.25
     color = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
     bnds = np.array([[0.0, 1.0], [0.0, 1.0], [0.0, 2.0]])
-    results = []
-    for rm in (0, 1):
-        gpu_ctx.set_round_mode(rm)
-        try:
-            vol = fusion.TSDFVolume(bnds, 0.0625, ctx=gpu_ctx)
-            ora = oracle_lib.TSDFVolume(bnds, 0.0625, round_mode=rm)
-            for _ in range(3):
-                vol.integrate(color, depth, K, pose)
-                ora.integrate(color, depth, K, pose)
-            _volumes_equal(vol, ora)
-            results.append(vol.get_volume()[0])
-        finally:
-            gpu_ctx.set_round_mode(0)
-    assert not np.array_equal(results[0], results[1]), "tie case not exercised"
+    # the mode belongs to the volume: both volumes live on ONE context and are integrated alternately.
+    # use_gpu picks the reference library's path: True = its CUDA kernel (roundf), False = its numpy path (np.round)
+    vols = [fusion.TSDFVolume(bnds, 0.0625, ctx=gpu_ctx, use_gpu=False), fusion.TSDFVolume(bnds, 0.0625, ctx=gpu_ctx, use_gpu=True)]
+    oras = [oracle_lib.TSDFVolume(bnds, 0.0625, round_mode=rm) for rm in (0, 1)]
+    assert [v.round_mode for v in vols] == [0, 1]
+    for _ in range(3):
+        for vol, ora in zip(vols, oras):
+            vol.integrate(color, depth, K, pose)
+            ora.integrate(color, depth, K, pose)
+    for vol, ora in zip(vols, oras):
+        _volumes_equal(vol, ora)
+    assert not np.array_equal(vols[0].get_volume()[0], vols[1].get_volume()[0]), "tie case not exercised"
 
 
 def test_accumulate_finalize_matches_oracle(gpu_ctx, oracle_lib, small_sequence):
