@@ -216,15 +216,24 @@ class Block(nn.Module):
         return x + self.mlp(self.norm2(x))
 
 
-class VisionTransformerHybrid(nn.Module):
-    """``timm.vit_base_resnet50_384`` as DPT uses it (``forward_flex``: any input size that is a multiple
-    of 16, position embedding resized bilinearly from its 24 x 24 training grid)."""
+class PatchEmbed(nn.Module):
+    """timm ``PatchEmbed``: one 16 x 16, stride-16 convolution (ViT-L/16 of DPT-Large)."""
 
-    def __init__(self, embed_dim=768, depth=12, num_heads=12, train_grid=24):
+    def __init__(self, embed_dim=1024, patch=16):
+        super().__init__()
+        self.proj = nn.Conv2d(3, embed_dim, kernel_size=patch, stride=patch)
+
+
+class VisionTransformerHybrid(nn.Module):
+    """``timm.vit_base_resnet50_384`` (``hybrid=True``) / ``timm.vit_large_patch16_384`` as DPT uses them
+    (``forward_flex``: any input size that is a multiple of 16, position embedding resized bilinearly from its
+    24 x 24 training grid)."""
+
+    def __init__(self, embed_dim=768, depth=12, num_heads=12, train_grid=24, hybrid=True):
         super().__init__()
         self.embed_dim, self.num_heads = embed_dim, num_heads
         self.patch_size = [16, 16]
-        self.patch_embed = HybridEmbed(embed_dim)
+        self.patch_embed = HybridEmbed(embed_dim) if hybrid else PatchEmbed(embed_dim)
         self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
         self.pos_embed = nn.Parameter(torch.zeros(1, train_grid * train_grid + 1, embed_dim))
         self.blocks = nn.Sequential(*[Block(embed_dim, num_heads) for _ in range(depth)])
@@ -317,20 +326,34 @@ class Interpolate(nn.Module):
         return F.interpolate(x, scale_factor=self.scale_factor, mode=self.mode, align_corners=self.align_corners)
 
 
-class _Pretrained(nn.Module):
-    """Backbone + reassemble stages; hooks of the reference (ResNet stage 0, stage 1, ViT block 8, 11)."""
+BACKBONES = {
+    # name: (hybrid, ViT width, depth, heads, reassemble features, hooks) -- isl-org/DPT `_make_encoder`
+    "vitb_rn50_384": (True, 768, 12, 12, (256, 512, 768, 768), (0, 1, 8, 11)),
+    "vitl16_384": (False, 1024, 24, 16, (256, 512, 1024, 1024), (5, 11, 17, 23)),
+}
 
-    def __init__(self, features=(256, 512, 768, 768), vit_features=768, hooks=(0, 1, 8, 11)):
+
+class _Pretrained(nn.Module):
+    """Backbone + reassemble stages.  Hybrid: hooks = ResNet stage 0, stage 1, ViT block 8, 11 (act_postprocess1 / 2
+    are identities).  ViT-L/16 (DPT-Large): four ViT hooks, the first two reassembled with transposed convolutions
+    (x4, x2).  Index 2 of each act_postprocess (nn.Unflatten in isl-org/DPT) depends on the input size and holds no
+    parameters."""
+
+    def __init__(self, backbone="vitb_rn50_384"):
         super().__init__()
-        self.hooks = hooks
-        self.model = VisionTransformerHybrid(embed_dim=vit_features)
-        self.act_postprocess1 = nn.Sequential(nn.Identity(), nn.Identity(), nn.Identity())
-        self.act_postprocess2 = nn.Sequential(nn.Identity(), nn.Identity(), nn.Identity())
-        # index 2 (nn.Unflatten in the reference) depends on the input size and holds no parameters
-        self.act_postprocess3 = nn.Sequential(ProjectReadout(vit_features), Transpose(1, 2), nn.Identity(),
-                                              nn.Conv2d(vit_features, features[2], 1, 1, 0))
-        self.act_postprocess4 = nn.Sequential(ProjectReadout(vit_features), Transpose(1, 2), nn.Identity(),
-                                              nn.Conv2d(vit_features, features[3], 1, 1, 0),
+        hybrid, d, depth, heads, features, hooks = BACKBONES[backbone]
+        self.hooks, self.hybrid, self.features = hooks, hybrid, features
+        self.model = VisionTransformerHybrid(embed_dim=d, depth=depth, num_heads=heads, hybrid=hybrid)
+        if hybrid:
+            self.act_postprocess1 = nn.Sequential(nn.Identity(), nn.Identity(), nn.Identity())
+            self.act_postprocess2 = nn.Sequential(nn.Identity(), nn.Identity(), nn.Identity())
+        else:
+            self.act_postprocess1 = nn.Sequential(ProjectReadout(d), Transpose(1, 2), nn.Identity(), nn.Conv2d(d, features[0], 1, 1, 0),
+                                                  nn.ConvTranspose2d(features[0], features[0], 4, 4, 0, bias=True))
+            self.act_postprocess2 = nn.Sequential(ProjectReadout(d), Transpose(1, 2), nn.Identity(), nn.Conv2d(d, features[1], 1, 1, 0),
+                                                  nn.ConvTranspose2d(features[1], features[1], 2, 2, 0, bias=True))
+        self.act_postprocess3 = nn.Sequential(ProjectReadout(d), Transpose(1, 2), nn.Identity(), nn.Conv2d(d, features[2], 1, 1, 0))
+        self.act_postprocess4 = nn.Sequential(ProjectReadout(d), Transpose(1, 2), nn.Identity(), nn.Conv2d(d, features[3], 1, 1, 0),
                                               nn.Conv2d(features[3], features[3], 3, 2, 1))
 
 
@@ -348,11 +371,11 @@ class _Scratch(nn.Module):
 
 
 class DPT(nn.Module):
-    def __init__(self, head, features=256, engine="hip"):
+    def __init__(self, head, features=256, engine="hip", backbone="vitb_rn50_384"):
         super().__init__()
         self.engine = engine
-        self.pretrained = _Pretrained()
-        self.scratch = _Scratch(features=features)
+        self.pretrained = _Pretrained(backbone)
+        self.scratch = _Scratch(in_shape=self.pretrained.features, features=features)
         self.scratch.output_conv = head
         self._vit_engine = None
         self._vit_stamp = None
@@ -362,16 +385,17 @@ class DPT(nn.Module):
 
     # -- ViT encoder ---------------------------------------------------------------------------
     def _run_blocks(self, tokens):
-        """tokens [B, N, 768] -> (output of block 8, output of block 11)."""
+        """tokens [B, N, D] -> outputs of the hooked ViT blocks (8, 11 for the hybrid; 5, 11, 17, 23 for ViT-L/16)."""
         vit = self.pretrained.model
+        hooks = self.pretrained.hooks[2:] if self.pretrained.hybrid else self.pretrained.hooks
         if self.engine == "torch":
             taps = {}
             x = tokens
             for i, blk in enumerate(vit.blocks):
                 x = blk(x)
-                if i in self.pretrained.hooks[2:]:
+                if i in hooks:
                     taps[i] = x
-            return taps[self.pretrained.hooks[2]], taps[self.pretrained.hooks[3]]
+            return tuple(taps[h] for h in hooks)
         if self.engine != "hip":
             raise ValueError(f"unknown engine {self.engine!r}")
         if tokens.dtype == torch.float32:
@@ -381,9 +405,9 @@ class DPT(nn.Module):
             x, taps = tokens, {}
             for i, blk in enumerate(vit.blocks):
                 x = blk(x)
-                if i in self.pretrained.hooks[2:]:
+                if i in hooks:
                     taps[i] = x
-            return taps[self.pretrained.hooks[2]], taps[self.pretrained.hooks[3]]
+            return tuple(taps[h] for h in hooks)
         # The engine packs private f32 copies of the biases / LayerNorm parameters (and bf16 copies of matrices that are not
         # bf16 already): rebuild it when any parameter was replaced or written (load_state_dict, .to(), optimiser step).
         stamp = tuple((p.data_ptr(), p._version) for p in vit.blocks.parameters())
@@ -393,37 +417,59 @@ class DPT(nn.Module):
                 self._vit_engine.close()
             self._vit_engine = VitEngine(vit)
             self._vit_stamp = stamp
-        return self._vit_engine.forward(tokens, taps=self.pretrained.hooks[2:])
+        return self._vit_engine.forward(tokens, taps=hooks)
 
-    def forward_backbone(self, x):
+    def forward_backbone(self, x, stages=None):
         p = self.pretrained
         vit = p.model
         b, _, h, w = x.shape
         gh, gw = h // vit.patch_size[1], w // vit.patch_size[0]
-        feat = vit.patch_embed.backbone.stem(x)
-        layer_1 = vit.patch_embed.backbone.stages[0](feat)
-        layer_2 = vit.patch_embed.backbone.stages[1](layer_1)
-        feat = vit.patch_embed.backbone.stages[2](layer_2)
+        cl = x.is_contiguous(memory_format=torch.channels_last)
+
+        def reassemble(tap, post):
+            # readout projection -> [B, D, gh, gw] -> the stage's convolutions (isl-org/DPT forward_vit)
+            y = post[1](post[0](tap)).reshape(b, -1, gh, gw)
+            if cl:
+                y = y.contiguous(memory_format=torch.channels_last)
+            for layer in post[3:]:
+                y = layer(y)
+            return y
+
+        if p.hybrid:
+            feat = vit.patch_embed.backbone.stem(x)
+            layer_1 = vit.patch_embed.backbone.stages[0](feat)
+            layer_2 = vit.patch_embed.backbone.stages[1](layer_1)
+            feat = vit.patch_embed.backbone.stages[2](layer_2)
+        else:
+            feat = x
         tokens = vit.patch_embed.proj(feat).flatten(2).transpose(1, 2)
         tokens = torch.cat((vit.cls_token.expand(b, -1, -1).to(tokens.dtype), tokens), dim=1)
         tokens = tokens + vit.resize_pos_embed(gh, gw).to(tokens.dtype)
-        tap3, tap4 = self._run_blocks(tokens)
-        layer_3 = p.act_postprocess3[1](p.act_postprocess3[0](tap3)).reshape(b, -1, gh, gw)
-        layer_4 = p.act_postprocess4[1](p.act_postprocess4[0](tap4)).reshape(b, -1, gh, gw)
-        if x.is_contiguous(memory_format=torch.channels_last):
-            layer_3 = layer_3.contiguous(memory_format=torch.channels_last)
-            layer_4 = layer_4.contiguous(memory_format=torch.channels_last)
-        layer_3 = p.act_postprocess3[3](layer_3)
-        layer_4 = p.act_postprocess4[4](p.act_postprocess4[3](layer_4))
+        taps = self._run_blocks(tokens)
+        if p.hybrid:
+            tap3, tap4 = taps
+        else:
+            tap1, tap2, tap3, tap4 = taps
+            layer_1 = reassemble(tap1, p.act_postprocess1)
+            layer_2 = reassemble(tap2, p.act_postprocess2)
+        layer_3 = reassemble(tap3, p.act_postprocess3)
+        layer_4 = reassemble(tap4, p.act_postprocess4)
+        if stages is not None:
+            stages.update(tokens=tokens, tap_3=tap3, tap_4=tap4, layer_1=layer_1, layer_2=layer_2, layer_3=layer_3, layer_4=layer_4)
         return layer_1, layer_2, layer_3, layer_4
 
-    def forward_decoder(self, x):
-        layer_1, layer_2, layer_3, layer_4 = self.forward_backbone(x)
+    def forward_decoder(self, x, stages=None):
+        """``stages`` (optional dict) receives the intermediate maps by the names isl-org/DPT's forward gives them
+        (layer_1..4, path_4..1; plus tokens and the two ViT taps) -- for the per-stage numerics tests."""
+        layer_1, layer_2, layer_3, layer_4 = self.forward_backbone(x, stages)
         s = self.scratch
         path_4 = s.refinenet4(s.layer4_rn(layer_4))
         path_3 = s.refinenet3(path_4, s.layer3_rn(layer_3))
         path_2 = s.refinenet2(path_3, s.layer2_rn(layer_2))
-        return s.refinenet1(path_2, s.layer1_rn(layer_1))
+        path_1 = s.refinenet1(path_2, s.layer1_rn(layer_1))
+        if stages is not None:
+            stages.update(path_4=path_4, path_3=path_3, path_2=path_2, path_1=path_1)
+        return path_1
 
     def forward(self, x):
         return self.scratch.output_conv(self.forward_decoder(x))
@@ -432,14 +478,15 @@ class DPT(nn.Module):
 class DPTDepthModel(DPT):
     """Same constructor as the reference's ``dpt.models.DPTDepthModel`` (dataset_adaptors.py:1366-1374).
 
-    ``backbone`` must be ``"vitb_rn50_384"`` (the only one the reference instantiates);
+    ``backbone``: ``"vitb_rn50_384"`` (DPT-Hybrid, the one the reference instantiates) or ``"vitl16_384"`` (DPT-Large,
+    BASELINE config 4; same decoder, ViT-L/16 encoder with hooks 5 / 11 / 17 / 23 as in isl-org/DPT).
     ``enable_attention_hooks`` must be False.  ``engine`` is this build's addition.
     """
 
     def __init__(self, path=None, non_negative=True, scale=1.0, shift=0.0, invert=False, backbone="vitb_rn50_384",
                  enable_attention_hooks=False, engine="hip", **kwargs):
-        if backbone != "vitb_rn50_384":
-            raise NotImplementedError(f"backbone {backbone!r}: only 'vitb_rn50_384' (DPT-Hybrid) is implemented")
+        if backbone not in BACKBONES:
+            raise NotImplementedError(f"backbone {backbone!r}: implemented are {sorted(BACKBONES)}")
         if enable_attention_hooks:
             raise NotImplementedError("attention hooks (visualisation) are not part of the hot path")
         features = kwargs.get("features", 256)
@@ -452,7 +499,7 @@ class DPTDepthModel(DPT):
             nn.ReLU(True) if non_negative else nn.Identity(),
             nn.Identity(),
         )
-        super().__init__(head, features=features, engine=engine)
+        super().__init__(head, features=features, engine=engine, backbone=backbone)
         self.scale, self.shift, self.invert = scale, shift, invert
         self.fused_head = True  # HIP engine, bf16: output_conv[1:] + the depth tail as one kernel (csrc/dpt_head.hip)
         if path is not None:
@@ -465,6 +512,8 @@ class DPTDepthModel(DPT):
         # the published checkpoints also carry the (unused) classification head / final norm of the ViT
         missing, unexpected = self.load_state_dict(parameters, strict=False)
         missing = [k for k in missing if not k.endswith("_std_weight")]
+        self.load_report = (list(missing), list(unexpected))  # (missing, unexpected) keys of the last load
+        self._vit_engine = None  # its packed copies of the encoder weights are stale now
         if missing:
             raise RuntimeError(f"checkpoint {path} lacks parameters: {missing[:8]}{'...' if len(missing) > 8 else ''}")
 
@@ -473,8 +522,9 @@ class DPTDepthModel(DPT):
         head = self.scratch.output_conv
         return head[3](head[2](head[1](head[0](self.forward_decoder(x)))))
 
-    def forward(self, x, handoff=None):
-        """[B, 3, h, w] -> depth [B, h, w] in **float32**.
+    def forward(self, x, handoff=None, stages=None):
+        """[B, 3, h, w] -> depth [B, h, w] in **float32**.  ``stages``: see ``forward_decoder`` (adds ``head_in``, the
+        128-channel map behind ``output_conv[0]``).
 
         The reference returns the network's working precision (fp16 on a GPU); the last 1x1 convolution and
         the inversion ``1 / (scale * x + shift)`` run in float32 here because bf16 cannot resolve metric depth
@@ -504,8 +554,10 @@ class DPTDepthModel(DPT):
             if fused:
                 # Interpolate + conv 128 -> 32 + ReLU + conv 32 -> 1 + inversion + hand-off: one HIP kernel (csrc/dpt_head.hip)
                 # (output_conv[0] runs without its bias: the kernel adds it while loading, one pass over 315 MB less)
-                lo = F.conv2d(self.forward_decoder(x), first.weight, None, first.stride, first.padding)
+                lo = F.conv2d(self.forward_decoder(x, stages), first.weight, None, first.stride, first.padding)
                 lo = lo.contiguous(memory_format=torch.channels_last)
+                if stages is not None:
+                    stages["head_in"] = lo + first.bias.view(1, -1, 1, 1)
                 b, c, h, w = lo.shape
                 depth = torch.empty((b, 2 * h, 2 * w), dtype=torch.float32, device=lo.device)
                 mm = torch.empty((b, 2 * h, 2 * w), dtype=torch.int16, device=lo.device) if handoff else None
@@ -516,7 +568,10 @@ class DPTDepthModel(DPT):
                     float(handoff[0]) if handoff else 0.0, _lib.ptr(mm), _lib.ptr(m)))
                 return (depth, mm, m) if handoff else depth
             # conv 128 -> 32 without its bias (MIOpen); bias + ReLU + conv 32 -> 1 + inversion + hand-off in one HIP kernel
-            feat = F.conv2d(head[1](head[0](self.forward_decoder(x))), pre.weight, None, pre.stride, pre.padding)
+            head_in = head[0](self.forward_decoder(x, stages))
+            if stages is not None:
+                stages["head_in"] = head_in
+            feat = F.conv2d(head[1](head_in), pre.weight, None, pre.stride, pre.padding)
             feat = feat.contiguous(memory_format=torch.channels_last)
             b, c, h, w = feat.shape
             depth = torch.empty((b, h, w), dtype=torch.float32, device=feat.device)
@@ -528,7 +583,10 @@ class DPTDepthModel(DPT):
                 float(self.scale), float(self.shift), depth.data_ptr(), 1.0 / 1000.0, float(handoff[0]) if handoff else 0.0,
                 _lib.ptr(mm), _lib.ptr(m)))
             return (depth, mm, m) if handoff else depth
-        feat = self.forward_head_features(x)
+        head_in = head[0](self.forward_decoder(x, stages))
+        if stages is not None:
+            stages["head_in"] = head_in
+        feat = head[3](head[2](head[1](head_in)))
         out = F.conv2d(feat.float(), conv.weight.float(), conv.bias.float()).squeeze(dim=1)
         if non_negative:
             out = F.relu(out)

@@ -1,0 +1,80 @@
+"""DPT restatement (hive_amd.dpt.models, PyTorch formulation, float32 on the CPU) against golden activations of an
+independent implementation of the published architecture (HuggingFace transformers' DPT; fixtures made by
+tests/golden/make_dpt_golden.py in the build container), plus the host logic around the network: the
+reference's resize rule, checkpoint loading.  The reference's own third_party/dpt is absent: this
+pins the architecture restatement to the published one, not to the reference's fork."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from dpt_weights import seeded_init, state_checksum
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _rel(a, b):
+    a, b = torch.as_tensor(a).float(), torch.as_tensor(b).float()
+    return float((a - b).norm() / b.norm())
+
+
+@pytest.mark.parametrize("fixture", ["dpt_hybrid_hf.npz", "dpt_large_hf.npz"])
+def test_restatement_matches_independent_implementation(fixture):
+    from hive_amd.dpt.models import DPTDepthModel
+    gold = np.load(os.path.join(GOLDEN, fixture))
+    model = DPTDepthModel(path=None, scale=1.0, shift=0.0, invert=False, engine="torch", backbone=str(gold["backbone"])).eval()
+    seeded_init(model, seed=int(gold["seed"]))
+    assert state_checksum(model) == str(gold["state_sha256"]), \
+        "seeded weights differ from the ones the fixture was made with (torch RNG drift?): rerun tests/golden/make_dpt_golden.py"
+    x = torch.from_numpy(gold["x"].astype(np.float32))
+    stages = {}
+    with torch.no_grad():
+        inv = model(x, stages=stages)
+    # float32 on both sides; the fixtures keep the big maps in float16 (relative rounding 5e-4)
+    assert _rel(inv, gold["inv_depth"]) < 1e-4
+    assert _rel(stages["tap_3"].mean(dim=2), gold["tap_3_mean"]) < 1e-4
+    assert _rel(stages["tap_4"], gold["tap_4"].astype(np.float32)) < 1e-3
+    assert _rel(stages["path_4"], gold["path_4"].astype(np.float32)) < 1e-3
+    assert _rel(stages["path_1"].mean(dim=1), gold["path_1_mean"]) < 1e-4
+    assert _rel(stages["head_in"].mean(dim=1), gold["head_in_mean"]) < 1e-4
+    assert float(inv.max()) > 1000 and float((inv == 0).float().mean()) < 0.05, "the seeded head must give a usable range"
+
+
+def test_resize_rule_of_the_reference_call_site():
+    """Resize(640, 480, keep_aspect_ratio, multiple of 32, "minimal") as constructed at
+    /root/reference/hive/dataset_adaptors.py:1376-1385: network sizes for the frame sizes of the BASELINE configs."""
+    from hive_amd.dpt import transforms as T
+    r = T.Resize(640, 480, resize_target=None, keep_aspect_ratio=True, ensure_multiple_of=32, resize_method="minimal",
+                 image_interpolation_method=T.INTER_CUBIC)
+    assert r.get_size(640, 480) == (640, 480)      # configs 1-3, 5: identity
+    assert r.get_size(1920, 1080) == (864, 480)    # config 4: 0.444 scale, width to a multiple of 32
+    assert r.get_size(320, 200) == (640, 384)      # "minimal": the scale closer to 1 (x2), 400 -> np.round(12.5) * 32 = 384
+    assert r.get_size(1280, 720) == (864, 480)
+    img = np.random.default_rng(0).random((200, 320, 3))
+    out = T.Compose([r, T.NormalizeImage([0.5] * 3, [0.5] * 3), T.PrepareForNet()])({"image": img})["image"]
+    assert out.shape == (3, 384, 640) and out.dtype == np.float32
+    same = T.Compose([r, T.PrepareForNet()])({"image": np.ones((480, 640, 3)) * 0.25})["image"]
+    assert same.shape == (3, 480, 640) and np.all(same == np.float32(0.25))
+
+
+def test_checkpoint_load_round_trip(tmp_path):
+    """DPTDepthModel(path) consumes every key of a checkpoint with the published parameter names, accepts the
+    {"optimizer", "model"} wrapper (isl-org/DPT `load`), and refuses a checkpoint that lacks parameters."""
+    from hive_amd.dpt.models import DPTDepthModel
+    src = DPTDepthModel(path=None, engine="torch").eval()
+    seeded_init(src, seed=5)
+    path = str(tmp_path / "dpt_hybrid_nyu.pt")
+    torch.save(src.state_dict(), path)
+    dst = DPTDepthModel(path=path, engine="torch").eval()
+    assert dst.load_report == ([], []), f"missing / unexpected keys: {dst.load_report}"
+    assert state_checksum(dst) == state_checksum(src)
+    wrapped = str(tmp_path / "wrapped.pt")
+    torch.save({"optimizer": {}, "model": src.state_dict()}, wrapped)
+    assert state_checksum(DPTDepthModel(path=wrapped, engine="torch")) == state_checksum(src)
+    broken = {k: v for k, v in src.state_dict().items() if not k.startswith("scratch.refinenet2.")}
+    torch.save(broken, str(tmp_path / "broken.pt"))
+    with pytest.raises(RuntimeError, match="lacks parameters"):
+        DPTDepthModel(path=str(tmp_path / "broken.pt"), engine="torch")
+    with pytest.raises(NotImplementedError):
+        DPTDepthModel(backbone="vitb16_384")
