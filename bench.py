@@ -1,16 +1,25 @@
 #!/usr/bin/env python3
 """Headline benchmark: frames/sec of the hot path (DPT-Hybrid depth + TSDF integrate) at 640 x 480 into a
-512^3 volume (BASELINE.json `metric`, configs[1]; configs[2] for --gpus > 1).
+512^3 volume (BASELINE.json `metric`; configs[1] at N = 1, configs[2] at N > 1).
 
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-A step = one batch of `--batch` synthetic frames, already resident in HBM as uint8, through
-preprocess -> DPT-Hybrid (random-init weights of the real architecture, bf16, HIP ViT engine) -> f32 head
-tail + uint16-mm hand-off -> TSDF integrate.  N > 1: frames are sharded over the ranks (weak scaling:
-fixed work per GPU), every rank fuses its shard into its own volume, and ONE all-reduce of the 5 accumulator planes
-+ finalize merges the shared static-scene volume inside the timed region.  Rank 0 prints one JSON line.
+The job: K * B frames of the seeded 150-frame synthetic sequence (wrapping), B = --batch (24).  A step = one batch of B
+frames: uint8 frames start in PINNED HOST memory and are uploaded inside the timed region (double-buffered on a copy stream,
+SURVEY.md 8d) -> preprocess -> DPT-Hybrid (random-init weights of the real architecture, bf16, HIP engine) -> f32 depth tail
++ uint16-mm hand-off -> TSDF integrate.
+
+N > 1 (BASELINE configs[2]: the SAME sequence frame-sharded; `--scaling strong`, default): the K * B frames are split in
+contiguous blocks over the ranks, identical per-frame work to N = 1, then the shared static-scene volume is merged INSIDE the
+timed region:
+  --merge sum   (default; north_star's design): every rank fuses its block into its own volume; reduce-scatter of the 5
+                accumulator planes -> every rank folds its 1 / N of the voxels -> all-gather of the 3 result planes.
+  --merge exact (bit-identical to one GPU): depth + colour frames are all-gathered, every rank integrates all frames in
+                sequence order into its x-slab of the volume, the slabs are all-gathered.
+`--scaling weak` keeps the round-1 mode (every rank runs K full steps on its own sequence, one merge at the end).
+Rank 0 prints one JSON line.
 """
 import argparse
 import json
@@ -30,18 +39,20 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=24, help="frames per step and GPU (the sequence wraps around; 20-28 measured 3-5 %% above 16)")
-    ap.add_argument("--frames", type=int, default=150, help="length of the synthetic sequence (per GPU)")
+    ap.add_argument("--batch", type=int, default=24, help="frames per step (20-28 measured 3-5 %% above 16)")
+    ap.add_argument("--frames", type=int, default=150, help="length of the synthetic sequence")
     ap.add_argument("--voxel", type=float, default=0.01, help="0.01 -> 512^3 over the 5.12 m volume")
     ap.add_argument("--engine", default="hip", choices=["hip", "torch"], help="'torch' = PyTorch-op ViT blocks (comparison only)")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"], help="N > 1: shard the same job (strong) or repeat it per rank (weak)")
+    ap.add_argument("--merge", default="sum", choices=["sum", "exact"], help="N > 1: how the shared volume is merged")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
 
 def cpu_baseline(seq, voxel, K):
     """The CPU path timed on this box's host cores, on a bounded sample of the same workload: the numpy
-    port of the integrate step (bit-identical arithmetic to the C oracle) on one 640 x 480 frame into the
-    same 512^3 volume, and the fp32 torch-CPU DPT-Hybrid on two frames (after one warm-up)."""
+    port of the integrate step (bit-identical arithmetic to the C oracle; numpy runs it on ONE thread) on one 640 x 480
+    frame into the same 512^3 volume, and the fp32 torch-CPU DPT-Hybrid on two frames (after one warm-up, all cores)."""
     import oracle
     from hive_amd import synthetic
     from hive_amd.dpt.models import DPTDepthModel
@@ -59,11 +70,50 @@ def cpu_baseline(seq, voxel, K):
     tsdf, weight, color = ora._tsdf, ora._weight, ora._color
     t0 = time.time()
     n_upd = oracle.integrate_numpy(tsdf, weight, color, ora._vol_origin, ora._voxel_size, np.float32(ora._trunc_margin), seq["color"][0],
-                                   depth_np, K, seq["poses"][0])
+                                   depth_np, K, seq["poses"][0], round_mode=ora.round_mode)
     t_tsdf = time.time() - t0
     return {"value": 1.0 / (t_dpt + t_tsdf), "unit": "frames/s", "cores": threads, "kind": "port",
             "sample": f"2 frames DPT-Hybrid fp32 torch-CPU ({threads} threads, {t_dpt:.2f} s/frame) + 1 frame numpy TSDF integrate "
-                      f"into {'x'.join(str(int(d)) for d in ora._vol_dim)} (1 thread, {t_tsdf:.2f} s/frame, N_upd {n_upd})"}
+                      f"into {'x'.join(str(int(d)) for d in ora._vol_dim)} (numpy: 1 thread, {t_tsdf:.2f} s/frame, N_upd {n_upd})"}
+
+
+class FrameFeeder:
+    """uint8 frames in pinned host memory -> device, one batch ahead of the compute stream (two device buffers, a copy stream)."""
+
+    def __init__(self, frames_host, batch, device):
+        self.host = frames_host  # pinned [T, H, W, 3]
+        self.T = frames_host.shape[0]
+        self.B = batch
+        self.bufs = [torch.empty((batch,) + tuple(frames_host.shape[1:]), dtype=torch.uint8, device=device) for _ in range(2)]
+        self.ready = [torch.cuda.Event(), torch.cuda.Event()]  # copy into buffer i has landed
+        self.free = [torch.cuda.Event(), torch.cuda.Event()]   # compute that read buffer i is done
+        self.copy_stream = torch.cuda.Stream(device=device)
+        self.slot = 0
+        for e in self.free:
+            e.record(torch.cuda.current_stream())
+
+    def prefetch(self, frame_ids):
+        i = self.slot
+        with torch.cuda.stream(self.copy_stream):
+            self.copy_stream.wait_event(self.free[i])
+            n = len(frame_ids)
+            start = frame_ids[0]
+            if frame_ids[-1] == start + n - 1:  # one contiguous block of the sequence: one copy
+                self.bufs[i][:n].copy_(self.host[start:start + n], non_blocking=True)
+            else:
+                for j, f in enumerate(frame_ids):
+                    self.bufs[i][j].copy_(self.host[f], non_blocking=True)
+            self.ready[i].record(self.copy_stream)
+        self.slot ^= 1
+        return i, n
+
+    def acquire(self, token):
+        i, n = token
+        torch.cuda.current_stream().wait_event(self.ready[i])
+        return self.bufs[i][:n]
+
+    def release(self, token):
+        self.free[token[0]].record(torch.cuda.current_stream())
 
 
 def main():
@@ -80,79 +130,154 @@ def main():
     device = torch.device("cuda", dev_index)
     torch.backends.cudnn.benchmark = True
 
-    H, W = 480, 640
-    B = args.batch
-    # synthetic sequence: every rank owns `frames` frames of the 150-pose room trajectory (its shard of
-    # world * frames), generated from the seed
-    T = args.frames
-    seq = synthetic.make_sequence(num_frames=T, height=H, width=W, seed=1234 + rank, yaw_step_deg=360.0 / T)
+    H, W, B, T = 480, 640, args.batch, args.frames
+    strong = world > 1 and args.scaling == "strong"
+    exact = world > 1 and args.merge == "exact"
+    # the synthetic sequence (every rank generates the same one in strong mode; its own in weak mode)
+    seq = synthetic.make_sequence(num_frames=T, height=H, width=W, seed=1234 + (0 if strong or world == 1 else rank), yaw_step_deg=360.0 / T)
     K = seq["K"]
-    frames_dev = torch.from_numpy(seq["color"]).to(device)  # uint8 [T, H, W, 3] resident in HBM
     poses = seq["poses"]
+    frames_host = torch.from_numpy(seq["color"]).pin_memory()  # uint8 [T, H, W, 3]
 
     ctx = _lib.default_context(dev_index)
     model = depth_mod.build_model(None, device=device, dtype=torch.bfloat16, engine=args.engine)
-    volume = fusion.TSDFVolume(synthetic.room_bounds(), args.voxel, ctx=ctx)
-    stream = depth_mod.DepthFusionStream(model, volume, K)  # every rank fuses its shard with the same kernels as one GPU
+    if exact:
+        merger = hdist.ExactSlabFusion(synthetic.room_bounds(), args.voxel, ctx=ctx)
+        volume = merger.slab
+    else:
+        merger = None
+        volume = fusion.TSDFVolume(synthetic.room_bounds(), args.voxel, ctx=ctx)
+    stream = depth_mod.DepthFusionStream(model, volume, K)
+    feeder = FrameFeeder(frames_host, B, device)
 
-    def batch_indices(step):
-        return [(step * B + j) % T for j in range(B)]
+    # the job: frames job[0 .. K * B) of the wrapping sequence; this rank's contiguous block of it
+    def job_frames(first_step, n_steps):
+        ids = [(first_step * B + j) % T for j in range(n_steps * B)]
+        if strong:
+            lo, hi = hdist.shard_range(len(ids), rank, world)
+            return ids[lo:hi], [b - a for a, b in (hdist.shard_range(len(ids), r, world) for r in range(world))]
+        return ids, [len(ids)] * world
 
-    def run_step(step):
-        idx = batch_indices(step)
-        if idx[-1] == idx[0] + B - 1:
-            fr = frames_dev[idx[0]:idx[0] + B]
+    def batches(ids):
+        return [ids[i:i + B] for i in range(0, len(ids), B)]
+
+    def run_job(first_step, n_steps, keep_depth=False):
+        """All of this rank's batches: upload (one batch ahead) -> depth -> integrate (or, exact mode, keep the depth maps)."""
+        ids, counts = job_frames(first_step, n_steps)
+        todo = batches(ids)
+        kept = []
+        token = feeder.prefetch(todo[0]) if todo else None
+        for bi, batch_ids in enumerate(todo):
+            fr = feeder.acquire(token)
+            nxt = feeder.prefetch(todo[bi + 1]) if bi + 1 < len(todo) else None
+            if exact:
+                depth_m, _ = stream.depth(fr)
+                kept.append((fr.clone(), depth_m))
+            else:
+                depth_m = stream.step(fr, poses[batch_ids])
+                if keep_depth:
+                    kept.append((batch_ids, depth_m))
+            feeder.release(token)
+            token = nxt
+        if exact:  # all-gather the frames, integrate every frame of the job in sequence order into this rank's x-slab
+            color = torch.cat([c for c, _ in kept]) if kept else torch.empty((0, H, W, 3), dtype=torch.uint8, device=device)
+            depth = torch.cat([d for _, d in kept]) if kept else torch.empty((0, H, W), dtype=torch.float32, device=device)
+            all_ids = [(first_step * B + j) % T for j in range(n_steps * B)]
+            merger.integrate(color, depth, K, poses[all_ids], counts)
+        return kept
+
+    for s in range(0, args.warmup):
+        run_job(s, 1)
+    if world > 1 and args.warmup > 0:  # warm-up of the collectives too (RCCL sets up its channels on the first large transfer)
+        if exact:
+            merger.gather()
         else:
-            fr = frames_dev[torch.tensor(idx, device=device)]
-        return stream.step(fr, poses[idx])
-
-    for s in range(args.warmup):
-        run_step(s)
-    if world > 1 and args.warmup > 0:
-        hdist.fuse_sharded(volume)  # warm-up of the collective too (RCCL sets up its channels on the first large all-reduce)
+            hdist.fuse_sharded(volume)
     torch.cuda.synchronize()
-    # reset the volume so that the timed job starts from an empty scene
-    volume.reset()
+    volume.reset()  # the timed job starts from an empty scene
     ctx.set_timing(True)
     hdist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for s in range(args.steps):
-        run_step(args.warmup + s)
+    if strong:
+        run_job(args.warmup, args.steps)
+    else:
+        for s in range(args.steps):
+            run_job(args.warmup + s, 1)
     if world > 1:
-        hdist.fuse_sharded(volume)  # volumes -> sums, one all-reduce of the 5 planes, finalize
+        merged = merger.gather() if exact else hdist.fuse_sharded(volume)
     torch.cuda.synchronize()
     hdist.barrier()
     elapsed = time.perf_counter() - t0
     n_launch, kernel_ms = ctx.kernel_time_total()
     ctx.set_timing(False)
     elapsed = hdist.max_over_ranks(elapsed, device=device if world > 1 else "cpu")
+    if world > 1:
+        del merged
 
-    # untimed: N_upd of the timed frames (depends on depth + pose only, not on the volume state)
-    n_upd = []
+    # ---- untimed: what the timed launches processed --------------------------------------------------------------------
+    # N_upd of EVERY frame this rank integrated in the timed region (depends on depth + pose only, not on the volume state)
+    def measure(frame_sets, depth_of):
+        n_upd, leg_ms = [], []
+        for ids in frame_sets:
+            fr = torch.from_numpy(seq["color"][ids]).to(device)
+            depth_m = depth_of(fr, ids)
+            for j, i in enumerate(ids):
+                n_upd.append(volume.integrate(fr[j], depth_m[j], K, poses[i], return_n_updated=True))
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            volume.integrate_batch(fr, depth_m, K, poses[ids])  # pack + work list + sweep, per frame, back to back
+            e1.record()
+            e1.synchronize()
+            leg_ms.append(e0.elapsed_time(e1) / len(ids))
+        return float(np.mean(n_upd)), float(np.mean(leg_ms))
+
+    def roofline(n_upd_mean, launch_us, traffic_key):
+        alg = 24.0 * n_upd_mean + 8.0 * H * W  # 3 volumes read + written for every updated voxel + one read of depth / colour
+        achieved = alg / (launch_us * 1e-6) / 1e9
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "integrate_traffic.json")
+        if os.path.exists(tf):
+            try:
+                traffic = json.load(open(tf)).get(traffic_key)
+            except Exception:
+                traffic = None
+        return {"kernel": "integrate_kernel", "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                "traffic": traffic, "algorithmic_bytes_per_launch": alg, "avg_launch_us": launch_us, "n_upd_mean": n_upd_mean,
+                "n_upd_fraction": n_upd_mean / (volume.num_voxels * (world if exact else 1))}
+
     with torch.no_grad():
-        for s in range(min(args.steps, 4)):
-            idx = batch_indices(args.warmup + s)
-            depth_m, _ = stream.depth(frames_dev[torch.tensor(idx, device=device)])
-            for j, i in enumerate(idx):
-                n_upd.append(volume.integrate(frames_dev[i], depth_m[j], K, poses[i], return_n_updated=True))
-    n_upd_mean = float(np.mean(n_upd))
-    bytes_per_voxel = 24  # 3 volumes read + written
-    alg_bytes = bytes_per_voxel * n_upd_mean + 8.0 * H * W
-    avg_kernel_s = kernel_ms / max(n_launch, 1) * 1e-3
-    achieved = alg_bytes / avg_kernel_s / 1e9
-    traffic = None
-    traffic_file = os.path.join(ROOT, "profiles", "integrate_traffic.json")
-    if os.path.exists(traffic_file):
-        try:
-            traffic = json.load(open(traffic_file)).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+        if exact:
+            timed_sets = batches([(args.warmup * B + j) % T for j in range(args.steps * B)])
+        elif strong:
+            timed_sets = batches(job_frames(args.warmup, args.steps)[0])
+        else:
+            timed_sets = [job_frames(args.warmup + s, 1)[0] for s in range(args.steps)]
+        n_upd_dpt, leg_dpt = measure(timed_sets, lambda fr, ids: stream.depth(fr)[0])
+        main_roof = roofline(n_upd_dpt, kernel_ms / max(n_launch, 1) * 1e3, "hbm_bytes_per_launch")
+        main_roof["launches"] = n_launch
+        main_roof["tsdf_leg_us_per_frame"] = leg_dpt * 1e3
+        # the room scene: the same integrate on the ray-cast (analytic) depth of the sequence -- real depth variation, a
+        # surface inside the volume; the DPT-fed scene above has random-weight depth (nearly constant, free space only)
+        room_ids = list(range(0, T, max(1, T // 30)))[:30]
+        volume.reset()
+        ctx.set_timing(True)
+        n_upd_room, leg_room = measure([room_ids], lambda fr, ids: torch.from_numpy(seq["depth"][ids]).to(device))
+        n_room, ms_room = ctx.kernel_time_total()
+        ctx.set_timing(False)
+        room_roof = roofline(n_upd_room, ms_room / max(n_room, 1) * 1e3, "hbm_bytes_per_launch_room")
+        room_roof["launches"] = n_room
+        room_roof["tsdf_leg_us_per_frame"] = leg_room * 1e3
+        room_roof["scene"] = "analytic ray-cast depth of the same trajectory (surface inside the volume), 30 frames"
 
     if rank != 0:
         return
-    total_frames = args.steps * B * world
-    dims = "x".join(str(int(d)) for d in volume.vol_dim)
+    total_frames = args.steps * B * (1 if strong or world == 1 else world)
+    dims = "x".join(str(int(d)) for d in (merger.dims if exact else volume.vol_dim))
+    merge_note = ""
+    if world > 1:
+        merge_note = (", frames all-gathered, every rank integrates all frames into its x-slab (bit-identical to 1 GPU), slabs all-gathered"
+                      if exact else ", frame-sharded, shared volume merged by reduce-scatter of the 5 accumulator planes + all-gather of the 3 volumes (RCCL)")
     out = {
         "metric": "frames/sec (depth+TSDF integrate) @640x480, 512^3 vol",
         "value": total_frames / elapsed,
@@ -162,22 +287,18 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if strong else "weak",
         "vs_baseline": None,
         "dtype": "bf16",
         "data": "synthetic",
         "config": {
-            "workload": f"synthetic {W}x{H}x{T} RGB (seeded room trajectory), DPT-Hybrid depth (random-init weights, bf16, "
-                        f"{args.engine} ViT engine) + {dims} TSDF integrate, {B} frames/step/GPU"
-                        + (", frame-sharded, one RCCL all-reduce of the 5 accumulator planes" if world > 1 else ""),
-            "frames_per_step_per_gpu": B, "image": [H, W], "volume": dims, "voxel_m": args.voxel,
-            "n_upd_mean": n_upd_mean, "n_upd_fraction": n_upd_mean / volume.num_voxels,
+            "workload": f"synthetic {W}x{H}x{T} RGB (seeded room trajectory), host-resident uint8 frames uploaded in the timed region, DPT-Hybrid depth "
+                        f"(random-init weights, bf16, {args.engine} engine) + {dims} TSDF integrate, {B} frames/step" + merge_note,
+            "frames_per_step": B, "frames_total": total_frames, "image": [H, W], "volume": dims, "voxel_m": args.voxel,
+            "n_upd_mean": n_upd_dpt, "n_upd_fraction": main_roof["n_upd_fraction"], "merge": (args.merge if world > 1 else None),
         },
-        "roofline": {
-            "kernel": "integrate_kernel", "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-            "frac": achieved / 8000.0, "traffic": traffic,
-            "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": avg_kernel_s * 1e6, "launches": n_launch,
-        },
+        "roofline": main_roof,
+        "roofline_room": room_roof,
     }
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(seq, args.voxel, K)

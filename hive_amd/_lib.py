@@ -36,6 +36,8 @@ SIGNATURES = {
     "hive_ctx_kernel_time_total": (c_int, [c_void_p, P(c_int), P(c_float)]),
     "hive_tsdf_dims": (c_int, [c_void_p, c_double, c_void_p]),
     "hive_tsdf_create": (c_int, [c_void_p, c_void_p, c_double, c_void_p, c_void_p, c_void_p, P(c_void_p)]),
+    "hive_tsdf_create_slab": (c_int, [c_void_p, c_void_p, c_double, c_int64, c_int64, c_void_p, c_void_p, c_void_p, P(c_void_p)]),
+    "hive_tsdf_slab_info": (c_int, [c_void_p, P(c_int64), P(c_int64)]),
     "hive_tsdf_destroy": (c_int, [c_void_p]),
     "hive_tsdf_set_round_mode": (c_int, [c_void_p, c_int]),
     "hive_tsdf_reset": (c_int, [c_void_p]),
@@ -54,8 +56,12 @@ SIGNATURES = {
     "hive_tsdf_accum_integrate": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_float,
                                           c_int]),
     "hive_tsdf_accum_finalize": (c_int, [c_void_p, c_void_p]),
+    "hive_tsdf_accum_finalize_to": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     "hive_tsdf_accum_from_volume": (c_int, [c_void_p, c_void_p]),
     "hive_view_frustum": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    "hive_view_frustum_batch": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    "hive_depth_apply_mask": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "hive_depth_mm_to_m": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_float, c_void_p]),
     "hive_unproject": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                c_void_p, c_void_p, c_int64, P(c_int64)]),
     "hive_image2world": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_double, c_int, c_void_p]),
@@ -79,6 +85,8 @@ SIGNATURES = {
                                      c_void_p]),
     "hive_nhwc_bias_act": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "hive_nhwc_upsample2x": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "hive_nhwc_conv3x3": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                  c_void_p, c_void_p]),
     "hive_depth_quantize": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p]),
 }
 

@@ -116,6 +116,8 @@ int hive_ctx_create(int device_id, void *stream, hive_ctx **out) {
         }
     }
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_scalars, 64 * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMalloc(&ctx->d_zeros, 256);
+    if (e == hipSuccess) e = hipMemset(ctx->d_zeros, 0, 256);
     if (e != hipSuccess) {
         int rc = hive_fail(nullptr, HIVE_ERR_DEVICE, "hive_ctx_create: %s", hipGetErrorString(e));
         delete ctx;
@@ -139,6 +141,7 @@ int hive_ctx_destroy(hive_ctx *ctx) {
     if (ctx->d_frame) (void)hipFree(ctx->d_frame);
     if (ctx->d_in) (void)hipFree(ctx->d_in);
     if (ctx->d_scalars) (void)hipFree(ctx->d_scalars);
+        if (ctx->d_zeros) (void)hipFree(ctx->d_zeros);
         if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
     }
     delete ctx;

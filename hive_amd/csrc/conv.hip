@@ -1,0 +1,227 @@
+// Implicit-GEMM 3 x 3 convolution (stride 1, padding 1) on channels-last bf16 for gfx950, with the bias / ReLU / skip adds
+// of DPT's decoder fused into the epilogue.  No vendor library.
+//
+// Replaces the 3 x 3 convolutions of the reference's (absent) third_party/dpt decoder inside `DPTDepthModel.forward`
+// (call site /root/reference/hive/dataset_adaptors.py:1419): `scratch.layer{1..4}_rn`, the two convolutions of every
+// `ResidualConvUnit_custom` of the four `FeatureFusionBlock_custom`s (out = conv2(relu(conv1(relu(x)))) + x (+ skip)) and
+// `scratch.output_conv[0]` -- 272 of the network's 530 GFLOP per 480 x 640 frame.
+//
+// Formulation: out[m][co] = sum_k A[m][k] W[co][k] with m = (image, y, x), k = (ky, kx, ci).  With channels-last activations
+// the 64-channel slice of one tap of one output pixel is 128 contiguous bytes of the input, so the im2col matrix is never
+// built: the LDS-DMA that stages the A tile (global_load_lds_dwordx4, per-lane source address) reads it straight from the
+// shifted pixel -- and from a 128-byte page of zeros where the tap falls into the padding.  The weight tensor
+// [Cout][Cin][3][3] in channels-last memory format IS W[co][(ky, kx, ci)].
+//
+// Tile: 256 output pixels x TN output channels (TN = 256: 8 waves as 2 x 4, 128 x 64 each; TN = 128: 4 x 2, 64 x 64 each),
+// K-step 64 = one tap x 64 input channels, v_mfma_f32_16x16x32_bf16, two LDS stages filled by LDS-DMA with the bank swizzle
+// on the source side (conflict-free ds_read_b128), one raw s_barrier per K-step, XCD-aware tile order: consecutive tiles are
+// consecutive image rows, so an XCD's run of tiles re-reads its three-row halo from its own L2.  K = 9 Cin >= 2304 gives
+// 36+ K-steps per tile (the ViT GEMMs have 12), so the tile's ends are a small share.
+#include "hive_internal.hpp"
+
+#include <algorithm>
+
+typedef __bf16 bf16;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+// byte offset of 16-byte chunk `c` (0..7) of row `r` in a tile with 128-byte rows (same layout as csrc/vit.hip): the chunk
+// is XORed with (r >> 1) & 7 so that any 16 consecutive rows at one chunk index land on 16 distinct 16-byte slots
+__device__ __forceinline__ int swz(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
+
+struct ConvParams {
+    const bf16 *x;      // [NB][H][W][Cin]
+    const bf16 *w;      // [Cout][9 Cin], k = (ky, kx, ci)
+    const bf16 *bias;   // [Cout] or nullptr
+    const bf16 *res1;   // [M][Cout] or nullptr
+    const bf16 *res2;   // [M][Cout] or nullptr
+    bf16 *out;          // [M][Cout]
+    bf16 *out_relu;     // [M][Cout] or nullptr: relu(out)
+    const bf16 *zeros;  // >= 128 bytes of zeros (padding taps)
+    int H, W, Cin, Cout, relu;
+    int M;              // NB * H * W
+};
+
+constexpr int TM = 256, BK = 64, A_GROUPS = TM / 8;
+
+template <int TN>
+__global__ __launch_bounds__(512, 1) void conv3x3_kernel(ConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // 2 stages x (A tile 256 x 64, W tile TN x 64)
+    constexpr int W_GROUPS = TN / 8, GROUPS = A_GROUPS + W_GROUPS, PER_WAVE = GROUPS / 8;
+    constexpr int STAGE_BYTES = GROUPS * 1024;
+    constexpr int WN = TN / 64, WM = 8 / WN, RW = TM / WM, MT = RW / 16;  // waves along N / M, rows per wave, M fragments
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WN, wc = wave % WN;
+    // XCD-aware tile order (workgroups are dealt round-robin over the 8 XCDs): each XCD gets a contiguous run of tiles
+    const int nwg = gridDim.x, xcd = blockIdx.x & 7, q = nwg >> 3, r = nwg & 7;
+    const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+    const int tiles_n = p.Cout / TN;
+    const int m0 = (tile / tiles_n) * TM, n0 = (tile % tiles_n) * TN;
+    const int K = 9 * p.Cin, CPT = p.Cin / BK;  // K-steps per tap
+
+    // the A rows this lane stages (the same ones in every K-step): groups wave, wave + 8, wave + 16, wave + 24
+    int py[4], px[4];
+    const bf16 *pbase[4];
+    int a_chunk[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = (wave + 8 * j) * 8 + (lane >> 3);
+        const int m = min(m0 + row, p.M - 1);  // rows past the end are never stored
+        const int img = m / (p.H * p.W), rem = m - img * (p.H * p.W);
+        py[j] = rem / p.W;
+        px[j] = rem - py[j] * p.W;
+        a_chunk[j] = ((lane & 7) ^ ((row >> 1) & 7)) * 8;  // source-side swizzle: LDS slot (lane & 7) receives this chunk
+        pbase[j] = p.x + (size_t)m * p.Cin + a_chunk[j];
+    }
+    const int w_lane_row = lane >> 3;
+
+    auto issue_stage = [&](int stage, int tap, int cc) {
+        unsigned char *st = lds + stage * STAGE_BYTES;
+        const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+        const long long shift = ((long long)dy * p.W + dx) * p.Cin + cc * BK;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool inside = (unsigned)(py[j] + dy) < (unsigned)p.H && (unsigned)(px[j] + dx) < (unsigned)p.W;
+            const bf16 *g = inside ? pbase[j] + shift : p.zeros + a_chunk[j];
+            __builtin_amdgcn_global_load_lds((const void *)g, (__attribute__((address_space(3))) void *)(st + (wave + 8 * j) * 1024), 16, 0, 0);
+        }
+        const int k0 = tap * p.Cin + cc * BK;
+#pragma unroll
+        for (int j = 4; j < PER_WAVE; ++j) {
+            const int grp = wave + 8 * (j - 4);  // W group: rows grp * 8 .. + 7 of the weight tile
+            const int row = grp * 8 + w_lane_row;
+            const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+            const bf16 *g = p.w + (size_t)(n0 + row) * K + k0 + chunk * 8;
+            __builtin_amdgcn_global_load_lds((const void *)g, (__attribute__((address_space(3))) void *)(st + (A_GROUPS + grp) * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[4][MT];  // acc[nt][mt] = W_frag . A_frag^T : rows = output channel, cols = pixel
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int KT = 9 * CPT;
+    int nx_tap = 0, nx_cc = 0;  // (tap, channel block) of the next stage to issue
+    issue_stage(0, 0, 0);
+    if (++nx_cc == CPT) nx_cc = 0, ++nx_tap;
+    const int fr = lane & 15, fq = lane >> 4;
+    for (int kt = 0; kt < KT; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // everyone's stage kt landed; everyone finished reading stage kt - 1
+        if (kt + 1 < KT) {
+            issue_stage((kt + 1) & 1, nx_tap, nx_cc);  // overwrites the buffer of stage kt - 1
+            if (++nx_cc == CPT) nx_cc = 0, ++nx_tap;
+        }
+        const unsigned char *a_t = lds + (kt & 1) * STAGE_BYTES, *w_t = a_t + A_GROUPS * 1024;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            bf16x8 af[MT], wf[4];
+#pragma unroll
+            for (int t = 0; t < MT; ++t) af[t] = *reinterpret_cast<const bf16x8 *>(a_t + swz(wr * RW + t * 16 + fr, sub * 4 + fq));
+#pragma unroll
+            for (int t = 0; t < 4; ++t) wf[t] = *reinterpret_cast<const bf16x8 *>(w_t + swz(wc * 64 + t * 16 + fr, sub * 4 + fq));
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], af[mt], acc[nt][mt], 0, 0, 0);
+        }
+    }
+
+    // epilogue: a lane owns 4 consecutive output channels of one pixel; everything in f32, one rounding to bf16
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int n = n0 + wc * 64 + nt * 16 + fq * 4;
+        float b[4] = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) {
+            const bf16x4 bv = *reinterpret_cast<const bf16x4 *>(p.bias + n);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = (float)bv[j];
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int m = m0 + wr * RW + mt * 16 + fr;
+            if (m < p.M) {
+                const size_t o_off = (size_t)m * p.Cout + n;
+                float o[4] = {acc[nt][mt][0] + b[0], acc[nt][mt][1] + b[1], acc[nt][mt][2] + b[2], acc[nt][mt][3] + b[3]};
+                if (p.res1) {
+                    const bf16x4 rs = *reinterpret_cast<const bf16x4 *>(p.res1 + o_off);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] += (float)rs[j];
+                }
+                if (p.res2) {
+                    const bf16x4 rs = *reinterpret_cast<const bf16x4 *>(p.res2 + o_off);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] += (float)rs[j];
+                }
+                if (p.relu) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = fmaxf(o[j], 0.0f);
+                }
+                bf16x4 ov;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ov[j] = (bf16)o[j];
+                *reinterpret_cast<bf16x4 *>(p.out + o_off) = ov;
+                if (p.out_relu) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) ov[j] = (bf16)fmaxf(o[j], 0.0f);
+                    *reinterpret_cast<bf16x4 *>(p.out_relu + o_off) = ov;
+                }
+            }
+        }
+    }
+}
+
+bool g_conv_attr_set[64] = {};
+
+int ensure_conv_attrs(hive_ctx *ctx) {
+    if (ctx->device < 64 && g_conv_attr_set[ctx->device]) return HIVE_OK;
+    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)conv3x3_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (A_GROUPS + 32) * 1024));
+    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)conv3x3_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (A_GROUPS + 16) * 1024));
+    if (ctx->device < 64) g_conv_attr_set[ctx->device] = true;
+    return HIVE_OK;
+}
+
+}  // namespace
+
+extern "C" int hive_nhwc_conv3x3(hive_ctx *ctx, const void *d_x, int dtype, int N, int H, int W, int C_in, int C_out, const void *d_w,
+                                 const void *d_bias, int relu, const void *d_residual, const void *d_residual2, void *d_out,
+                                 void *d_out_relu) {
+    HIVE_ENTER(ctx);
+    if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
+    HIVE_REQUIRE(ctx, d_x && d_w && d_out, "nhwc_conv3x3: NULL argument");
+    HIVE_REQUIRE(ctx, dtype == HIVE_BF16, "nhwc_conv3x3: bf16 only");
+    HIVE_REQUIRE(ctx, N > 0 && H > 0 && W > 0 && (long long)N * H * W < (1ll << 31), "nhwc_conv3x3: bad sizes %d x %d x %d", N, H, W);
+    HIVE_REQUIRE(ctx, C_in > 0 && C_in % 64 == 0 && C_out > 0 && C_out % 128 == 0, "nhwc_conv3x3: need C_in %% 64 == 0 and C_out %% 128 == 0, got %d -> %d",
+                 C_in, C_out);
+    HIVE_REQUIRE(ctx, d_out != d_x && d_out_relu != d_x, "nhwc_conv3x3: the output must not alias the input (3 x 3 halo)");
+    ConvParams p{};
+    p.x = (const bf16 *)d_x;
+    p.w = (const bf16 *)d_w;
+    p.bias = (const bf16 *)d_bias;
+    p.res1 = (const bf16 *)d_residual;
+    p.res2 = (const bf16 *)d_residual2;
+    p.out = (bf16 *)d_out;
+    p.out_relu = (bf16 *)d_out_relu;
+    p.zeros = (const bf16 *)ctx->d_zeros;
+    p.H = H;
+    p.W = W;
+    p.Cin = C_in;
+    p.Cout = C_out;
+    p.relu = relu;
+    p.M = N * H * W;
+    const int tiles_m = (p.M + TM - 1) / TM;
+    int rc = ensure_conv_attrs(ctx);
+    if (rc) return rc;
+    if (C_out % 256 == 0)
+        hipLaunchKernelGGL(conv3x3_kernel<256>, dim3(tiles_m * (C_out / 256)), dim3(512), 2 * (size_t)(A_GROUPS + 32) * 1024, ctx->stream, p);
+    else
+        hipLaunchKernelGGL(conv3x3_kernel<128>, dim3(tiles_m * (C_out / 128)), dim3(512), 2 * (size_t)(A_GROUPS + 16) * 1024, ctx->stream, p);
+    HIVE_CHECK_HIP(ctx, hipGetLastError());
+    return HIVE_OK;
+}

@@ -25,6 +25,18 @@ __global__ __launch_bounds__(256) void max_depth_kernel(const float *__restrict_
     if ((threadIdx.x & 63) == 0 && bits) atomicMax(max_bits, bits);
 }
 
+// one launch for a whole frame set: blockIdx.y = frame
+__global__ __launch_bounds__(256) void max_depth_batch_kernel(const float *__restrict__ depth, int n_px, unsigned *max_bits) {
+    const float *d = depth + (size_t)blockIdx.y * n_px;
+    unsigned bits = 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n_px; i += gridDim.x * 256) {
+        const float v = d[i];
+        if (v > 0.f) bits = max(bits, __float_as_uint(v));
+    }
+    for (int off = 32; off > 0; off >>= 1) bits = max(bits, (unsigned)__shfl_xor((int)bits, off));
+    if ((threadIdx.x & 63) == 0 && bits) atomicMax(max_bits + blockIdx.y, bits);
+}
+
 // ------------------------------------------------------------------------------------------------
 constexpr int UP_VPT = 4;
 constexpr int UP_TILE = 256 * UP_VPT;
@@ -221,6 +233,52 @@ __global__ __launch_bounds__(256) void dilate_cols_kernel(const uint8_t *__restr
     out[i] = m;
 }
 
+// frame-set versions of the two passes (blockIdx.y = frame; no bleeding across frame borders), and the masking itself:
+// mode 0 (background, hive/fusion.py:118-121): depth = 0 where the dilated mask is set;
+// mode 1 (foreground = the complement): depth = 0 where the (undilated) mask is clear or is another instance's.
+__global__ __launch_bounds__(256) void dilate_rows_batch_kernel(const uint8_t *__restrict__ in, int H, int W, int r, int instance,
+                                                                uint8_t *__restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= H * W) return;
+    const size_t base = (size_t)blockIdx.y * H * W;
+    const int v = i / W, u = i % W;
+    uint8_t m = 0;
+    for (int uu = max(0, u - r); uu <= min(W - 1, u + r); ++uu) {
+        const uint8_t s = in[base + (size_t)v * W + uu];
+        m |= instance ? (s == instance) : (s != 0);
+    }
+    out[base + i] = m;
+}
+
+__global__ __launch_bounds__(256) void dilate_cols_apply_kernel(const uint8_t *__restrict__ rows, int H, int W, int r,
+                                                                const float *__restrict__ depth, float *__restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= H * W) return;
+    const size_t base = (size_t)blockIdx.y * H * W;
+    const int v = i / W, u = i % W;
+    uint8_t m = 0;
+    for (int vv = max(0, v - r); vv <= min(H - 1, v + r); ++vv) m |= rows[base + (size_t)vv * W + u];
+    out[base + i] = m ? 0.0f : depth[base + i];
+}
+
+__global__ __launch_bounds__(256) void keep_mask_kernel(const uint8_t *__restrict__ mask, size_t n, int instance,
+                                                        const float *__restrict__ depth, float *__restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint8_t s = mask[i];
+    const bool keep = instance ? (s == instance) : (s != 0);
+    out[i] = keep ? depth[i] : 0.0f;
+}
+
+__global__ __launch_bounds__(256) void depth_mm_to_m_kernel(const uint16_t *__restrict__ mm, size_t n, float depth_scale, float max_depth,
+                                                            float *__restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float m = depth_scale * (float)mm[i];
+    if (m > max_depth) m = 0.0f;
+    out[i] = m;
+}
+
 template <typename T>
 __device__ __forceinline__ float load_depth(const void *p, int i);
 template <>
@@ -269,6 +327,21 @@ static int to_device(hive_ctx *ctx, const void *src, size_t bytes, size_t offset
 
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// fusion.get_view_frustum: apex + the four image corners at max(depth), camera -> world.  15 float64 values from one
+// scalar: evaluated on the host, in the reference library's float64
+static void frustum_corners(float max_depth, int H, int W, const float K[9], const double cam_pose[16], double out[15]) {
+    const double md = (double)max_depth;
+    const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
+    const double col[5] = {0, 0, 0, (double)W, (double)W};
+    const double row[5] = {0, 0, (double)H, 0, (double)H};
+    const double dep[5] = {0, md, md, md, md};
+    for (int c = 0; c < 5; ++c) {
+        const double p[3] = {(col[c] - cx) * dep[c] / fx, (row[c] - cy) * dep[c] / fy, dep[c]};
+        for (int r = 0; r < 3; ++r)
+            out[r * 5 + c] = cam_pose[4 * r + 0] * p[0] + cam_pose[4 * r + 1] * p[1] + cam_pose[4 * r + 2] * p[2] + cam_pose[4 * r + 3];
+    }
+}
+
 extern "C" {
 
 int hive_view_frustum(hive_ctx *ctx, const float *depth, int H, int W, const float K[9], const double cam_pose[16], int mem,
@@ -292,17 +365,69 @@ int hive_view_frustum(hive_ctx *ctx, const float *depth, int H, int W, const flo
     HIVE_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     float max_depth;
     memcpy(&max_depth, &bits, 4);
-    // 15 float64 values from 1 scalar: evaluated on the host, in the reference library's float64
-    const double md = (double)max_depth;
-    const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
-    const double col[5] = {0, 0, 0, (double)W, (double)W};
-    const double row[5] = {0, 0, (double)H, 0, (double)H};
-    const double dep[5] = {0, md, md, md, md};
-    for (int c = 0; c < 5; ++c) {
-        const double p[3] = {(col[c] - cx) * dep[c] / fx, (row[c] - cy) * dep[c] / fy, dep[c]};
-        for (int r = 0; r < 3; ++r)
-            out[r * 5 + c] = cam_pose[4 * r + 0] * p[0] + cam_pose[4 * r + 1] * p[1] + cam_pose[4 * r + 2] * p[2] + cam_pose[4 * r + 3];
+    frustum_corners(max_depth, H, W, K, cam_pose, out);
+    return HIVE_OK;
+}
+
+int hive_view_frustum_batch(hive_ctx *ctx, const float *depth, int n, int H, int W, const float K[9], const double *cam_poses, int mem,
+                            double *out) {
+    HIVE_ENTER(ctx);
+    if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
+    HIVE_REQUIRE(ctx, depth && K && cam_poses && out, "view_frustum_batch: NULL argument");
+    HIVE_REQUIRE(ctx, n > 0 && n <= 65535 && H > 0 && W > 0 && (long long)H * W < (1ll << 30), "view_frustum_batch: bad sizes n=%d %dx%d", n, H, W);
+    const int n_px = H * W;
+    const size_t bytes = (size_t)n * n_px * sizeof(float);
+    const void *d_depth;
+    int rc;
+    if (mem == HIVE_MEM_HOST && (rc = hive_reserve_device(ctx, &ctx->d_in, &ctx->in_bytes, bytes))) return rc;
+    if ((rc = to_device(ctx, depth, bytes, 0, mem, &d_depth))) return rc;
+    // per-frame maxima in the generic scratch (n words), ONE launch and ONE read-back for the whole frame set
+    if ((rc = hive_reserve_device(ctx, &ctx->d_scratch, &ctx->scratch_bytes, (size_t)n * sizeof(unsigned)))) return rc;
+    unsigned *d_max = (unsigned *)ctx->d_scratch;
+    HIVE_CHECK_HIP(ctx, hipMemsetAsync(d_max, 0, (size_t)n * sizeof(unsigned), ctx->stream));
+    hipLaunchKernelGGL(max_depth_batch_kernel, dim3(std::min((n_px + 255) / 256, 64), n), dim3(256), 0, ctx->stream, (const float *)d_depth,
+                       n_px, d_max);
+    HIVE_CHECK_HIP(ctx, hipGetLastError());
+    std::vector<unsigned> bits((size_t)n);
+    HIVE_CHECK_HIP(ctx, hipMemcpyAsync(bits.data(), d_max, (size_t)n * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+    HIVE_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int f = 0; f < n; ++f) {
+        float max_depth;
+        memcpy(&max_depth, &bits[f], 4);
+        frustum_corners(max_depth, H, W, K, cam_poses + 16 * (size_t)f, out + 15 * (size_t)f);
     }
+    return HIVE_OK;
+}
+
+int hive_depth_apply_mask(hive_ctx *ctx, const float *d_depth, const uint8_t *d_mask, int n, int H, int W, int iterations, int mode,
+                          int instance_id, float *d_out) {
+    HIVE_ENTER(ctx);
+    if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
+    HIVE_REQUIRE(ctx, d_depth && d_mask && d_out, "depth_apply_mask: NULL argument");
+    HIVE_REQUIRE(ctx, n > 0 && n <= 65535 && H > 0 && W > 0 && iterations >= 0, "depth_apply_mask: bad arguments n=%d %dx%d, %d iterations", n, H, W, iterations);
+    HIVE_REQUIRE(ctx, mode == 0 || mode == 1, "depth_apply_mask: mode must be 0 (zero under the dilated mask) or 1 (keep the mask only)");
+    HIVE_REQUIRE(ctx, instance_id >= 0 && instance_id <= 255, "depth_apply_mask: instance id %d", instance_id);
+    const size_t n_px = (size_t)H * W, total = n_px * (size_t)n;
+    if (mode == 1) {
+        hipLaunchKernelGGL(keep_mask_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, d_mask, total, instance_id, d_depth, d_out);
+    } else {
+        int rc = hive_reserve_device(ctx, &ctx->d_scratch, &ctx->scratch_bytes, total);
+        if (rc) return rc;
+        uint8_t *rows = (uint8_t *)ctx->d_scratch;
+        const dim3 grid((unsigned)((n_px + 255) / 256), n);
+        hipLaunchKernelGGL(dilate_rows_batch_kernel, grid, dim3(256), 0, ctx->stream, d_mask, H, W, iterations, instance_id, rows);
+        hipLaunchKernelGGL(dilate_cols_apply_kernel, grid, dim3(256), 0, ctx->stream, (const uint8_t *)rows, H, W, iterations, d_depth, d_out);
+    }
+    HIVE_CHECK_HIP(ctx, hipGetLastError());
+    return HIVE_OK;
+}
+
+int hive_depth_mm_to_m(hive_ctx *ctx, const uint16_t *d_mm, int64_t n, float depth_scale, float max_depth, float *d_out) {
+    HIVE_ENTER(ctx);
+    if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
+    HIVE_REQUIRE(ctx, d_mm && d_out && n > 0, "depth_mm_to_m: bad argument");
+    hipLaunchKernelGGL(depth_mm_to_m_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_mm, (size_t)n, depth_scale, max_depth, d_out);
+    HIVE_CHECK_HIP(ctx, hipGetLastError());
     return HIVE_OK;
 }
 

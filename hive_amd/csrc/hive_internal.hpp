@@ -42,6 +42,7 @@ struct hive_ctx {
     void *d_in = nullptr;  // device copy of host inputs
     size_t in_bytes = 0;
     unsigned *d_scalars = nullptr;  // [0]=max depth bits, [2..3]=u64 counter, ...
+    void *d_zeros = nullptr;        // 256 bytes of zeros: the source of padding taps in the implicit-GEMM convolutions
 
     // HIP-event timing of the dominant kernel
     bool timing = false;
@@ -98,6 +99,8 @@ struct hive_tsdf {
     hive_ctx *ctx = nullptr;
     int64_t dim[3] = {0, 0, 0};
     int64_t n = 0;
+    int64_t x_off = 0;      // x-slab of a larger scene grid: this volume holds grid voxels x_off <= x < x_off + dim[0]
+    int64_t grid_dim0 = 0;  // x dimension of the whole grid
     double bnds[6] = {0, 0, 0, 0, 0, 0};
     float origin[3] = {0, 0, 0};
     float voxel_size = 0.f;

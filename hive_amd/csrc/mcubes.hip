@@ -334,6 +334,9 @@ extern "C" {
 
 int hive_tsdf_extract_mesh(hive_tsdf *v, int64_t *n_verts, int64_t *n_faces) {
     HIVE_ENTER(v ? v->ctx : nullptr);
+    if (v && (v->x_off != 0 || v->dim[0] != v->grid_dim0))
+        return hive_fail(v->ctx, HIVE_ERR_STATE, "extract_mesh: this volume is an x-slab [%lld, %lld) of a %lld-wide grid; gather the slabs into a "
+                                                 "whole volume first", (long long)v->x_off, (long long)(v->x_off + v->dim[0]), (long long)v->grid_dim0);
     if (!v) return hive_fail(nullptr, HIVE_ERR_INVALID, "vol is NULL");
     hive_ctx *ctx = v->ctx;
     HIVE_CHECK_HIP(ctx, hipSetDevice(ctx->device));

@@ -28,6 +28,7 @@ struct FrameParams {
     float fx, fy, cx, cy;
     float ox, oy, oz, vs, trunc, obs_w;
     int X, Y, Z, H, W;
+    int x_off;                      // x-slab volumes: voxel (x, y, z) of this volume is voxel (x + x_off, y, z) of the scene grid
     const uint2 *frame;             // {depth bits, r | g<<8 | b<<16}
     const unsigned *max_depth_bits;  // float bits of max(depth) of this frame
     unsigned long long *n_updated;
@@ -81,7 +82,13 @@ __global__ __launch_bounds__(256) void pack_frame_kernel(const float *__restrict
 // A wave sweeps 64 / SEG_LANES segments at once (one per 16-lane group): the clipped intervals are short
 // (mean 120-190 voxels at 512^3), so with one 256-voxel item per wave 59 % of the lanes were padding --
 // 16-lane segments (64 voxels, 256 contiguous bytes per volume) cut the wave count by 40 %.
-constexpr int SEG_LANES = 16;
+#ifndef HIVE_SEG_LANES
+#define HIVE_SEG_LANES 16
+#endif
+#ifndef HIVE_GRID_MULT
+#define HIVE_GRID_MULT 16
+#endif
+constexpr int SEG_LANES = HIVE_SEG_LANES;
 struct WorkItem {
     unsigned xy;  // x | y << 16
     unsigned zz;  // segment start z | interval end z << 16
@@ -141,7 +148,7 @@ __global__ __launch_bounds__(1024) void build_worklist_kernel(FrameParams p, Wor
     if (row < (long long)p.X * p.Y) {
         x = (int)(row / p.Y);
         y = (int)(row % p.Y);
-        const float tx = (p.ox + (float)x * p.vs) - p.T[0];
+        const float tx = (p.ox + (float)(x + p.x_off) * p.vs) - p.T[0];
         const float ty = (p.oy + (float)y * p.vs) - p.T[1];
         const float ax = p.R[0] * tx + p.R[3] * ty;
         const float ay = p.R[1] * tx + p.R[4] * ty;
@@ -232,11 +239,11 @@ __device__ __forceinline__ V div_exact(V a, V d, V y) {
 
 // Geometry half of the per-voxel work (no memory access) for NV consecutive z voxels starting at z:
 // camera depth and the pixel each voxel centre rounds to, or -1 (behind the camera / outside the image).
-template <int RM, typename V, int NV>
+template <int RM, typename V, int NV, int ZSTEP = 1>
 __device__ __forceinline__ void voxel_pixels(const FrameParams &p, float ax, float ay, float az, int z, V &cam_z, int (&pix)[NV]) {
     V zf;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) v_set(zf, i, (float)(z + i));
+    for (int i = 0; i < NV; ++i) v_set(zf, i, (float)(z + i * ZSTEP));
     const V pt_z = v_splat(p.oz, zf) + zf * v_splat(p.vs, zf);
     const V tz = pt_z - v_splat(p.T[2], zf);
     const V cam_x = v_splat(ax, zf) + v_splat(p.R[6], zf) * tz;
@@ -265,6 +272,17 @@ __device__ __forceinline__ void voxel_pixels(const FrameParams &p, float ax, flo
         const bool ok = v_get(cam_z, i) > 0.0f && (fx_ >= 0.0f) && (fx_ < (float)p.W) && (fy_ >= 0.0f) && (fy_ < (float)p.H);
         pix[i] = ok ? (__mul24((int)fy_, p.W) + (int)fx_) : -1;  // H, W < 2^23 (checked on the host)
     }
+}
+
+// Camera depth of NV consecutive z voxels: the cam_z expressions of voxel_pixels, verbatim (bit-identical results).
+template <typename V, int NV>
+__device__ __forceinline__ V voxel_cam_z(const FrameParams &p, float az, int z) {
+    V zf;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v_set(zf, i, (float)(z + i));
+    const V pt_z = v_splat(p.oz, zf) + zf * v_splat(p.vs, zf);
+    const V tz = pt_z - v_splat(p.T[2], zf);
+    return v_splat(az, zf) + v_splat(p.R[8], zf) * tz;
 }
 
 // Running-average update of NV voxels; lanes / elements with ok == false keep their values.
@@ -312,8 +330,8 @@ __device__ __forceinline__ void vol_store4(float *dst, const float *src) {
 __device__ __forceinline__ float vol_load1(const float *src) { return *src; }
 __device__ __forceinline__ void vol_store1(float *dst, float v) { *dst = v; }
 
-// One lane's share of a work item (VPT consecutive z voxels of one segment): geometry done, texel gathers
-// issued.  The VPT voxels are NG groups of NV (= 2 packed, or 1 for the scalar kernel).
+// Shape of one lane's share of a work item: VPT consecutive z voxels of one segment, as NG groups of NV (= 2 packed,
+// or 1 for the scalar kernel).
 template <int VPT>
 struct ItemShape {
     static constexpr int NV = VPT >= 2 ? 2 : 1;
@@ -321,53 +339,24 @@ struct ItemShape {
     typedef typename std::conditional<NV == 2, f2, float>::type V;
 };
 
-template <int VPT>
-struct ItemState {
-    int x, y, zb;
-    bool live;          // this lane has voxels inside the item's clipped interval
-    int pix[VPT];       // pixel index or -1
-    typename ItemShape<VPT>::V cam_z[ItemShape<VPT>::NG];
-    uint2 tex[VPT];     // {depth bits, rgb} of the voxel's pixel (gather result)
-};
-
-template <int VPT, int RM>
-__device__ __forceinline__ void issue_item(const FrameParams &p, const WorkItem item, int seg_lane, ItemState<VPT> &s) {
-    typedef ItemShape<VPT> Sh;
-    s.x = (int)(item.xy & 0xffffu);
-    s.y = (int)(item.xy >> 16);
-    s.zb = (int)(item.zz & 0xffffu) + seg_lane * VPT;
-    s.live = s.zb < (int)(item.zz >> 16);
-    // row constants, in the contract's operation order
-    const float tx = (p.ox + (float)s.x * p.vs) - p.T[0];
-    const float ty = (p.oy + (float)s.y * p.vs) - p.T[1];
-    const float ax = p.R[0] * tx + p.R[3] * ty;
-    const float ay = p.R[1] * tx + p.R[4] * ty;
-    const float az = p.R[2] * tx + p.R[5] * ty;
-#pragma unroll
-    for (int g = 0; g < Sh::NG; ++g) {
-        int pix[Sh::NV];
-        voxel_pixels<RM, typename Sh::V, Sh::NV>(p, ax, ay, az, s.zb + g * Sh::NV, s.cam_z[g], pix);
-#pragma unroll
-        for (int i = 0; i < Sh::NV; ++i) {
-            s.pix[g * Sh::NV + i] = pix[i];
-            s.tex[g * Sh::NV + i] = p.frame[max(pix[i], 0)];
-        }
-    }
-}
-
 // Grid-stride sweep over the work list: a wave takes 64 / SEG_LANES consecutive segments per trip (16 lanes
 // x VPT voxels each; VPT = 4 needs Z % 4 == 0), 16-byte accesses per lane and volume.  Lanes past the end of
 // the list or of their row's clipped interval are dead (no volume access).
 //
-// What bounds it (512^3, room scene, ~100 us / frame; experiments in DESIGN.md section 5): the CU's vector
-// memory pipeline, per INSTRUCTION.  A trip issues 4 texel gathers (8 B / lane) + 3 volume loads + 3 volume
-// stores (16 B / lane); each costs the pipeline about 70-100 cycles whatever its lanes do (the dwordx4 stream
-// ceiling of ~10 B / cycle / CU is the same figure).  Removing the gathers (a scalar broadcast read instead)
-// gives 61 us, one gather instead of four 76 us, four 98 us -- 7.5 us per gather instruction, = 65 k trips x
-// ~73 cycles / 256 CUs.  Coalescing the gathers, masking dead lanes, reusing texels between voxels of one
-// pixel, software pipelining, speculative volume loads, non-temporal policies, 2 x / 8 x the grid and 4- or
-// 8-lane segments all measured within +-3 % of this kernel; what does pay is fewer instructions per updated
-// voxel: denser waves (the 16-lane segments: 40 % fewer trips than one 256-voxel item per wave).
+// What bounds it (512^3, room scene; experiments in DESIGN.md section 5): the CU's vector-memory pipeline, per
+// INSTRUCTION.  A trip issues 4 texel gathers (8 B / lane) + 3 volume loads + 3 volume stores (16 B / lane).  A
+// 16-byte streaming instruction costs the pipeline ~120 cycles at the HBM rate; a gather costs ~2.3 cycles per
+// DISTINCT 64-byte line its 64 lanes touch (tools/ubench/gather.hip: 150 cycles for 64 lines, 31 for 12, the same for
+// 4- and 8-byte texels), so what a gather instruction costs is decided by which voxels share it.
+//   * volume role: lane j of a segment owns voxels 4j .. 4j+3 (one 16-byte access per volume).  Gathering in this
+//     role puts voxels 4 apart (~12 pixels, 96 bytes) on neighbouring lanes: 64 lines per instruction.
+//   * gather role (VPT = 4): for the texel fetch the lanes of a segment take CONSECUTIVE voxels -- gather k covers
+//     voxels 16k .. 16k+15 of each of the wave's 4 segments -- so neighbouring lanes hit neighbouring pixels (a z run
+//     projects to a pixel run; ~3 lanes per line when it runs along the image rows).  The fetched {depth, rgb} pairs
+//     go through a 2 KB per-wave LDS exchange (ds_write_b64 / 2 x ds_read_b128, no workgroup barrier: LDS operations
+//     of one wave complete in order) into the volume role, which recomputes its own camera depths (two packed
+//     instructions) and runs the update.  Pixels outside the image / behind the camera are sent as depth 0, which the
+//     depth test rejects -- the same outcome as the contract's separate test.
 // ACCUM = false: running-average update of (tsdf, weight, colour) -- the reference semantics.
 // ACCUM = true : add into the 5 accumulator planes [num, w, r, g, b] (frame-sharded fusion).
 template <int VPT, int RM, bool COUNT, bool ACCUM>
@@ -375,42 +364,98 @@ __global__ __launch_bounds__(256) void integrate_kernel(FrameParams p, const Wor
                                                         const unsigned *__restrict__ n_items_ptr, float *__restrict__ v0,
                                                         float *__restrict__ v1, float *__restrict__ v2, long long plane) {
     constexpr int PER_WAVE = 64 / SEG_LANES;
+    typedef ItemShape<VPT> Sh;
+    typedef typename Sh::V V;
+    constexpr int SEG_VOX = SEG_LANES * 4;                           // voxels of a segment (VPT = 4)
+    __shared__ uint2 xchg[VPT == 4 ? 4 * PER_WAVE * SEG_VOX : 1];  // per wave: PER_WAVE segments x SEG_VOX voxels x {depth bits, rgb}
     const int lane = threadIdx.x & 63;
+    const int seg = lane / SEG_LANES, sl = lane % SEG_LANES;
     const unsigned n_items = *n_items_ptr;
     const unsigned n_trips = (n_items + PER_WAVE - 1) / PER_WAVE;
     const unsigned stride = gridDim.x * 4;
     const float trunc_rcp = refined_rcp(p.trunc);
     unsigned n_upd = 0;
     for (unsigned trip = blockIdx.x * 4 + (threadIdx.x >> 6); trip < n_trips; trip += stride) {
-        const unsigned ii = trip * PER_WAVE + (unsigned)(lane / SEG_LANES);
+        const unsigned ii = trip * PER_WAVE + (unsigned)seg;
         WorkItem item;
         item.xy = item.zz = 0u;  // interval end 0: dead lanes
         if (ii < n_items) item = items[ii];
-        ItemState<VPT> cur;
-        issue_item<VPT, RM>(p, item, lane % SEG_LANES, cur);
-        // finish the inclusion tests of the current item (waits for its gathers)
-        typedef ItemShape<VPT> Sh;
-        typedef typename Sh::V V;
-        V dist[Sh::NG];
+        const int x = (int)(item.xy & 0xffffu), y = (int)(item.xy >> 16);
+        const int zseg = (int)(item.zz & 0xffffu);
+        const int zb = zseg + sl * VPT;  // volume role: this lane's first voxel
+        const bool live = zb < (int)(item.zz >> 16);
+        // row constants, in the contract's operation order
+        const float tx = (p.ox + (float)(x + p.x_off) * p.vs) - p.T[0];
+        const float ty = (p.oy + (float)y * p.vs) - p.T[1];
+        const float ax = p.R[0] * tx + p.R[3] * ty;
+        const float ay = p.R[1] * tx + p.R[4] * ty;
+        const float az = p.R[2] * tx + p.R[5] * ty;
+        V cam_z[Sh::NG];
+        float depth_v[VPT];
         unsigned rgb[VPT];
+        if (VPT == 4) {
+            // gather role: voxels zseg + SEG_LANES k + sl, k = 0 .. 3 (packed pairs k = {0, 1}, {2, 3})
+            uint2 tex[4];
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                V cz;
+                int pix[Sh::NV];
+                voxel_pixels<RM, V, Sh::NV, SEG_LANES>(p, ax, ay, az, zseg + sl + 2 * SEG_LANES * g, cz, pix);
+#pragma unroll
+                for (int i = 0; i < Sh::NV; ++i) {
+                    uint2 t = p.frame[max(pix[i], 0)];
+                    if (pix[i] < 0) t.x = 0u;  // outside the image / behind the camera: rejected by the depth test
+                    tex[g * Sh::NV + i] = t;
+                }
+            }
+            uint2 *mine = xchg + ((threadIdx.x >> 6) * PER_WAVE + seg) * SEG_VOX;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) mine[SEG_LANES * k + sl] = tex[k];
+            // same wave writes and reads: LDS operations of a wave complete in issue order, no workgroup barrier
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const uint4 lo = *reinterpret_cast<const uint4 *>(mine + 4 * sl);
+            const uint4 hi = *reinterpret_cast<const uint4 *>(mine + 4 * sl + 2);
+            depth_v[0] = __uint_as_float(lo.x), rgb[0] = lo.y;
+            depth_v[VPT > 1 ? 1 : 0] = __uint_as_float(lo.z), rgb[VPT > 1 ? 1 : 0] = lo.w;
+            depth_v[VPT > 2 ? 2 : 0] = __uint_as_float(hi.x), rgb[VPT > 2 ? 2 : 0] = hi.y;
+            depth_v[VPT > 3 ? 3 : 0] = __uint_as_float(hi.z), rgb[VPT > 3 ? 3 : 0] = hi.w;
+            __builtin_amdgcn_wave_barrier();  // the next trip's writes stay behind these reads
+#pragma unroll
+            for (int g = 0; g < Sh::NG; ++g) cam_z[g] = voxel_cam_z<V, Sh::NV>(p, az, zb + g * Sh::NV);
+        } else {
+#pragma unroll
+            for (int g = 0; g < Sh::NG; ++g) {
+                int pix[Sh::NV];
+                voxel_pixels<RM, V, Sh::NV>(p, ax, ay, az, zb + g * Sh::NV, cam_z[g], pix);
+#pragma unroll
+                for (int i = 0; i < Sh::NV; ++i) {
+                    const uint2 t = p.frame[max(pix[i], 0)];
+                    depth_v[g * Sh::NV + i] = pix[i] < 0 ? 0.0f : __uint_as_float(t.x);
+                    rgb[g * Sh::NV + i] = t.y;
+                }
+            }
+        }
+        // inclusion tests
+        V dist[Sh::NG];
         bool ok[VPT];
         bool any = false;
 #pragma unroll
         for (int g = 0; g < Sh::NG; ++g) {
             V depth;
 #pragma unroll
-            for (int i = 0; i < Sh::NV; ++i) v_set(depth, i, __uint_as_float(cur.tex[g * Sh::NV + i].x));
-            const V diff = depth - cur.cam_z[g];
+            for (int i = 0; i < Sh::NV; ++i) v_set(depth, i, depth_v[g * Sh::NV + i]);
+            const V diff = depth - cam_z[g];
             dist[g] = v_min(v_splat(1.0f, diff), div_exact(diff, v_splat(p.trunc, diff), v_splat(trunc_rcp, diff)));
 #pragma unroll
             for (int i = 0; i < Sh::NV; ++i) {
                 const int j = g * Sh::NV + i;
-                ok[j] = cur.live && cur.pix[j] >= 0 && (v_get(depth, i) != 0.0f) && !(v_get(diff, i) < -p.trunc);
-                rgb[j] = cur.tex[j].y;
+                ok[j] = live && (v_get(depth, i) != 0.0f) && !(v_get(diff, i) < -p.trunc);
                 any = any || ok[j];
             }
         }
-        const long long idx = ((long long)cur.x * p.Y + cur.y) * p.Z + cur.zb;
+        const long long idx = ((long long)x * p.Y + y) * p.Z + zb;
         float t[VPT], w[VPT], c[VPT];  // ACCUM: planes 0..2
         float c3[VPT], c4[VPT];        // ACCUM: planes 3..4
         if (any) {
@@ -526,18 +571,19 @@ __global__ __launch_bounds__(256) void fill3_kernel(float *__restrict__ a, float
     }
 }
 
+// acc: 5 planes of `plane` floats each, of which elements [0, n) are folded into tsdf / weight / color [0, n)
 template <int RM>
-__global__ __launch_bounds__(256) void finalize_kernel(const float *__restrict__ acc, long long n, float *__restrict__ tsdf,
+__global__ __launch_bounds__(256) void finalize_kernel(const float *__restrict__ acc, long long plane, long long n, float *__restrict__ tsdf,
                                                        float *__restrict__ weight, float *__restrict__ color) {
     const long long stride = (long long)gridDim.x * 256;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
-        const float w = acc[1 * n + i];
+        const float w = acc[1 * plane + i];
         float t = 1.0f, c = 0.0f;
         if (w > 0.0f) {
-            t = acc[0 * n + i] / w;
-            const float r = fminf(hive_round<RM>(acc[2 * n + i] / w), 255.0f);
-            const float g = fminf(hive_round<RM>(acc[3 * n + i] / w), 255.0f);
-            const float b = fminf(hive_round<RM>(acc[4 * n + i] / w), 255.0f);
+            t = acc[0 * plane + i] / w;
+            const float r = fminf(hive_round<RM>(acc[2 * plane + i] / w), 255.0f);
+            const float g = fminf(hive_round<RM>(acc[3 * plane + i] / w), 255.0f);
+            const float b = fminf(hive_round<RM>(acc[4 * plane + i] / w), 255.0f);
             c = b * 65536.0f + g * 256.0f + r;
         }
         tsdf[i] = t;
@@ -624,6 +670,7 @@ static int launch_integrate(hive_tsdf *v, float *accum, int H, int W, const floa
     p.trunc = v->trunc;
     p.obs_w = obs_weight;
     p.X = (int)v->dim[0];
+    p.x_off = (int)v->x_off;
     p.Y = (int)v->dim[1];
     p.Z = (int)v->dim[2];
     p.H = H;
@@ -646,10 +693,11 @@ static int launch_integrate(hive_tsdf *v, float *accum, int H, int W, const floa
         hipLaunchKernelGGL(build_worklist_kernel<4>, wl_grid, dim3(1024), 0, ctx->stream, p, items, n_items);
     else
         hipLaunchKernelGGL(build_worklist_kernel<1>, wl_grid, dim3(1024), 0, ctx->stream, p, items, n_items);
-    // grid-stride sweep: 4 x the resident wave count (8 workgroups of 4 waves per CU), so that the dispatcher
-    // evens out trips of unequal cost (measured: 120 -> 110 us at 512^3); a wave takes 64 / SEG_LANES items per trip
+    // grid-stride sweep: HIVE_GRID_MULT (16) x the resident workgroup count (8 workgroups of 4 waves per CU), so that the
+    // dispatcher evens out trips of unequal cost (room scene, 512^3: x2 97, x4 90-94, x8 91, x16 87, x32 95 us; at x16 the
+    // 32768 workgroups hold ~0.5 trips each: most waves run exactly one); a wave takes 64 / SEG_LANES items per trip
     const long long max_trips = (long long)((max_items + 64 / SEG_LANES - 1) / (64 / SEG_LANES));
-    const dim3 grid((unsigned)std::min<long long>((long long)ctx->num_cus * 8 * 4, (max_trips + 3) / 4)), block(256);
+    const dim3 grid((unsigned)std::min<long long>((long long)ctx->num_cus * 8 * HIVE_GRID_MULT, (max_trips + 3) / 4)), block(256);
     if ((rc = hive_time_begin(ctx))) return rc;
 #define HIVE_LAUNCH(VPT, RM, CNT)                                                                                      \
     hipLaunchKernelGGL((integrate_kernel<VPT, RM, CNT, ACCUM>), grid, block, 0, ctx->stream, p, items, n_items, a0, \
@@ -691,6 +739,11 @@ int hive_tsdf_dims(const double vol_bnds[6], double voxel_size, int64_t vol_dim[
 
 int hive_tsdf_create(hive_ctx *ctx, const double vol_bnds[6], double voxel_size, float *d_tsdf, float *d_weight,
                      float *d_color, hive_tsdf **out) {
+    return hive_tsdf_create_slab(ctx, vol_bnds, voxel_size, 0, -1, d_tsdf, d_weight, d_color, out);
+}
+
+int hive_tsdf_create_slab(hive_ctx *ctx, const double vol_bnds[6], double voxel_size, int64_t x_begin, int64_t x_end, float *d_tsdf,
+                          float *d_weight, float *d_color, hive_tsdf **out) {
     HIVE_ENTER(ctx);
     if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
     HIVE_REQUIRE(ctx, out && vol_bnds, "hive_tsdf_create: NULL argument");
@@ -701,14 +754,21 @@ int hive_tsdf_create(hive_ctx *ctx, const double vol_bnds[6], double voxel_size,
     HIVE_REQUIRE(ctx, dim[0] > 0 && dim[1] > 0 && dim[2] > 0, "hive_tsdf_create: empty volume %lld x %lld x %lld",
                  (long long)dim[0], (long long)dim[1], (long long)dim[2]);
     HIVE_REQUIRE(ctx, dim[0] < 65536 && dim[1] < 65536 && dim[2] < 65536, "hive_tsdf_create: a volume dimension exceeds 65535");
+    const int64_t gdim0 = dim[0];
+    if (x_end < 0) x_end = gdim0;  // the whole grid
+    HIVE_REQUIRE(ctx, 0 <= x_begin && x_begin < x_end && x_end <= gdim0, "hive_tsdf_create_slab: x range [%lld, %lld) outside [0, %lld)",
+                 (long long)x_begin, (long long)x_end, (long long)gdim0);
+    dim[0] = x_end - x_begin;
     const bool external = d_tsdf || d_weight || d_color;
     HIVE_REQUIRE(ctx, !external || (d_tsdf && d_weight && d_color), "hive_tsdf_create: pass all three volume pointers or none");
     hive_tsdf *v = new hive_tsdf();
     v->ctx = ctx;
+    v->x_off = x_begin;
+    v->grid_dim0 = gdim0;
     for (int a = 0; a < 3; ++a) {
         v->dim[a] = dim[a];
         v->bnds[2 * a] = vol_bnds[2 * a];
-        v->bnds[2 * a + 1] = vol_bnds[2 * a] + (double)dim[a] * voxel_size;  // as the reference library adjusts them
+        v->bnds[2 * a + 1] = vol_bnds[2 * a] + (double)(a == 0 ? gdim0 : dim[a]) * voxel_size;  // as the reference library adjusts them
         v->origin[a] = (float)vol_bnds[2 * a];
     }
     v->n = dim[0] * dim[1] * dim[2];
@@ -784,6 +844,13 @@ int hive_tsdf_info(hive_tsdf *v, int64_t vol_dim[3], float origin[3], double vol
     return HIVE_OK;
 }
 
+int hive_tsdf_slab_info(hive_tsdf *v, int64_t *x_begin, int64_t *grid_dim_x) {
+    if (!v) return hive_fail(nullptr, HIVE_ERR_INVALID, "vol is NULL");
+    if (x_begin) *x_begin = v->x_off;
+    if (grid_dim_x) *grid_dim_x = v->grid_dim0;
+    return HIVE_OK;
+}
+
 int hive_tsdf_device_ptrs(hive_tsdf *v, float **d_tsdf, float **d_weight, float **d_color) {
     HIVE_ENTER(v ? v->ctx : nullptr);
     if (!v) return hive_fail(nullptr, HIVE_ERR_INVALID, "vol is NULL");
@@ -835,9 +902,9 @@ int hive_tsdf_get_volume(hive_tsdf *v, float *h_tsdf, float *h_color, float *h_w
     if (!v) return hive_fail(nullptr, HIVE_ERR_INVALID, "vol is NULL");
     hive_ctx *ctx = v->ctx;
     const size_t bytes = (size_t)v->n * sizeof(float);
-    if (h_tsdf) HIVE_CHECK_HIP(ctx, hipMemcpyAsync(h_tsdf, v->d_tsdf, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    if (h_color) HIVE_CHECK_HIP(ctx, hipMemcpyAsync(h_color, v->d_color, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    if (h_weight) HIVE_CHECK_HIP(ctx, hipMemcpyAsync(h_weight, v->d_weight, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (h_tsdf) HIVE_CHECK_HIP(ctx, hipMemcpyAsync(h_tsdf, v->d_tsdf, bytes, hipMemcpyDefault, ctx->stream));
+    if (h_color) HIVE_CHECK_HIP(ctx, hipMemcpyAsync(h_color, v->d_color, bytes, hipMemcpyDefault, ctx->stream));
+    if (h_weight) HIVE_CHECK_HIP(ctx, hipMemcpyAsync(h_weight, v->d_weight, bytes, hipMemcpyDefault, ctx->stream));
     HIVE_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return HIVE_OK;
 }
@@ -847,9 +914,9 @@ int hive_tsdf_set_volume(hive_tsdf *v, const float *h_tsdf, const float *h_color
     if (!v) return hive_fail(nullptr, HIVE_ERR_INVALID, "vol is NULL");
     hive_ctx *ctx = v->ctx;
     const size_t bytes = (size_t)v->n * sizeof(float);
-    if (h_tsdf) HIVE_CHECK_HIP(ctx, hipMemcpyAsync(v->d_tsdf, h_tsdf, bytes, hipMemcpyHostToDevice, ctx->stream));
-    if (h_color) HIVE_CHECK_HIP(ctx, hipMemcpyAsync(v->d_color, h_color, bytes, hipMemcpyHostToDevice, ctx->stream));
-    if (h_weight) HIVE_CHECK_HIP(ctx, hipMemcpyAsync(v->d_weight, h_weight, bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (h_tsdf) HIVE_CHECK_HIP(ctx, hipMemcpyAsync(v->d_tsdf, h_tsdf, bytes, hipMemcpyDefault, ctx->stream));
+    if (h_color) HIVE_CHECK_HIP(ctx, hipMemcpyAsync(v->d_color, h_color, bytes, hipMemcpyDefault, ctx->stream));
+    if (h_weight) HIVE_CHECK_HIP(ctx, hipMemcpyAsync(v->d_weight, h_weight, bytes, hipMemcpyDefault, ctx->stream));
     HIVE_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     v->n_verts = v->n_faces = -1;
     return HIVE_OK;
@@ -887,19 +954,26 @@ int hive_tsdf_accum_from_volume(hive_tsdf *v, float *d_accum) {
 }
 
 int hive_tsdf_accum_finalize(hive_tsdf *v, const float *d_accum) {
+    if (!v) return hive_fail(nullptr, HIVE_ERR_INVALID, "vol is NULL");
+    int rc = hive_tsdf_accum_finalize_to(v, d_accum, v->n, v->n, v->d_tsdf, v->d_weight, v->d_color);
+    v->n_verts = v->n_faces = -1;
+    return rc;
+}
+
+int hive_tsdf_accum_finalize_to(hive_tsdf *v, const float *d_accum, int64_t plane_stride, int64_t count, float *d_tsdf, float *d_weight,
+                                float *d_color) {
     HIVE_ENTER(v ? v->ctx : nullptr);
     if (!v) return hive_fail(nullptr, HIVE_ERR_INVALID, "vol is NULL");
     hive_ctx *ctx = v->ctx;
-    HIVE_REQUIRE(ctx, d_accum, "accum_finalize: d_accum is NULL");
-    const int blocks = (int)std::min<long long>((v->n + 255) / 256, 256 * 32);
+    HIVE_REQUIRE(ctx, d_accum && d_tsdf && d_weight && d_color, "accum_finalize: NULL argument");
+    HIVE_REQUIRE(ctx, count >= 0 && plane_stride >= count, "accum_finalize_to: %lld voxels, plane stride %lld", (long long)count, (long long)plane_stride);
+    if (count == 0) return HIVE_OK;
+    const int blocks = (int)std::min<long long>((count + 255) / 256, 256 * 32);
     if (v->round_mode)
-        hipLaunchKernelGGL(finalize_kernel<1>, dim3(blocks), dim3(256), 0, ctx->stream, d_accum, (long long)v->n, v->d_tsdf,
-                           v->d_weight, v->d_color);
+        hipLaunchKernelGGL(finalize_kernel<1>, dim3(blocks), dim3(256), 0, ctx->stream, d_accum, (long long)plane_stride, (long long)count, d_tsdf, d_weight, d_color);
     else
-        hipLaunchKernelGGL(finalize_kernel<0>, dim3(blocks), dim3(256), 0, ctx->stream, d_accum, (long long)v->n, v->d_tsdf,
-                           v->d_weight, v->d_color);
+        hipLaunchKernelGGL(finalize_kernel<0>, dim3(blocks), dim3(256), 0, ctx->stream, d_accum, (long long)plane_stride, (long long)count, d_tsdf, d_weight, d_color);
     HIVE_CHECK_HIP(ctx, hipGetLastError());
-    v->n_verts = v->n_faces = -1;
     return HIVE_OK;
 }
 

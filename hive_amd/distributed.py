@@ -67,18 +67,141 @@ def max_over_ranks(value, device="cpu"):
     return float(t.item())
 
 
+class VoxelPartition:
+    """Equal, contiguous shares of a volume's N voxels over the ranks: rank r owns [r * chunk, r * chunk + count).  The planes
+    are padded to world * chunk elements so that reduce-scatter / all-gather see equal pieces."""
+
+    def __init__(self, n_voxels, world=None, rank=None, align=256):
+        self.world = world if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
+        self.rank = rank if rank is not None else (dist.get_rank() if dist.is_initialized() else 0)
+        self.n = int(n_voxels)
+        per = -(-self.n // self.world)
+        self.chunk = -(-per // align) * align
+        self.padded = self.chunk * self.world
+        self.first = self.rank * self.chunk
+        self.count = max(0, min(self.chunk, self.n - self.first))
+
+
+def reduce_scatter_planes(accum, part):
+    """accum: float32 [5, part.padded] -> this rank's summed share [5, part.chunk].  One reduce-scatter per plane (a plane is
+    world equal pieces, in rank order).  Each GPU sends (W - 1) / W of a plane per plane -- over xGMI's point-to-point links
+    that is W - 1 concurrent transfers of 1 / W of the data each, instead of the two passes of an all-reduce."""
+    assert accum.dim() == 2 and accum.shape[1] == part.padded
+    out = torch.empty((accum.shape[0], part.chunk), dtype=accum.dtype, device=accum.device)
+    if part.world == 1:
+        out.copy_(accum)
+        return out
+    for p in range(accum.shape[0]):
+        dist.reduce_scatter_tensor(out[p], accum[p], op=dist.ReduceOp.SUM)
+    return out
+
+
+def all_gather_shares(full, part):
+    """full: [part.padded] with this rank's share already in place at [first, first + chunk): fills in everyone else's."""
+    assert full.dim() == 1 and full.numel() == part.padded
+    if part.world > 1:
+        dist.all_gather_into_tensor(full, full[part.first:part.first + part.chunk])
+    return full
+
+
 def fuse_sharded(volume, stream_or_accum=None):
-    """Merge the per-rank fusions into the shared static-scene volume, on every rank: ONE all-reduce of the
-    accumulator planes, then ``finalize``.
+    """Merge the per-rank fusions into the shared static-scene volume, on every rank:
+    reduce-scatter of the 5 accumulator planes -> every rank folds ITS 1 / W of the voxels (`finalize_range`) -> all-gather of
+    the 3 result planes.  Against all-reduce + full finalize on every rank this moves 8 / 10 of the bytes
+    ((5 + 3) N (W - 1) / W instead of 2 x 5 N (W - 1) / W floats per GPU) and divides the finalize pass by W.
 
     ``stream_or_accum=None`` (what ``bench.py --gpus N`` does): every rank fused its own frames with the ordinary
     ``integrate`` (same kernel and cost as on one GPU); its volumes are converted to the sums
     ``[tsdf * w, w, r * w, g * w, b * w]`` here.  Otherwise: the accumulators of a ``DepthFusionStream(accumulate=True)``
     or a raw accumulator tensor filled with ``accum_integrate`` (sums of the raw observations, 40 B / voxel / frame)."""
+    n = volume.num_voxels
+    part = VoxelPartition(n)
     accum = getattr(stream_or_accum, "accum", stream_or_accum)
+    planes = torch.empty((5, part.padded), dtype=torch.float32, device="cuda")
+    if part.padded > n:
+        planes[:, n:].zero_()
     if accum is None:
-        accum = torch.empty(5 * volume.num_voxels, dtype=torch.float32, device="cuda")
-        volume.accum_from_volume(accum)
-    allreduce_accumulators(accum)
-    volume.accum_finalize(accum)
+        tight = torch.empty(5 * n, dtype=torch.float32, device="cuda")
+        volume.accum_from_volume(tight)
+        planes[:, :n].copy_(tight.view(5, n))
+        del tight
+    else:
+        planes[:, :n].copy_(accum.view(5, n))
+    mine = reduce_scatter_planes(planes, part)
+    del planes
+    out = [torch.empty(part.padded, dtype=torch.float32, device="cuda") for _ in range(3)]  # tsdf, weight, colour
+    volume.accum_finalize_range(mine, part.chunk, part.count, [o[part.first:] for o in out])
+    for o in out:
+        all_gather_shares(o, part)
+    volume.set_volume_device(tsdf=out[0][:n], weight=out[1][:n], color=out[2][:n])
     return volume
+
+
+# ------------------------------------------------------------------------------------------------
+# Bit-exact mode (SURVEY.md §8e, the alternative): the FRAMES are all-gathered (2.15 MB each: 323 MB for 150 VGA frames),
+# the VOLUME is sharded in x-slabs, and every rank integrates every frame, in sequence order, into its slab.  A voxel's update
+# reads only its own pixel, and a slab voxel keeps the world position it has in the whole grid (hive_tsdf_create_slab), so
+# each slab is bit for bit the slice of the sequential single-GPU volume -- colours included, which the sum-based merge
+# above cannot give.  Depth estimation stays frame-sharded (the expensive part); integrate work per rank is 1 / W of the
+# voxels of every frame.
+def allgather_frames(local, counts):
+    """local: this rank's frames [n_r, ...] (contiguous block of the sequence, rank order = sequence order); counts[r] = n_r.
+    Returns all frames [sum(counts), ...] in sequence order on every rank."""
+    world = len(counts)
+    if world == 1:
+        return local
+    most = max(counts)
+    padded = torch.zeros((most,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    padded[:local.shape[0]].copy_(local)
+    gathered = torch.empty((world * most,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(gathered, padded)
+    if all(c == most for c in counts):
+        return gathered
+    return torch.cat([gathered[r * most:r * most + counts[r]] for r in range(world)], dim=0)
+
+
+def allgather_slabs(slab, x_ranges, row_elems):
+    """slab: this rank's [x1 - x0, Y, Z] (flattened or not); x_ranges[r] = (x0, x1) of rank r.  Returns the whole [X * Y * Z]
+    array on every rank."""
+    world = len(x_ranges)
+    flat = slab.reshape(-1)
+    if world == 1:
+        return flat
+    most = max(b - a for a, b in x_ranges) * row_elems
+    padded = torch.zeros(most, dtype=flat.dtype, device=flat.device)
+    padded[:flat.numel()].copy_(flat)
+    gathered = torch.empty(world * most, dtype=flat.dtype, device=flat.device)
+    dist.all_gather_into_tensor(gathered, padded)
+    return torch.cat([gathered[r * most:r * most + (x_ranges[r][1] - x_ranges[r][0]) * row_elems] for r in range(world)])
+
+
+class ExactSlabFusion:
+    """The bit-exact multi-GPU fusion on the MI355X: one x-slab ``TSDFVolume`` per rank."""
+
+    def __init__(self, vol_bnds, voxel_size, ctx=None, **volume_kwargs):
+        from hive_amd import fusion
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.vol_bnds, self.voxel_size, self._kwargs, self._ctx = vol_bnds, voxel_size, volume_kwargs, ctx
+        dims = fusion.volume_dims(vol_bnds, voxel_size)
+        self.dims = tuple(int(d) for d in dims)
+        self.x_ranges = [shard_range(self.dims[0], r, self.world) for r in range(self.world)]
+        self.slab = fusion.TSDFVolume(vol_bnds, voxel_size, ctx=ctx, x_range=self.x_ranges[self.rank], **volume_kwargs)
+
+    def integrate(self, color_local, depth_local, cam_intr, poses_all, counts, obs_weight=1.0):
+        """color_local u8 [n_r, H, W, 3] / depth_local f32 [n_r, H, W]: this rank's block of the sequence (device tensors,
+        e.g. its DPT depth maps); poses_all [T, 4, 4] for the whole sequence; counts[r] = frames of rank r."""
+        color = allgather_frames(color_local, counts)
+        depth = allgather_frames(depth_local, counts)
+        assert depth.shape[0] == len(poses_all)
+        self.slab.integrate_batch(color, depth, cam_intr, poses_all, obs_weight=obs_weight)
+
+    def gather(self):
+        """The whole volume on every rank (for marching cubes): all-gather of the slabs' three planes."""
+        from hive_amd import fusion
+        row = self.dims[1] * self.dims[2]
+        full = fusion.TSDFVolume(self.vol_bnds, self.voxel_size, ctx=self._ctx, **self._kwargs)
+        t, w, c = self.slab.device_tensors()
+        full.set_volume_device(tsdf=allgather_slabs(t, self.x_ranges, row), weight=allgather_slabs(w, self.x_ranges, row),
+                               color=allgather_slabs(c, self.x_ranges, row))
+        return full

@@ -41,12 +41,12 @@ class StdConv2dSame(nn.Conv2d):
     def __init__(self, in_chs, out_chs, kernel_size, stride=1, eps=1e-8):
         super().__init__(in_chs, out_chs, kernel_size, stride=stride, padding=0, bias=False)
         self.eps = eps
-        self._std_weight = None
+        self._std_weight, self._std_stamp = None, None
 
     def standardized_weight(self):
         w = self.weight
-        if not self.training and self._std_weight is not None and self._std_weight.dtype == w.dtype \
-                and self._std_weight.device == w.device:
+        stamp = (w.data_ptr(), w._version, w.dtype, w.device)  # load_state_dict / optimiser steps write in place: _version moves
+        if not self.training and self._std_weight is not None and self._std_stamp == stamp:
             return self._std_weight
         w32 = w.float()
         flat = w32.reshape(w32.shape[0], -1)
@@ -56,7 +56,7 @@ class StdConv2dSame(nn.Conv2d):
         if w.dim() == 4 and w.is_contiguous(memory_format=torch.channels_last):
             std_w = std_w.contiguous(memory_format=torch.channels_last)
         if not self.training:
-            self._std_weight = std_w.detach()
+            self._std_weight, self._std_stamp = std_w.detach(), stamp
         return std_w
 
     def train(self, mode=True):
@@ -296,10 +296,11 @@ class FeatureFusionBlock(nn.Module):
         self.resConfUnit1 = ResidualConvUnit(features)
         self.resConfUnit2 = ResidualConvUnit(features)
 
-    def forward(self, *xs):
-        output, output_relu = xs[0], None
+    def forward(self, *xs, relu_of_last=None):
+        """``relu_of_last``: relu(xs[-1]) if its producer already wrote it (saves the residual unit a pass)."""
+        output, output_relu = xs[0], relu_of_last
         if len(xs) == 2:  # output + resConfUnit1(xs[1]), and its ReLU for resConfUnit2 from the same kernel
-            output, output_relu = self.resConfUnit1(xs[1], skip=output, also_relu=True)
+            output, output_relu = self.resConfUnit1(xs[1], skip=output, also_relu=True, x_relu=relu_of_last)
         output = self.resConfUnit2(output, x_relu=output_relu)
         if self.engine == "hip":
             # The reference interpolates, then applies the 1x1 out_conv.  A 1x1 convolution (per-pixel, with
@@ -463,10 +464,20 @@ class DPT(nn.Module):
         (layer_1..4, path_4..1; plus tokens and the two ViT taps) -- for the per-stage numerics tests."""
         layer_1, layer_2, layer_3, layer_4 = self.forward_backbone(x, stages)
         s = self.scratch
-        path_4 = s.refinenet4(s.layer4_rn(layer_4))
-        path_3 = s.refinenet3(path_4, s.layer3_rn(layer_3))
-        path_2 = s.refinenet2(path_3, s.layer2_rn(layer_2))
-        path_1 = s.refinenet1(path_2, s.layer1_rn(layer_1))
+
+        def rn(conv, x):  # scratch.layerN_rn (3 x 3, no bias) -> (y, relu(y)): the residual unit behind it starts with a ReLU
+            if self.engine == "hip" and dpt_ops.conv3x3_eligible(x, conv):
+                return dpt_ops.conv3x3(x, conv, also_relu=True)
+            return conv(x), None
+
+        l4, l4_relu = rn(s.layer4_rn, layer_4)
+        path_4 = s.refinenet4(l4, relu_of_last=l4_relu)
+        l3, l3_relu = rn(s.layer3_rn, layer_3)
+        path_3 = s.refinenet3(path_4, l3, relu_of_last=l3_relu)
+        l2, l2_relu = rn(s.layer2_rn, layer_2)
+        path_2 = s.refinenet2(path_3, l2, relu_of_last=l2_relu)
+        l1, l1_relu = rn(s.layer1_rn, layer_1)
+        path_1 = s.refinenet1(path_2, l1, relu_of_last=l1_relu)
         if stages is not None:
             stages.update(path_4=path_4, path_3=path_3, path_2=path_2, path_1=path_1)
         return path_1
@@ -554,8 +565,11 @@ class DPTDepthModel(DPT):
             if fused:
                 # Interpolate + conv 128 -> 32 + ReLU + conv 32 -> 1 + inversion + hand-off: one HIP kernel (csrc/dpt_head.hip)
                 # (output_conv[0] runs without its bias: the kernel adds it while loading, one pass over 315 MB less)
-                lo = F.conv2d(self.forward_decoder(x, stages), first.weight, None, first.stride, first.padding)
-                lo = lo.contiguous(memory_format=torch.channels_last)
+                path_1 = self.forward_decoder(x, stages)
+                if dpt_ops.conv3x3_eligible(path_1, first):
+                    lo = dpt_ops.conv3x3(path_1, first, with_bias=False)  # its bias is added by the fused head while loading
+                else:
+                    lo = F.conv2d(path_1, first.weight, None, first.stride, first.padding).contiguous(memory_format=torch.channels_last)
                 if stages is not None:
                     stages["head_in"] = lo + first.bias.view(1, -1, 1, 1)
                 b, c, h, w = lo.shape

@@ -36,10 +36,57 @@ def group_norm_act(x, num_groups, weight, bias, eps, relu=True, residual=None, e
     return F.relu(y) if relu else y
 
 
+_cl_weights = {}  # id(conv) -> (stamp, channels-last weight): only for models that were not converted to channels_last
+
+
+def _conv3x3_weight(conv):
+    """[C_out][3][3][C_in] view of the weights = the weight tensor in channels-last memory format (what
+    ``model.to(memory_format=torch.channels_last)`` already stores)."""
+    w = conv.weight
+    if w.is_contiguous(memory_format=torch.channels_last):
+        return w
+    stamp = (w.data_ptr(), w._version)
+    hit = _cl_weights.get(id(conv))
+    if hit is None or hit[0] != stamp:
+        hit = _cl_weights[id(conv)] = (stamp, w.detach().contiguous(memory_format=torch.channels_last))
+    return hit[1]
+
+
+def conv3x3_eligible(x, conv):
+    """The hand-written implicit-GEMM kernel (csrc/conv.hip) covers 3 x 3, stride 1, padding 1 on bf16 channels-last with
+    C_in % 64 == 0 and C_out % 128 == 0 -- every 3 x 3 convolution of DPT's decoder."""
+    return (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)
+            and tuple(conv.kernel_size) == (3, 3) and tuple(conv.stride) == (1, 1) and tuple(conv.padding) == (1, 1)
+            and tuple(conv.dilation) == (1, 1) and conv.groups == 1 and conv.in_channels % 64 == 0 and conv.out_channels % 128 == 0
+            and conv.weight.dtype == torch.bfloat16 and x.shape[1] == conv.in_channels)
+
+
+def conv3x3(x, conv, relu=False, residual=None, residual2=None, also_relu=False, with_bias=True):
+    """relu?(conv(x) (+ bias) (+ residual) (+ residual2)) [and relu of it] in ONE HIP kernel; see ``conv3x3_eligible``."""
+    n, _, h, w = x.shape
+    out = torch.empty((n, conv.out_channels, h, w), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    out_relu = torch.empty_like(out) if also_relu else None
+    for r in (residual, residual2):
+        assert r is None or (r.shape == out.shape and r.dtype == out.dtype and r.is_contiguous(memory_format=torch.channels_last))
+    bias = conv.bias if (with_bias and conv.bias is not None) else None
+    ctx = _lib.default_context(x.device.index or 0)
+    ctx.check(ctx.lib.hive_nhwc_conv3x3(ctx.handle, x.data_ptr(), _lib.BF16, n, h, w, conv.in_channels, conv.out_channels,
+                                        _conv3x3_weight(conv).data_ptr(), _lib.ptr(bias), int(bool(relu)), _lib.ptr(residual),
+                                        _lib.ptr(residual2), out.data_ptr(), _lib.ptr(out_relu)))
+    return (out, out_relu) if also_relu else out
+
+
 def conv_bias_act(x, conv, relu=False, residual=None, residual2=None, engine="torch", also_relu=False):
-    """relu?(conv(x) (+ residual) (+ residual2)) for an ``nn.Conv2d`` with bias.  With the HIP engine the convolution runs
-    without its bias (MIOpen) and one fused kernel adds bias, skip connection and ReLU.  ``also_relu=True`` returns
-    ``(y, relu(y))``: the second tensor is what the next residual unit feeds to its first convolution."""
+    """relu?(conv(x) (+ residual) (+ residual2)) for an ``nn.Conv2d`` with bias.  HIP engine: the decoder's 3 x 3
+    convolutions run in the hand-written implicit-GEMM kernel with bias, skip connections and ReLU in its epilogue; other
+    shapes run the convolution without its bias (MIOpen) and one fused kernel adds bias, skip connection and ReLU.
+    ``also_relu=True`` returns ``(y, relu(y))``: the second tensor is what the next residual unit feeds to its first convolution."""
+    if engine == "hip" and conv3x3_eligible(x, conv) and (conv.bias is None or conv.bias.dtype == x.dtype):
+        if residual is not None:
+            residual = residual.contiguous(memory_format=torch.channels_last)
+        if residual2 is not None:
+            residual2 = residual2.contiguous(memory_format=torch.channels_last)
+        return conv3x3(x, conv, relu=relu, residual=residual, residual2=residual2, also_relu=also_relu)
     if engine == "hip" and conv.bias is not None and _hip_eligible(x) and conv.out_channels % 8 == 0 and conv.bias.dtype == x.dtype:
         y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
         if _hip_eligible(y):

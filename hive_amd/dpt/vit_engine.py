@@ -50,6 +50,7 @@ class VitEngine:
         """tokens [B, N, D] (any float dtype, on the GPU) -> tuple of block outputs (bf16 -> tokens.dtype) at ``taps``."""
         B, N, D = tokens.shape
         assert D == self.dim
+        self.ctx.follow_torch_stream()  # the tokens were produced on torch's current stream: queue behind them
         x = tokens.to(torch.bfloat16).contiguous()
         outs = [torch.empty_like(x) for _ in taps]
         tap_idx = (ctypes.c_int * len(taps))(*[int(t) for t in taps])

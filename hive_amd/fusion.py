@@ -46,6 +46,14 @@ def get_view_frustum(depth_im, cam_intr, cam_pose, ctx=None):
     return out
 
 
+def volume_dims(vol_bnds, voxel_size):
+    """vol_dim = ceil((max - min) / voxel_size) of the reference library, without creating a volume."""
+    bnds = np.ascontiguousarray(vol_bnds, dtype=np.float64).reshape(3, 2)
+    dim = np.zeros(3, np.int64)
+    _lib.check(_lib.load().hive_tsdf_dims(ptr(bnds), float(voxel_size), ptr(dim)))
+    return dim
+
+
 class TSDFVolume:
     """Volumetric TSDF Fusion of RGB-D Images, resident in MI355X HBM.
 
@@ -53,7 +61,7 @@ class TSDFVolume:
     ignored: there is only the GPU path, and it fails loudly without a device).
     """
 
-    def __init__(self, vol_bnds, voxel_size, use_gpu=True, ctx=None, round_mode=None, storage=None):
+    def __init__(self, vol_bnds, voxel_size, use_gpu=True, ctx=None, round_mode=None, storage=None, x_range=None):
         """
         :param vol_bnds: (3, 2) array of the xyz bounds (min/max) in metres.
         :param voxel_size: The volume discretisation in metres.
@@ -65,6 +73,8 @@ class TSDFVolume:
         :param round_mode: explicit ``hive_amd._lib.ROUND_HALF_EVEN / ROUND_HALF_AWAY``; overrides ``use_gpu``.
         :param storage: optional 3-tuple of float32 torch tensors (tsdf, weight, colour), each with
             prod(vol_dim) elements, to keep the volume in caller-owned device memory.
+        :param x_range: ``(x0, x1)``: hold only the x-slab ``x0 <= x < x1`` of the grid defined by ``vol_bnds`` (bit-exact
+            multi-GPU mode, ``hive_amd.distributed.ExactSlabFusion``); ``vol_dim`` is then the slab's.
         """
         vol_bnds = np.asarray(vol_bnds, dtype=np.float64)
         assert vol_bnds.shape == (3, 2), "[!] `vol_bnds` should be of shape (3, 2)."
@@ -80,8 +90,9 @@ class TSDFVolume:
         handle = ctypes.c_void_p()
         bnds = np.ascontiguousarray(vol_bnds)
         s = storage or (None, None, None)
-        self._ctx.check(lib.hive_tsdf_create(self._ctx.handle, ptr(bnds), self._voxel_size, ptr(s[0]), ptr(s[1]), ptr(s[2]),
-                                             ctypes.byref(handle)))
+        x0, x1 = (0, -1) if x_range is None else (int(x_range[0]), int(x_range[1]))
+        self._ctx.check(lib.hive_tsdf_create_slab(self._ctx.handle, ptr(bnds), self._voxel_size, x0, x1, ptr(s[0]), ptr(s[1]), ptr(s[2]),
+                                                  ctypes.byref(handle)))
         self._handle = handle
         self._ctx.check(lib.hive_tsdf_set_round_mode(handle, self.round_mode))  # per volume, not per context
         dim = np.zeros(3, np.int64)
@@ -104,6 +115,7 @@ class TSDFVolume:
         return int(np.prod(self._vol_dim.astype(np.int64)))
 
     def _frame_args(self, color_im, depth_im):
+        self._ctx.follow_torch_stream()  # device tensors are ordered on torch's current stream
         if _is_torch(depth_im):
             import torch
             assert _is_torch(color_im), "colour and depth must both be device tensors or both numpy arrays"
@@ -160,12 +172,29 @@ class TSDFVolume:
     def reset(self):
         self._ctx.check(self._ctx.lib.hive_tsdf_reset(self._handle))
 
+    def set_volume_device(self, tsdf=None, color=None, weight=None):
+        """Overwrite the volume from float32 device tensors (device-to-device copies on the volume's stream)."""
+        self._ctx.follow_torch_stream()
+        arrs = [None if a is None else a.contiguous() for a in (tsdf, color, weight)]
+        for a in arrs:
+            assert a is None or (a.numel() == self.num_voxels and str(a.dtype) == "torch.float32" and a.is_cuda)
+        self._ctx.check(self._ctx.lib.hive_tsdf_set_volume(self._handle, ptr(arrs[0]), ptr(arrs[1]), ptr(arrs[2])))
+
+    def device_tensors(self):
+        """Copies of (tsdf, weight, colour) as float32 device tensors of num_voxels elements."""
+        import torch
+        self._ctx.follow_torch_stream()
+        outs = [torch.empty(self.num_voxels, dtype=torch.float32, device=f"cuda:{self._ctx.device}") for _ in range(3)]
+        self._ctx.check(self._ctx.lib.hive_tsdf_get_volume(self._handle, ptr(outs[0]), ptr(outs[2]), ptr(outs[1])))
+        return tuple(outs)
+
     def device_ptrs(self):
         a, b, c = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
         self._ctx.check(self._ctx.lib.hive_tsdf_device_ptrs(self._handle, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
         return a.value, b.value, c.value
 
     def _extract(self):
+        self._ctx.follow_torch_stream()
         nv, nf = ctypes.c_int64(0), ctypes.c_int64(0)
         rc = self._ctx.lib.hive_tsdf_extract_mesh(self._handle, ctypes.byref(nv), ctypes.byref(nf))
         if rc == _lib.ERR_EMPTY:
@@ -215,6 +244,13 @@ class TSDFVolume:
     def accum_finalize(self, accum):
         self._ctx.check(self._ctx.lib.hive_tsdf_accum_finalize(self._handle, ptr(accum)))
 
+    def accum_finalize_range(self, planes, plane_stride, count, outputs):
+        """Fold ``count`` voxels of 5 summed planes (``planes[p * plane_stride + i]``) into ``outputs = (tsdf, weight, colour)``
+        device tensors at [0, count): a rank's share after the reduce-scatter (``hive_amd.distributed.fuse_sharded``)."""
+        self._ctx.follow_torch_stream()
+        self._ctx.check(self._ctx.lib.hive_tsdf_accum_finalize_to(self._handle, ptr(planes), int(plane_stride), int(count),
+                                                                  ptr(outputs[0]), ptr(outputs[1]), ptr(outputs[2])))
+
     def close(self):
         if getattr(self, "_handle", None) and _lib.alive():
             self._ctx.lib.hive_tsdf_destroy(self._handle)
@@ -228,81 +264,172 @@ class TSDFVolume:
 
 
 # ------------------------------------------------------------------------------------------------
-# Driver functions of /root/reference/hive/fusion.py:37-134
-def adjust_voxel_size(dataset, options, frame_set: List[int]) -> Tuple[float, np.ndarray]:
-    """Calculate the scene bounds and adjust voxel size to keep within the specified budget
-    (/root/reference/hive/fusion.py:37-76).  Bounds always contain the world origin (:48)."""
-    logging.info("Estimating voxel volume bounds...")
-    vol_bnds = np.zeros((3, 2))
-    # poses are world-to-cam on disk; the TSDF volume expects cam-to-world (fusion.py:50-51)
-    camera_trajectory = dataset.camera_trajectory.inverse().to_homogenous_transforms()
+# Driver: the roles of `adjust_voxel_size` / `tsdf_fusion` (/root/reference/hive/fusion.py:37-134), organised around a frame
+# set that is decoded ONCE and then lives in HBM.  The reference walks the dataset twice on the host -- every depth map is
+# decoded for the bounds pass (:53-61) and again, with colour and mask, for the integrate loop (:113-124), with one
+# `cv2.dilate` x N and one upload per frame.  Here: one decode per frame -> `DeviceFrames`; the bounds of the whole set come
+# from one reduction launch (`hive_view_frustum_batch`); masks are dilated and applied to all depth maps in two launches
+# (`hive_depth_apply_mask`); `integrate_batch` sweeps the frames in order.  Results are identical to the reference order of
+# operations (min / max are exact, masking is elementwise, integration order is kept).
+MASK_BACKGROUND, MASK_FOREGROUND = 0, 1
 
-    for i in frame_set:
-        depth_im = dataset.bg_depth_dataset[i]
-        cam_pose = camera_trajectory[i]
-        view_frust_pts = get_view_frustum(depth_im, dataset.camera_matrix, cam_pose)
-        vol_bnds[:, 0] = np.minimum(vol_bnds[:, 0], np.amin(view_frust_pts, axis=1))
-        vol_bnds[:, 1] = np.maximum(vol_bnds[:, 1], np.amax(view_frust_pts, axis=1))
 
-    voxel_count = np.ceil(np.prod((vol_bnds[:, 1] - vol_bnds[:, 0]) / options.sdf_voxel_size))
+class DeviceFrames:
+    """Colour u8 [n, H, W, 3], depth f32 [n, H, W] (metres, 0 = invalid) and optionally masks u8 [n, H, W] of a frame
+    set as device tensors, plus the camera-to-world poses f64 [n, 4, 4] (host)."""
 
-    if options.sdf_max_voxels and voxel_count > options.sdf_max_voxels:
-        voxel_size = (np.prod(vol_bnds[:, 1] - vol_bnds[:, 0]) / options.sdf_max_voxels) ** (1 / 3)
-        logging.info(f"Increasing voxel size to {voxel_size:.3f}: Using a voxel size of {options.sdf_voxel_size} would "
-                     f"result in {voxel_count:,.0f} voxels, which is above the specified limit of "
-                     f"{options.sdf_max_voxels:,d}.")
+    def __init__(self, color, depth, poses_c2w, masks=None):
+        assert color.shape[:3] == depth.shape and tuple(color.shape[3:]) == (3,)
+        assert masks is None or masks.shape == depth.shape
+        self.color, self.depth, self.masks = color, depth, masks
+        self.poses = np.ascontiguousarray(poses_c2w, dtype=np.float64).reshape(-1, 4, 4)
+        assert len(self.poses) == depth.shape[0]
+
+    def __len__(self):
+        return int(self.depth.shape[0])
+
+    @classmethod
+    def from_dataset(cls, dataset, frame_set, with_masks, device="cuda"):
+        """Reads frame ``i`` of ``bg_rgb_dataset`` / ``bg_depth_dataset`` (/ ``mask_dataset``) once for every ``i`` in
+        ``frame_set``, through pinned host buffers.  Poses: the dataset stores world-to-camera; the volume wants
+        camera-to-world (hive/fusion.py:50-51)."""
+        import torch
+        frame_set = list(frame_set)
+        assert len(frame_set) > 0, "empty frame set"
+        poses = dataset.camera_trajectory.inverse().to_homogenous_transforms()[frame_set]
+        first = np.asarray(dataset.bg_depth_dataset[frame_set[0]])
+        h, w = first.shape
+        n = len(frame_set)
+        color = torch.empty((n, h, w, 3), dtype=torch.uint8).pin_memory()
+        depth = torch.empty((n, h, w), dtype=torch.float32).pin_memory()
+        masks = torch.empty((n, h, w), dtype=torch.uint8).pin_memory() if with_masks else None
+        c_np, d_np = color.numpy(), depth.numpy()
+        for j, i in enumerate(frame_set):
+            d_np[j] = first if j == 0 else dataset.bg_depth_dataset[i]
+            c_np[j] = dataset.bg_rgb_dataset[i]
+            if with_masks:
+                masks.numpy()[j] = dataset.mask_dataset[i]
+        to_dev = lambda t: None if t is None else t.to(device, non_blocking=True)
+        return cls(to_dev(color), to_dev(depth), poses, to_dev(masks))
+
+    def masked_depth(self, iterations, mode=MASK_BACKGROUND, instance_id=0, ctx=None):
+        """Depth maps with the mask applied on the device: MASK_BACKGROUND = `depth[dilate(mask) > 0] = 0`
+        (hive/fusion.py:118-121), MASK_FOREGROUND = the complement (only pixels of the undilated mask keep their depth)."""
+        import torch
+        assert self.masks is not None, "this frame set was loaded without masks"
+        ctx = ctx or _lib.default_context(self.depth.device.index or 0)
+        out = torch.empty_like(self.depth)
+        n, h, w = self.depth.shape
+        ctx.check(ctx.lib.hive_depth_apply_mask(ctx.handle, self.depth.data_ptr(), self.masks.data_ptr(), n, h, w, int(iterations),
+                                                int(mode), int(instance_id), out.data_ptr()))
+        return out
+
+
+def view_frusta(depth_ims, cam_intr, cam_poses, ctx=None):
+    """``get_view_frustum`` for n frames at once -> (n, 3, 5) float64: one reduction launch, one read-back."""
+    ctx = ctx or _lib.default_context()
+    if _is_torch(depth_ims):
+        depth, mem = depth_ims.contiguous(), MEM_DEVICE
+        assert str(depth.dtype) == "torch.float32"
     else:
-        voxel_size = options.sdf_voxel_size
+        depth, mem = np.ascontiguousarray(depth_ims, dtype=np.float32), MEM_HOST
+    assert depth.ndim == 3, "depth_ims must be (n, H, W)"
+    n, h, w = (int(v) for v in depth.shape)
+    K = np.ascontiguousarray(cam_intr, dtype=np.float32).reshape(3, 3)
+    poses = np.ascontiguousarray(cam_poses, dtype=np.float64).reshape(n, 4, 4)
+    out = np.empty((n, 3, 5), np.float64)
+    ctx.check(ctx.lib.hive_view_frustum_batch(ctx.handle, ptr(depth), n, h, w, ptr(K), ptr(poses), mem, ptr(out)))
+    return out
 
-    return voxel_size, vol_bnds
+
+def scene_bounds(frames: DeviceFrames, cam_intr, ctx=None) -> np.ndarray:
+    """Axis-aligned bounds of the union of the view frusta of a frame set and the world origin -- the reference starts
+    from `zeros((3, 2))`, so the origin is always inside (hive/fusion.py:48, 60-61)."""
+    corners = view_frusta(frames.depth, cam_intr, frames.poses, ctx)  # (n, 3, 5)
+    lo = np.minimum(0.0, corners.min(axis=(0, 2)))
+    hi = np.maximum(0.0, corners.max(axis=(0, 2)))
+    return np.stack([lo, hi], axis=1)
+
+
+def voxel_size_for_budget(vol_bnds, options) -> float:
+    """`sdf_voxel_size`, or the size at which the volume has exactly `sdf_max_voxels` voxels when that would be exceeded
+    (hive/fusion.py:66-74)."""
+    extent = vol_bnds[:, 1] - vol_bnds[:, 0]
+    wanted = np.ceil(np.prod(extent / options.sdf_voxel_size))
+    if options.sdf_max_voxels and wanted > options.sdf_max_voxels:
+        voxel_size = (np.prod(extent) / options.sdf_max_voxels) ** (1 / 3)
+        logging.info("voxel size %.4f m instead of %s m: %.0f voxels would exceed the budget of %d", voxel_size, options.sdf_voxel_size,
+                     wanted, options.sdf_max_voxels)
+        return voxel_size
+    return options.sdf_voxel_size
+
+
+def adjust_voxel_size(dataset, options, frame_set: List[int], frames: Optional[DeviceFrames] = None) -> Tuple[float, np.ndarray]:
+    """(voxel size, scene bounds (3, 2)) for a frame set -- signature of /root/reference/hive/fusion.py:37.
+    ``frames``: the already loaded frame set (``tsdf_fusion`` passes it so that nothing is decoded twice)."""
+    if frames is None:
+        frames = DeviceFrames.from_dataset(dataset, frame_set, with_masks=False)
+    vol_bnds = scene_bounds(frames, dataset.camera_matrix)
+    return voxel_size_for_budget(vol_bnds, options), vol_bnds
+
+
+def _resolve_frames(dataset, num_frames, frame_set):
+    if num_frames == -1:
+        num_frames = dataset.num_frames
+    return list(range(num_frames)) if frame_set is None else list(frame_set)
 
 
 def tsdf_fusion(dataset, options=None, num_frames=-1, frame_set: Optional[List[int]] = None, return_volume=False):
-    """Run TSDF fusion on a dataset (/root/reference/hive/fusion.py:79-134).
+    """Static-scene reconstruction of a dataset (/root/reference/hive/fusion.py:79-134): bounds -> voxel size -> volume ->
+    every frame of the set, dynamic objects masked out of the depth unless the dataset carries inpainted frames -> mesh.
 
-    ``dataset`` needs the attributes the reference reads: ``num_frames``, ``camera_trajectory``,
-    ``camera_matrix``, ``bg_rgb_dataset``, ``bg_depth_dataset``, ``mask_dataset``,
-    ``has_inpainted_frame_data``.  Returns a ``trimesh.Trimesh`` when trimesh is installed, otherwise
-    a ``hive_amd.mesh.Mesh`` with the same ``vertices / faces / vertex_normals / visual.vertex_colors``.
+    ``dataset`` needs what the reference reads: ``num_frames``, ``camera_trajectory``, ``camera_matrix``, ``bg_rgb_dataset``,
+    ``bg_depth_dataset``, ``mask_dataset``, ``has_inpainted_frame_data``.  Returns a ``trimesh.Trimesh`` when trimesh is
+    installed, otherwise a ``hive_amd.mesh.Mesh`` with the same ``vertices / faces / vertex_normals / visual.vertex_colors``.
     """
-    from hive_amd.image_processing import dilate_mask
     from hive_amd.mesh import make_mesh
-    from hive_amd.options import BackgroundMeshOptions, MaskDilationOptions
+    from hive_amd.options import BackgroundMeshOptions
 
-    if options is None:
-        options = BackgroundMeshOptions()
-
-    if num_frames == -1:
-        num_frames = dataset.num_frames
-
-    if frame_set is None:
-        frame_set = range(num_frames)
-
-    mask_dilation_options = MaskDilationOptions(num_iterations=options.depth_mask_dilation_iterations)
-
-    voxel_size, volume_bounds = adjust_voxel_size(dataset=dataset, options=options, frame_set=frame_set)
-    logging.info("Initializing voxel volume...")
+    options = options or BackgroundMeshOptions()
+    frame_set = _resolve_frames(dataset, num_frames, frame_set)
+    needs_masks = not dataset.has_inpainted_frame_data
+    frames = DeviceFrames.from_dataset(dataset, frame_set, with_masks=needs_masks)
+    voxel_size, volume_bounds = adjust_voxel_size(dataset, options, frame_set, frames=frames)
     tsdf_vol = TSDFVolume(volume_bounds, voxel_size=voxel_size)
-
-    logging.info("Fusing frames...")
-    has_inpainted_frame_data = dataset.has_inpainted_frame_data
-    camera_trajectory = dataset.camera_trajectory.inverse().to_homogenous_transforms()
-
-    for i in frame_set:
-        color_image = dataset.bg_rgb_dataset[i]
-        depth_im = dataset.bg_depth_dataset[i]
-        cam_pose = camera_trajectory[i]
-
-        if not has_inpainted_frame_data:
-            mask = dataset.mask_dataset[i]
-            mask = dilate_mask(mask, mask_dilation_options)
-            depth_im[mask > 0] = 0.0
-
-        tsdf_vol.integrate(color_image, depth_im, dataset.camera_matrix, cam_pose, obs_weight=1.)
-
+    depth = frames.masked_depth(options.depth_mask_dilation_iterations, MASK_BACKGROUND) if needs_masks else frames.depth
+    tsdf_vol.integrate_batch(frames.color, depth, dataset.camera_matrix, frames.poses, obs_weight=1.)
     verts, faces, norms, colors = tsdf_vol.get_mesh()
     mesh = make_mesh(vertices=verts, faces=faces, vertex_colors=colors, vertex_normals=norms)
+    return (mesh, tsdf_vol) if return_volume else mesh
 
-    if return_volume:
-        return mesh, tsdf_vol
-    return mesh
+
+def tsdf_fusion_fg_bg(dataset, options=None, num_frames=-1, frame_set: Optional[List[int]] = None, instance_id=0):
+    """Dynamic-object variant (BASELINE config 5): two volumes over the same bounds and voxel size from one resident frame
+    set -- background = depth with the dilated instance masks zeroed (exactly ``tsdf_fusion``'s volume, from
+    ``dataset.depth_dataset`` / ``rgb_dataset``), foreground = the complement (depth kept only on the undilated masks, or on
+    one ``instance_id``).  Returns ``{"bg": TSDFVolume, "fg": TSDFVolume}``; call ``get_mesh()`` on either (the foreground
+    raises ``ValueError`` if no object pixel ever produced a surface)."""
+    from hive_amd.options import BackgroundMeshOptions
+
+    options = options or BackgroundMeshOptions()
+    frame_set = _resolve_frames(dataset, num_frames, frame_set)
+    frames = DeviceFrames.from_dataset(_RawFrames(dataset), frame_set, with_masks=True)
+    vol_bnds = scene_bounds(frames, dataset.camera_matrix)
+    voxel_size = voxel_size_for_budget(vol_bnds, options)
+    volumes = {}
+    for name, mode, iterations in (("bg", MASK_BACKGROUND, options.depth_mask_dilation_iterations), ("fg", MASK_FOREGROUND, 0)):
+        vol = TSDFVolume(vol_bnds, voxel_size=voxel_size)
+        depth = frames.masked_depth(iterations, mode, instance_id if mode == MASK_FOREGROUND else 0)
+        vol.integrate_batch(frames.color, depth, dataset.camera_matrix, frames.poses, obs_weight=1.)
+        volumes[name] = vol
+    return volumes
+
+
+class _RawFrames:
+    """View of a dataset whose bg_* accessors are the captured (not inpainted) frames: the dynamic path masks them itself."""
+
+    def __init__(self, dataset):
+        self.camera_trajectory = dataset.camera_trajectory
+        self.bg_rgb_dataset = dataset.rgb_dataset
+        self.bg_depth_dataset = dataset.depth_dataset
+        self.mask_dataset = dataset.mask_dataset

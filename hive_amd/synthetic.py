@@ -78,6 +78,23 @@ def make_sequence(num_frames=150, height=480, width=640, volume_size=5.12, room_
     return {"color": color, "depth": depth, "K": K, "poses": poses}
 
 
+def ellipse_masks(num_frames, height, width, num_objects=3, seed=1234):
+    """Instance masks of BASELINE config 5: 1-3 ellipses drifting across the image, uint8 ids 1..k on 0
+    (the format `create_masks` writes, /root/reference/hive/io.py:214-218).  Later objects overwrite earlier ones."""
+    rng = np.random.default_rng(seed)
+    v, u = np.mgrid[0:height, 0:width]
+    centre = rng.uniform([0.2 * height, 0.2 * width], [0.8 * height, 0.8 * width], size=(num_objects, 2))
+    drift = rng.uniform(-0.004, 0.004, size=(num_objects, 2)) * [height, width]
+    axes = rng.uniform([0.08 * height, 0.04 * width], [0.25 * height, 0.12 * width], size=(num_objects, 2))
+    masks = np.zeros((num_frames, height, width), np.uint8)
+    for t in range(num_frames):
+        for k in range(num_objects):
+            cv, cu = centre[k] + drift[k] * t
+            inside = ((v - cv) / axes[k, 0]) ** 2 + ((u - cu) / axes[k, 1]) ** 2 <= 1.0
+            masks[t][inside] = k + 1
+    return masks
+
+
 def room_bounds(volume_size=5.12):
     """vol_bnds of the TSDF volume enclosing the synthetic room: [0, volume_size]^3 (512^3 at 1 cm voxels)."""
     return np.array([[0.0, volume_size]] * 3, dtype=np.float64)

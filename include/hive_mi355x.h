@@ -90,6 +90,14 @@ int hive_ctx_kernel_time_total(hive_ctx *ctx, int *n_launches, float *total_ms);
 int hive_tsdf_dims(const double vol_bnds[6], double voxel_size, int64_t vol_dim[3]);
 int hive_tsdf_create(hive_ctx *ctx, const double vol_bnds[6], double voxel_size,
                      float *d_tsdf, float *d_weight, float *d_color, hive_tsdf **out);
+/* An x-slab of the same scene grid: the volume holds grid voxels x_begin <= x < x_end (all y, z), dims (x_end - x_begin, Y, Z),
+ * and every voxel keeps the world position it has in the whole grid (origin + index * voxel_size with the GRID index, bit for
+ * bit) -- so integrating a frame into the slabs of a partition gives exactly the slices of integrating it into the whole
+ * volume.  For the bit-exact multi-GPU mode (frames all-gathered, volume sharded in x-slabs).  x_end < 0 = the
+ * whole grid.  hive_tsdf_info reports the slab's dims and the grid's origin / bounds; extract_mesh needs a whole volume. */
+int hive_tsdf_create_slab(hive_ctx *ctx, const double vol_bnds[6], double voxel_size, int64_t x_begin, int64_t x_end,
+                          float *d_tsdf, float *d_weight, float *d_color, hive_tsdf **out);
+int hive_tsdf_slab_info(hive_tsdf *vol, int64_t *x_begin, int64_t *grid_dim_x);
 int hive_tsdf_destroy(hive_tsdf *vol);
 /* Rounding of THIS volume's pixel projection and colour average (integrate, accum_finalize): the reference library has two
  * arithmetic paths -- its CUDA kernel rounds with roundf (HIVE_ROUND_HALF_AWAY; what `TSDFVolume(..., use_gpu=True)` runs when
@@ -114,7 +122,8 @@ int hive_tsdf_integrate(hive_tsdf *vol, const uint8_t *color, const float *depth
 int hive_tsdf_integrate_batch(hive_tsdf *vol, int n, const uint8_t *color, const float *depth,
                               int H, int W, const float K[9], const double *cam_poses,
                               float obs_weight, int mem);
-/* TSDFVolume.get_volume(): copies tsdf and colour (and weight) to host arrays (any may be NULL) */
+/* TSDFVolume.get_volume(): copies tsdf and colour (and weight) out (any may be NULL).  The destinations / sources of
+ * get_volume / set_volume may be host OR device memory (unified addressing decides the copy direction). */
 int hive_tsdf_get_volume(hive_tsdf *vol, float *h_tsdf, float *h_color, float *h_weight);
 int hive_tsdf_set_volume(hive_tsdf *vol, const float *h_tsdf, const float *h_color, const float *h_weight);
 
@@ -142,11 +151,22 @@ int hive_tsdf_accum_integrate(hive_tsdf *vol, float *d_accum, const uint8_t *col
                               int H, int W, const float K[9], const double cam_pose[16],
                               float obs_weight, int mem);
 int hive_tsdf_accum_finalize(hive_tsdf *vol, const float *d_accum);
+/* The same arithmetic (and the volume's round mode) for `count` voxels of 5 planes of `plane_stride` floats each, into explicit
+ * device arrays d_tsdf / d_weight / d_color [count]: what a rank runs on ITS share of the voxels after a reduce-scatter of the
+ * planes; the three result arrays are then all-gathered (hive_amd.distributed.fuse_sharded). */
+int hive_tsdf_accum_finalize_to(hive_tsdf *vol, const float *d_accum, int64_t plane_stride, int64_t count, float *d_tsdf,
+                                float *d_weight, float *d_color);
 
 /* ---- fusion.get_view_frustum(depth_im, cam_intr, cam_pose) -- hive/fusion.py:59 ------ */
 /* out: float64 row-major [3][5] (apex + 4 corners at max(depth)), world coordinates */
 int hive_view_frustum(hive_ctx *ctx, const float *depth, int H, int W, const float K[9],
                       const double cam_pose[16], int mem, double out[15]);
+
+/* The bounds pass of adjust_voxel_size (hive/fusion.py:53-61) for a whole frame set at once: n depth maps [n][H][W] (already in HBM
+ * when mem = HIVE_MEM_DEVICE), poses f64 [n][16] -> out f64 [n][3][5]; ONE reduction launch and ONE read-back of n maxima instead
+ * of n launches + n synchronisations.  Same values as n calls of hive_view_frustum. */
+int hive_view_frustum_batch(hive_ctx *ctx, const float *depth, int n, int H, int W, const float K[9],
+                            const double *cam_poses, int mem, double *out);
 
 /* ---- hive/geometric.py ------------------------------------------------------------- */
 /* point_cloud_from_depth(depth, mask, K, R, t)  -- hive/geometric.py:107-126 (+ image2world :183-206)
@@ -180,6 +200,17 @@ int hive_project_bbox(hive_ctx *ctx, const double *points, int64_t n, const doub
  * (cv2.dilate border = no contribution from outside).  mask/out u8 [H][W], non-zero = set. */
 int hive_dilate_mask(hive_ctx *ctx, const uint8_t *mask, int H, int W, int iterations, int mem,
                      uint8_t *out);
+
+/* Masking of the depth maps of a frame set on the device (all pointers device memory; d_out may alias d_depth):
+ *   mode 0 -- background volume, hive/fusion.py:118-121: `mask = dilate_mask(mask, iterations); depth[mask > 0] = 0`;
+ *   mode 1 -- foreground volume (BASELINE config 5: the complement): depth is kept where the UNDILATED mask is set, 0 elsewhere.
+ * d_mask u8 [n][H][W] instance ids (hive/io.py:214-218: 0 = background, 1..k = objects); instance_id > 0 restricts "set" to that
+ * object, 0 = any object. */
+int hive_depth_apply_mask(hive_ctx *ctx, const float *d_depth, const uint8_t *d_mask, int n, int H, int W, int iterations,
+                          int mode, int instance_id, float *d_out);
+/* The loader's depth transform on the device (hive/io.py:1032-1039): uint16 millimetres -> float32 metres
+ * (`depth_scale * mm`), `> max_depth -> 0`. */
+int hive_depth_mm_to_m(hive_ctx *ctx, const uint16_t *d_mm, int64_t n, float depth_scale, float max_depth, float *d_out);
 
 /* ---- depth hand-off DPT -> TSDF ----------------------------------------------------- */
 /* dataset_adaptors.py:1432-1433 (x1000 -> uint16 truncation) then io.py:1032-1039
@@ -270,6 +301,17 @@ int hive_nhwc_bias_act(hive_ctx *ctx, const void *d_x, int dtype, int64_t n_px, 
  * and the depth head's `interpolate(scale_factor=2, mode="bilinear", align_corners=True)`.  d_bias (optional, [C], tensor
  * dtype) is added to the input on load, rounded to the tensor dtype first: the bias pass of the producing convolution. */
 int hive_nhwc_upsample2x(hive_ctx *ctx, const void *d_in, const void *d_bias, int dtype, int N, int H, int W, int C, void *d_out);
+
+/* 3 x 3 convolution, stride 1, padding 1, channels-last bf16, as an implicit GEMM on the matrix cores with the decoder's
+ * element-wise tail fused:  out = relu?( conv(x, w) (+ bias) (+ residual) (+ residual2) ), and optionally out_relu = relu(out).
+ * The 3 x 3 convolutions of isl-org/DPT's decoder reached from DPTDepthModel.forward (hive/dataset_adaptors.py:1419):
+ * scratch.layer{1..4}_rn, ResidualConvUnit_custom.conv1 / conv2, scratch.output_conv[0].
+ * d_x [N][H][W][C_in]; d_w [C_out][3][3][C_in] (= the [C_out][C_in][3][3] weight tensor in channels-last memory format);
+ * d_bias [C_out] in the tensor dtype or NULL; residuals / outputs [N][H][W][C_out].  C_in % 64 == 0, C_out % 128 == 0;
+ * the outputs must not alias the input. */
+int hive_nhwc_conv3x3(hive_ctx *ctx, const void *d_x, int dtype, int N, int H, int W, int C_in, int C_out, const void *d_w,
+                      const void *d_bias, int relu, const void *d_residual, const void *d_residual2, void *d_out,
+                      void *d_out_relu);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,97 @@
+"""The hand-written implicit-GEMM 3 x 3 convolution (csrc/conv.hip, through the C ABI) against torch's float32 conv2d on the
+same bf16-exact operands.  Tolerance: float32 accumulation on both sides, one rounding of the result to bf16 (2^-9 relative)
+plus accumulation-order noise over K = 9 C_in products."""
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(n, cin, cout, h, w, bias, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    x = torch.randn(n, cin, h, w, generator=g).bfloat16()
+    conv = nn.Conv2d(cin, cout, 3, 1, 1, bias=bias)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) * (2.0 / (9 * cin)) ** 0.5)
+        if bias:
+            conv.bias.copy_(torch.randn(cout, generator=g) * 0.3)
+    conv = conv.to(memory_format=torch.channels_last).to(torch.bfloat16).cuda()
+    return x.cuda().contiguous(memory_format=torch.channels_last), conv
+
+
+def _check(out, ref, what):
+    assert out.shape == ref.shape and out.dtype == torch.bfloat16 and out.is_contiguous(memory_format=torch.channels_last)
+    err = (out.float() - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    assert err <= 2 ** -7 * scale + 1e-3, f"{what}: max error {err:.4g} vs scale {scale:.4g}"
+    rel = ((out.float() - ref).norm() / ref.norm()).item()
+    assert rel < 3e-3, f"{what}: relative Frobenius error {rel:.4g}"
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w", [
+    (2, 768, 256, 15, 20),    # layer4_rn at 480 x 640
+    (1, 512, 256, 60, 80),    # layer2_rn
+    (3, 256, 256, 7, 9),      # M = 189: one partial tile; every pixel near a border
+    (1, 256, 256, 33, 41),    # M = 1353: tiles end mid-row
+    (2, 256, 128, 24, 32),    # output_conv[0]: 128 output channels (the 64 x 64 per wave tiling)
+    (1, 64, 128, 16, 16),     # one K-step per tap
+])
+def test_conv3x3_plain(gpu_ctx, n, cin, cout, h, w):
+    from hive_amd.dpt import ops
+    x, conv = _mk(n, cin, cout, h, w, bias=False, seed=cin + h)
+    assert ops.conv3x3_eligible(x, conv)
+    out = ops.conv3x3(x, conv)
+    ref = F.conv2d(x.float(), conv.weight.float(), None, 1, 1)
+    _check(out, ref, "conv")
+
+
+def test_conv3x3_fused_epilogue(gpu_ctx):
+    """bias + two skip connections + ReLU variants: out = relu?(conv + b + r1 + r2), out_relu = relu(out)."""
+    from hive_amd.dpt import ops
+    x, conv = _mk(2, 256, 256, 30, 40, bias=True, seed=5)
+    g = torch.Generator(device="cpu").manual_seed(9)
+    r1 = torch.randn(2, 256, 30, 40, generator=g).bfloat16().cuda().contiguous(memory_format=torch.channels_last)
+    r2 = torch.randn(2, 256, 30, 40, generator=g).bfloat16().cuda().contiguous(memory_format=torch.channels_last)
+    base = F.conv2d(x.float(), conv.weight.float(), conv.bias.float(), 1, 1)
+    _check(ops.conv3x3(x, conv, relu=True), F.relu(base), "bias + relu")
+    _check(ops.conv3x3(x, conv, residual=r1), base + r1.float(), "bias + residual")
+    out, out_relu = ops.conv3x3(x, conv, residual=r1, residual2=r2, also_relu=True)
+    ref = base + r1.float() + r2.float()
+    _check(out, ref, "bias + two residuals")
+    _check(out_relu, F.relu(ref), "relu copy")
+    assert torch.equal(out_relu, F.relu(out)), "out_relu must be relu(out) of the SAME rounded values"
+    _check(ops.conv3x3(x, conv, with_bias=False), F.conv2d(x.float(), conv.weight.float(), None, 1, 1), "bias skipped")
+    # reproducible: no atomics, fixed accumulation order
+    assert torch.equal(ops.conv3x3(x, conv, relu=True), ops.conv3x3(x, conv, relu=True))
+
+
+def test_conv3x3_full_resolution_refinenet1(gpu_ctx):
+    """The largest decoder shape of the benchmark: 240 x 320 x 256 -> 256, two images (M = 153,600 = 600 full tiles)."""
+    from hive_amd.dpt import ops
+    x, conv = _mk(2, 256, 256, 240, 320, bias=True, seed=11)
+    out = ops.conv3x3(x, conv, relu=True)
+    ref = F.relu(F.conv2d(x.float(), conv.weight.float(), conv.bias.float(), 1, 1))
+    _check(out, ref, "240 x 320")
+
+
+def test_conv3x3_weights_not_channels_last_and_rejections(gpu_ctx):
+    from hive_amd import _lib
+    from hive_amd.dpt import ops
+    x, conv = _mk(1, 64, 128, 8, 8, bias=True, seed=1)
+    conv_nchw = nn.Conv2d(64, 128, 3, 1, 1).to(torch.bfloat16).cuda()  # default (contiguous) weight layout
+    with torch.no_grad():
+        conv_nchw.weight.copy_(conv.weight)
+        conv_nchw.bias.copy_(conv.bias)
+    assert not conv_nchw.weight.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(ops.conv3x3(x, conv_nchw), ops.conv3x3(x, conv))
+    assert not ops.conv3x3_eligible(x, nn.Conv2d(64, 128, 3, 2, 1).to(torch.bfloat16).cuda())   # stride 2
+    assert not ops.conv3x3_eligible(x, nn.Conv2d(64, 96, 3, 1, 1).to(torch.bfloat16).cuda())    # C_out % 128
+    assert not ops.conv3x3_eligible(x.float(), conv)
+    ctx = gpu_ctx
+    out = torch.empty_like(x)
+    rc = ctx.lib.hive_nhwc_conv3x3(ctx.handle, x.data_ptr(), _lib.BF16, 1, 8, 8, 64, 96, conv.weight.data_ptr(), None, 0, None, None, out.data_ptr(), None)
+    assert rc == _lib.ERR_INVALID
+    rc = ctx.lib.hive_nhwc_conv3x3(ctx.handle, x.data_ptr(), _lib.BF16, 1, 8, 8, 64, 128, conv.weight.data_ptr(), None, 0, None, None, x.data_ptr(), None)
+    assert rc == _lib.ERR_INVALID, "in-place convolution must be refused"

@@ -86,3 +86,108 @@ def test_single_process_helpers_are_noops():
     assert hdist.allreduce_accumulators(t) is t
     assert hdist.max_over_ranks(3.5) == 3.5
     hdist.barrier()
+
+
+def _worker_reduce_scatter(rank, world, port, out_path):
+    """fuse_sharded's collective shape with the oracle standing in for the HIP kernels: planes -> reduce-scatter -> fold own
+    share -> all-gather of the three result planes."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import ctypes
+    import torch
+    import oracle
+    from hive_amd import distributed as hdist, synthetic
+    hdist.init_from_env(backend="gloo")
+    seq = synthetic.make_sequence(num_frames=8, height=60, width=80, yaw_step_deg=45.0)
+    lo, hi = hdist.shard_range(8, rank, world)
+    own = oracle.TSDFVolume(synthetic.room_bounds(), 0.16, use_gpu=False)
+    for i in range(lo, hi):
+        own.integrate(seq["color"][i], seq["depth"][i], seq["K"], seq["poses"][i])
+    n = own._tsdf.size
+    part = hdist.VoxelPartition(n, align=64)
+    assert part.padded >= n and part.padded % world == 0 and part.chunk % 64 == 0
+    planes = torch.zeros((5, part.padded), dtype=torch.float32)
+    planes[:, :n] = torch.from_numpy(oracle.AccumVolume.planes_from_volume(own).reshape(5, n))
+    mine = hdist.reduce_scatter_planes(planes, part)
+    assert mine.shape == (5, part.chunk)
+    outs = [torch.zeros(part.padded, dtype=torch.float32) for _ in range(3)]
+    share = [np.zeros(part.chunk, np.float32) for _ in range(3)]
+    acc = np.ascontiguousarray(mine.numpy())
+    oracle.lib().oracle_tsdf_accum_finalize(acc.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(part.chunk), share[0].ctypes.data_as(ctypes.c_void_p),
+                                            share[1].ctypes.data_as(ctypes.c_void_p), share[2].ctypes.data_as(ctypes.c_void_p), own.round_mode)
+    for o, s in zip(outs, share):
+        o[part.first:part.first + part.chunk] = torch.from_numpy(s)
+        hdist.all_gather_shares(o, part)
+    if rank == 0:
+        np.savez(out_path, tsdf=outs[0][:n].numpy(), weight=outs[1][:n].numpy(), color=outs[2][:n].numpy())
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_reduce_scatter_merge_matches_sequential(tmp_path, oracle_lib):
+    """reduce-scatter -> fold own share -> all-gather == what the all-reduce merge gives (bit for bit at two ranks: a sum of two
+    terms has one order), and the sequential reference within the stated tolerance."""
+    import torch.multiprocessing as mp
+    from hive_amd import synthetic
+    out = str(tmp_path / "rank0.npz")
+    mp.start_processes(_worker_reduce_scatter, args=(2, _free_port(), out), nprocs=2, join=True, start_method="spawn")
+    got = np.load(out)
+    seq = synthetic.make_sequence(num_frames=8, height=60, width=80, yaw_step_deg=45.0)
+    ref = oracle_lib.TSDFVolume(synthetic.room_bounds(), 0.16, use_gpu=False)
+    halves = [oracle_lib.TSDFVolume(synthetic.room_bounds(), 0.16, use_gpu=False) for _ in range(2)]
+    for i in range(8):
+        ref.integrate(seq["color"][i], seq["depth"][i], seq["K"], seq["poses"][i])
+        halves[i // 4].integrate(seq["color"][i], seq["depth"][i], seq["K"], seq["poses"][i])
+    merged = oracle_lib.AccumVolume(synthetic.room_bounds(), 0.16, use_gpu=False)
+    merged.accum[...] = oracle_lib.AccumVolume.planes_from_volume(halves[0]) + oracle_lib.AccumVolume.planes_from_volume(halves[1])
+    exp = merged.finalize()
+    assert np.array_equal(got["tsdf"], exp._tsdf.reshape(-1)) and np.array_equal(got["color"], exp._color.reshape(-1))
+    assert np.array_equal(got["weight"], ref._weight.reshape(-1)), "weights (and the observed set) must be exact"
+    np.testing.assert_allclose(got["tsdf"], ref._tsdf.reshape(-1), rtol=0, atol=1e-5)
+
+
+def _worker_exact(rank, world, port, out_path):
+    """The bit-exact mode's collective shape: frames all-gathered (uneven blocks), x-slabs (uneven), slabs all-gathered."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import oracle
+    from hive_amd import distributed as hdist, synthetic
+    hdist.init_from_env(backend="gloo")
+    T = 7
+    seq = synthetic.make_sequence(num_frames=T, height=60, width=80, yaw_step_deg=50.0)
+    counts = [b - a for a, b in (hdist.shard_range(T, r, world) for r in range(world))]
+    lo, hi = hdist.shard_range(T, rank, world)
+    # this rank only HAS its own block of frames (on the GPU: the depth maps its DPT shard produced)
+    color = hdist.allgather_frames(torch.from_numpy(seq["color"][lo:hi].copy()), counts)
+    depth = hdist.allgather_frames(torch.from_numpy(seq["depth"][lo:hi].copy()), counts)
+    assert color.shape[0] == T and depth.shape[0] == T
+    bounds, voxel = np.array([[0.0, 5.12], [0.0, 5.12], [0.0, 5.12]]), 0.155  # 34 x 34 x 34: slabs of 17 x-rows
+    full = oracle.TSDFVolume(bounds, voxel)
+    X, Y, Z = (int(d) for d in full._vol_dim)
+    x_ranges = [hdist.shard_range(X, r, world) for r in range(world)]
+    x0, x1 = x_ranges[rank]
+    for i in range(T):  # the oracle has no slab form: integrate the whole grid, KEEP only this rank's slab (voxels are independent)
+        full.integrate(color[i].numpy(), depth[i].numpy(), seq["K"], seq["poses"][i])
+    slabs = [torch.from_numpy(np.ascontiguousarray(a[x0:x1])) for a in (full._tsdf, full._weight, full._color)]
+    poison = [torch.full_like(s, float("nan")) for s in slabs]  # what the other ranks hold is NOT available here
+    del full
+    gathered = [hdist.allgather_slabs(s, x_ranges, Y * Z) for s in slabs]
+    assert all(g.numel() == X * Y * Z for g in gathered) and not any(torch.isnan(g).any() for g in gathered) and len(poison) == 3
+    if rank == 1:
+        np.savez(out_path, tsdf=gathered[0].numpy(), weight=gathered[1].numpy(), color=gathered[2].numpy(), dims=np.array([X, Y, Z]))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_exact_slab_mode_is_bit_identical_to_sequential(tmp_path, oracle_lib):
+    import torch.multiprocessing as mp
+    from hive_amd import synthetic
+    out = str(tmp_path / "rank1.npz")
+    mp.start_processes(_worker_exact, args=(2, _free_port(), out), nprocs=2, join=True, start_method="spawn")
+    got = np.load(out)
+    seq = synthetic.make_sequence(num_frames=7, height=60, width=80, yaw_step_deg=50.0)
+    ref = oracle_lib.TSDFVolume(np.array([[0.0, 5.12], [0.0, 5.12], [0.0, 5.12]]), 0.155)
+    for i in range(7):
+        ref.integrate(seq["color"][i], seq["depth"][i], seq["K"], seq["poses"][i])
+    assert tuple(got["dims"]) == tuple(int(d) for d in ref._vol_dim)
+    for name, arr in (("tsdf", ref._tsdf), ("weight", ref._weight), ("color", ref._color)):
+        assert np.array_equal(got[name], arr.reshape(-1)), f"{name}: the slab mode must be BIT-identical to the sequential fusion"

@@ -27,6 +27,9 @@ class FakeDataset:
     def bg_depth_dataset(self):
         return [d.copy() for d in self._seq["depth"]]  # tsdf_fusion mutates depth in place (fusion.py:121)
 
+    rgb_dataset = bg_rgb_dataset      # the captured frames (no inpainted folders in this fake)
+    depth_dataset = bg_depth_dataset
+
 
 def _oracle_fusion(oracle_lib, dataset, options, frame_set):
     """hive/fusion.py:37-134 restated with the oracle (CPU)."""
@@ -139,3 +142,95 @@ def test_accumulate_stream_then_fuse_single_rank(gpu_ctx, oracle_lib):
     ref = ora.finalize()
     tsdf, color, weight = vol.get_volume(with_weight=True)
     assert np.array_equal(tsdf, ref._tsdf) and np.array_equal(color, ref._color) and np.array_equal(weight, ref._weight)
+
+
+def test_view_frusta_batch_equals_single_calls(gpu_ctx, oracle_lib, small_sequence):
+    """The bounds pass for a whole frame set in one launch == n calls of get_view_frustum == the oracle, bit for bit,
+    from host arrays and from depth maps already in HBM."""
+    import torch
+    from hive_amd import fusion
+    seq = small_sequence
+    batch = fusion.view_frusta(seq["depth"], seq["K"], seq["poses"], ctx=gpu_ctx)
+    batch_dev = fusion.view_frusta(torch.from_numpy(seq["depth"]).cuda(), seq["K"], seq["poses"], ctx=gpu_ctx)
+    assert batch.shape == (8, 3, 5) and np.array_equal(batch, batch_dev)
+    for i in range(8):
+        single = fusion.get_view_frustum(seq["depth"][i], seq["K"], seq["poses"][i], ctx=gpu_ctx)
+        assert np.array_equal(batch[i], single)
+        assert np.array_equal(batch[i], oracle_lib.view_frustum(seq["depth"][i], seq["K"], seq["poses"][i]))
+    frames = fusion.DeviceFrames(torch.from_numpy(seq["color"]).cuda(), torch.from_numpy(seq["depth"]).cuda(), seq["poses"])
+    bnds = fusion.scene_bounds(frames, seq["K"], ctx=gpu_ctx)
+    assert np.array_equal(bnds[:, 0], np.minimum(0, batch.min(axis=(0, 2)))) and np.array_equal(bnds[:, 1], np.maximum(0, batch.max(axis=(0, 2))))
+
+
+@pytest.mark.parametrize("iterations", [0, 3, 10])
+def test_depth_apply_mask_matches_oracle(gpu_ctx, oracle_lib, iterations):
+    """On-device `depth[dilate(mask) > 0] = 0` (hive/fusion.py:118-121) and its complement, for a frame set, vs the oracle's
+    literal iterated 3 x 3 dilation per frame; masks touching the image border, instance ids, frame borders."""
+    import torch
+    from hive_amd import fusion, synthetic
+    rng = np.random.default_rng(iterations)
+    n, H, W = 5, 60, 80
+    depth = rng.uniform(0.5, 4.0, (n, H, W)).astype(np.float32)
+    masks = synthetic.ellipse_masks(n, H, W, num_objects=3, seed=3)
+    masks[0, :2, :] = 2      # touches the top border of frame 0: must not bleed into frame 1 / wrap around
+    masks[2, -1, -5:] = 1    # bottom-right corner of frame 2
+    frames = fusion.DeviceFrames(torch.zeros((n, H, W, 3), dtype=torch.uint8, device="cuda"), torch.from_numpy(depth).cuda(),
+                                 np.tile(np.eye(4), (n, 1, 1)), torch.from_numpy(masks).cuda())
+    bg = frames.masked_depth(iterations, fusion.MASK_BACKGROUND, ctx=gpu_ctx).cpu().numpy()
+    fg = frames.masked_depth(0, fusion.MASK_FOREGROUND, ctx=gpu_ctx).cpu().numpy()
+    fg2 = frames.masked_depth(0, fusion.MASK_FOREGROUND, instance_id=2, ctx=gpu_ctx).cpu().numpy()
+    for i in range(n):
+        expect = depth[i].copy()
+        expect[oracle_lib.dilate_mask(masks[i], iterations) > 0] = 0.0
+        assert np.array_equal(bg[i], expect), f"frame {i}"
+        assert np.array_equal(fg[i], np.where(masks[i] > 0, depth[i], 0).astype(np.float32))
+        assert np.array_equal(fg2[i], np.where(masks[i] == 2, depth[i], 0).astype(np.float32))
+    assert (bg == 0).any() and (fg2 > 0).any()
+
+
+def test_fg_bg_volumes_match_oracle(gpu_ctx, oracle_lib):
+    """BASELINE config 5 in miniature: instance masks (moving ellipses), background volume = masked depth, foreground volume =
+    the complement, both from one resident frame set; each volume bit-exact against the oracle fed with numpy-masked depth."""
+    from hive_amd import fusion, synthetic
+    from hive_amd.options import BackgroundMeshOptions
+    n = 6
+    seq = synthetic.make_sequence(num_frames=n, height=60, width=80, yaw_step_deg=25.0)
+    masks = synthetic.ellipse_masks(n, 60, 80, num_objects=2, seed=5)
+    options = BackgroundMeshOptions(sdf_voxel_size=0.05, sdf_max_voxels=400_000, depth_mask_dilation_iterations=2)
+    ds = FakeDataset(seq, list(masks))
+    vols = fusion.tsdf_fusion_fg_bg(ds, options)
+    c2w = ds.camera_trajectory.inverse().to_homogenous_transforms()
+    o_voxel, o_bnds, o_bg = _oracle_fusion(oracle_lib, FakeDataset(seq, list(masks)), options, range(n))
+    o_fg = oracle_lib.TSDFVolume(o_bnds, o_voxel)
+    for i in range(n):
+        o_fg.integrate(seq["color"][i], np.where(masks[i] > 0, seq["depth"][i], 0).astype(np.float32), seq["K"], c2w[i])
+    for name, ora in (("bg", o_bg), ("fg", o_fg)):
+        tsdf, color, weight = vols[name].get_volume(with_weight=True)
+        assert np.array_equal(weight, ora._weight) and np.array_equal(tsdf, ora._tsdf) and np.array_equal(color, ora._color), name
+    assert o_fg._weight.max() > 0 and (o_bg._weight > 0).sum() > (o_fg._weight > 0).sum()
+    # the static-scene driver computes the same background volume
+    mesh, vol = fusion.tsdf_fusion(ds, options, return_volume=True)
+    assert np.array_equal(vol.get_volume()[0], o_bg._tsdf)
+
+
+def test_fg_bg_partition_property_full_size(gpu_ctx):
+    """Size-independent property at the benchmark's size (640 x 480 frames, 512^3): with no dilation the background and
+    foreground depth maps partition every frame's valid pixels, and a voxel's update depends on its own pixel only, so the
+    observation counts add up exactly: weight_bg + weight_fg == weight of the unmasked fusion, voxel for voxel."""
+    import torch
+    from hive_amd import fusion, synthetic
+    n = 6
+    seq = synthetic.make_sequence(num_frames=n, yaw_step_deg=30.0)
+    masks = synthetic.ellipse_masks(n, 480, 640, num_objects=3, seed=9)
+    frames = fusion.DeviceFrames(torch.from_numpy(seq["color"]).cuda(), torch.from_numpy(seq["depth"]).cuda(), seq["poses"],
+                                 torch.from_numpy(masks).cuda())
+    weights = {}
+    for name, depth in (("full", frames.depth), ("bg", frames.masked_depth(0, fusion.MASK_BACKGROUND, ctx=gpu_ctx)),
+                        ("fg", frames.masked_depth(0, fusion.MASK_FOREGROUND, ctx=gpu_ctx))):
+        vol = fusion.TSDFVolume(synthetic.room_bounds(), 0.01, ctx=gpu_ctx)
+        assert tuple(vol.vol_dim) == (512, 512, 512)
+        vol.integrate_batch(frames.color, depth, seq["K"], frames.poses)
+        weights[name] = torch.from_numpy(vol.get_volume(with_weight=True)[2])
+        vol.close()
+    assert float(weights["fg"].max()) > 0
+    assert torch.equal(weights["bg"] + weights["fg"], weights["full"])
