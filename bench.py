@@ -217,20 +217,27 @@ def main():
 
     # ---- untimed: what the timed launches processed --------------------------------------------------------------------
     # N_upd of EVERY frame this rank integrated in the timed region (depends on depth + pose only, not on the volume state)
-    def measure(frame_sets, depth_of):
-        n_upd, leg_ms = [], []
+    def measure(frame_sets, depth_of, time_kernel=False):
+        """(mean N_upd, ms per frame of the TSDF leg = pack + work list + sweep, [mean sweep-kernel us, launches])."""
+        n_upd, leg_ms, k_ms, k_n = [], [], 0.0, 0
         for ids in frame_sets:
             fr = torch.from_numpy(seq["color"][ids]).to(device)
             depth_m = depth_of(fr, ids)
-            for j, i in enumerate(ids):
+            for j, i in enumerate(ids):  # the counting variant of the kernel (one atomic per wave): never timed
                 n_upd.append(volume.integrate(fr[j], depth_m[j], K, poses[i], return_n_updated=True))
+            if time_kernel:
+                ctx.set_timing(True)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            volume.integrate_batch(fr, depth_m, K, poses[ids])  # pack + work list + sweep, per frame, back to back
+            volume.integrate_batch(fr, depth_m, K, poses[ids])  # per frame, back to back
             e1.record()
             e1.synchronize()
             leg_ms.append(e0.elapsed_time(e1) / len(ids))
-        return float(np.mean(n_upd)), float(np.mean(leg_ms))
+            if time_kernel:
+                n, ms = ctx.kernel_time_total()
+                ctx.set_timing(False)
+                k_ms, k_n = k_ms + ms, k_n + n
+        return float(np.mean(n_upd)), float(np.mean(leg_ms)), (k_ms / max(k_n, 1) * 1e3, k_n)
 
     def roofline(n_upd_mean, launch_us, traffic_key):
         alg = 24.0 * n_upd_mean + 8.0 * H * W  # 3 volumes read + written for every updated voxel + one read of depth / colour
@@ -253,7 +260,7 @@ def main():
             timed_sets = batches(job_frames(args.warmup, args.steps)[0])
         else:
             timed_sets = [job_frames(args.warmup + s, 1)[0] for s in range(args.steps)]
-        n_upd_dpt, leg_dpt = measure(timed_sets, lambda fr, ids: stream.depth(fr)[0])
+        n_upd_dpt, leg_dpt, _ = measure(timed_sets, lambda fr, ids: stream.depth(fr)[0])
         main_roof = roofline(n_upd_dpt, kernel_ms / max(n_launch, 1) * 1e3, "hbm_bytes_per_launch")
         main_roof["launches"] = n_launch
         main_roof["tsdf_leg_us_per_frame"] = leg_dpt * 1e3
@@ -261,11 +268,8 @@ def main():
         # surface inside the volume; the DPT-fed scene above has random-weight depth (nearly constant, free space only)
         room_ids = list(range(0, T, max(1, T // 30)))[:30]
         volume.reset()
-        ctx.set_timing(True)
-        n_upd_room, leg_room = measure([room_ids], lambda fr, ids: torch.from_numpy(seq["depth"][ids]).to(device))
-        n_room, ms_room = ctx.kernel_time_total()
-        ctx.set_timing(False)
-        room_roof = roofline(n_upd_room, ms_room / max(n_room, 1) * 1e3, "hbm_bytes_per_launch_room")
+        n_upd_room, leg_room, (us_room, n_room) = measure([room_ids], lambda fr, ids: torch.from_numpy(seq["depth"][ids]).to(device), time_kernel=True)
+        room_roof = roofline(n_upd_room, us_room, "hbm_bytes_per_launch_room")
         room_roof["launches"] = n_room
         room_roof["tsdf_leg_us_per_frame"] = leg_room * 1e3
         room_roof["scene"] = "analytic ray-cast depth of the same trajectory (surface inside the volume), 30 frames"

@@ -17,6 +17,11 @@
 // on the source side (conflict-free ds_read_b128), one raw s_barrier per K-step, XCD-aware tile order: consecutive tiles are
 // consecutive image rows, so an XCD's run of tiles re-reads its three-row halo from its own L2.  K = 9 Cin >= 2304 gives
 // 36+ K-steps per tile (the ViT GEMMs have 12), so the tile's ends are a small share.
+//
+// Measured (tools/probe_conv3x3.py, 24 frames): 840-910 TFLOP/s on the 120 x 160 / 60 x 80 / 240 x 320 shapes (MIOpen on the same
+// tensors: 770-920), 500-580 at 30 x 40 (113 tiles for 256 CUs) and 140-160 at 15 x 20 (29 tiles).  Built, measured and taken
+// out again: a deep LDS ring (K-step 32, 3 / 4 / 5 stages of 32 KiB in flight, counted vmcnt) -- 725-780 TFLOP/s whatever the
+// depth, i.e. the fill latency is NOT what bounds the K-step, and the second barrier per 64 k costs 13 %.
 #include "hive_internal.hpp"
 
 #include <algorithm>
@@ -45,6 +50,55 @@ struct ConvParams {
     int M;              // NB * H * W
 };
 
+// epilogue: a lane owns 4 consecutive output channels of one pixel; everything in f32, one rounding to bf16
+template <int MT>
+__device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x4 (&acc)[4][MT], int m_base, int n_base, int fr, int fq) {
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int n = n_base + nt * 16 + fq * 4;
+        float b[4] = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) {
+            const bf16x4 bv = *reinterpret_cast<const bf16x4 *>(p.bias + n);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = (float)bv[j];
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int m = m_base + mt * 16 + fr;
+            if (m < p.M) {
+                const size_t o_off = (size_t)m * p.Cout + n;
+                float o[4] = {acc[nt][mt][0] + b[0], acc[nt][mt][1] + b[1], acc[nt][mt][2] + b[2], acc[nt][mt][3] + b[3]};
+                if (p.res1) {
+                    const bf16x4 rs = *reinterpret_cast<const bf16x4 *>(p.res1 + o_off);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] += (float)rs[j];
+                }
+                if (p.res2) {
+                    const bf16x4 rs = *reinterpret_cast<const bf16x4 *>(p.res2 + o_off);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] += (float)rs[j];
+                }
+                if (p.relu) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = fmaxf(o[j], 0.0f);
+                }
+                bf16x4 ov;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ov[j] = (bf16)o[j];
+                *reinterpret_cast<bf16x4 *>(p.out + o_off) = ov;
+                if (p.out_relu) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) ov[j] = (bf16)fmaxf(o[j], 0.0f);
+                    *reinterpret_cast<bf16x4 *>(p.out_relu + o_off) = ov;
+                }
+            }
+        }
+    }
+}
+
+#ifndef HIVE_CONV_PIPE
+#define HIVE_CONV_PIPE 1
+#endif
 constexpr int TM = 256, BK = 64, A_GROUPS = TM / 8;
 
 template <int TN>
@@ -119,6 +173,40 @@ __global__ __launch_bounds__(512, 1) void conv3x3_kernel(ConvParams p) {
             if (++nx_cc == CPT) nx_cc = 0, ++nx_tap;
         }
         const unsigned char *a_t = lds + (kt & 1) * STAGE_BYTES, *w_t = a_t + A_GROUPS * 1024;
+#if HIVE_CONV_PIPE
+        {
+            // Software-pipelined fragment stream.  The K-step is 2 MT slots (sub-step, M fragment) of 4 MFMAs each; the A
+            // fragment of slot s + 3 and the W fragments of the second sub-step are read from LDS while the MFMAs of slot s
+            // run, so one LDS round trip is exposed per K-step instead of one per 8 MFMAs (what the compiler's own schedule
+            // gave: 6 ds_read -> s_waitcnt lgkmcnt(0) -> 8 v_mfma, eight times per K-step).  The sched_group_barrier sequence
+            // pins the interleave: [7 DS reads] then per slot [its DS reads][4 MFMA].
+            constexpr int SLOTS = 2 * MT, D = 3;
+            auto rd_a = [&](int sl) { return *reinterpret_cast<const bf16x8 *>(a_t + swz(wr * RW + (sl % MT) * 16 + fr, (sl / MT) * 4 + fq)); };
+            auto rd_w = [&](int sub, int t) { return *reinterpret_cast<const bf16x8 *>(w_t + swz(wc * 64 + t * 16 + fr, sub * 4 + fq)); };
+            bf16x8 ring[4], wfr[2][4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) wfr[0][t] = rd_w(0, t);
+#pragma unroll
+            for (int sl = 0; sl < D; ++sl) ring[sl] = rd_a(sl);
+#pragma unroll
+            for (int sl = 0; sl < SLOTS; ++sl) {
+                if (sl + D < SLOTS) ring[(sl + D) & 3] = rd_a(sl + D);
+                if (sl < 4) wfr[1][sl] = rd_w(1, sl);
+                const int sub = sl / MT, mt = sl % MT;
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[sub][nt], ring[sl & 3], acc[nt][mt], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, 4 + D, 0);
+#pragma unroll
+            for (int sl = 0; sl < SLOTS; ++sl) {
+                if (sl + D < SLOTS && sl < 4)
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                else if (sl + D < SLOTS || sl < 4)
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            }
+        }
+#else
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
             bf16x8 af[MT], wf[4];
@@ -131,50 +219,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_kernel(ConvParams p) {
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], af[mt], acc[nt][mt], 0, 0, 0);
         }
+#endif
     }
 
-    // epilogue: a lane owns 4 consecutive output channels of one pixel; everything in f32, one rounding to bf16
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-        const int n = n0 + wc * 64 + nt * 16 + fq * 4;
-        float b[4] = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias) {
-            const bf16x4 bv = *reinterpret_cast<const bf16x4 *>(p.bias + n);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = (float)bv[j];
-        }
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int m = m0 + wr * RW + mt * 16 + fr;
-            if (m < p.M) {
-                const size_t o_off = (size_t)m * p.Cout + n;
-                float o[4] = {acc[nt][mt][0] + b[0], acc[nt][mt][1] + b[1], acc[nt][mt][2] + b[2], acc[nt][mt][3] + b[3]};
-                if (p.res1) {
-                    const bf16x4 rs = *reinterpret_cast<const bf16x4 *>(p.res1 + o_off);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] += (float)rs[j];
-                }
-                if (p.res2) {
-                    const bf16x4 rs = *reinterpret_cast<const bf16x4 *>(p.res2 + o_off);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] += (float)rs[j];
-                }
-                if (p.relu) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] = fmaxf(o[j], 0.0f);
-                }
-                bf16x4 ov;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) ov[j] = (bf16)o[j];
-                *reinterpret_cast<bf16x4 *>(p.out + o_off) = ov;
-                if (p.out_relu) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) ov[j] = (bf16)fmaxf(o[j], 0.0f);
-                    *reinterpret_cast<bf16x4 *>(p.out_relu + o_off) = ov;
-                }
-            }
-        }
-    }
+    conv_epilogue<MT>(p, acc, m0 + wr * RW, n0 + wc * 64, fr, fq);
 }
 
 bool g_conv_attr_set[64] = {};

@@ -384,12 +384,34 @@ __global__ __launch_bounds__(256) void integrate_kernel(FrameParams p, const Wor
         const int zseg = (int)(item.zz & 0xffffu);
         const int zb = zseg + sl * VPT;  // volume role: this lane's first voxel
         const bool live = zb < (int)(item.zz >> 16);
-        // row constants, in the contract's operation order
-        const float tx = (p.ox + (float)(x + p.x_off) * p.vs) - p.T[0];
-        const float ty = (p.oy + (float)y * p.vs) - p.T[1];
-        const float ax = p.R[0] * tx + p.R[3] * ty;
-        const float ay = p.R[1] * tx + p.R[4] * ty;
-        const float az = p.R[2] * tx + p.R[5] * ty;
+        const long long idx = ((long long)x * p.Y + y) * p.Z + zb;
+        float t[VPT], w[VPT], c[VPT];  // ACCUM: planes 0..2
+        float c3[VPT], c4[VPT];        // ACCUM: planes 3..4
+        auto load_volume = [&]() {
+            if (VPT == 4) {
+                vol_load4(t, v0 + idx);
+                if (!ACCUM) {
+                    vol_load4(w, v1 + idx);
+                    vol_load4(c, v2 + idx);
+                } else {
+                    vol_load4(w, v0 + plane + idx);
+                    vol_load4(c, v0 + 2 * plane + idx);
+                    vol_load4(c3, v0 + 3 * plane + idx);
+                    vol_load4(c4, v0 + 4 * plane + idx);
+                }
+            } else {
+                t[0] = vol_load1(v0 + idx);
+                if (!ACCUM) {
+                    w[0] = vol_load1(v1 + idx);
+                    c[0] = vol_load1(v2 + idx);
+                } else {
+                    w[0] = vol_load1(v0 + plane + idx);
+                    c[0] = vol_load1(v0 + 2 * plane + idx);
+                    c3[0] = vol_load1(v0 + 3 * plane + idx);
+                    c4[0] = vol_load1(v0 + 4 * plane + idx);
+                }
+            }
+        };
         V cam_z[Sh::NG];
         float depth_v[VPT];
         unsigned rgb[VPT];
@@ -455,34 +477,9 @@ __global__ __launch_bounds__(256) void integrate_kernel(FrameParams p, const Wor
                 any = any || ok[j];
             }
         }
-        const long long idx = ((long long)x * p.Y + y) * p.Z + zb;
-        float t[VPT], w[VPT], c[VPT];  // ACCUM: planes 0..2
-        float c3[VPT], c4[VPT];        // ACCUM: planes 3..4
-        if (any) {
-            if (VPT == 4) {
-                vol_load4(t, v0 + idx);
-                if (!ACCUM) {
-                    vol_load4(w, v1 + idx);
-                    vol_load4(c, v2 + idx);
-                } else {
-                    vol_load4(w, v0 + plane + idx);
-                    vol_load4(c, v0 + 2 * plane + idx);
-                    vol_load4(c3, v0 + 3 * plane + idx);
-                    vol_load4(c4, v0 + 4 * plane + idx);
-                }
-            } else {
-                t[0] = vol_load1(v0 + idx);
-                if (!ACCUM) {
-                    w[0] = vol_load1(v1 + idx);
-                    c[0] = vol_load1(v2 + idx);
-                } else {
-                    w[0] = vol_load1(v0 + plane + idx);
-                    c[0] = vol_load1(v0 + 2 * plane + idx);
-                    c3[0] = vol_load1(v0 + 3 * plane + idx);
-                    c4[0] = vol_load1(v0 + 4 * plane + idx);
-                }
-            }
-        }
+        // (measured and rejected: issuing these loads for all live lanes BEFORE the geometry, beside the texel gathers, to take one
+        // round trip out of the wave's dependency chain -- 95 vs 92 us: the bytes loaded for lanes that then fail the test cost more)
+        if (any) load_volume();
         if (any) {
             if (!ACCUM) {
 #pragma unroll

@@ -1,0 +1,107 @@
+"""Foreground per-frame meshing inner loops of ``Pipeline._create_scene`` (/root/reference/hive/pipeline.py:340-483) on the
+MI355X: the steps behind ``point_cloud_from_depth`` that are dense per-pixel work -- triangulation of the valid pixels, the
+face filter, the texture window and UV coordinates.  Decimation (openmesh), connected-component clean-up and atlas packing
+(trimesh / numpy glue) stay with the reference.
+
+  ``grid_faces``                 fused ``_triangulate_faces`` + ``_filter_faces`` for one object mask of one frame
+  ``triangulate_faces``          ``Pipeline._triangulate_faces(points)`` (:651-667) for lattice points
+  ``filter_faces``               ``Pipeline._filter_faces(points2d, depth, faces, options)`` (:670-694), any face list
+  ``get_mesh_texture_and_uv``    ``Pipeline._get_mesh_texture_and_uv(...)`` (:782-808)
+
+The triangulation is the implicit one of the pixel grid (csrc/fgmesh.hip): the reference's Qhull Delaunay of the same lattice
+points differs from it only in which diagonal splits a unit square (arbitrary: four co-circular points) and in the faces
+that bridge one-pixel holes; tests/test_fgmesh_gpu.py measures both against scipy.
+"""
+import ctypes
+
+import numpy as np
+
+from hive_amd import _lib
+from hive_amd._lib import MEM_DEVICE, MEM_HOST, ptr
+from hive_amd.options import MeshFilteringOptions
+from hive_amd.utils import validate_camera_parameter_shapes, validate_shape
+
+
+def _is_torch(x):
+    return hasattr(x, "data_ptr")
+
+
+def grid_faces(depth, mask, options: MeshFilteringOptions = None, ctx=None, return_vertex_count=False):
+    """Faces of the valid pixels (``mask & (depth > 0)``) of one depth map, already filtered: int32 (F, 3) indices into the
+    rows of ``point_cloud_from_depth(depth, mask, ...)``.  ``depth`` float32 (H, W) (numpy or device tensor), ``mask`` bool /
+    uint8 (H, W) or None."""
+    options = options or MeshFilteringOptions()
+    ctx = ctx or _lib.default_context()
+    if _is_torch(depth):
+        import torch
+        d = depth.contiguous()
+        assert d.dtype == torch.float32
+        m = None if mask is None else mask.to(torch.uint8).contiguous()
+        mem = MEM_DEVICE
+    else:
+        d = np.ascontiguousarray(depth, dtype=np.float32)
+        m = None if mask is None else np.ascontiguousarray(np.asarray(mask) != 0, dtype=np.uint8)
+        mem = MEM_HOST
+    assert d.ndim == 2 and (m is None or tuple(m.shape) == tuple(d.shape)), "depth (H, W) and mask (H, W)"
+    h, w = (int(v) for v in d.shape)
+    nf, nv = ctypes.c_int64(0), ctypes.c_int64(0)
+    args = (ctx.handle, ptr(d), ptr(m), h, w, float(options.max_pixel_distance), float(options.max_depth_distance), mem)
+    ctx.check(ctx.lib.hive_grid_mesh(*args, None, 0, ctypes.byref(nf), ctypes.byref(nv)))  # size the output
+    if mem == MEM_DEVICE:
+        import torch
+        faces = torch.empty((nf.value, 3), dtype=torch.int32, device=d.device)
+    else:
+        faces = np.empty((nf.value, 3), np.int32)
+    if nf.value:
+        ctx.check(ctx.lib.hive_grid_mesh(*args, ptr(faces), nf.value, ctypes.byref(nf), ctypes.byref(nv)))
+    return (faces, nv.value) if return_vertex_count else faces
+
+
+def triangulate_faces(points, ctx=None):
+    """``Pipeline._triangulate_faces``: faces of a set of 2D lattice points (N, 2) = (u, v) integer pixel coordinates in
+    row-major order (what ``np.vstack((u, v)).T`` of ``valid.nonzero()`` gives, pipeline.py:392-395) -- no filtering."""
+    validate_shape(points, 'points', expected_shape=(None, 2))
+    pts = np.asarray(points)
+    assert np.issubdtype(pts.dtype, np.integer) and len(pts) > 0, "lattice (integer pixel) points expected"
+    u0, v0 = pts[:, 0].min(), pts[:, 1].min()
+    w, h = int(pts[:, 0].max() - u0 + 1), int(pts[:, 1].max() - v0 + 1)
+    grid = np.zeros((h, w), np.float32)
+    grid[pts[:, 1] - v0, pts[:, 0] - u0] = 1.0
+    order = np.lexsort((pts[:, 0], pts[:, 1]))
+    assert np.array_equal(order, np.arange(len(pts))), "points must be in row-major (v, then u) order"
+    return grid_faces(grid, None, MeshFilteringOptions(max_pixel_distance=np.inf, max_depth_distance=np.inf), ctx=ctx)
+
+
+def filter_faces(points2d, depth, faces, options: MeshFilteringOptions, ctx=None):
+    """``Pipeline._filter_faces``: the faces whose three edges are at most ``max_pixel_distance`` long in image space and span
+    at most ``max_depth_distance`` of depth; order preserved.  Works on any triangulation of the points."""
+    validate_shape(points2d, 'points2d', expected_shape=(None, 2))
+    validate_shape(depth, 'depth', expected_shape=(points2d.shape[0],))
+    validate_shape(faces, 'faces', expected_shape=(None, 3))
+    ctx = ctx or _lib.default_context()
+    p = np.ascontiguousarray(points2d, dtype=np.int32)
+    d = np.ascontiguousarray(depth, dtype=np.float32)
+    f = np.ascontiguousarray(faces, dtype=np.int32)
+    out = np.empty_like(f)
+    n = ctypes.c_int64(0)
+    ctx.check(ctx.lib.hive_filter_faces(ctx.handle, ptr(p), ptr(d), len(p), ptr(f), len(f), float(options.max_pixel_distance),
+                                        float(options.max_depth_distance), MEM_HOST, ptr(out), ctypes.byref(n)))
+    return out[:n.value].astype(np.asarray(faces).dtype, copy=False)
+
+
+def get_mesh_texture_and_uv(vertices, image, camera_matrix, rotation=np.eye(3), translation=np.zeros((3, 1)), scale_factor=1.0, ctx=None):
+    """``Pipeline._get_mesh_texture_and_uv``: (cropped texture, UV coordinates relative to the crop's corner)."""
+    validate_shape(vertices, 'vertices', expected_shape=(None, 3))
+    validate_shape(image, 'image', expected_shape=(None, None, 3))
+    validate_camera_parameter_shapes(camera_matrix, rotation, translation)
+    ctx = ctx or _lib.default_context()
+    pts = np.ascontiguousarray(vertices, dtype=np.float64)
+    K = np.ascontiguousarray(camera_matrix, dtype=np.float64).reshape(3, 3)
+    R = np.ascontiguousarray(rotation, dtype=np.float64).reshape(3, 3)
+    t = np.ascontiguousarray(translation, dtype=np.float64).reshape(3)
+    uv = np.empty((len(pts), 2), np.int32)  # world2image's default dtype: rounded pixel coordinates
+    box = np.zeros(4, np.int32)
+    ctx.check(ctx.lib.hive_texture_window(ctx.handle, ptr(pts), len(pts), ptr(K), ptr(R), ptr(t), float(scale_factor), MEM_HOST, ptr(uv), ptr(box)))
+    min_u, min_v, max_u, max_v = (int(b) for b in box)
+    texture = image[min_v:max_v, min_u:max_u, :].copy()
+    return texture, uv

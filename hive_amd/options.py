@@ -56,6 +56,28 @@ class MaskDilationOptions(Options):
         return MaskDilationOptions(num_iterations=args.dilate_mask_iter)
 
 
+class MeshFilteringOptions(Options):
+    """Limits of the per-frame face filter (/root/reference/hive/options.py:271-306): a face survives when every edge is at
+    most ``max_pixel_distance`` pixels long in image space and spans at most ``max_depth_distance`` metres of depth."""
+
+    def __init__(self, max_pixel_distance=2, max_depth_distance=0.1, min_num_components=5):
+        self.max_pixel_distance = max_pixel_distance
+        self.max_depth_distance = max_depth_distance
+        self.min_num_components = min_num_components
+
+    @staticmethod
+    def add_args(parser: argparse.ArgumentParser):
+        group = parser.add_argument_group('Mesh Filtering Options')
+        group.add_argument('--max_depth_dist', type=float, default=0.1, help='largest depth difference between the vertices of a face')
+        group.add_argument('--max_pixel_dist', type=float, default=2, help='largest image-space distance between the vertices of a face')
+        group.add_argument('--min_num_components', type=float, default=5, help='fragments with fewer connected faces are culled')
+
+    @staticmethod
+    def from_args(args) -> 'MeshFilteringOptions':
+        return MeshFilteringOptions(max_pixel_distance=args.max_pixel_dist, max_depth_distance=args.max_depth_dist,
+                                    min_num_components=args.min_num_components)
+
+
 class MeshReconstructionMethod(enum.Enum):
     TSDFFusion = enum.auto()
     BundleFusion = enum.auto()

@@ -195,6 +195,27 @@ int hive_project(hive_ctx *ctx, const double *points, int64_t n, const double K[
 int hive_project_bbox(hive_ctx *ctx, const double *points, int64_t n, const double K[9], const double R[9],
                       const double t[3], int W, int H, int mem, int32_t out[5]);
 
+/* ---- foreground per-frame meshes: Pipeline._create_scene's inner loops -- hive/pipeline.py:340-483 ------------------ */
+/* _triangulate_faces (:651-667) + _filter_faces (:670-694) in one pass over the frame: the valid pixels (mask & depth > 0) of
+ * a depth map are a lattice, so the triangulation is the implicit one of the pixel grid (two triangles per fully valid 2 x 2
+ * block, one per block with three valid corners) and only faces whose edges are all <= max_pixel_distance pixels long and span
+ * <= max_depth_distance metres are emitted (hive/options.py:271-286: defaults 2 and 0.1).  out_faces i32 [capacity][3] index the
+ * rows of hive_unproject's output for the same depth / mask (valid pixels in row-major order), wound like the reference's
+ * reversed Delaunay simplices; face order: row-major by block.  *n_faces = number of faces found (may exceed capacity: call
+ * with capacity 0 to size the buffer); *n_vertices (optional) = number of valid pixels. */
+int hive_grid_mesh(hive_ctx *ctx, const float *depth, const uint8_t *mask, int H, int W, double max_pixel_distance,
+                   double max_depth_distance, int mem, int32_t *out_faces, int64_t capacity, int64_t *n_faces,
+                   int64_t *n_vertices);
+/* _filter_faces (:670-694) for an explicit face list of any triangulation: points2d i32 [n][2] (u, v), depth f32 [n], faces i32
+ * [F][3] -> the faces whose three edges pass both limits, order preserved, into out_faces (capacity F). */
+int hive_filter_faces(hive_ctx *ctx, const int32_t *points2d, const float *depth, int64_t n_points, const int32_t *faces,
+                      int64_t n_faces_in, double max_pixel_distance, double max_depth_distance, int mem, int32_t *out_faces,
+                      int64_t *n_faces_out);
+/* _get_mesh_texture_and_uv (:782-808): uv = world2image(vertices) in its default int32 form (np.round); bbox = {min_u, min_v,
+ * max_u + 1, max_v + 1} -- the crop `image[min_v:max_v, min_u:max_u]` that becomes the texture; out_uv i32 [n][2] = uv - (min_u, min_v). */
+int hive_texture_window(hive_ctx *ctx, const double *points, int64_t n, const double K[9], const double R[9], const double t[3],
+                        double scale_factor, int mem, int32_t *out_uv, int32_t bbox[4]);
+
 /* ---- dilate_mask(mask, MaskDilationOptions(num_iterations)) -- hive/image_processing.py:30-45 */
 /* 3x3 rectangular structuring element applied `iterations` times == one (2*it+1)^2 box max
  * (cv2.dilate border = no contribution from outside).  mask/out u8 [H][W], non-zero = set. */

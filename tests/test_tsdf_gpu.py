@@ -213,3 +213,50 @@ def test_mesh_matches_oracle(gpu_ctx, oracle_lib, small_sequence):
     np.testing.assert_allclose(n, on, rtol=0, atol=1e-6)
     pc = vol.get_point_cloud()
     assert pc.shape == (v.shape[0], 6)
+
+
+def test_x_slab_volumes_are_slices_of_the_whole_volume(gpu_ctx, oracle_lib, small_sequence):
+    """The bit-exact multi-GPU mode's kernel side (hive_tsdf_create_slab): three uneven x-slabs of one grid, every frame
+    integrated into each -- concatenated they are bit for bit the whole volume, and the oracle's."""
+    from hive_amd import _lib, fusion, synthetic
+    seq = small_sequence
+    bounds, voxel = synthetic.room_bounds(), 0.0641  # 80^3
+    whole = fusion.TSDFVolume(bounds, voxel, ctx=gpu_ctx)
+    ora = oracle_lib.TSDFVolume(bounds, voxel)
+    X = int(whole.vol_dim[0])
+    cuts = [0, 27, 28, X]  # slabs of 27, 1 and 52 rows
+    slabs = [fusion.TSDFVolume(bounds, voxel, ctx=gpu_ctx, x_range=(a, b)) for a, b in zip(cuts, cuts[1:])]
+    assert [int(s.vol_dim[0]) for s in slabs] == [27, 1, X - 28] and all(np.array_equal(s._vol_origin, whole._vol_origin) for s in slabs)
+    for i in range(seq["depth"].shape[0]):
+        args = (seq["color"][i], seq["depth"][i], seq["K"], seq["poses"][i])
+        whole.integrate(*args)
+        ora.integrate(*args)
+        n_parts = [s.integrate(*args, return_n_updated=True) for s in slabs]
+        assert sum(n_parts) == ora.last_n_updated
+    _volumes_equal(whole, ora)
+    parts = [s.get_volume(with_weight=True) for s in slabs]
+    for k, ref in enumerate((ora._tsdf, ora._color, ora._weight)):
+        assert np.array_equal(np.concatenate([p[k] for p in parts], axis=0), ref)
+    with pytest.raises(_lib.HiveError):
+        slabs[0].get_mesh()  # marching cubes needs the gathered volume
+    with pytest.raises(_lib.HiveError):
+        fusion.TSDFVolume(bounds, voxel, ctx=gpu_ctx, x_range=(10, X + 1))
+
+
+def test_exact_slab_fusion_single_rank_and_device_volume_copies(gpu_ctx, oracle_lib, small_sequence):
+    """hive_amd.distributed.ExactSlabFusion with one rank (no process group): frames 'all-gathered', integrated, slabs
+    'all-gathered' into a whole volume whose mesh can be extracted; set_volume_device / device_tensors round trip."""
+    import torch
+    from hive_amd import distributed as hdist, synthetic
+    seq = small_sequence
+    fus = hdist.ExactSlabFusion(synthetic.room_bounds(), 0.08, ctx=gpu_ctx)
+    ora = oracle_lib.TSDFVolume(synthetic.room_bounds(), 0.08)
+    n = seq["depth"].shape[0]
+    fus.integrate(torch.from_numpy(seq["color"]).cuda(), torch.from_numpy(seq["depth"]).cuda(), seq["K"], seq["poses"], [n])
+    for i in range(n):
+        ora.integrate(seq["color"][i], seq["depth"][i], seq["K"], seq["poses"][i])
+    full = fus.gather()
+    _volumes_equal(full, ora)
+    verts, faces, _, _ = full.get_mesh()
+    o_verts, o_faces, _, _ = ora.get_mesh()
+    assert np.array_equal(faces, o_faces) and np.array_equal(verts, o_verts)
