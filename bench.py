@@ -46,6 +46,7 @@ def parse_args():
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"], help="N > 1: shard the same job (strong) or repeat it per rank (weak)")
     ap.add_argument("--merge", default="sum", choices=["sum", "exact"], help="N > 1: how the shared volume is merged")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--timed-only", action="store_true", help="profiling runs: skip the untimed roofline measurements behind the timed region")
     return ap.parse_args()
 
 
@@ -214,6 +215,12 @@ def main():
     elapsed = hdist.max_over_ranks(elapsed, device=device if world > 1 else "cpu")
     if world > 1:
         del merged
+
+    if args.timed_only:
+        if rank == 0:
+            print(json.dumps({"value": args.steps * B * (1 if strong or world == 1 else world) / elapsed, "unit": "frames/s", "ms_per_step": elapsed / args.steps * 1e3,
+                              "avg_integrate_us": kernel_ms / max(n_launch, 1) * 1e3, "note": "--timed-only: no roofline / cpu_baseline legs"}))
+        return
 
     # ---- untimed: what the timed launches processed --------------------------------------------------------------------
     # N_upd of EVERY frame this rank integrated in the timed region (depends on depth + pose only, not on the volume state)

@@ -412,6 +412,12 @@ __global__ __launch_bounds__(256) void integrate_kernel(FrameParams p, const Wor
                 }
             }
         };
+        // row constants, in the contract's operation order
+        const float tx = (p.ox + (float)(x + p.x_off) * p.vs) - p.T[0];
+        const float ty = (p.oy + (float)y * p.vs) - p.T[1];
+        const float ax = p.R[0] * tx + p.R[3] * ty;
+        const float ay = p.R[1] * tx + p.R[4] * ty;
+        const float az = p.R[2] * tx + p.R[5] * ty;
         V cam_z[Sh::NG];
         float depth_v[VPT];
         unsigned rgb[VPT];

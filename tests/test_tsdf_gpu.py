@@ -105,6 +105,30 @@ def test_full_size_512_vga(gpu_ctx, oracle_lib):
     assert np.isfinite(verts).all() and np.abs(np.linalg.norm(norms, axis=1) - 1).max() < 1e-4
 
 
+def test_full_size_1024_cubed_1080p(gpu_ctx, oracle_lib):
+    """BASELINE config 4's TSDF side: a 1920 x 1080 frame into a 1024^3 volume (5 mm voxels, 12.9 GB of volumes in HBM).
+    One frame bit-exact against the C oracle (26 GB of host arrays), then the size-independent properties on the device:
+    the same observation again leaves tsdf / colour unchanged and doubles the weights; N_upd = weighted voxels."""
+    import torch
+    from hive_amd import fusion, synthetic
+    seq = synthetic.make_sequence(num_frames=1, height=1080, width=1920, yaw_step_deg=40.0)
+    vol = fusion.TSDFVolume(synthetic.room_bounds(), 0.005, ctx=gpu_ctx)
+    assert tuple(vol.vol_dim) == (1024, 1024, 1024) and vol.num_voxels == 2 ** 30
+    args = (seq["color"][0], seq["depth"][0], seq["K"], seq["poses"][0])
+    n1 = vol.integrate(*args, return_n_updated=True)
+    ora = oracle_lib.TSDFVolume(synthetic.room_bounds(), 0.005)
+    ora.integrate(*args)
+    assert n1 == ora.last_n_updated and n1 > 50_000_000
+    tsdf, color, weight = vol.get_volume(with_weight=True)
+    assert np.array_equal(weight, ora._weight) and np.array_equal(tsdf, ora._tsdf) and np.array_equal(color, ora._color)
+    assert int(np.count_nonzero(weight)) == n1
+    del ora, tsdf, color, weight
+    t1, w1, c1 = vol.device_tensors()
+    n2 = vol.integrate(*args, return_n_updated=True)
+    t2, w2, c2 = vol.device_tensors()
+    assert n2 == n1 and torch.equal(t1, t2) and torch.equal(c1, c2) and torch.equal(w2, 2 * w1)
+
+
 def test_integrate_batch_and_device_inputs(gpu_ctx, oracle_lib, small_sequence):
     import torch
     from hive_amd import fusion, synthetic
