@@ -23,6 +23,7 @@
 // out again: a deep LDS ring (K-step 32, 3 / 4 / 5 stages of 32 KiB in flight, counted vmcnt) -- 725-780 TFLOP/s whatever the
 // depth, i.e. the fill latency is NOT what bounds the K-step, and the second barrier per 64 k costs 13 %.
 #include "hive_internal.hpp"
+#include "mfma_pipe.hpp"
 
 #include <algorithm>
 
@@ -32,10 +33,6 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
-
-// byte offset of 16-byte chunk `c` (0..7) of row `r` in a tile with 128-byte rows (same layout as csrc/vit.hip): the chunk
-// is XORed with (r >> 1) & 7 so that any 16 consecutive rows at one chunk index land on 16 distinct 16-byte slots
-__device__ __forceinline__ int swz(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
 
 struct ConvParams {
     const bf16 *x;      // [NB][H][W][Cin]
@@ -96,9 +93,6 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x4 (&acc)[
     }
 }
 
-#ifndef HIVE_CONV_PIPE
-#define HIVE_CONV_PIPE 1
-#endif
 constexpr int TM = 256, BK = 64, A_GROUPS = TM / 8;
 
 template <int TN>
@@ -133,25 +127,26 @@ __global__ __launch_bounds__(512, 1) void conv3x3_kernel(ConvParams p) {
     }
     const int w_lane_row = lane >> 3;
 
-    auto issue_stage = [&](int stage, int tap, int cc) {
+    // one LDS-DMA wave-instruction of a stage: j < 4 an A group (8 output pixels x 128 B of one tap), else a W group
+    auto issue_piece = [&](int stage, int tap, int cc, int j) {
         unsigned char *st = lds + stage * STAGE_BYTES;
-        const int dy = tap / 3 - 1, dx = tap % 3 - 1;
-        const long long shift = ((long long)dy * p.W + dx) * p.Cin + cc * BK;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        if (j < 4) {
+            const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+            const long long shift = ((long long)dy * p.W + dx) * p.Cin + cc * BK;
             const bool inside = (unsigned)(py[j] + dy) < (unsigned)p.H && (unsigned)(px[j] + dx) < (unsigned)p.W;
             const bf16 *g = inside ? pbase[j] + shift : p.zeros + a_chunk[j];
             __builtin_amdgcn_global_load_lds((const void *)g, (__attribute__((address_space(3))) void *)(st + (wave + 8 * j) * 1024), 16, 0, 0);
-        }
-        const int k0 = tap * p.Cin + cc * BK;
-#pragma unroll
-        for (int j = 4; j < PER_WAVE; ++j) {
+        } else {
             const int grp = wave + 8 * (j - 4);  // W group: rows grp * 8 .. + 7 of the weight tile
             const int row = grp * 8 + w_lane_row;
             const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-            const bf16 *g = p.w + (size_t)(n0 + row) * K + k0 + chunk * 8;
+            const bf16 *g = p.w + (size_t)(n0 + row) * K + tap * p.Cin + cc * BK + chunk * 8;
             __builtin_amdgcn_global_load_lds((const void *)g, (__attribute__((address_space(3))) void *)(st + (A_GROUPS + grp) * 1024), 16, 0, 0);
         }
+    };
+    auto issue_stage = [&](int stage, int tap, int cc) {
+#pragma unroll
+        for (int j = 0; j < PER_WAVE; ++j) issue_piece(stage, tap, cc, j);
     };
 
     f32x4 acc[4][MT];  // acc[nt][mt] = W_frag . A_frag^T : rows = output channel, cols = pixel
@@ -161,67 +156,32 @@ __global__ __launch_bounds__(512, 1) void conv3x3_kernel(ConvParams p) {
         for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int KT = 9 * CPT;
+    // K order: channel block OUTER, tap INNER.  The nine taps of one 64-channel block read the same input rows shifted by a
+    // pixel or a row, so consecutive K-steps re-read bytes the previous ones just brought into the XCD's L2 (a tile's window
+    // for one channel block is ~74 KB; 32 concurrent tiles per XCD: 2.4 MB of its 4 MB).  With taps outer the re-use distance
+    // is a whole sweep over the channels (300 KB per tile, 9.6 MB per XCD) and eight of nine A loads came from the Infinity
+    // Cache instead (tools/ubench/ldsdma.hip: a 64 KiB stage takes 2550 cycles from L2, 5400 from beyond it; 2048 cycles of MFMA).
     int nx_tap = 0, nx_cc = 0;  // (tap, channel block) of the next stage to issue
     issue_stage(0, 0, 0);
-    if (++nx_cc == CPT) nx_cc = 0, ++nx_tap;
+    if (++nx_tap == 9) nx_tap = 0, ++nx_cc;
     const int fr = lane & 15, fq = lane >> 4;
     for (int kt = 0; kt < KT; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();  // everyone's stage kt landed; everyone finished reading stage kt - 1
-        if (kt + 1 < KT) {
-            issue_stage((kt + 1) & 1, nx_tap, nx_cc);  // overwrites the buffer of stage kt - 1
-            if (++nx_cc == CPT) nx_cc = 0, ++nx_tap;
-        }
+        // The next stage is issued UNCONDITIONALLY (past the end: the last stage again, into the buffer nobody reads any more),
+        // piece by piece BETWEEN this step's MFMA slots (mfma_pipe.hpp).  A CU's texture-address unit accepts a vector-memory
+        // wave-instruction every ~40 cycles (64 per step and CU = the 2550 cycles tools/ubench/ldsdma.hip measures for a bare
+        // stage fill), and an in-order wave that issues its 8 back to back stands in that queue before its first MFMA.  The
+        // compiler keeps the order: an LDS-DMA and the ds_reads around it may alias (same LDS array), so neither is moved
+        // across the other.
+        const int is_tap = min(nx_tap, 8), is_cc = min(nx_cc, CPT - 1), is_stage = (kt + 1) & 1;
+        if (++nx_tap == 9) nx_tap = 0, ++nx_cc;
+        if (nx_cc >= CPT) nx_cc = CPT - 1, nx_tap = 8;
         const unsigned char *a_t = lds + (kt & 1) * STAGE_BYTES, *w_t = a_t + A_GROUPS * 1024;
-#if HIVE_CONV_PIPE
-        {
-            // Software-pipelined fragment stream.  The K-step is 2 MT slots (sub-step, M fragment) of 4 MFMAs each; the A
-            // fragment of slot s + 3 and the W fragments of the second sub-step are read from LDS while the MFMAs of slot s
-            // run, so one LDS round trip is exposed per K-step instead of one per 8 MFMAs (what the compiler's own schedule
-            // gave: 6 ds_read -> s_waitcnt lgkmcnt(0) -> 8 v_mfma, eight times per K-step).  The sched_group_barrier sequence
-            // pins the interleave: [7 DS reads] then per slot [its DS reads][4 MFMA].
-            constexpr int SLOTS = 2 * MT, D = 3;
-            auto rd_a = [&](int sl) { return *reinterpret_cast<const bf16x8 *>(a_t + swz(wr * RW + (sl % MT) * 16 + fr, (sl / MT) * 4 + fq)); };
-            auto rd_w = [&](int sub, int t) { return *reinterpret_cast<const bf16x8 *>(w_t + swz(wc * 64 + t * 16 + fr, sub * 4 + fq)); };
-            bf16x8 ring[4], wfr[2][4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) wfr[0][t] = rd_w(0, t);
-#pragma unroll
-            for (int sl = 0; sl < D; ++sl) ring[sl] = rd_a(sl);
-#pragma unroll
-            for (int sl = 0; sl < SLOTS; ++sl) {
-                if (sl + D < SLOTS) ring[(sl + D) & 3] = rd_a(sl + D);
-                if (sl < 4) wfr[1][sl] = rd_w(1, sl);
-                const int sub = sl / MT, mt = sl % MT;
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[sub][nt], ring[sl & 3], acc[nt][mt], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_group_barrier(0x100, 4 + D, 0);
-#pragma unroll
-            for (int sl = 0; sl < SLOTS; ++sl) {
-                if (sl + D < SLOTS && sl < 4)
-                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                else if (sl + D < SLOTS || sl < 4)
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-            }
-        }
-#else
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
-            bf16x8 af[MT], wf[4];
-#pragma unroll
-            for (int t = 0; t < MT; ++t) af[t] = *reinterpret_cast<const bf16x8 *>(a_t + swz(wr * RW + t * 16 + fr, sub * 4 + fq));
-#pragma unroll
-            for (int t = 0; t < 4; ++t) wf[t] = *reinterpret_cast<const bf16x8 *>(w_t + swz(wc * 64 + t * 16 + fr, sub * 4 + fq));
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], af[mt], acc[nt][mt], 0, 0, 0);
-        }
-#endif
+        hive_mfma::kstep64<MT, false>(a_t, w_t, wr * RW, wc * 64, fr, fq, acc, PER_WAVE, [&](int j) { issue_piece(is_stage, is_tap, is_cc, j); });
     }
 
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the redundant last stage)
     conv_epilogue<MT>(p, acc, m0 + wr * RW, n0 + wc * 64, fr, fq);
 }
 

@@ -1,0 +1,56 @@
+// One 64-deep K-step of the bf16 MFMA tile kernels (csrc/vit.hip GEMMs, csrc/conv.hip), shared so that the schedule that was
+// measured once is the schedule everywhere.  gfx950 only.
+//
+// A wave owns MT x 4 accumulators of 16 x 16 (MT fragments along the A rows, 4 along the W rows); operands sit in LDS as
+// 128-byte rows with the source-side chunk swizzle (swz).  The step is 2 MT "slots" (sub-step of 32 k, A fragment) of 4
+// v_mfma_f32_16x16x32_bf16 each.  Two things are woven between the slots, in SOURCE order (the compiler keeps it: an LDS-DMA
+// and the ds_reads around it may alias, so neither moves across the other):
+//   * fragment reads run ahead: the A fragment of slot s + 3 and the W fragments of the second sub-step are read while the
+//     MFMAs of slot s issue (one exposed LDS round trip per step instead of one per 8 MFMAs);
+//   * the NEXT stage's LDS-DMA pieces (`issue(j)`, j < n_pieces) go out one per slot instead of back to back behind the
+//     barrier: a CU's texture-address unit accepts one vector-memory wave-instruction per ~40 cycles (64 per 64 KiB stage and CU
+//     = the 2550 cycles tools/ubench/ldsdma.hip measures for a bare fill), and an in-order wave that issues its 8 at once
+//     stands in that queue before its first MFMA.
+// Measured on the decoder convolutions (tools/probe_conv3x3.py): 820-910 -> 900-1030 TFLOP/s.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace hive_mfma {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// byte offset of 16-byte chunk `c` (0..7) of row `r` in a tile with 128-byte rows: the chunk is XORed with (r >> 1) & 7 so that
+// any 16 consecutive rows at one chunk index land on 16 distinct 16-byte slots
+__device__ __forceinline__ int swz(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
+
+// SWAP = false: acc[nt][mt] += W_frag[nt] . A_frag[mt]^T (rows = W rows: a lane owns 4 consecutive W rows of one A row)
+// SWAP = true : acc[mt][nt] += A_frag[mt] . W_frag[nt]^T (MT == 4 only: the transposed v^T store of the QKV GEMM)
+template <int MT, bool SWAP, typename Acc, typename Issue>
+__device__ __forceinline__ void kstep64(const unsigned char *a_t, const unsigned char *w_t, int a_row0, int w_row0, int fr, int fq, Acc &acc,
+                                        int n_pieces, Issue &&issue) {
+    constexpr int SLOTS = 2 * MT, D = 3;
+    auto rd_a = [&](int sl) { return *reinterpret_cast<const bf16x8 *>(a_t + swz(a_row0 + (sl % MT) * 16 + fr, (sl / MT) * 4 + fq)); };
+    auto rd_w = [&](int sub, int t) { return *reinterpret_cast<const bf16x8 *>(w_t + swz(w_row0 + t * 16 + fr, sub * 4 + fq)); };
+    bf16x8 ring[4], wfr[2][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) wfr[0][t] = rd_w(0, t);
+#pragma unroll
+    for (int sl = 0; sl < D; ++sl) ring[sl] = rd_a(sl);
+#pragma unroll
+    for (int sl = 0; sl < SLOTS; ++sl) {
+        if (sl + D < SLOTS) ring[(sl + D) & 3] = rd_a(sl + D);
+        if (sl < 4) wfr[1][sl] = rd_w(1, sl);
+        const int sub = sl / MT, mt = sl % MT;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            if (SWAP)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ring[sl & 3], wfr[sub][nt], acc[mt][nt], 0, 0, 0);
+            else
+                acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[sub][nt], ring[sl & 3], acc[nt][mt], 0, 0, 0);
+        }
+        if (sl < n_pieces) issue(sl);
+    }
+}
+
+}  // namespace hive_mfma

@@ -8,7 +8,7 @@
 // Data layout (device, bf16 unless noted), sized for HBM residency of a whole batch:
 //   tokens      x      [B][Np][D]      Np = tokens per image padded to a multiple of 64 (pad rows are zero)
 //   q | k       qk     [B*Np][2D]      head h, channel c at column h*64 + c  (k at D + h*64 + c)
-//   v^T         vT     [B][H][64][Np]  written transposed by the QKV GEMM epilogue, so that P.V contracts
+//   v^T         vT     [B][H][64][Np]  (token quads 4..7 and 8..11 of every 16 swapped: vt_slot) written transposed by the QKV GEMM epilogue, so that P.V contracts
 //                                      over a contiguous axis and the attention needs no transposed reads
 //   weights            [out][in] row-major (nn.Linear), bias / LayerNorm affine in f32
 //
@@ -24,6 +24,7 @@
 // query on the lane and the keys in the accumulator registers, so the online softmax (base 2, deferred maximum)
 // is in-register with one cross-half shuffle, and the probabilities are already the B operand of O^T += V^T P^T.
 #include "hive_internal.hpp"
+#include "mfma_pipe.hpp"
 
 #include <algorithm>
 #include <cstdlib>
@@ -37,10 +38,15 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RESIDUAL = 2, EPI_QKV = 3 };
 
-// byte offset of 16-byte chunk `c` (0..7) of row `r` in a tile with 128-byte rows; rows r and r+1 share a
-// 256-byte bank row, the chunk is XORed with (r >> 1) & 7 so that any 16 consecutive rows at one chunk
-// index land on 16 distinct 16-byte slots
-__device__ __forceinline__ int swz(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
+// v^T key order.  The attention's P.V step holds the probabilities of a lane in accumulator order: its 8 k-slots of one
+// 32x32x16 MFMA are keys {0..3, 8..11} (+ 4 for the upper half-wave) of a 16-key group -- the S^T accumulator layout, not a
+// choice.  V^T is therefore STORED with the two middle quads of every 16-token group swapped (slot = token with bits 2 and 3
+// exchanged; an involution on multiples of 4), so that those 8 keys are 16 contiguous bytes: one conflict-free ds_read_b128
+// per operand instead of two 8-byte reads that collide under the 16-byte chunk swizzle (39 % LDS bank-conflict rate in
+// round 1's counters).
+__device__ __forceinline__ int vt_slot(int tok) { return (tok & ~12) | ((tok & 4) << 1) | ((tok & 8) >> 1); }
+
+using hive_mfma::swz;  // byte offset of 16-byte chunk c of row r in a 128-byte-row tile, chunk XORed with (r >> 1) & 7
 
 // ------------------------------------------------------------------------------------------------
 // LayerNorm over the last dimension D (multiple of 256), one wave per row, f32 statistics
@@ -157,62 +163,53 @@ __global__ __launch_bounds__(TM * 2, 1) void gemm_kernel(GemmParams p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
-    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so give each XCD a contiguous
-    // run of tiles (n fastest) -- neighbours then share their A panel in that XCD's L2 (bijective remap)
-    const int nwg = gridDim.x, xcd = blockIdx.x & 7, q = nwg >> 3, r = nwg & 7;
-    const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
-    const int tiles_n = p.N / BN;
-    const int m0 = (tile / tiles_n) * TM, n0 = (tile % tiles_n) * BN;
+    // PERSISTENT workgroups, XCD-aware: the grid is a multiple of 8 (<= 2 workgroups per CU); workgroups are dealt round-robin
+    // over the 8 XCDs, each XCD owns a contiguous run of tiles (n fastest: neighbours share their A panel in that XCD's L2)
+    // and its workgroups walk the run with a stride of gridDim / 8.  The K-steps of a workgroup's tiles form ONE stream: the
+    // first stage of the next tile is prefetched between the MFMAs of the last K-step of the current one and lands while its
+    // epilogue (GELU, residual, stores) runs -- at K = 768 a tile is 12 steps, and its exposed first fill was a step's worth.
+    const int tiles_n = p.N / BN, n_tiles = ((p.M + TM - 1) / TM) * tiles_n;
+    const int xcd = blockIdx.x & 7, per_xcd = gridDim.x >> 3, tq = n_tiles >> 3, tr = n_tiles & 7;
+    const int run0 = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq, run_n = tq + (xcd < tr ? 1 : 0);
+    int tl = blockIdx.x >> 3;  // position in the XCD's run
+    if (tl >= run_n) return;   // (whole workgroup)
+    int m0 = ((run0 + tl) / tiles_n) * TM, n0 = ((run0 + tl) % tiles_n) * BN;
 
-    auto issue_stage = [&](int kt) {
-        unsigned char *st = lds + (kt % NST) * STAGE_BYTES;
-#pragma unroll
-        for (int j = 0; j < PER_WAVE; ++j) {
-            const int g = wave + j * NWAVES;
-            if (g < A_GROUPS)
-                stage_group(p.A, p.K, m0, p.M - 1, kt * BK, st, g, lane);
-            else
-                stage_group(p.W, p.K, n0, p.N - 1, kt * BK, st + A_GROUPS * 1024, g - A_GROUPS, lane);
-        }
+    static_assert(NST == 2, "the K-step below issues the next stage between its MFMA slots: two stages");
+    // one LDS-DMA wave-instruction: group g = wave + j * NWAVES (8 rows x 128 B of A or of W) of K-step kt of tile (tm0, tn0)
+    auto issue_piece = [&](int tm0, int tn0, int kt, int buf, int j) {
+        unsigned char *st = lds + buf * STAGE_BYTES;
+        const int g = wave + j * NWAVES;
+        if (g < A_GROUPS)
+            stage_group(p.A, p.K, tm0, p.M - 1, kt * BK, st, g, lane);
+        else
+            stage_group(p.W, p.K, tn0, p.N - 1, kt * BK, st + A_GROUPS * 1024, g - A_GROUPS, lane);
     };
 
+    const int KT = p.K / BK;
+#pragma unroll
+    for (int j = 0; j < PER_WAVE; ++j) issue_piece(m0, n0, 0, 0, j);
+    const int fr = lane & 15, fq = lane >> 4;
+    int buf = 0;  // LDS stage of the current K-step (alternates along the whole stream)
+    for (;;) {
+    const bool has_next = tl + per_xcd < run_n;
+    const int nm0 = has_next ? ((run0 + tl + per_xcd) / tiles_n) * TM : m0, nn0 = has_next ? ((run0 + tl + per_xcd) % tiles_n) * BN : n0;
     f32x4 acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int KT = p.K / BK;
-    issue_stage(0);
-    if (NST == 3 && KT > 1) issue_stage(1);
-    const int fr = lane & 15, fq = lane >> 4;
     for (int kt = 0; kt < KT; ++kt) {
-        // NST = 3: my stage-kt loads have landed once at most one younger stage (PER_WAVE instructions) is outstanding
-        if (NST == 3 && kt + 1 < KT)
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_WAVE) : "memory");
-        else
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();  // everyone's stage kt landed; everyone finished reading stage kt-1
-        if (kt + NST - 1 < KT) issue_stage(kt + NST - 1);  // overwrites the buffer of stage kt-1
-        const unsigned char *a_t = lds + (kt % NST) * STAGE_BYTES, *w_t = a_t + A_GROUPS * 1024;
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
-            bf16x8 af[4], wf[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                af[t] = *reinterpret_cast<const bf16x8 *>(a_t + swz(wr * 64 + t * 16 + fr, sub * 4 + fq));
-                wf[t] = *reinterpret_cast<const bf16x8 *>(w_t + swz(wc * 64 + t * 16 + fr, sub * 4 + fq));
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (VT)  // acc[mt][nt] = A_frag . W_frag^T : rows = m, cols = n
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], wf[j], acc[i][j], 0, 0, 0);
-                    else     // acc[nt][mt] = W_frag . A_frag^T : rows = n, cols = m
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
-                }
-        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // everyone's current stage landed; everyone finished reading the previous one
+        // the next stage of the stream (next K-step; first K-step of the next tile; at the very end the last stage again,
+        // into the buffer nobody reads any more) goes out piece by piece between this step's MFMA slots (mfma_pipe.hpp)
+        const bool last = kt + 1 == KT;
+        const int sm0 = last ? nm0 : m0, sn0 = last ? nn0 : n0, sk = last ? (has_next ? 0 : KT - 1) : kt + 1;
+        const unsigned char *a_t = lds + buf * STAGE_BYTES, *w_t = a_t + A_GROUPS * 1024;
+        // VT: acc[mt][nt] = A_frag . W_frag^T (rows = m, cols = n); else acc[nt][mt] = W_frag . A_frag^T (rows = n, cols = m)
+        hive_mfma::kstep64<4, VT>(a_t, w_t, wr * 64, wc * 64, fr, fq, acc, PER_WAVE, [&](int j) { issue_piece(sm0, sn0, sk, buf ^ 1, j); });
+        buf ^= 1;
     }
 
     // epilogue
@@ -257,7 +254,7 @@ __global__ __launch_bounds__(TM * 2, 1) void gemm_kernel(GemmParams p) {
             for (int mt = 0; mt < 4; ++mt) {
                 const int m = m0 + wr * 64 + mt * 16 + fq * 4;  // multiple of 4; Np is a multiple of 64
                 if (m < p.M) {
-                    const int img = m / p.Np, tok = m % p.Np;
+                    const int img = m / p.Np, tok = vt_slot(m % p.Np);
                     bf16x4 ov;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) ov[j] = (bf16)(acc[mt][nt][j] + b);
@@ -266,6 +263,12 @@ __global__ __launch_bounds__(TM * 2, 1) void gemm_kernel(GemmParams p) {
             }
         }
     }
+    if (!has_next) break;
+    tl += per_xcd;
+    m0 = nm0;
+    n0 = nn0;
+    }  // persistent tile loop
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the redundant last stage
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -287,16 +290,13 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(GemmParams p) {
     const int tiles_n = p.N / T256;
     const int m0 = (tile / tiles_n) * T256, n0 = (tile % tiles_n) * T256;
 
-    auto issue_stage = [&](int kt) {
-        unsigned char *st = lds + (kt & 1) * T256_STAGE;
-#pragma unroll
-        for (int j = 0; j < PER_WAVE; ++j) {
-            const int g = wave + j * 8;
-            if (g < A_GROUPS)
-                stage_group(p.A, p.K, m0, p.M - 1, kt * BK, st, g, lane);
-            else
-                stage_group(p.W, p.K, n0, p.N - 1, kt * BK, st + A_GROUPS * 1024, g - A_GROUPS, lane);
-        }
+    auto issue_piece = [&](int kt, int stage, int j) {
+        unsigned char *st = lds + stage * T256_STAGE;
+        const int g = wave + j * 8;
+        if (g < A_GROUPS)
+            stage_group(p.A, p.K, m0, p.M - 1, kt * BK, st, g, lane);
+        else
+            stage_group(p.W, p.K, n0, p.N - 1, kt * BK, st + A_GROUPS * 1024, g - A_GROUPS, lane);
     };
 
     f32x4 acc[4][8];  // acc[nt][mt] = W_frag . A_frag^T : rows = n, cols = m
@@ -306,26 +306,17 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(GemmParams p) {
         for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int KT = p.K / BK;
-    issue_stage(0);
+#pragma unroll
+    for (int j = 0; j < PER_WAVE; ++j) issue_piece(0, 0, j);
     const int fr = lane & 15, fq = lane >> 4;
     for (int kt = 0; kt < KT; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();  // everyone's stage kt landed; everyone finished reading stage kt-1
-        if (kt + 1 < KT) issue_stage(kt + 1);  // overwrites the buffer of stage kt-1
+        __builtin_amdgcn_s_barrier();  // everyone's stage kt landed; everyone finished reading stage kt - 1
+        const int nk = min(kt + 1, KT - 1);  // next stage (past the end: the last one again), issued between the MFMA slots
         const unsigned char *a_t = lds + (kt & 1) * T256_STAGE, *w_t = a_t + A_GROUPS * 1024;
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
-            bf16x8 af[8], wf[4];
-#pragma unroll
-            for (int t = 0; t < 8; ++t) af[t] = *reinterpret_cast<const bf16x8 *>(a_t + swz(wr * 128 + t * 16 + fr, sub * 4 + fq));
-#pragma unroll
-            for (int t = 0; t < 4; ++t) wf[t] = *reinterpret_cast<const bf16x8 *>(w_t + swz(wc * 64 + t * 16 + fr, sub * 4 + fq));
-#pragma unroll
-            for (int mt = 0; mt < 8; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], af[mt], acc[nt][mt], 0, 0, 0);
-        }
+        hive_mfma::kstep64<8, false>(a_t, w_t, wr * 128, wc * 64, fr, fq, acc, PER_WAVE, [&](int j) { issue_piece(nk, (kt + 1) & 1, j); });
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the redundant last stage
 
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
@@ -466,23 +457,16 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
                 pf[kb][i >> 3][i & 7] = (bf16)e;
             }
         l_run += l_tile;
-        // O^T[ch][q] += V^T[ch][key] P^T[key][q]; k index j of half hh <-> key 32 kb + 16 s + 8 (j >> 2) + 4 hh + (j & 3)
+        // O^T[ch][q] += V^T[ch][key] P^T[key][q]; k index j of half hh <-> key 32 kb + 16 s + 8 (j >> 2) + 4 hh + (j & 3) (see vt_slot)
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
                 for (int db = 0; db < 2; ++db) {
-                    const int r = db * 32 + lq;
-                    const int u = (kb * 32 + s * 16 + 4 * hh) >> 2;  // 8-byte unit of the first 4 keys; second group is u + 2
-                    // V^T rows are read 8 bytes at a time (two groups of 4 keys); with the 16-byte chunk swizzle of the DMA
-                    // image rows r and r + 16 of a 32-lane read share a bank slot (2-way, +2 LDS cycles per read: cheap
-                    // next to the 49 us per call that register staging + ds_write cost)
-                    const int sw = (r >> 1) & 7;
-                    const uint2 lo = *reinterpret_cast<const uint2 *>(v_t + r * 128 + ((((u >> 1) ^ sw) << 4) | ((u & 1) << 3)));
-                    const uint2 hi = *reinterpret_cast<const uint2 *>(v_t + r * 128 + (((((u >> 1) + 1) ^ sw) << 4) | ((u & 1) << 3)));
-                    uint4 raw = make_uint4(lo.x, lo.y, hi.x, hi.y);
-                    const bf16x8 vf = *reinterpret_cast<const bf16x8 *>(&raw);
+                    // the lane's 8 keys {16 s + 4 hh + 0..3, + 8..11} of key block kb sit in slots 16 s + 8 hh .. + 7 of the stored
+                    // (quad-swapped) order: chunk 4 kb + 2 s + hh of the row, one 16-byte read through the tile's swizzle
+                    const bf16x8 vf = *reinterpret_cast<const bf16x8 *>(v_t + swz(db * 32 + lq, 4 * kb + 2 * s + hh));
                     oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kb][s], oacc[db], 0, 0, 0);
                 }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my pieces of tile t+1 have landed
@@ -636,7 +620,9 @@ static int launch_gemm(hive_ctx *ctx, int epi, const GemmParams &p) {
     static const char *force = getenv("HIVE_GEMM_TILE");  // "256" / "128": tuning override
     const long long tiles256 = (long long)((p.M + T256 - 1) / T256) * (p.N / T256);
     if (epi != EPI_QKV && p.N % T256 == 0 && ((force && force[0] == '2') || (!force && p.N >= 2048 && tiles256 >= ctx->num_cus))) return launch_gemm256(ctx, epi, p);
-    const dim3 grid((unsigned)(((p.M + GEMM_TM - 1) / GEMM_TM) * (p.N / BN))), block(GEMM_TM * 2);
+    // persistent workgroups: two per CU (64 KiB of LDS each), a multiple of 8 so that every XCD gets the same number
+    const long long tiles = (long long)((p.M + GEMM_TM - 1) / GEMM_TM) * (p.N / BN);
+    const dim3 grid((unsigned)std::min<long long>((tiles + 7) / 8 * 8, (long long)(2 * ctx->num_cus) / 8 * 8)), block(GEMM_TM * 2);
     switch (epi) {
         case EPI_BIAS: hipLaunchKernelGGL((gemm_kernel<EPI_BIAS, GEMM_TM, GEMM_NST>), grid, block, GEMM_LDS, ctx->stream, p); break;
         case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm_kernel<EPI_BIAS_GELU, GEMM_TM, GEMM_NST>), grid, block, GEMM_LDS, ctx->stream, p); break;

@@ -104,13 +104,17 @@ def test_qkv_and_attention(gpu_ctx, B, N):
     ref_qkv = x.float().reshape(B * Np, D) @ W.float().t() + bias
     _close(qk, ref_qkv[:, :2 * D], "q|k")
     ref_v = ref_qkv[:, 2 * D:].reshape(B, Np, H, 64).permute(0, 2, 3, 1)
-    _close(vT, ref_v, "v^T")
+    # v^T is stored with token quads 4..7 and 8..11 of every 16 swapped (bits 2 and 3 of the token index exchanged): undo it
+    tok = torch.arange(Np, device="cuda")
+    slot = (tok & ~12) | ((tok & 4) << 1) | ((tok & 8) >> 1)
+    vT_tokens = vT[..., slot]  # column t of the logical v^T lives in column slot[t]
+    _close(vT_tokens, ref_v, "v^T")
     out = torch.empty(B * Np, D, device="cuda", dtype=torch.bfloat16)
     gpu_ctx.check(gpu_ctx.lib.hive_vit_attention(gpu_ctx.handle, qk.data_ptr(), vT.data_ptr(), out.data_ptr(), B, N, Np, D, H))
     # reference on the kernel's own bf16 q, k, v
     q = qk[:, :D].float().reshape(B, Np, H, 64).permute(0, 2, 1, 3)[:, :, :N]
     k = qk[:, D:].float().reshape(B, Np, H, 64).permute(0, 2, 1, 3)[:, :, :N]
-    v = vT.float().permute(0, 1, 3, 2)[:, :, :N]
+    v = vT_tokens.float().permute(0, 1, 3, 2)[:, :, :N]
     attn = torch.softmax(q @ k.transpose(-1, -2) * 0.125, dim=-1)
     ref = (attn @ v).permute(0, 2, 1, 3).reshape(B, N, D)
     _close(out.reshape(B, Np, D)[:, :N], ref, "attention")
