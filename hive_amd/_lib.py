@@ -90,6 +90,8 @@ SIGNATURES = {
     "hive_nhwc_upsample2x": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "hive_nhwc_conv3x3": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                   c_void_p, c_void_p]),
+    "hive_nhwc_conv": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                               c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "hive_depth_quantize": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p]),
 }
 

@@ -36,15 +36,18 @@ namespace {
 
 struct ConvParams {
     const bf16 *x;      // [NB][H][W][Cin]
-    const bf16 *w;      // [Cout][9 Cin], k = (ky, kx, ci)
+    const bf16 *w;      // [Cout][R S Cin], k = (ky, kx, ci)
     const bf16 *bias;   // [Cout] or nullptr
     const bf16 *res1;   // [M][Cout] or nullptr
     const bf16 *res2;   // [M][Cout] or nullptr
     bf16 *out;          // [M][Cout]
     bf16 *out_relu;     // [M][Cout] or nullptr: relu(out)
     const bf16 *zeros;  // >= 128 bytes of zeros (padding taps)
-    int H, W, Cin, Cout, relu;
-    int M;              // NB * H * W
+    int H, W, Cin, Cout, relu;  // H, W: INPUT size
+    int Ho, Wo;         // output size
+    int S, taps;        // kernel width (1 or 3), R * S
+    int stride, pad_t, pad_l;  // input row of tap ky for output row oy: oy * stride + ky - pad_t
+    int M;              // NB * Ho * Wo
 };
 
 // epilogue: a lane owns 4 consecutive output channels of one pixel; everything in f32, one rounding to bf16
@@ -96,11 +99,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x4 (&acc)[
 constexpr int TM = 256, BK = 64, A_GROUPS = TM / 8;
 
 template <int TN>
-__global__ __launch_bounds__(512, 1) void conv3x3_kernel(ConvParams p) {
+__global__ __launch_bounds__(512, 1) void conv_kernel(ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // 2 stages x (A tile 256 x 64, W tile TN x 64)
     constexpr int W_GROUPS = TN / 8, GROUPS = A_GROUPS + W_GROUPS, PER_WAVE = GROUPS / 8;
     constexpr int STAGE_BYTES = GROUPS * 1024;
-    constexpr int WN = TN / 64, WM = 8 / WN, RW = TM / WM, MT = RW / 16;  // waves along N / M, rows per wave, M fragments
+    constexpr int WN = TN / 64, WM = 8 / WN, RW = TM / WM, MT = RW / 16;  // waves along N / M, rows per wave, M fragments (TN = 64: 8 x 1 waves of 32 x 64)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave / WN, wc = wave % WN;
@@ -109,7 +112,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_kernel(ConvParams p) {
     const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
     const int tiles_n = p.Cout / TN;
     const int m0 = (tile / tiles_n) * TM, n0 = (tile % tiles_n) * TN;
-    const int K = 9 * p.Cin, CPT = p.Cin / BK;  // K-steps per tap
+    const int K = p.taps * p.Cin, CPT = p.Cin / BK;  // CPT: K-steps (channel blocks) per tap
 
     // the A rows this lane stages (the same ones in every K-step): groups wave, wave + 8, wave + 16, wave + 24
     int py[4], px[4];
@@ -119,11 +122,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3_kernel(ConvParams p) {
     for (int j = 0; j < 4; ++j) {
         const int row = (wave + 8 * j) * 8 + (lane >> 3);
         const int m = min(m0 + row, p.M - 1);  // rows past the end are never stored
-        const int img = m / (p.H * p.W), rem = m - img * (p.H * p.W);
-        py[j] = rem / p.W;
-        px[j] = rem - py[j] * p.W;
+        const int img = m / (p.Ho * p.Wo), rem = m - img * (p.Ho * p.Wo);
+        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        py[j] = oy * p.stride - p.pad_t;  // input pixel of tap (0, 0)
+        px[j] = ox * p.stride - p.pad_l;
         a_chunk[j] = ((lane & 7) ^ ((row >> 1) & 7)) * 8;  // source-side swizzle: LDS slot (lane & 7) receives this chunk
-        pbase[j] = p.x + (size_t)m * p.Cin + a_chunk[j];
+        pbase[j] = p.x + (((long long)img * p.H + py[j]) * p.W + px[j]) * p.Cin + a_chunk[j];  // may point before the image: used only when inside
     }
     const int w_lane_row = lane >> 3;
 
@@ -131,7 +135,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_kernel(ConvParams p) {
     auto issue_piece = [&](int stage, int tap, int cc, int j) {
         unsigned char *st = lds + stage * STAGE_BYTES;
         if (j < 4) {
-            const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+            const int dy = tap / p.S, dx = tap - dy * p.S;
             const long long shift = ((long long)dy * p.W + dx) * p.Cin + cc * BK;
             const bool inside = (unsigned)(py[j] + dy) < (unsigned)p.H && (unsigned)(px[j] + dx) < (unsigned)p.W;
             const bf16 *g = inside ? pbase[j] + shift : p.zeros + a_chunk[j];
@@ -155,7 +159,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_kernel(ConvParams p) {
 #pragma unroll
         for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int KT = 9 * CPT;
+    const int KT = p.taps * CPT, last_tap = p.taps - 1;
     // K order: channel block OUTER, tap INNER.  The nine taps of one 64-channel block read the same input rows shifted by a
     // pixel or a row, so consecutive K-steps re-read bytes the previous ones just brought into the XCD's L2 (a tile's window
     // for one channel block is ~74 KB; 32 concurrent tiles per XCD: 2.4 MB of its 4 MB).  With taps outer the re-use distance
@@ -163,7 +167,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_kernel(ConvParams p) {
     // Cache instead (tools/ubench/ldsdma.hip: a 64 KiB stage takes 2550 cycles from L2, 5400 from beyond it; 2048 cycles of MFMA).
     int nx_tap = 0, nx_cc = 0;  // (tap, channel block) of the next stage to issue
     issue_stage(0, 0, 0);
-    if (++nx_tap == 9) nx_tap = 0, ++nx_cc;
+    if (++nx_tap == p.taps) nx_tap = 0, ++nx_cc;
     const int fr = lane & 15, fq = lane >> 4;
     for (int kt = 0; kt < KT; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -174,9 +178,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_kernel(ConvParams p) {
         // stage fill), and an in-order wave that issues its 8 back to back stands in that queue before its first MFMA.  The
         // compiler keeps the order: an LDS-DMA and the ds_reads around it may alias (same LDS array), so neither is moved
         // across the other.
-        const int is_tap = min(nx_tap, 8), is_cc = min(nx_cc, CPT - 1), is_stage = (kt + 1) & 1;
-        if (++nx_tap == 9) nx_tap = 0, ++nx_cc;
-        if (nx_cc >= CPT) nx_cc = CPT - 1, nx_tap = 8;
+        const int is_tap = min(nx_tap, last_tap), is_cc = min(nx_cc, CPT - 1), is_stage = (kt + 1) & 1;
+        if (++nx_tap == p.taps) nx_tap = 0, ++nx_cc;
+        if (nx_cc >= CPT) nx_cc = CPT - 1, nx_tap = last_tap;
         const unsigned char *a_t = lds + (kt & 1) * STAGE_BYTES, *w_t = a_t + A_GROUPS * 1024;
         hive_mfma::kstep64<MT, false>(a_t, w_t, wr * RW, wc * 64, fr, fq, acc, PER_WAVE, [&](int j) { issue_piece(is_stage, is_tap, is_cc, j); });
     }
@@ -189,25 +193,26 @@ bool g_conv_attr_set[64] = {};
 
 int ensure_conv_attrs(hive_ctx *ctx) {
     if (ctx->device < 64 && g_conv_attr_set[ctx->device]) return HIVE_OK;
-    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)conv3x3_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (A_GROUPS + 32) * 1024));
-    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)conv3x3_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (A_GROUPS + 16) * 1024));
+    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)conv_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (A_GROUPS + 32) * 1024));
+    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)conv_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (A_GROUPS + 16) * 1024));
+    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)conv_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (A_GROUPS + 8) * 1024));
     if (ctx->device < 64) g_conv_attr_set[ctx->device] = true;
     return HIVE_OK;
 }
 
-}  // namespace
-
-extern "C" int hive_nhwc_conv3x3(hive_ctx *ctx, const void *d_x, int dtype, int N, int H, int W, int C_in, int C_out, const void *d_w,
-                                 const void *d_bias, int relu, const void *d_residual, const void *d_residual2, void *d_out,
-                                 void *d_out_relu) {
-    HIVE_ENTER(ctx);
-    if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
-    HIVE_REQUIRE(ctx, d_x && d_w && d_out, "nhwc_conv3x3: NULL argument");
-    HIVE_REQUIRE(ctx, dtype == HIVE_BF16, "nhwc_conv3x3: bf16 only");
-    HIVE_REQUIRE(ctx, N > 0 && H > 0 && W > 0 && (long long)N * H * W < (1ll << 31), "nhwc_conv3x3: bad sizes %d x %d x %d", N, H, W);
-    HIVE_REQUIRE(ctx, C_in > 0 && C_in % 64 == 0 && C_out > 0 && C_out % 128 == 0, "nhwc_conv3x3: need C_in %% 64 == 0 and C_out %% 128 == 0, got %d -> %d",
-                 C_in, C_out);
-    HIVE_REQUIRE(ctx, d_out != d_x && d_out_relu != d_x, "nhwc_conv3x3: the output must not alias the input (3 x 3 halo)");
+int launch_conv(hive_ctx *ctx, const char *what, const void *d_x, int dtype, int N, int H, int W, int C_in, int C_out, int R, int stride, int pad_t,
+                       int pad_l, int Ho, int Wo, const void *d_w, const void *d_bias, int relu, const void *d_residual, const void *d_residual2,
+                       void *d_out, void *d_out_relu) {
+    HIVE_REQUIRE(ctx, d_x && d_w && d_out, "%s: NULL argument", what);
+    HIVE_REQUIRE(ctx, dtype == HIVE_BF16, "%s: bf16 only", what);
+    HIVE_REQUIRE(ctx, N > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && (long long)N * H * W < (1ll << 31) && (long long)N * Ho * Wo < (1ll << 31),
+                 "%s: bad sizes %d x %d x %d -> %d x %d", what, N, H, W, Ho, Wo);
+    HIVE_REQUIRE(ctx, (R == 1 || R == 3) && (stride == 1 || stride == 2) && pad_t >= 0 && pad_t < R && pad_l >= 0 && pad_l < R,
+                 "%s: kernel %d, stride %d, padding (%d, %d)", what, R, stride, pad_t, pad_l);
+    HIVE_REQUIRE(ctx, (long long)(Ho - 1) * stride - pad_t < H && (long long)(Wo - 1) * stride - pad_l < W, "%s: output %d x %d reaches outside the %d x %d input", what, Ho,
+                 Wo, H, W);
+    HIVE_REQUIRE(ctx, C_in > 0 && C_in % 64 == 0 && C_out > 0 && C_out % 64 == 0, "%s: need C_in %% 64 == 0 and C_out %% 64 == 0, got %d -> %d", what, C_in, C_out);
+    HIVE_REQUIRE(ctx, (R == 1 && stride == 1) || (d_out != d_x && d_out_relu != d_x), "%s: the output must not alias the input", what);
     ConvParams p{};
     p.x = (const bf16 *)d_x;
     p.w = (const bf16 *)d_w;
@@ -222,14 +227,44 @@ extern "C" int hive_nhwc_conv3x3(hive_ctx *ctx, const void *d_x, int dtype, int 
     p.Cin = C_in;
     p.Cout = C_out;
     p.relu = relu;
-    p.M = N * H * W;
+    p.Ho = Ho;
+    p.Wo = Wo;
+    p.S = R;
+    p.taps = R * R;
+    p.stride = stride;
+    p.pad_t = pad_t;
+    p.pad_l = pad_l;
+    p.M = N * Ho * Wo;
     const int tiles_m = (p.M + TM - 1) / TM;
     int rc = ensure_conv_attrs(ctx);
     if (rc) return rc;
     if (C_out % 256 == 0)
-        hipLaunchKernelGGL(conv3x3_kernel<256>, dim3(tiles_m * (C_out / 256)), dim3(512), 2 * (size_t)(A_GROUPS + 32) * 1024, ctx->stream, p);
+        hipLaunchKernelGGL(conv_kernel<256>, dim3(tiles_m * (C_out / 256)), dim3(512), 2 * (size_t)(A_GROUPS + 32) * 1024, ctx->stream, p);
+    else if (C_out % 128 == 0)
+        hipLaunchKernelGGL(conv_kernel<128>, dim3(tiles_m * (C_out / 128)), dim3(512), 2 * (size_t)(A_GROUPS + 16) * 1024, ctx->stream, p);
     else
-        hipLaunchKernelGGL(conv3x3_kernel<128>, dim3(tiles_m * (C_out / 128)), dim3(512), 2 * (size_t)(A_GROUPS + 16) * 1024, ctx->stream, p);
+        hipLaunchKernelGGL(conv_kernel<64>, dim3(tiles_m * (C_out / 64)), dim3(512), 2 * (size_t)(A_GROUPS + 8) * 1024, ctx->stream, p);
     HIVE_CHECK_HIP(ctx, hipGetLastError());
     return HIVE_OK;
+}
+
+}  // namespace
+
+extern "C" int hive_nhwc_conv3x3(hive_ctx *ctx, const void *d_x, int dtype, int N, int H, int W, int C_in, int C_out, const void *d_w,
+                                 const void *d_bias, int relu, const void *d_residual, const void *d_residual2, void *d_out,
+                                 void *d_out_relu) {
+    HIVE_ENTER(ctx);
+    if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
+    HIVE_REQUIRE(ctx, C_out % 128 == 0, "nhwc_conv3x3: need C_out %% 128 == 0, got %d", C_out);
+    HIVE_REQUIRE(ctx, d_out != d_x && d_out_relu != d_x, "nhwc_conv3x3: the output must not alias the input (3 x 3 halo)");
+    return launch_conv(ctx, "nhwc_conv3x3", d_x, dtype, N, H, W, C_in, C_out, 3, 1, 1, 1, H, W, d_w, d_bias, relu, d_residual, d_residual2, d_out, d_out_relu);
+}
+
+extern "C" int hive_nhwc_conv(hive_ctx *ctx, const void *d_x, int dtype, int N, int H, int W, int C_in, int C_out, int kernel, int stride, int pad_top,
+                              int pad_left, int H_out, int W_out, const void *d_w, const void *d_bias, int relu, const void *d_residual,
+                              const void *d_residual2, void *d_out, void *d_out_relu) {
+    HIVE_ENTER(ctx);
+    if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
+    return launch_conv(ctx, "nhwc_conv", d_x, dtype, N, H, W, C_in, C_out, kernel, stride, pad_top, pad_left, H_out, W_out, d_w, d_bias, relu, d_residual,
+                       d_residual2, d_out, d_out_relu);
 }

@@ -30,6 +30,8 @@ template <int MT, bool SWAP, typename Acc, typename Issue>
 __device__ __forceinline__ void kstep64(const unsigned char *a_t, const unsigned char *w_t, int a_row0, int w_row0, int fr, int fq, Acc &acc,
                                         int n_pieces, Issue &&issue) {
     constexpr int SLOTS = 2 * MT, D = 3;
+    constexpr int WPS = MT >= 4 ? 1 : 4 / MT;  // W fragments of sub-step 1 prefetched per slot
+    static_assert(MT == 2 || MT == 4 || MT == 8, "A fragments per wave");
     auto rd_a = [&](int sl) { return *reinterpret_cast<const bf16x8 *>(a_t + swz(a_row0 + (sl % MT) * 16 + fr, (sl / MT) * 4 + fq)); };
     auto rd_w = [&](int sub, int t) { return *reinterpret_cast<const bf16x8 *>(w_t + swz(w_row0 + t * 16 + fr, sub * 4 + fq)); };
     bf16x8 ring[4], wfr[2][4];
@@ -40,7 +42,10 @@ __device__ __forceinline__ void kstep64(const unsigned char *a_t, const unsigned
 #pragma unroll
     for (int sl = 0; sl < SLOTS; ++sl) {
         if (sl + D < SLOTS) ring[(sl + D) & 3] = rd_a(sl + D);
-        if (sl < 4) wfr[1][sl] = rd_w(1, sl);
+        if (sl < 4 / WPS) {  // the second sub-step's W fragments, all four before slot MT
+#pragma unroll
+            for (int k = 0; k < WPS; ++k) wfr[1][sl * WPS + k] = rd_w(1, sl * WPS + k);
+        }
         const int sub = sl / MT, mt = sl % MT;
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
@@ -51,6 +56,7 @@ __device__ __forceinline__ void kstep64(const unsigned char *a_t, const unsigned
         }
         if (sl < n_pieces) issue(sl);
     }
+    for (int j = SLOTS; j < n_pieces; ++j) issue(j);  // more pieces than slots (narrow tiles)
 }
 
 }  // namespace hive_mfma

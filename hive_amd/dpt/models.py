@@ -38,6 +38,8 @@ class StdConv2dSame(nn.Conv2d):
     """Conv2d with weight standardisation and TensorFlow "SAME" padding (timm ``StdConv2dSame``, eps=1e-8
     for the ViT hybrids).  The standardised weight is cached in eval mode (weights are frozen there)."""
 
+    engine = "torch"  # set to "hip" by DPT(engine="hip"): hand-written implicit-GEMM convolution (csrc/conv.hip)
+
     def __init__(self, in_chs, out_chs, kernel_size, stride=1, eps=1e-8):
         super().__init__(in_chs, out_chs, kernel_size, stride=stride, padding=0, bias=False)
         self.eps = eps
@@ -68,6 +70,8 @@ class StdConv2dSame(nn.Conv2d):
         return super()._apply(fn, *args, **kwargs)
 
     def forward(self, x):
+        if self.engine == "hip" and dpt_ops.conv_eligible(x, self):
+            return dpt_ops.conv2d(x, self, weight=self.standardized_weight(), same_pad=True)
         ih, iw = x.shape[-2:]
         kh, kw = self.kernel_size
         ph, pw = _same_pad(ih, kh, self.stride[0]), _same_pad(iw, kw, self.stride[1])
@@ -309,7 +313,11 @@ class FeatureFusionBlock(nn.Module):
             # rounding order (covered by the tolerance of tests/test_vit_gpu.py against the torch engine).
             # (and its bias is added by the upsampling kernel while loading)
             oc = self.out_conv
-            return dpt_ops.upsample2x(F.conv2d(output, oc.weight, None, oc.stride, oc.padding), engine=self.engine, bias=oc.bias)
+            if dpt_ops.conv_eligible(output, oc):
+                low = dpt_ops.conv2d(output, oc, with_bias=False)
+            else:
+                low = F.conv2d(output, oc.weight, None, oc.stride, oc.padding)
+            return dpt_ops.upsample2x(low, engine=self.engine, bias=oc.bias)
         output = dpt_ops.upsample2x(output, engine=self.engine)  # bilinear, align_corners=True
         return self.out_conv(output)
 
@@ -381,7 +389,7 @@ class DPT(nn.Module):
         self._vit_engine = None
         self._vit_stamp = None
         for m in self.modules():  # the fused channels-last glue kernels follow the engine choice
-            if isinstance(m, (GroupNormAct, FeatureFusionBlock, Interpolate, ResidualConvUnit)):
+            if isinstance(m, (GroupNormAct, FeatureFusionBlock, Interpolate, ResidualConvUnit, StdConv2dSame)):
                 m.engine = engine
 
     # -- ViT encoder ---------------------------------------------------------------------------
@@ -420,6 +428,12 @@ class DPT(nn.Module):
             self._vit_stamp = stamp
         return self._vit_engine.forward(tokens, taps=hooks)
 
+    def _conv(self, layer, x):
+        """An nn.Conv2d of the reassemble / embedding stages: the hand-written kernel where it applies (1 x 1, 3 x 3 stride 2)."""
+        if self.engine == "hip" and isinstance(layer, nn.Conv2d) and not isinstance(layer, nn.ConvTranspose2d) and dpt_ops.conv_eligible(x, layer):
+            return dpt_ops.conv2d(x, layer)
+        return layer(x)
+
     def forward_backbone(self, x, stages=None):
         p = self.pretrained
         vit = p.model
@@ -433,7 +447,7 @@ class DPT(nn.Module):
             if cl:
                 y = y.contiguous(memory_format=torch.channels_last)
             for layer in post[3:]:
-                y = layer(y)
+                y = self._conv(layer, y)
             return y
 
         if p.hybrid:
@@ -443,7 +457,7 @@ class DPT(nn.Module):
             feat = vit.patch_embed.backbone.stages[2](layer_2)
         else:
             feat = x
-        tokens = vit.patch_embed.proj(feat).flatten(2).transpose(1, 2)
+        tokens = self._conv(vit.patch_embed.proj, feat).flatten(2).transpose(1, 2)
         tokens = torch.cat((vit.cls_token.expand(b, -1, -1).to(tokens.dtype), tokens), dim=1)
         tokens = tokens + vit.resize_pos_embed(gh, gw).to(tokens.dtype)
         taps = self._run_blocks(tokens)

@@ -76,6 +76,49 @@ def conv3x3(x, conv, relu=False, residual=None, residual2=None, also_relu=False,
     return (out, out_relu) if also_relu else out
 
 
+def conv_geometry(conv, ih, iw, same_pad=False):
+    """(kernel, stride, pad_top, pad_left, out_h, out_w) of a square-kernel convolution on an ih x iw input.  ``same_pad``:
+    timm's StdConv2dSame (TensorFlow "SAME": total padding max((ceil(i / s) - 1) s + k - i, 0), the odd pixel at the bottom /
+    right); otherwise nn.Conv2d's symmetric ``padding``."""
+    k, st = conv.kernel_size[0], conv.stride[0]
+    if same_pad:
+        oh, ow = -(-ih // st), -(-iw // st)
+        ph, pw = max((oh - 1) * st + k - ih, 0), max((ow - 1) * st + k - iw, 0)
+        return k, st, ph // 2, pw // 2, oh, ow
+    p = conv.padding[0]
+    return k, st, p, p, (ih + 2 * p - k) // st + 1, (iw + 2 * p - k) // st + 1
+
+
+def conv_eligible(x, conv):
+    """csrc/conv.hip covers square kernels 1 / 3, stride 1 / 2, bf16 channels-last, C_in % 64 == 0, C_out % 64 == 0, no groups /
+    dilation -- every convolution of DPT-Hybrid except the 7 x 7 stem (its own kernel)."""
+    k = conv.kernel_size
+    return (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)
+            and k[0] == k[1] and k[0] in (1, 3) and conv.stride[0] == conv.stride[1] and conv.stride[0] in (1, 2)
+            and tuple(conv.dilation) == (1, 1) and conv.groups == 1 and conv.in_channels % 64 == 0 and conv.out_channels % 64 == 0
+            and conv.weight.dtype == torch.bfloat16 and x.shape[1] == conv.in_channels and conv.padding[0] == conv.padding[1] and conv.padding[0] < k[0])
+
+
+def conv2d(x, conv, weight=None, same_pad=False, relu=False, residual=None, residual2=None, also_relu=False, with_bias=True):
+    """relu?(conv(x) (+ bias) (+ residuals)) through hive_nhwc_conv (see ``conv_eligible``).  ``weight``: use this tensor
+    instead of ``conv.weight`` (the standardised weight of a StdConv2dSame), [C_out, C_in, k, k] in channels-last memory format."""
+    n, _, ih, iw = x.shape
+    k, st, pt, pl, oh, ow = conv_geometry(conv, ih, iw, same_pad)
+    w = weight if weight is not None else _conv3x3_weight(conv)
+    if not w.is_contiguous(memory_format=torch.channels_last):
+        w = w.contiguous(memory_format=torch.channels_last)
+    out = torch.empty((n, conv.out_channels, oh, ow), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    out_relu = torch.empty_like(out) if also_relu else None
+    for r in (residual, residual2):
+        assert r is None or (r.shape == out.shape and r.dtype == out.dtype and r.is_contiguous(memory_format=torch.channels_last))
+    bias = conv.bias if (with_bias and conv.bias is not None) else None
+    ctx = _lib.default_context(x.device.index or 0)
+    ctx.check(ctx.lib.hive_nhwc_conv(ctx.handle, x.data_ptr(), _lib.BF16, n, ih, iw, conv.in_channels, conv.out_channels, k, st, pt, pl, oh, ow,
+                                     w.data_ptr(), _lib.ptr(bias), int(bool(relu)), _lib.ptr(residual), _lib.ptr(residual2), out.data_ptr(),
+                                     _lib.ptr(out_relu)))
+    return (out, out_relu) if also_relu else out
+
+
 def conv_bias_act(x, conv, relu=False, residual=None, residual2=None, engine="torch", also_relu=False):
     """relu?(conv(x) (+ residual) (+ residual2)) for an ``nn.Conv2d`` with bias.  HIP engine: the decoder's 3 x 3
     convolutions run in the hand-written implicit-GEMM kernel with bias, skip connections and ReLU in its epilogue; other

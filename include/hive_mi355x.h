@@ -336,6 +336,15 @@ int hive_nhwc_conv3x3(hive_ctx *ctx, const void *d_x, int dtype, int N, int H, i
                       const void *d_bias, int relu, const void *d_residual, const void *d_residual2, void *d_out,
                       void *d_out_relu);
 
+/* The same implicit-GEMM kernel family for the other convolutions of the network (ResNetV2-50 stages of the hybrid backbone --
+ * timm StdConv2dSame with its "SAME" padding --, the 1 x 1 projections of the reassemble stages and fusion blocks, the stride-2
+ * 3 x 3 of act_postprocess4): kernel 1 or 3 (square), stride 1 or 2, explicit top / left padding (the bottom / right padding
+ * is whatever H_out, W_out imply), C_in % 64 == 0, C_out % 64 == 0, d_w [C_out][kernel][kernel][C_in].  Same fused epilogue.
+ * Input pixel of tap (ky, kx) for output (oy, ox): (oy * stride + ky - pad_top, ox * stride + kx - pad_left), zero outside. */
+int hive_nhwc_conv(hive_ctx *ctx, const void *d_x, int dtype, int N, int H, int W, int C_in, int C_out, int kernel, int stride,
+                   int pad_top, int pad_left, int H_out, int W_out, const void *d_w, const void *d_bias, int relu,
+                   const void *d_residual, const void *d_residual2, void *d_out, void *d_out_relu);
+
 #ifdef __cplusplus
 }
 #endif
