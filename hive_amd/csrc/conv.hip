@@ -12,7 +12,7 @@
 // shifted pixel -- and from a 128-byte page of zeros where the tap falls into the padding.  The weight tensor
 // [Cout][Cin][3][3] in channels-last memory format IS W[co][(ky, kx, ci)].
 //
-// Tile: 256 output pixels x TN output channels (TN = 256: 8 waves as 2 x 4, 128 x 64 each; TN = 128: 4 x 2, 64 x 64 each),
+// Tile: TM = 256 (or 128, for small maps) output pixels x TN = 256 / 128 / 64 output channels, 8 waves (256 x 256: 2 x 4 waves of 128 x 64),
 // K-step 64 = one tap x 64 input channels, v_mfma_f32_16x16x32_bf16, two LDS stages filled by LDS-DMA with the bank swizzle
 // on the source side (conflict-free ds_read_b128), one raw s_barrier per K-step, XCD-aware tile order: consecutive tiles are
 // consecutive image rows, so an XCD's run of tiles re-reads its three-row halo from its own L2.  K = 9 Cin >= 2304 gives
@@ -96,106 +96,137 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x4 (&acc)[
     }
 }
 
-constexpr int TM = 256, BK = 64, A_GROUPS = TM / 8;
+constexpr int BK = 64;
 
-template <int TN>
+template <int TM, int TN>
 __global__ __launch_bounds__(512, 1) void conv_kernel(ConvParams p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // 2 stages x (A tile 256 x 64, W tile TN x 64)
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // 2 stages x (A tile TM x 64, W tile TN x 64)
+    constexpr int A_GROUPS = TM / 8, A_PW = A_GROUPS / 8;  // 1 KiB groups of the A tile, and how many each wave stages
     constexpr int W_GROUPS = TN / 8, GROUPS = A_GROUPS + W_GROUPS, PER_WAVE = GROUPS / 8;
     constexpr int STAGE_BYTES = GROUPS * 1024;
     constexpr int WN = TN / 64, WM = 8 / WN, RW = TM / WM, MT = RW / 16;  // waves along N / M, rows per wave, M fragments (TN = 64: 8 x 1 waves of 32 x 64)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave / WN, wc = wave % WN;
-    // XCD-aware tile order (workgroups are dealt round-robin over the 8 XCDs): each XCD gets a contiguous run of tiles
-    const int nwg = gridDim.x, xcd = blockIdx.x & 7, q = nwg >> 3, r = nwg & 7;
-    const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
-    const int tiles_n = p.Cout / TN;
-    const int m0 = (tile / tiles_n) * TM, n0 = (tile % tiles_n) * TN;
+    // PERSISTENT workgroups, XCD-aware (one per CU: the two stages take 96-128 KiB of LDS): the grid is a multiple of 8;
+    // workgroups are dealt round-robin over the 8 XCDs, each XCD owns a contiguous run of tiles (consecutive image rows: its
+    // tiles re-read their three-row halo from its own L2) and its workgroups walk the run with a stride of gridDim / 8.  The
+    // K-steps of a workgroup's tiles form ONE stream: the first stage of the next tile is issued between the MFMAs of the last
+    // K-step of the current one and lands while its epilogue runs -- what the 1 x 1 convolutions of the ResNet stages need
+    // (K = 64 .. 1024: one to sixteen K-steps per tile, then 64-128 KiB of output to store).
+    const int tiles_n = p.Cout / TN, n_tiles = ((p.M + TM - 1) / TM) * tiles_n;
+    const int xcd = blockIdx.x & 7, per_xcd = gridDim.x >> 3, tq = n_tiles >> 3, tr = n_tiles & 7;
+    const int run0 = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq, run_n = tq + (xcd < tr ? 1 : 0);
+    int tl = blockIdx.x >> 3;  // position in the XCD's run
+    if (tl >= run_n) return;   // (whole workgroup)
     const int K = p.taps * p.Cin, CPT = p.Cin / BK;  // CPT: K-steps (channel blocks) per tap
 
-    // the A rows this lane stages (the same ones in every K-step): groups wave, wave + 8, wave + 16, wave + 24
-    int py[4], px[4];
-    const bf16 *pbase[4];
-    int a_chunk[4];
+    // per tile: the A rows this lane stages (the same ones in every K-step): groups wave, wave + 8, ...
+    struct Tile {
+        int m0, n0;
+        int py[A_PW], px[A_PW];
+        const bf16 *pbase[A_PW];
+    };
+    int a_chunk[A_PW];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < A_PW; ++j) {
         const int row = (wave + 8 * j) * 8 + (lane >> 3);
-        const int m = min(m0 + row, p.M - 1);  // rows past the end are never stored
-        const int img = m / (p.Ho * p.Wo), rem = m - img * (p.Ho * p.Wo);
-        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-        py[j] = oy * p.stride - p.pad_t;  // input pixel of tap (0, 0)
-        px[j] = ox * p.stride - p.pad_l;
         a_chunk[j] = ((lane & 7) ^ ((row >> 1) & 7)) * 8;  // source-side swizzle: LDS slot (lane & 7) receives this chunk
-        pbase[j] = p.x + (((long long)img * p.H + py[j]) * p.W + px[j]) * p.Cin + a_chunk[j];  // may point before the image: used only when inside
     }
+    auto setup = [&](int t, Tile &T) {
+        T.m0 = (t / tiles_n) * TM;
+        T.n0 = (t % tiles_n) * TN;
+#pragma unroll
+        for (int j = 0; j < A_PW; ++j) {
+            const int row = (wave + 8 * j) * 8 + (lane >> 3);
+            const int m = min(T.m0 + row, p.M - 1);  // rows past the end are never stored
+            const int img = m / (p.Ho * p.Wo), rem = m - img * (p.Ho * p.Wo);
+            const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+            T.py[j] = oy * p.stride - p.pad_t;  // input pixel of tap (0, 0)
+            T.px[j] = ox * p.stride - p.pad_l;
+            T.pbase[j] = p.x + (((long long)img * p.H + T.py[j]) * p.W + T.px[j]) * p.Cin + a_chunk[j];  // may point before the image: used only when inside
+        }
+    };
     const int w_lane_row = lane >> 3;
 
-    // one LDS-DMA wave-instruction of a stage: j < 4 an A group (8 output pixels x 128 B of one tap), else a W group
-    auto issue_piece = [&](int stage, int tap, int cc, int j) {
+    // one LDS-DMA wave-instruction of a stage: j < A_PW an A group (8 output pixels x 128 B of one tap), else a W group
+    auto issue_piece = [&](const Tile &T, int stage, int tap, int cc, int j) {
         unsigned char *st = lds + stage * STAGE_BYTES;
-        if (j < 4) {
+        if (j < A_PW) {
             const int dy = tap / p.S, dx = tap - dy * p.S;
             const long long shift = ((long long)dy * p.W + dx) * p.Cin + cc * BK;
-            const bool inside = (unsigned)(py[j] + dy) < (unsigned)p.H && (unsigned)(px[j] + dx) < (unsigned)p.W;
-            const bf16 *g = inside ? pbase[j] + shift : p.zeros + a_chunk[j];
+            const bool inside = (unsigned)(T.py[j] + dy) < (unsigned)p.H && (unsigned)(T.px[j] + dx) < (unsigned)p.W;
+            const bf16 *g = inside ? T.pbase[j] + shift : p.zeros + a_chunk[j];
             __builtin_amdgcn_global_load_lds((const void *)g, (__attribute__((address_space(3))) void *)(st + (wave + 8 * j) * 1024), 16, 0, 0);
         } else {
-            const int grp = wave + 8 * (j - 4);  // W group: rows grp * 8 .. + 7 of the weight tile
+            const int grp = wave + 8 * (j - A_PW);  // W group: rows grp * 8 .. + 7 of the weight tile
             const int row = grp * 8 + w_lane_row;
             const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-            const bf16 *g = p.w + (size_t)(n0 + row) * K + tap * p.Cin + cc * BK + chunk * 8;
+            const bf16 *g = p.w + (size_t)(T.n0 + row) * K + tap * p.Cin + cc * BK + chunk * 8;
             __builtin_amdgcn_global_load_lds((const void *)g, (__attribute__((address_space(3))) void *)(st + (A_GROUPS + grp) * 1024), 16, 0, 0);
         }
     };
-    auto issue_stage = [&](int stage, int tap, int cc) {
-#pragma unroll
-        for (int j = 0; j < PER_WAVE; ++j) issue_piece(stage, tap, cc, j);
-    };
-
-    f32x4 acc[4][MT];  // acc[nt][mt] = W_frag . A_frag^T : rows = output channel, cols = pixel
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int KT = p.taps * CPT, last_tap = p.taps - 1;
-    // K order: channel block OUTER, tap INNER.  The nine taps of one 64-channel block read the same input rows shifted by a
-    // pixel or a row, so consecutive K-steps re-read bytes the previous ones just brought into the XCD's L2 (a tile's window
-    // for one channel block is ~74 KB; 32 concurrent tiles per XCD: 2.4 MB of its 4 MB).  With taps outer the re-use distance
-    // is a whole sweep over the channels (300 KB per tile, 9.6 MB per XCD) and eight of nine A loads came from the Infinity
-    // Cache instead (tools/ubench/ldsdma.hip: a 64 KiB stage takes 2550 cycles from L2, 5400 from beyond it; 2048 cycles of MFMA).
-    int nx_tap = 0, nx_cc = 0;  // (tap, channel block) of the next stage to issue
-    issue_stage(0, 0, 0);
-    if (++nx_tap == p.taps) nx_tap = 0, ++nx_cc;
+    // K order within a tile: channel block OUTER, tap INNER.  The taps of one 64-channel block read the same input rows shifted
+    // by a pixel or a row, so consecutive K-steps re-read bytes the previous ones just brought into the XCD's L2 (a tile's window
+    // for one channel block is ~74 KB; 32 concurrent tiles per XCD: 2.4 MB of its 4 MB); with taps outer the re-use distance is
+    // a whole sweep over the channels (tools/ubench/ldsdma.hip: a 64 KiB stage takes 2550 cycles from L2, 5400 from beyond it).
+    Tile T;  // the tile whose stages are being ISSUED (one K-step ahead of the MFMAs: the next tile's during a tile's last step)
+    setup(run0 + tl, T);
+#pragma unroll
+    for (int j = 0; j < PER_WAVE; ++j) issue_piece(T, 0, 0, 0, j);
     const int fr = lane & 15, fq = lane >> 4;
-    for (int kt = 0; kt < KT; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();  // everyone's stage kt landed; everyone finished reading stage kt - 1
-        // The next stage is issued UNCONDITIONALLY (past the end: the last stage again, into the buffer nobody reads any more),
-        // piece by piece BETWEEN this step's MFMA slots (mfma_pipe.hpp).  A CU's texture-address unit accepts a vector-memory
-        // wave-instruction every ~40 cycles (64 per step and CU = the 2550 cycles tools/ubench/ldsdma.hip measures for a bare
-        // stage fill), and an in-order wave that issues its 8 back to back stands in that queue before its first MFMA.  The
-        // compiler keeps the order: an LDS-DMA and the ds_reads around it may alias (same LDS array), so neither is moved
-        // across the other.
-        const int is_tap = min(nx_tap, last_tap), is_cc = min(nx_cc, CPT - 1), is_stage = (kt + 1) & 1;
-        if (++nx_tap == p.taps) nx_tap = 0, ++nx_cc;
-        if (nx_cc >= CPT) nx_cc = CPT - 1, nx_tap = last_tap;
-        const unsigned char *a_t = lds + (kt & 1) * STAGE_BYTES, *w_t = a_t + A_GROUPS * 1024;
-        hive_mfma::kstep64<MT, false>(a_t, w_t, wr * RW, wc * 64, fr, fq, acc, PER_WAVE, [&](int j) { issue_piece(is_stage, is_tap, is_cc, j); });
+    int buf = 0;  // LDS stage of the current K-step (alternates along the whole stream)
+    for (;;) {
+        const bool has_next = tl + per_xcd < run_n;
+        const int em0 = T.m0, en0 = T.n0;  // the tile being multiplied (for its epilogue)
+        f32x4 acc[4][MT];  // acc[nt][mt] = W_frag . A_frag^T : rows = output channel, cols = pixel
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        int nx_tap = 1, nx_cc = 0;  // (tap, channel block) of K-step kt + 1
+        if (nx_tap == p.taps) nx_tap = 0, nx_cc = 1;
+        for (int kt = 0; kt < KT; ++kt) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();  // everyone's current stage landed; everyone finished reading the previous one
+            // The next stage of the stream (next K-step; first K-step of the next tile; at the very end the last stage again, into
+            // the buffer nobody reads any more) is issued UNCONDITIONALLY, piece by piece BETWEEN this step's MFMA slots
+            // (mfma_pipe.hpp): a CU's texture-address unit accepts a vector-memory wave-instruction every ~40 cycles, and an
+            // in-order wave that issues its 8 back to back stands in that queue before its first MFMA.
+            int is_tap = nx_tap, is_cc = nx_cc;
+            if (kt + 1 == KT) {
+                if (has_next) {
+                    setup(run0 + tl + per_xcd, T);  // this tile's rows are not needed any more: its last stage is in LDS
+                    is_tap = 0, is_cc = 0;
+                } else {
+                    is_tap = last_tap, is_cc = CPT - 1;
+                }
+            }
+            if (++nx_tap == p.taps) nx_tap = 0, ++nx_cc;
+            const unsigned char *a_t = lds + buf * STAGE_BYTES, *w_t = a_t + A_GROUPS * 1024;
+            hive_mfma::kstep64<MT, false>(a_t, w_t, wr * RW, wc * 64, fr, fq, acc, PER_WAVE, [&](int j) { issue_piece(T, buf ^ 1, is_tap, is_cc, j); });
+            buf ^= 1;
+        }
+        conv_epilogue<MT>(p, acc, em0 + wr * RW, en0 + wc * 64, fr, fq);
+        if (!has_next) break;
+        tl += per_xcd;
     }
-
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the redundant last stage)
-    conv_epilogue<MT>(p, acc, m0 + wr * RW, n0 + wc * 64, fr, fq);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the redundant last stage
 }
+
+constexpr int conv_lds(int tm, int tn) { return 2 * (tm / 8 + tn / 8) * 1024; }  // two stages of (A tile + W tile), 128-byte rows
 
 bool g_conv_attr_set[64] = {};
 
 int ensure_conv_attrs(hive_ctx *ctx) {
     if (ctx->device < 64 && g_conv_attr_set[ctx->device]) return HIVE_OK;
-    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)conv_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (A_GROUPS + 32) * 1024));
-    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)conv_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (A_GROUPS + 16) * 1024));
-    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)conv_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (A_GROUPS + 8) * 1024));
+    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)conv_kernel<256, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds(256, 256)));
+    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)conv_kernel<256, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds(256, 128)));
+    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)conv_kernel<256, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds(256, 64)));
+    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)conv_kernel<128, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds(128, 256)));
+    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)conv_kernel<128, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds(128, 128)));
     if (ctx->device < 64) g_conv_attr_set[ctx->device] = true;
     return HIVE_OK;
 }
@@ -235,15 +266,25 @@ int launch_conv(hive_ctx *ctx, const char *what, const void *d_x, int dtype, int
     p.pad_t = pad_t;
     p.pad_l = pad_l;
     p.M = N * Ho * Wo;
-    const int tiles_m = (p.M + TM - 1) / TM;
     int rc = ensure_conv_attrs(ctx);
     if (rc) return rc;
-    if (C_out % 256 == 0)
-        hipLaunchKernelGGL(conv_kernel<256>, dim3(tiles_m * (C_out / 256)), dim3(512), 2 * (size_t)(A_GROUPS + 32) * 1024, ctx->stream, p);
-    else if (C_out % 128 == 0)
-        hipLaunchKernelGGL(conv_kernel<128>, dim3(tiles_m * (C_out / 128)), dim3(512), 2 * (size_t)(A_GROUPS + 16) * 1024, ctx->stream, p);
+    const int tn = C_out % 256 == 0 ? 256 : (C_out % 128 == 0 ? 128 : 64);
+    // 256 output pixels per tile, or 128 where that would leave CUs without a tile (30 x 40 and 15 x 20 maps: 113 / 29 tiles of 256)
+    const int tm = (tn >= 128 && (long long)((p.M + 255) / 256) * (C_out / tn) < ctx->num_cus) ? 128 : 256;
+    // persistent workgroups, one per CU, a multiple of 8 so that every XCD gets the same number
+    const long long tiles = (long long)((p.M + tm - 1) / tm) * (C_out / tn);
+    const dim3 grid((unsigned)std::min<long long>((tiles + 7) / 8 * 8, (long long)ctx->num_cus / 8 * 8));
+    const size_t lds = (size_t)conv_lds(tm, tn);
+    if (tm == 256 && tn == 256)
+        hipLaunchKernelGGL((conv_kernel<256, 256>), grid, dim3(512), lds, ctx->stream, p);
+    else if (tm == 256 && tn == 128)
+        hipLaunchKernelGGL((conv_kernel<256, 128>), grid, dim3(512), lds, ctx->stream, p);
+    else if (tm == 256)
+        hipLaunchKernelGGL((conv_kernel<256, 64>), grid, dim3(512), lds, ctx->stream, p);
+    else if (tn == 256)
+        hipLaunchKernelGGL((conv_kernel<128, 256>), grid, dim3(512), lds, ctx->stream, p);
     else
-        hipLaunchKernelGGL(conv_kernel<64>, dim3(tiles_m * (C_out / 64)), dim3(512), 2 * (size_t)(A_GROUPS + 8) * 1024, ctx->stream, p);
+        hipLaunchKernelGGL((conv_kernel<128, 128>), grid, dim3(512), lds, ctx->stream, p);
     HIVE_CHECK_HIP(ctx, hipGetLastError());
     return HIVE_OK;
 }

@@ -95,3 +95,52 @@ def test_conv3x3_weights_not_channels_last_and_rejections(gpu_ctx):
     assert rc == _lib.ERR_INVALID
     rc = ctx.lib.hive_nhwc_conv3x3(ctx.handle, x.data_ptr(), _lib.BF16, 1, 8, 8, 64, 128, conv.weight.data_ptr(), None, 0, None, None, x.data_ptr(), None)
     assert rc == _lib.ERR_INVALID, "in-place convolution must be refused"
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,h,w,same", [
+    (64, 64, 1, 1, 24, 32, True),      # stage-0 conv1: 64-wide output tile
+    (64, 64, 3, 1, 24, 32, True),      # stage-0 conv2
+    (64, 256, 1, 1, 24, 32, True),     # stage-0 conv3 / downsample
+    (256, 128, 1, 1, 24, 32, True),    # stage-1 block-0 conv1
+    (128, 128, 3, 2, 24, 32, True),    # stage-1 block-0 conv2: stride 2, SAME padding = 0 top / left, 1 bottom / right
+    (128, 128, 3, 2, 23, 31, True),    # odd input: SAME padding 1 / 1
+    (256, 512, 1, 2, 24, 32, True),    # stage-1 downsample: 1 x 1 stride 2
+    (1024, 256, 1, 1, 15, 20, True),   # stage-2 conv1
+    (256, 1024, 1, 1, 15, 20, True),   # stage-2 conv3
+    (1024, 768, 1, 1, 15, 20, False),  # patch_embed.proj (with bias)
+    (768, 768, 3, 2, 15, 20, False),   # act_postprocess4[4]: 3 x 3 stride 2 padding 1
+    (256, 256, 1, 1, 30, 40, False),   # FeatureFusionBlock.out_conv
+])
+def test_general_conv_matches_torch(gpu_ctx, cin, cout, k, stride, h, w, same):
+    """hive_nhwc_conv on every convolution shape family of the hybrid backbone, against float32 torch with the same padding
+    rule (timm StdConv2dSame's TensorFlow 'SAME' padding or nn.Conv2d's symmetric one)."""
+    from hive_amd.dpt import ops
+    from hive_amd.dpt.models import StdConv2dSame
+    g = torch.Generator(device="cpu").manual_seed(cin * 7 + k * 3 + stride + h)
+    x = torch.randn(2, cin, h, w, generator=g).bfloat16().cuda().contiguous(memory_format=torch.channels_last)
+    if same:
+        conv = StdConv2dSame(cin, cout, k, stride=stride)
+    else:
+        conv = nn.Conv2d(cin, cout, k, stride, 1 if k == 3 else 0, bias=True)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) * (2.0 / (k * k * cin)) ** 0.5)
+        if conv.bias is not None:
+            conv.bias.copy_(torch.randn(cout, generator=g) * 0.3)
+    conv = conv.to(memory_format=torch.channels_last).to(torch.bfloat16).cuda().eval()
+    assert ops.conv_eligible(x, conv)
+    if same:
+        conv.engine = "torch"
+        with torch.no_grad():
+            wt = conv.standardized_weight()
+            ih, iw = h, w
+            oh, ow = -(-ih // stride), -(-iw // stride)
+            ph, pw = max((oh - 1) * stride + k - ih, 0), max((ow - 1) * stride + k - iw, 0)
+            xp = F.pad(x.float(), (pw // 2, pw - pw // 2, ph // 2, ph - ph // 2))
+            ref = F.conv2d(xp, wt.float(), None, stride, 0)
+            conv.engine = "hip"
+            out = conv(x)  # StdConv2dSame.forward -> the HIP kernel
+    else:
+        with torch.no_grad():
+            ref = F.conv2d(x.float(), conv.weight.float(), conv.bias.float(), stride, conv.padding)
+            out = ops.conv2d(x, conv)
+    _check(out, ref, f"{cin}->{cout} k{k} s{stride}")
