@@ -72,6 +72,8 @@ class StdConv2dSame(nn.Conv2d):
     def forward(self, x):
         if self.engine == "hip" and dpt_ops.conv_eligible(x, self):
             return dpt_ops.conv2d(x, self, weight=self.standardized_weight(), same_pad=True)
+        if self.engine == "hip" and dpt_ops.stem_conv_eligible(x, self):
+            return dpt_ops.stem_conv(x, self, self.standardized_weight())
         ih, iw = x.shape[-2:]
         kh, kw = self.kernel_size
         ph, pw = _same_pad(ih, kh, self.stride[0]), _same_pad(iw, kw, self.stride[1])
@@ -96,11 +98,17 @@ class GroupNormAct(nn.GroupNorm):
 
 
 class MaxPool2dSame(nn.Module):
+    engine = "torch"
+
     def __init__(self, kernel_size=3, stride=2):
         super().__init__()
         self.k, self.s = kernel_size, stride
 
     def forward(self, x):
+        if self.engine == "hip" and (self.k, self.s) == (3, 2):
+            y = dpt_ops.maxpool3x3s2_same(x, engine="hip")
+            if y is not None:
+                return y
         ih, iw = x.shape[-2:]
         ph, pw = _same_pad(ih, self.k, self.s), _same_pad(iw, self.k, self.s)
         x = F.pad(x, (pw // 2, pw - pw // 2, ph // 2, ph - ph // 2), value=float("-inf"))
@@ -389,7 +397,7 @@ class DPT(nn.Module):
         self._vit_engine = None
         self._vit_stamp = None
         for m in self.modules():  # the fused channels-last glue kernels follow the engine choice
-            if isinstance(m, (GroupNormAct, FeatureFusionBlock, Interpolate, ResidualConvUnit, StdConv2dSame)):
+            if isinstance(m, (GroupNormAct, FeatureFusionBlock, Interpolate, ResidualConvUnit, StdConv2dSame, MaxPool2dSame)):
                 m.engine = engine
 
     # -- ViT encoder ---------------------------------------------------------------------------

@@ -119,6 +119,41 @@ def conv2d(x, conv, weight=None, same_pad=False, relu=False, residual=None, resi
     return (out, out_relu) if also_relu else out
 
 
+_stem_weights = {}  # id(conv) -> (stamp, [64][7][32] weights)
+
+
+def stem_conv_eligible(x, conv):
+    return (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and x.shape[1] == 3 and x.is_contiguous(memory_format=torch.channels_last)
+            and tuple(conv.kernel_size) == (7, 7) and tuple(conv.stride) == (2, 2) and conv.in_channels == 3 and conv.out_channels == 64
+            and conv.bias is None and x.shape[2] >= 7 and x.shape[3] >= 7)
+
+
+def stem_conv(x, conv, weight):
+    """The 7 x 7 / 2 "SAME" stem convolution (csrc/stem.hip).  ``weight``: the standardised [64, 3, 7, 7] weights."""
+    stamp = (weight.data_ptr(), weight._version)
+    hit = _stem_weights.get(id(conv))
+    if hit is None or hit[0] != stamp:
+        w = torch.zeros((64, 7, 32), dtype=torch.bfloat16, device=weight.device)
+        w[:, :, :21] = weight.detach().permute(0, 2, 3, 1).reshape(64, 7, 21)  # (ky, (kx, c)), a kernel row padded to 32
+        hit = _stem_weights[id(conv)] = (stamp, w.contiguous())
+    n, _, h, w_ = x.shape
+    out = torch.empty((n, 64, (h + 1) // 2, (w_ + 1) // 2), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    ctx = _lib.default_context(x.device.index or 0)
+    ctx.check(ctx.lib.hive_resnet_stem_conv(ctx.handle, x.data_ptr(), _lib.BF16, n, h, w_, hit[1].data_ptr(), out.data_ptr()))
+    return out
+
+
+def maxpool3x3s2_same(x, engine="torch"):
+    """MaxPool2dSame(3, 2) of the ResNetV2 stem."""
+    if engine == "hip" and _hip_eligible(x) and x.dtype == torch.bfloat16:
+        n, c, h, w = x.shape
+        out = torch.empty((n, c, (h + 1) // 2, (w + 1) // 2), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        ctx = _lib.default_context(x.device.index or 0)
+        ctx.check(ctx.lib.hive_nhwc_maxpool3x3s2(ctx.handle, x.data_ptr(), _lib.BF16, n, h, w, c, out.data_ptr()))
+        return out
+    return None
+
+
 def conv_bias_act(x, conv, relu=False, residual=None, residual2=None, engine="torch", also_relu=False):
     """relu?(conv(x) (+ residual) (+ residual2)) for an ``nn.Conv2d`` with bias.  HIP engine: the decoder's 3 x 3
     convolutions run in the hand-written implicit-GEMM kernel with bias, skip connections and ReLU in its epilogue; other

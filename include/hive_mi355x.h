@@ -345,6 +345,13 @@ int hive_nhwc_conv(hive_ctx *ctx, const void *d_x, int dtype, int N, int H, int 
                    int pad_top, int pad_left, int H_out, int W_out, const void *d_w, const void *d_bias, int relu,
                    const void *d_residual, const void *d_residual2, void *d_out, void *d_out_relu);
 
+/* ResNetV2 stem of the hybrid backbone (timm 0.5.4 ResNetV2.stem, reached from DPTDepthModel.forward): the 7 x 7 stride-2
+ * weight-standardised convolution 3 -> 64 with TensorFlow "SAME" padding on the channels-last frame d_x [N][H][W][3] ->
+ * d_out [N][ceil(H/2)][ceil(W/2)][64]; d_w = the standardised weights as [64][7][32] ((kx, c) of a kernel row padded from 21 to
+ * 32 with zeros).  And MaxPool2dSame(3, 2): [N][H][W][C] -> [N][ceil(H/2)][ceil(W/2)][C], C % 8 == 0. */
+int hive_resnet_stem_conv(hive_ctx *ctx, const void *d_x, int dtype, int N, int H, int W, const void *d_w, void *d_out);
+int hive_nhwc_maxpool3x3s2(hive_ctx *ctx, const void *d_x, int dtype, int N, int H, int W, int C, void *d_out);
+
 #ifdef __cplusplus
 }
 #endif

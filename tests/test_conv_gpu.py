@@ -144,3 +144,33 @@ def test_general_conv_matches_torch(gpu_ctx, cin, cout, k, stride, h, w, same):
             ref = F.conv2d(x.float(), conv.weight.float(), conv.bias.float(), stride, conv.padding)
             out = ops.conv2d(x, conv)
     _check(out, ref, f"{cin}->{cout} k{k} s{stride}")
+
+
+@pytest.mark.parametrize("n,h,w", [(2, 480, 640), (1, 96, 128), (1, 61, 77)])
+def test_stem_conv_and_maxpool_match_torch(gpu_ctx, n, h, w):
+    """ResNetV2 stem on the HIP engine (csrc/stem.hip): the 7 x 7 / 2 weight-standardised "SAME" convolution from the 3-channel
+    channels-last frame and MaxPool2dSame(3, 2), against the PyTorch formulation of the same modules in float32."""
+    from hive_amd.dpt.models import MaxPool2dSame, StdConv2dSame
+    g = torch.Generator(device="cpu").manual_seed(h)
+    x = (torch.rand(n, 3, h, w, generator=g) * 2 - 1).bfloat16().cuda().contiguous(memory_format=torch.channels_last)
+    conv = StdConv2dSame(3, 64, 7, stride=2)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g))
+    conv = conv.to(memory_format=torch.channels_last).to(torch.bfloat16).cuda().eval()
+    with torch.no_grad():
+        conv.engine = "torch"
+        wt = conv.standardized_weight().float()
+        oh, ow = (h + 1) // 2, (w + 1) // 2
+        ph, pw = max((oh - 1) * 2 + 7 - h, 0), max((ow - 1) * 2 + 7 - w, 0)
+        ref = F.conv2d(F.pad(x.float(), (pw // 2, pw - pw // 2, ph // 2, ph - ph // 2)), wt, None, 2, 0)
+        conv.engine = "hip"
+        out = conv(x)
+    _check(out, ref, "stem 7x7/2")
+    pool = MaxPool2dSame(3, 2)
+    y = out  # bf16 channels-last [n, 64, oh, ow]
+    pool.engine = "torch"
+    ref_p = pool(y.float())
+    pool.engine = "hip"
+    got_p = pool(y)
+    assert got_p.shape == ref_p.shape and got_p.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(got_p.float(), ref_p), "max pooling is exact"
