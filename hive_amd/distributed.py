@@ -62,9 +62,33 @@ def max_over_ranks(value, device="cpu"):
     """Max of a Python float over all ranks (for timing)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return float(value)
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    t = torch.tensor([float(value)], dtype=torch.float64, device="cpu" if _host_staged() else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def _host_staged():
+    """True when the process group cannot move device tensors itself (gloo rehearsals of the N > 1 path on a box with fewer GPUs
+    than ranks, ``HIVE_DIST_BACKEND=gloo``): collectives then go through host copies.  RCCL (backend "nccl") never does."""
+    return dist.is_initialized() and dist.get_backend() == "gloo"
+
+
+def _reduce_scatter(out, inp):
+    if _host_staged() and inp.is_cuda:
+        o, i = out.cpu(), inp.cpu()
+        dist.reduce_scatter_tensor(o, i, op=dist.ReduceOp.SUM)
+        out.copy_(o)
+    else:
+        dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.SUM)
+
+
+def _all_gather(out, inp):
+    if _host_staged() and inp.is_cuda:
+        o = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(o, inp.cpu())
+        out.copy_(o)
+    else:
+        dist.all_gather_into_tensor(out, inp)
 
 
 class VoxelPartition:
@@ -92,7 +116,7 @@ def reduce_scatter_planes(accum, part):
         out.copy_(accum)
         return out
     for p in range(accum.shape[0]):
-        dist.reduce_scatter_tensor(out[p], accum[p], op=dist.ReduceOp.SUM)
+        _reduce_scatter(out[p], accum[p])
     return out
 
 
@@ -100,7 +124,7 @@ def all_gather_shares(full, part):
     """full: [part.padded] with this rank's share already in place at [first, first + chunk): fills in everyone else's."""
     assert full.dim() == 1 and full.numel() == part.padded
     if part.world > 1:
-        dist.all_gather_into_tensor(full, full[part.first:part.first + part.chunk])
+        _all_gather(full, full[part.first:part.first + part.chunk].clone() if _host_staged() else full[part.first:part.first + part.chunk])
     return full
 
 
@@ -154,7 +178,7 @@ def allgather_frames(local, counts):
     padded = torch.zeros((most,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     padded[:local.shape[0]].copy_(local)
     gathered = torch.empty((world * most,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(gathered, padded)
+    _all_gather(gathered, padded)
     if all(c == most for c in counts):
         return gathered
     return torch.cat([gathered[r * most:r * most + counts[r]] for r in range(world)], dim=0)
@@ -171,7 +195,7 @@ def allgather_slabs(slab, x_ranges, row_elems):
     padded = torch.zeros(most, dtype=flat.dtype, device=flat.device)
     padded[:flat.numel()].copy_(flat)
     gathered = torch.empty(world * most, dtype=flat.dtype, device=flat.device)
-    dist.all_gather_into_tensor(gathered, padded)
+    _all_gather(gathered, padded)
     return torch.cat([gathered[r * most:r * most + (x_ranges[r][1] - x_ranges[r][0]) * row_elems] for r in range(world)])
 
 
