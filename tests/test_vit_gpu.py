@@ -191,29 +191,34 @@ def test_vit_forward_matches_fp32_blocks(gpu_ctx):
 
 
 def test_dpt_hip_engine_matches_torch_engine(gpu_ctx):
-    """Whole DPT-Hybrid (random weights): engine='hip' vs engine='torch' in bf16, and vs fp32."""
+    """Whole DPT-Hybrid at a small size (96 x 128), seeded non-degenerate weights (tests/dpt_weights.py): engine='hip' against
+    the float32 model and against PyTorch's own bf16 operators, in millimetres of depth; and the device hand-off arithmetic
+    of the reference (uint16 mm truncation, metres, > max_depth -> 0) bit for bit on the depth the engine produced.
+    (tests/test_dpt_gpu.py holds the per-stage comparison at the benchmark's 480 x 640.)"""
     import torch
+    from dpt_weights import seeded_init
     from hive_amd.dpt.models import DPTDepthModel
-    torch.manual_seed(4)
-    ref32 = DPTDepthModel(path=None, scale=0.000305, shift=0.1378, invert=True, engine="torch").eval().cuda()
+    ref32 = DPTDepthModel(path=None, scale=0.000305, shift=0.1378, invert=True, engine="torch").eval()
+    seeded_init(ref32, seed=4)
     hip = DPTDepthModel(path=None, scale=0.000305, shift=0.1378, invert=True, engine="hip").eval()
     hip.load_state_dict(ref32.state_dict())
-    hip = hip.to(torch.bfloat16).cuda()
+    hip = hip.to(memory_format=torch.channels_last).to(torch.bfloat16).cuda()
     tor = DPTDepthModel(path=None, scale=0.000305, shift=0.1378, invert=True, engine="torch").eval()
     tor.load_state_dict(ref32.state_dict())
-    tor = tor.to(torch.bfloat16).cuda()
-    x = torch.rand(2, 3, 96, 128, device="cuda") * 2 - 1
+    tor = tor.to(memory_format=torch.channels_last).to(torch.bfloat16).cuda()
+    ref32 = ref32.cuda()
+    x = (torch.rand(2, 3, 96, 128, device="cuda") * 2 - 1).bfloat16().float()
+    xb = x.bfloat16().contiguous(memory_format=torch.channels_last)
     with torch.no_grad():
         d32 = ref32(x)
-        d_hip, mm, m = hip(x.bfloat16().contiguous(memory_format=torch.channels_last), handoff=(10.0,))
-        d_tor, mm_t, m_t = tor(x.bfloat16().contiguous(memory_format=torch.channels_last), handoff=(10.0,))
+        d_hip, mm, m = hip(xb, handoff=(10.0,))
+        d_tor, mm_t, m_t = tor(xb, handoff=(10.0,))
     assert d_hip.shape == (2, 96, 128) and d_hip.dtype == torch.float32 and torch.isfinite(d_hip).all()
-    # bf16 network, f32 tail: compare the inverse depth (the network's own output) relative to its range.
-    # Tolerance: 12 bf16 transformer blocks + ~60 bf16 convolutions; 5 % of the output range.
-    inv = lambda d: (1.0 / d - 0.1378) / 0.000305
-    span = (inv(d32).max() - inv(d32).min()).item() + 1e-6
-    assert (inv(d_hip) - inv(d32)).abs().max().item() / span < 0.05
-    assert (inv(d_hip) - inv(d_tor)).abs().max().item() / span < 0.05
+    assert float(d32.max() - d32.min()) > 2.0, "seeded weights must give a depth range of metres"
+    med = lambda a, b: float(((a - b).abs() * 1000.0).flatten().median())
+    e_hip, e_tor = med(d_hip, d32), med(d_tor, d32)
+    assert e_hip <= 25.0, f"HIP engine vs float32: median {e_hip:.1f} mm"
+    assert e_hip <= 1.3 * e_tor + 2.0, f"HIP engine ({e_hip:.1f} mm) must not be less accurate than PyTorch's bf16 operators ({e_tor:.1f} mm)"
     # device hand-off == reference arithmetic on the same f32 depth: trunc(depth * 1000) -> uint16 -> / 1000 -> > 10 -> 0
     exp_mm = (d_hip * 1000.0).to(torch.int32)
     assert torch.equal(mm.to(torch.int32) & 0xFFFF, exp_mm)
