@@ -1,0 +1,319 @@
+// DPT-Hybrid as ONE C-ABI object: hive_dpt_create / hive_dpt_forward / hive_dpt_destroy.
+//
+// Replaces `dpt.models.DPTDepthModel.forward` of the reference's (absent) third_party/dpt + timm==0.5.4 as HIVE calls it
+// (/root/reference/hive/dataset_adaptors.py:1366-1374, 1419) together with the pre- and post-processing around it
+// (:1407-1417 `/ 255`, NormalizeImage(0.5, 0.5); :1432-1433 uint16 millimetres; hive/io.py:1032-1039 metres, > max_depth -> 0):
+// uint8 frames in HBM -> depth maps in HBM, no PyTorch in between.  Pure orchestration: every layer is one of the library's own
+// kernels (csrc/stem.hip, conv.hip, dpt_ops.hip, vit.hip, dpt_head.hip); this file adds the two token-shuffling kernels and the
+// activation arena.  The network's structure (module tree of isl-org/DPT `DPT` with the `vitb_rn50_384` backbone):
+//   stem (7x7/2 conv, GroupNorm+ReLU, max pool) -> ResNetV2 stages 3 / 4 / 9 bottlenecks (hooks: stage 0 -> layer_1, stage 1 ->
+//   layer_2) -> 1x1 patch projection + class token + position embedding -> 12 ViT blocks (hooks 8, 11) -> "project" readout ->
+//   1x1 (and 3x3/2) reassemble convs -> layer{1..4}_rn -> RefineNet fusion 4..1 -> depth head -> 1 / (scale x + shift).
+#include "hive_internal.hpp"
+
+#include <algorithm>
+#include <map>
+#include <string>
+
+typedef __bf16 bf16;
+
+namespace {
+
+// tokens[b][0] = cls + pos[0];  tokens[b][1 + i] = patch[b][i] + pos[1 + i]   (bf16, D % 8 == 0; the adds in float, one rounding)
+__global__ __launch_bounds__(256) void assemble_tokens_kernel(const bf16 *__restrict__ patch, const bf16 *__restrict__ cls, const bf16 *__restrict__ pos,
+                                                              bf16 *__restrict__ tokens, int B, int n_patch, int D) {
+    const int dv = D / 8;
+    const long long total = (long long)B * (n_patch + 1) * dv;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % dv) * 8;
+        const long long row = i / dv;
+        const int t = (int)(row % (n_patch + 1)), b = (int)(row / (n_patch + 1));
+        const bf16 *src = t == 0 ? cls + c : patch + ((size_t)b * n_patch + (t - 1)) * D + c;
+        const uint4 ra = *reinterpret_cast<const uint4 *>(src), rp = *reinterpret_cast<const uint4 *>(pos + (size_t)t * D + c);
+        const bf16 *a = reinterpret_cast<const bf16 *>(&ra), *p = reinterpret_cast<const bf16 *>(&rp);
+        bf16 o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (bf16)((float)a[j] + (float)p[j]);
+        *reinterpret_cast<uint4 *>(tokens + (size_t)row * D + c) = *reinterpret_cast<const uint4 *>(o);
+    }
+}
+
+// "project" readout input: out[b][i] = concat(tokens[b][1 + i], tokens[b][0])  -> [B * n_patch][2 D]
+__global__ __launch_bounds__(256) void readout_concat_kernel(const bf16 *__restrict__ tokens, bf16 *__restrict__ out, int B, int n_patch, int D) {
+    const int dv = D / 8;
+    const long long total = (long long)B * n_patch * 2 * dv;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % (2 * dv));
+        const long long row = i / (2 * dv);
+        const int b = (int)(row / n_patch), t = (int)(row % n_patch);
+        const bf16 *src = c < dv ? tokens + ((size_t)b * (n_patch + 1) + 1 + t) * D + c * 8 : tokens + (size_t)b * (n_patch + 1) * D + (c - dv) * 8;
+        *reinterpret_cast<uint4 *>(out + (size_t)row * 2 * D + c * 8) = *reinterpret_cast<const uint4 *>(src);
+    }
+}
+
+}  // namespace
+
+struct hive_dpt {
+    hive_ctx *ctx = nullptr;
+    hive_dpt_config cfg{};
+    std::map<std::string, const void *> w;
+    hive_vit *vit = nullptr;
+    void *arena = nullptr;
+    size_t arena_bytes = 0, arena_used = 0;
+    float *d_head_b0 = nullptr;  // f32 copy of output_conv[0].bias for the fused head
+
+    const void *get(const std::string &name) const {
+        auto it = w.find(name);
+        return it == w.end() ? nullptr : it->second;
+    }
+    bf16 *alloc(size_t elems) {  // bump allocation in the activation arena (sized by a dry run before the first launch)
+        const size_t bytes = (elems * sizeof(bf16) + 255) & ~(size_t)255;
+        bf16 *p = arena ? (bf16 *)((char *)arena + arena_used) : nullptr;
+        arena_used += bytes;
+        return p;
+    }
+};
+
+namespace {
+
+struct Map {  // a channels-last activation [N][H][W][C]
+    bf16 *p;
+    int H, W, C;
+};
+
+#define DPT_TRY(expr)              \
+    do {                           \
+        int _rc = (expr);          \
+        if (_rc) return _rc;       \
+    } while (0)
+
+// One forward.  dry = true only walks the allocation sequence (arena sizing); the launches are skipped.
+int run_forward(hive_dpt *d, bool dry, const uint8_t *d_rgb, int B, int H, int W, const void *d_pos, float *d_depth, float max_depth,
+                uint16_t *d_mm, float *d_m) {
+    hive_ctx *ctx = d->ctx;
+    const std::string bb = "pretrained.model.patch_embed.backbone.";
+    auto need = [&](const std::string &n, const void **out) -> int {
+        *out = d->get(n);
+        if (!*out) return hive_fail(ctx, HIVE_ERR_INVALID, "hive_dpt: tensor '%s' missing from the table", n.c_str());
+        return HIVE_OK;
+    };
+    auto same_out = [](int i, int s) { return (i + s - 1) / s; };
+    auto conv = [&](const Map &x, const std::string &wname, const char *bias_name, int cout, int k, int stride, bool same_pad, int relu, const bf16 *res1,
+                    const bf16 *res2, bool want_relu_copy, Map *out, Map *out_relu) -> int {
+        int pt, pl, oh, ow;
+        if (same_pad) {  // timm StdConv2dSame: TensorFlow "SAME", the odd pixel at the bottom / right
+            oh = same_out(x.H, stride);
+            ow = same_out(x.W, stride);
+            pt = std::max((oh - 1) * stride + k - x.H, 0) / 2;
+            pl = std::max((ow - 1) * stride + k - x.W, 0) / 2;
+        } else {  // nn.Conv2d(padding = k / 2)
+            pt = pl = k / 2;
+            oh = (x.H + 2 * pt - k) / stride + 1;
+            ow = (x.W + 2 * pl - k) / stride + 1;
+        }
+        *out = Map{d->alloc((size_t)B * oh * ow * cout), oh, ow, cout};
+        if (out_relu) *out_relu = Map{want_relu_copy ? d->alloc((size_t)B * oh * ow * cout) : nullptr, oh, ow, cout};
+        if (dry) return HIVE_OK;
+        const void *wp, *bp = nullptr;
+        DPT_TRY(need(wname, &wp));
+        if (bias_name) DPT_TRY(need(bias_name, &bp));
+        return hive_nhwc_conv(ctx, x.p, HIVE_BF16, B, x.H, x.W, x.C, cout, k, stride, pt, pl, oh, ow, wp, bp, relu, res1, res2, out->p,
+                              out_relu ? out_relu->p : nullptr);
+    };
+    auto group_norm = [&](const Map &x, const std::string &prefix, const bf16 *residual, int relu, Map *out) -> int {
+        *out = Map{d->alloc((size_t)B * x.H * x.W * x.C), x.H, x.W, x.C};
+        if (dry) return HIVE_OK;
+        const void *g, *b;
+        DPT_TRY(need(prefix + ".weight", &g));
+        DPT_TRY(need(prefix + ".bias", &b));
+        return hive_nhwc_group_norm(ctx, x.p, HIVE_BF16, B, x.H * x.W, x.C, 32, g, b, d->cfg.gn_eps, residual, relu, out->p);
+    };
+
+    // ---- pre-processing + ResNetV2 stem -----------------------------------------------------------------------------------
+    bf16 *xin = d->alloc((size_t)B * H * W * 3);
+    Map s0{d->alloc((size_t)B * same_out(H, 2) * same_out(W, 2) * 64), same_out(H, 2), same_out(W, 2), 64};
+    if (!dry) {
+        DPT_TRY(hive_dpt_preprocess(ctx, d_rgb, (int64_t)B * H * W * 3, 0.5f, 0.5f, HIVE_BF16, xin));
+        const void *sw;
+        DPT_TRY(need(bb + "stem.conv.weight", &sw));
+        DPT_TRY(hive_resnet_stem_conv(ctx, xin, HIVE_BF16, B, H, W, sw, s0.p));
+    }
+    Map s1, feat;
+    DPT_TRY(group_norm(s0, bb + "stem.norm", nullptr, 1, &s1));
+    feat = Map{d->alloc((size_t)B * same_out(s1.H, 2) * same_out(s1.W, 2) * 64), same_out(s1.H, 2), same_out(s1.W, 2), 64};
+    if (!dry) DPT_TRY(hive_nhwc_maxpool3x3s2(ctx, s1.p, HIVE_BF16, B, s1.H, s1.W, 64, feat.p));
+
+    // ---- ResNetV2 stages: non pre-activation bottlenecks, GroupNorm behind every convolution ------------------------------
+    const int depths[3] = {3, 4, 9}, chans[3] = {256, 512, 1024};
+    Map hook[2];
+    for (int s = 0; s < 3; ++s) {
+        for (int blk = 0; blk < depths[s]; ++blk) {
+            const std::string pre = bb + "stages." + std::to_string(s) + ".blocks." + std::to_string(blk) + ".";
+            const int cout = chans[s], mid = cout / 4, stride = (blk == 0 && s > 0) ? 2 : 1;
+            Map shortcut = feat, t, u;
+            if (blk == 0) {
+                DPT_TRY(conv(feat, pre + "downsample.conv.weight", nullptr, cout, 1, stride, true, 0, nullptr, nullptr, false, &t, nullptr));
+                DPT_TRY(group_norm(t, pre + "downsample.norm", nullptr, 0, &shortcut));
+            }
+            DPT_TRY(conv(feat, pre + "conv1.weight", nullptr, mid, 1, 1, true, 0, nullptr, nullptr, false, &t, nullptr));
+            DPT_TRY(group_norm(t, pre + "norm1", nullptr, 1, &u));
+            DPT_TRY(conv(u, pre + "conv2.weight", nullptr, mid, 3, stride, true, 0, nullptr, nullptr, false, &t, nullptr));
+            DPT_TRY(group_norm(t, pre + "norm2", nullptr, 1, &u));
+            DPT_TRY(conv(u, pre + "conv3.weight", nullptr, cout, 1, 1, true, 0, nullptr, nullptr, false, &t, nullptr));
+            DPT_TRY(group_norm(t, pre + "norm3", shortcut.p, 1, &feat));  // relu(norm3(.) + shortcut)
+        }
+        if (s < 2) hook[s] = feat;
+    }
+    const Map layer_1 = hook[0], layer_2 = hook[1];
+
+    // ---- patch projection, tokens, ViT blocks, readout ------------------------------------------------------------------------
+    const int gh = feat.H, gw = feat.W, n_patch = gh * gw, N = n_patch + 1, D = 768;
+    Map pe;
+    DPT_TRY(conv(feat, "pretrained.model.patch_embed.proj.weight", "pretrained.model.patch_embed.proj.bias", D, 1, 1, false, 0, nullptr, nullptr, false, &pe,
+                 nullptr));
+    bf16 *tokens = d->alloc((size_t)B * N * D), *tap3 = d->alloc((size_t)B * N * D), *tap4 = d->alloc((size_t)B * N * D);
+    bf16 *cat = d->alloc((size_t)B * n_patch * 2 * D);
+    Map map3{d->alloc((size_t)B * n_patch * D), gh, gw, D}, map4{d->alloc((size_t)B * n_patch * D), gh, gw, D};
+    if (!dry) {
+        const void *cls;
+        DPT_TRY(need("pretrained.model.cls_token", &cls));
+        const int blocks = (int)std::min<long long>(((long long)B * N * D / 8 + 255) / 256, (long long)ctx->num_cus * 16);
+        hipLaunchKernelGGL(assemble_tokens_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const bf16 *)pe.p, (const bf16 *)cls, (const bf16 *)d_pos, tokens, B,
+                           n_patch, D);
+        HIVE_CHECK_HIP(ctx, hipGetLastError());
+        const int taps[2] = {8, 11};
+        void *tap_out[2] = {tap3, tap4};
+        DPT_TRY(hive_vit_forward(d->vit, tokens, B, N, taps, 2, tap_out));
+        const bf16 *tap[2] = {tap3, tap4};
+        Map *maps[2] = {&map3, &map4};
+        for (int r = 0; r < 2; ++r) {
+            hipLaunchKernelGGL(readout_concat_kernel, dim3(blocks), dim3(256), 0, ctx->stream, tap[r], cat, B, n_patch, D);
+            HIVE_CHECK_HIP(ctx, hipGetLastError());
+            const std::string pre = std::string("pretrained.act_postprocess") + (r == 0 ? "3" : "4") + ".0.project.0.";
+            const void *rw, *rb;
+            DPT_TRY(need(pre + "weight", &rw));
+            DPT_TRY(need(pre + "bias", &rb));  // float32
+            DPT_TRY(hive_vit_linear(ctx, cat, rw, (const float *)rb, nullptr, maps[r]->p, B * n_patch, D, 2 * D, 1 /* GELU */));
+        }
+    }
+    Map layer_3, layer_4, t4;
+    DPT_TRY(conv(map3, "pretrained.act_postprocess3.3.weight", "pretrained.act_postprocess3.3.bias", D, 1, 1, false, 0, nullptr, nullptr, false, &layer_3, nullptr));
+    DPT_TRY(conv(map4, "pretrained.act_postprocess4.3.weight", "pretrained.act_postprocess4.3.bias", D, 1, 1, false, 0, nullptr, nullptr, false, &t4, nullptr));
+    DPT_TRY(conv(t4, "pretrained.act_postprocess4.4.weight", "pretrained.act_postprocess4.4.bias", D, 3, 2, false, 0, nullptr, nullptr, false, &layer_4, nullptr));
+
+    // ---- decoder: layerN_rn, four RefineNet fusion blocks --------------------------------------------------------------------
+    auto refinenet = [&](int n, const Map *path, const Map &lrn, const Map &lrn_relu, Map *out) -> int {
+        const std::string pre = "scratch.refinenet" + std::to_string(n) + ".";
+        Map o = lrn, o_relu = lrn_relu, t;
+        if (path) {  // output = path + resConfUnit1(layer_rn): conv2(relu(conv1(relu(x)))) + x + path, and its ReLU for the next unit
+            DPT_TRY(conv(lrn_relu, pre + "resConfUnit1.conv1.weight", (pre + "resConfUnit1.conv1.bias").c_str(), 256, 3, 1, false, 1, nullptr, nullptr, false, &t,
+                         nullptr));
+            DPT_TRY(conv(t, pre + "resConfUnit1.conv2.weight", (pre + "resConfUnit1.conv2.bias").c_str(), 256, 3, 1, false, 0, lrn.p, path->p, true, &o, &o_relu));
+        }
+        Map u, low;
+        DPT_TRY(conv(o_relu, pre + "resConfUnit2.conv1.weight", (pre + "resConfUnit2.conv1.bias").c_str(), 256, 3, 1, false, 1, nullptr, nullptr, false, &t, nullptr));
+        DPT_TRY(conv(t, pre + "resConfUnit2.conv2.weight", (pre + "resConfUnit2.conv2.bias").c_str(), 256, 3, 1, false, 0, o.p, nullptr, false, &u, nullptr));
+        // the 1x1 out_conv commutes with the bilinear interpolation: it runs on a quarter of the pixels, its bias is added on load
+        DPT_TRY(conv(u, pre + "out_conv.weight", nullptr, 256, 1, 1, false, 0, nullptr, nullptr, false, &low, nullptr));
+        *out = Map{d->alloc((size_t)B * 4 * low.H * low.W * 256), 2 * low.H, 2 * low.W, 256};
+        if (dry) return HIVE_OK;
+        const void *ob;
+        DPT_TRY(need(pre + "out_conv.bias", &ob));
+        return hive_nhwc_upsample2x(ctx, low.p, ob, HIVE_BF16, B, low.H, low.W, 256, out->p);
+    };
+    const Map *layers[4] = {&layer_1, &layer_2, &layer_3, &layer_4};
+    Map path{}, prev{};
+    for (int n = 4; n >= 1; --n) {
+        Map lrn, lrn_relu;
+        DPT_TRY(conv(*layers[n - 1], "scratch.layer" + std::to_string(n) + "_rn.weight", nullptr, 256, 3, 1, false, 0, nullptr, nullptr, true, &lrn, &lrn_relu));
+        DPT_TRY(refinenet(n, n == 4 ? nullptr : &prev, lrn, lrn_relu, &path));
+        prev = path;
+    }
+
+    // ---- depth head: conv 256 -> 128 (bias folded into the fused kernel), x2 upsample + conv 128 -> 32 + ReLU + 1x1 + ReLU + inversion
+    Map lo;
+    DPT_TRY(conv(path, "scratch.output_conv.0.weight", nullptr, 128, 3, 1, false, 0, nullptr, nullptr, false, &lo, nullptr));
+    if (dry) return HIVE_OK;
+    const void *w3;
+    DPT_TRY(need("scratch.output_conv.2.weight", &w3));  // [ky][kx][32][128]
+    HIVE_REQUIRE(ctx, 2 * lo.H == H && 2 * lo.W == W, "hive_dpt: frame size %d x %d must be a multiple of 32", H, W);
+    return hive_dpt_head_fused(ctx, lo.p, d->d_head_b0, HIVE_BF16, B, lo.H, lo.W, 128, 32, w3, d->cfg.head_b3, d->cfg.head_w1, d->cfg.head_b1,
+                               d->cfg.non_negative, d->cfg.invert, d->cfg.scale, d->cfg.shift, d_depth, 1.0f / 1000.0f, max_depth, d_mm, d_m);
+}
+
+}  // namespace
+
+extern "C" {
+
+int hive_dpt_create(hive_ctx *ctx, const hive_dpt_config *config, const hive_dpt_tensor *tensors, int n_tensors, hive_dpt **out) {
+    HIVE_ENTER(ctx);
+    if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
+    HIVE_REQUIRE(ctx, config && tensors && n_tensors > 0 && out, "hive_dpt_create: NULL argument");
+    HIVE_REQUIRE(ctx, config->backbone == 0, "hive_dpt_create: backbone %d (only 0 = vitb_rn50_384, the one HIVE instantiates)", config->backbone);
+    *out = nullptr;
+    hive_dpt *d = new hive_dpt();
+    d->ctx = ctx;
+    d->cfg = *config;
+    for (int i = 0; i < n_tensors; ++i)
+        if (tensors[i].name && tensors[i].data) d->w[tensors[i].name] = tensors[i].data;
+    // the ViT engine over the table's block weights
+    std::vector<hive_vit_block_weights> blocks(12);
+    const char *fields[12] = {"norm1.weight", "norm1.bias", "attn.qkv.weight", "attn.qkv.bias", "attn.proj.weight", "attn.proj.bias",
+                              "norm2.weight", "norm2.bias", "mlp.fc1.weight", "mlp.fc1.bias", "mlp.fc2.weight", "mlp.fc2.bias"};
+    for (int i = 0; i < 12; ++i) {
+        const void **dst = reinterpret_cast<const void **>(&blocks[i]);
+        for (int f = 0; f < 12; ++f) {
+            const std::string name = "pretrained.model.blocks." + std::to_string(i) + "." + fields[f];
+            dst[f] = d->get(name);
+            if (!dst[f]) {
+                int rc = hive_fail(ctx, HIVE_ERR_INVALID, "hive_dpt_create: tensor '%s' missing from the table", name.c_str());
+                delete d;
+                return rc;
+            }
+        }
+    }
+    int rc = hive_vit_create(ctx, 12, 768, 12, 3072, config->ln_eps, blocks.data(), &d->vit);
+    const void *b0 = d->get("scratch.output_conv.0.bias.f32");
+    if (!rc && !b0) rc = hive_fail(ctx, HIVE_ERR_INVALID, "hive_dpt_create: tensor 'scratch.output_conv.0.bias.f32' missing from the table");
+    if (rc) {
+        hive_dpt_destroy(d);
+        return rc;
+    }
+    d->d_head_b0 = (float *)b0;
+    *out = d;
+    return HIVE_OK;
+}
+
+int hive_dpt_forward(hive_dpt *d, const uint8_t *d_rgb, int B, int H, int W, const void *d_pos_embed, float *d_depth, float max_depth,
+                     uint16_t *d_out_mm, float *d_out_m) {
+    HIVE_ENTER(d ? d->ctx : nullptr);
+    if (!d) return hive_fail(nullptr, HIVE_ERR_INVALID, "dpt is NULL");
+    hive_ctx *ctx = d->ctx;
+    HIVE_REQUIRE(ctx, d_rgb && d_pos_embed && (d_depth || d_out_mm || d_out_m), "hive_dpt_forward: NULL argument");
+    HIVE_REQUIRE(ctx, B > 0 && H >= 32 && W >= 32 && H % 32 == 0 && W % 32 == 0, "hive_dpt_forward: frames must be a multiple of 32 (%d x %d x %d)", B, H, W);
+    // size the activation arena with a dry run of the same allocation sequence, then launch
+    void *arena = d->arena;
+    d->arena = nullptr;
+    d->arena_used = 0;
+    int rc = run_forward(d, true, d_rgb, B, H, W, d_pos_embed, d_depth, max_depth, d_out_mm, d_out_m);
+    d->arena = arena;
+    if (rc) return rc;
+    const size_t need = d->arena_used;
+    if ((rc = hive_reserve_device(ctx, &d->arena, &d->arena_bytes, need))) return rc;
+    d->arena_used = 0;
+    return run_forward(d, false, d_rgb, B, H, W, d_pos_embed, d_depth, max_depth, d_out_mm, d_out_m);
+}
+
+int hive_dpt_destroy(hive_dpt *d) {
+    if (!d) return HIVE_OK;
+    {
+        HIVE_ENTER(d->ctx);
+        (void)hipStreamSynchronize(d->ctx->stream);
+        if (d->vit) hive_vit_destroy(d->vit);
+        if (d->arena) (void)hipFree(d->arena);
+    }
+    delete d;
+    return HIVE_OK;
+}
+
+}  // extern "C"

@@ -108,8 +108,9 @@ class DepthFusionStream:
     frame-sharded multi-GPU fusion (``hive_amd.distributed``).
     """
 
-    def __init__(self, model, volume, cam_intr, max_depth=10.0, accumulate=False):
+    def __init__(self, model, volume, cam_intr, max_depth=10.0, accumulate=False, native=True):
         self.model = model
+        self.native = native  # run the network as one hive_dpt_forward call where it applies (bf16 hybrid, frame size % 32 == 0)
         self.volume = volume
         self.K = np.ascontiguousarray(cam_intr, dtype=np.float32)
         self.max_depth = float(max_depth)
@@ -122,6 +123,10 @@ class DepthFusionStream:
     @torch.no_grad()
     def depth(self, frames_u8):
         """[B, H, W, 3] uint8 (GPU) -> (depth_m f32 [B, H, W] after the hand-off, depth_mm int16-viewed-as-uint16)."""
+        if (self.native and self.dtype == torch.bfloat16 and frames_u8.shape[1] % 32 == 0 and frames_u8.shape[2] % 32 == 0
+                and getattr(self.model, "engine", None) == "hip" and self.model.pretrained.hybrid):
+            _, mm, m = self.model.forward_frames(frames_u8, max_depth=self.max_depth)  # ONE C-ABI call: hive_dpt_forward
+            return m, mm
         x = preprocess_on_device(frames_u8, self.dtype)
         _, mm, m = self.model(x, handoff=(self.max_depth,))
         return m, mm

@@ -265,6 +265,8 @@ class VisionTransformerHybrid(nn.Module):
 # ------------------------------------------------------------------------------------------------
 # DPT decoder
 class ProjectReadout(nn.Module):
+    engine = "torch"
+
     def __init__(self, in_features, start_index=1):
         super().__init__()
         self.start_index = start_index
@@ -272,7 +274,23 @@ class ProjectReadout(nn.Module):
 
     def forward(self, x):
         readout = x[:, 0].unsqueeze(1).expand_as(x[:, self.start_index:])
-        return self.project(torch.cat((x[:, self.start_index:], readout), -1))
+        cat = torch.cat((x[:, self.start_index:], readout), -1)
+        lin = self.project[0]
+        if (self.engine == "hip" and cat.is_cuda and cat.dtype == torch.bfloat16 and lin.weight.dtype == torch.bfloat16
+                and lin.out_features % 128 == 0 and lin.in_features % 64 == 0):
+            # Linear + GELU in the hand-written GEMM (bias and erf-GELU in its epilogue, one rounding): csrc/vit.hip
+            from hive_amd import _lib
+            key = (lin.bias.data_ptr(), lin.bias._version)
+            if getattr(self, "_bias32", (None,))[0] != key:
+                self._bias32 = (key, lin.bias.detach().float().contiguous())
+            b, n, k = cat.shape
+            cat = cat.contiguous()
+            out = torch.empty((b, n, lin.out_features), dtype=cat.dtype, device=cat.device)
+            ctx = _lib.default_context(cat.device.index or 0)
+            ctx.check(ctx.lib.hive_vit_linear(ctx.handle, cat.data_ptr(), lin.weight.data_ptr(), self._bias32[1].data_ptr(), None, out.data_ptr(),
+                                              b * n, lin.out_features, k, 1))
+            return out
+        return self.project(cat)
 
 
 class Transpose(nn.Module):
@@ -397,7 +415,7 @@ class DPT(nn.Module):
         self._vit_engine = None
         self._vit_stamp = None
         for m in self.modules():  # the fused channels-last glue kernels follow the engine choice
-            if isinstance(m, (GroupNormAct, FeatureFusionBlock, Interpolate, ResidualConvUnit, StdConv2dSame, MaxPool2dSame)):
+            if isinstance(m, (GroupNormAct, FeatureFusionBlock, Interpolate, ResidualConvUnit, StdConv2dSame, MaxPool2dSame, ProjectReadout)):
                 m.engine = engine
 
     # -- ViT encoder ---------------------------------------------------------------------------
@@ -549,6 +567,22 @@ class DPTDepthModel(DPT):
         self._vit_engine = None  # its packed copies of the encoder weights are stale now
         if missing:
             raise RuntimeError(f"checkpoint {path} lacks parameters: {missing[:8]}{'...' if len(missing) > 8 else ''}")
+
+    def native(self):
+        """The network as one C-ABI object (``hive_dpt_create``, csrc/dpt_net.hip): rebuilt when a parameter was replaced or
+        written.  bf16 hybrid models on the GPU only."""
+        from hive_amd.dpt.native import NativeDPT, parameter_stamp
+        cur = getattr(self, "_native", None)
+        if cur is None or cur.stamp != parameter_stamp(self):
+            if cur is not None:
+                cur.close()
+            self._native = cur = NativeDPT(self)
+        return cur
+
+    def forward_frames(self, frames_u8, max_depth=None):
+        """uint8 frames [B, H, W, 3] in HBM -> (depth, depth_mm, depth_m) through ``hive_dpt_forward``: pre-processing, the whole
+        network and the depth hand-off in one C-ABI call (H, W multiples of 32)."""
+        return self.native().forward(frames_u8, max_depth=max_depth)
 
     def forward_head_features(self, x):
         """Everything up to (and including) the ReLU before the last 1x1 convolution: [B, 32, h, w]."""

@@ -352,6 +352,47 @@ int hive_nhwc_conv(hive_ctx *ctx, const void *d_x, int dtype, int N, int H, int 
 int hive_resnet_stem_conv(hive_ctx *ctx, const void *d_x, int dtype, int N, int H, int W, const void *d_w, void *d_out);
 int hive_nhwc_maxpool3x3s2(hive_ctx *ctx, const void *d_x, int dtype, int N, int H, int W, int C, void *d_out);
 
+/* ---- the whole DPT-Hybrid network behind one handle ------------------------------------------------------------------------
+ * dpt.models.DPTDepthModel(path, scale, shift, invert, backbone="vitb_rn50_384", non_negative) + .forward(), with the frame
+ * pre-processing and the depth hand-off around it, as HIVE's estimate_depth_dpt uses them (hive/dataset_adaptors.py:1366-1374,
+ * 1407-1419, 1432-1433; hive/io.py:1032-1039): uint8 RGB frames in HBM -> depth maps in HBM.
+ *
+ * The weights come as a table of (name, device pointer).  Names are the parameter names of the published isl-org/DPT checkpoint
+ * (`dpt_hybrid_nyu-2ce69ec7.pt`); every tensor is bf16 unless noted:
+ *   pretrained.model.patch_embed.backbone.stem.conv.weight        [64][7][32]: STANDARDISED weights, (ky, (kx, c) padded 21 -> 32)
+ *   ...backbone.stem.norm.{weight,bias}, ...stages.S.blocks.B.{norm1,norm2,norm3,downsample.norm}.{weight,bias}     [C]
+ *   ...stages.S.blocks.B.{conv1,conv2,conv3,downsample.conv}.weight   [C_out][k][k][C_in]: STANDARDISED (timm StdConv2dSame, eps 1e-8)
+ *   pretrained.model.patch_embed.proj.{weight [768][1][1][1024], bias [768]},  pretrained.model.cls_token [768]
+ *   pretrained.model.blocks.I.{norm1,norm2}.{weight,bias} f32 [768]; attn.qkv.weight [2304][768], attn.qkv.bias f32; attn.proj.*;
+ *   mlp.fc1.weight [3072][768], mlp.fc1.bias f32; mlp.fc2.weight [768][3072], mlp.fc2.bias f32            (I = 0 .. 11)
+ *   pretrained.act_postprocess{3,4}.0.project.0.{weight [768][1536], bias f32 [768]}
+ *   pretrained.act_postprocess3.3.*, act_postprocess4.3.* ([768][1][1][768] + bias), act_postprocess4.4.* ([768][3][3][768] + bias)
+ *   scratch.layer{1..4}_rn.weight [256][3][3][C_in];  scratch.refinenet{1..4}.resConfUnit{1,2}.conv{1,2}.{weight [256][3][3][256], bias};
+ *   scratch.refinenet{1..4}.out_conv.{weight [256][1][1][256], bias}
+ *   scratch.output_conv.0.weight [128][3][3][256]; scratch.output_conv.0.bias.f32 (f32 [128]); scratch.output_conv.2.weight as
+ *   [ky][kx][32][128]; the last two layers' host values go in the config (head_b3 = output_conv.2.bias, head_w1 / head_b1 = output_conv.4).
+ * All convolution weights are [C_out][ky][kx][C_in] (= the PyTorch tensor in channels-last memory format).  The pointers must
+ * stay valid for the life of the handle. */
+typedef struct hive_dpt hive_dpt;
+typedef struct hive_dpt_tensor {
+    const char *name;
+    const void *data;
+} hive_dpt_tensor;
+typedef struct hive_dpt_config {
+    int backbone;                 /* 0 = vitb_rn50_384 (DPT-Hybrid: the one HIVE instantiates) */
+    float scale, shift;           /* depth = 1 / max(scale * x + shift, 1e-8) when invert */
+    int invert, non_negative;
+    float gn_eps, ln_eps;         /* 1e-5 (GroupNorm), 1e-6 (timm ViT LayerNorm) */
+    float head_b3[32], head_w1[32], head_b1;
+} hive_dpt_config;
+int hive_dpt_create(hive_ctx *ctx, const hive_dpt_config *config, const hive_dpt_tensor *tensors, int n_tensors, hive_dpt **out);
+/* d_rgb u8 [B][H][W][3] (H, W multiples of 32), d_pos_embed bf16 [(H/16)(W/16) + 1][768] = the position embedding resized to this
+ * token grid (dpt `_resize_pos_embed`: evaluated once per frame size by the host binding).  Outputs [B][H][W], any may be NULL (not
+ * all): d_depth f32 metres; d_out_mm = uint16(depth * 1000); d_out_m = mm / 1000 with > max_depth -> 0. */
+int hive_dpt_forward(hive_dpt *dpt, const uint8_t *d_rgb, int B, int H, int W, const void *d_pos_embed, float *d_depth, float max_depth,
+                     uint16_t *d_out_mm, float *d_out_m);
+int hive_dpt_destroy(hive_dpt *dpt);
+
 #ifdef __cplusplus
 }
 #endif

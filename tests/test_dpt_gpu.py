@@ -243,3 +243,28 @@ def test_engine_follows_weight_updates(gpu_ctx):
         d_c = fresh(x)
     assert _median_mm(d_a, d_b) > 100.0, "the two seeds must give different depth maps"
     assert _median_mm(d_b, d_c) <= 20.0, "stale packed parameters in the ViT engine after load_state_dict"
+
+
+def test_native_network_object_equals_python_orchestration(gpu_ctx):
+    """hive_dpt_create / forward / destroy (the whole DPT-Hybrid + pre-processing + depth hand-off behind ONE C-ABI call,
+    csrc/dpt_net.hip) against the same kernels orchestrated from Python layer by layer: bit-identical depth, millimetres and
+    metres (both paths are reproducible), at the benchmark's frame size and at a second size; rebuilt after a weight update."""
+    from hive_amd import depth as depth_mod
+    _, hip = _pair()
+    rng = np.random.default_rng(1)
+    for (b, h, w) in ((3, 480, 640), (2, 96, 160)):
+        frames = torch.from_numpy(rng.integers(0, 256, (b, h, w, 3), dtype=np.uint8)).cuda()
+        with torch.no_grad():
+            d_py, mm_py, m_py = hip(depth_mod.preprocess_on_device(frames, torch.bfloat16), handoff=(10.0,))
+            d_c, mm_c, m_c = hip.forward_frames(frames, max_depth=10.0)
+        assert d_c.shape == (b, h, w) and torch.isfinite(d_c).all()
+        assert torch.equal(d_c, d_py), f"depth differs by up to {float((d_c - d_py).abs().max()) * 1000:.3f} mm"
+        assert torch.equal(mm_c, mm_py) and torch.equal(m_c, m_py)
+    nat = hip.native()
+    assert hip.native() is nat, "the native object is cached while the parameters are unchanged"
+    with torch.no_grad():
+        hip.scratch.output_conv[4].bias.add_(50.0)
+        d2, _, _ = hip.forward_frames(frames, max_depth=10.0)
+    assert hip.native() is not nat and not torch.equal(d2, d_c), "a parameter update must rebuild the native network"
+    with pytest.raises(Exception):
+        hip.forward_frames(frames[:, :90], max_depth=10.0)  # 90 rows: not a multiple of 32
