@@ -21,7 +21,11 @@
 // Measured (tools/probe_conv3x3.py, 24 frames): 840-910 TFLOP/s on the 120 x 160 / 60 x 80 / 240 x 320 shapes (MIOpen on the same
 // tensors: 770-920), 500-580 at 30 x 40 (113 tiles for 256 CUs) and 140-160 at 15 x 20 (29 tiles).  Built, measured and taken
 // out again: a deep LDS ring (K-step 32, 3 / 4 / 5 stages of 32 KiB in flight, counted vmcnt) -- 725-780 TFLOP/s whatever the
-// depth, i.e. the fill latency is NOT what bounds the K-step, and the second barrier per 64 k costs 13 %.
+// depth, i.e. the fill latency is NOT what bounds the K-step, and the second barrier per 64 k costs 13 %.  What does bound it: a CU's
+// vector-memory path moves one 64-byte line per ~2.3 cycles (tools/ubench/gather.hip, ldsdma.hip), so the 64 KiB of a 256 x 256 x 64
+// stage take 2550+ cycles to arrive against 2048 cycles of MFMA -- per-workgroup clocks (tools/probe_gemm_stamps.py) show 2100 busy +
+// 800 waiting cycles per K-step.  Also tried and taken out: start delays that de-phase the persistent workgroups (so that their
+// epilogues' stores do not hit HBM together): no change where the delay is free (workgroups with one tile fewer), slower elsewhere.
 #include "hive_internal.hpp"
 #include "mfma_pipe.hpp"
 
@@ -50,57 +54,56 @@ struct ConvParams {
     int M;              // NB * Ho * Wo
 };
 
-// epilogue: a lane owns 4 consecutive output channels of one pixel; everything in f32, one rounding to bf16
+// epilogue: through the wave's 4 KiB of LDS (mfma_pipe.hpp staged_rows) so that the residual loads and the stores are 16 bytes
+// per lane on whole 128-byte lines; a lane gets 8 consecutive output channels (always the same ones) of one pixel; everything in
+// f32, one rounding
 template <int MT>
-__device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x4 (&acc)[4][MT], int m_base, int n_base, int fr, int fq) {
+__device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x4 (&acc)[4][MT], int m_base, int n_base, unsigned char *stage, int lane) {
+    const int n = n_base + (lane & 7) * 8;
+    float b[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
+        const bf16x8 bv = *reinterpret_cast<const bf16x8 *>(p.bias + n);
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-        const int n = n_base + nt * 16 + fq * 4;
-        float b[4] = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias) {
-            const bf16x4 bv = *reinterpret_cast<const bf16x4 *>(p.bias + n);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = (float)bv[j];
-        }
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int m = m_base + mt * 16 + fr;
-            if (m < p.M) {
-                const size_t o_off = (size_t)m * p.Cout + n;
-                float o[4] = {acc[nt][mt][0] + b[0], acc[nt][mt][1] + b[1], acc[nt][mt][2] + b[2], acc[nt][mt][3] + b[3]};
-                if (p.res1) {
-                    const bf16x4 rs = *reinterpret_cast<const bf16x4 *>(p.res1 + o_off);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] += (float)rs[j];
-                }
-                if (p.res2) {
-                    const bf16x4 rs = *reinterpret_cast<const bf16x4 *>(p.res2 + o_off);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] += (float)rs[j];
-                }
-                if (p.relu) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] = fmaxf(o[j], 0.0f);
-                }
-                bf16x4 ov;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) ov[j] = (bf16)o[j];
-                *reinterpret_cast<bf16x4 *>(p.out + o_off) = ov;
-                if (p.out_relu) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) ov[j] = (bf16)fmaxf(o[j], 0.0f);
-                    *reinterpret_cast<bf16x4 *>(p.out_relu + o_off) = ov;
-                }
-            }
-        }
+        for (int j = 0; j < 8; ++j) b[j] = (float)bv[j];
     }
+    hive_mfma::staged_rows<MT>(stage, acc, lane, [&](int r, int, const f32x4 &lo, const f32x4 &hi) {
+        const int m = m_base + r;
+        if (m >= p.M) return;
+        const size_t o_off = (size_t)m * p.Cout + n;
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = lo[j] + b[j], o[4 + j] = hi[j] + b[4 + j];
+        if (p.res1) {
+            const bf16x8 rs = *reinterpret_cast<const bf16x8 *>(p.res1 + o_off);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] += (float)rs[j];
+        }
+        if (p.res2) {
+            const bf16x8 rs = *reinterpret_cast<const bf16x8 *>(p.res2 + o_off);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] += (float)rs[j];
+        }
+        if (p.relu) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = fmaxf(o[j], 0.0f);
+        }
+        bf16x8 ov;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ov[j] = (bf16)o[j];
+        *reinterpret_cast<bf16x8 *>(p.out + o_off) = ov;
+        if (p.out_relu) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ov[j] = (bf16)fmaxf(o[j], 0.0f);
+            *reinterpret_cast<bf16x8 *>(p.out_relu + o_off) = ov;
+        }
+    });
 }
 
 constexpr int BK = 64;
 
 template <int TM, int TN>
 __global__ __launch_bounds__(512, 1) void conv_kernel(ConvParams p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // 2 stages x (A tile TM x 64, W tile TN x 64)
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // 2 stages x (A tile TM x 64, W tile TN x 64) + 8 x 4 KiB for the epilogue
     constexpr int A_GROUPS = TM / 8, A_PW = A_GROUPS / 8;  // 1 KiB groups of the A tile, and how many each wave stages
     constexpr int W_GROUPS = TN / 8, GROUPS = A_GROUPS + W_GROUPS, PER_WAVE = GROUPS / 8;
     constexpr int STAGE_BYTES = GROUPS * 1024;
@@ -209,14 +212,14 @@ __global__ __launch_bounds__(512, 1) void conv_kernel(ConvParams p) {
             hive_mfma::kstep64<MT, false>(a_t, w_t, wr * RW, wc * 64, fr, fq, acc, PER_WAVE, [&](int j) { issue_piece(T, buf ^ 1, is_tap, is_cc, j); });
             buf ^= 1;
         }
-        conv_epilogue<MT>(p, acc, em0 + wr * RW, en0 + wc * 64, fr, fq);
+        conv_epilogue<MT>(p, acc, em0 + wr * RW, en0 + wc * 64, lds + 2 * STAGE_BYTES + wave * 4096, lane);
         if (!has_next) break;
         tl += per_xcd;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the redundant last stage
 }
 
-constexpr int conv_lds(int tm, int tn) { return 2 * (tm / 8 + tn / 8) * 1024; }  // two stages of (A tile + W tile), 128-byte rows
+constexpr int conv_lds(int tm, int tn) { return 2 * (tm / 8 + tn / 8) * 1024 + hive_mfma::STAGED_ROWS_LDS; }  // two stages of (A tile + W tile), 128-byte rows; the epilogue's 8 x 4 KiB
 
 bool g_conv_attr_set[64] = {};
 

@@ -59,4 +59,39 @@ __device__ __forceinline__ void kstep64(const unsigned char *a_t, const unsigned
     for (int j = SLOTS; j < n_pieces; ++j) issue(j);  // more pieces than slots (narrow tiles)
 }
 
+// Epilogue of the SWAP = false accumulators through LDS.  In the MFMA layout a lane owns 4 consecutive W rows (output columns) of
+// one A row, so a direct store writes 16 rows x 32 bytes per wave-instruction, 8 bytes per lane.  A CU's vector-memory path takes a
+// wave-instruction every 40-47 cycles whatever its width (per-workgroup clocks, tools/probe_gemm_stamps.py: 23 000 cycles for the
+// 8 x 32 such stores of a 256 x 256 tile -- as long as 8 of the tile's 12 K-steps at K = 768), so the epilogue wants FEW, WIDE
+// instructions on whole lines.  Each wave turns one 16-row fragment row (16 x 64 f32 = 4 KiB) around in a PRIVATE 4 KiB of LDS:
+// ds_write_b128 in the MFMA layout, two ds_read_b128 with 8 lanes along a row; `finish(row, col, lo, hi)` then gets 8 consecutive
+// columns with the lanes of a row side by side: its 16-byte loads / stores cover 8 rows x 128 contiguous bytes per instruction
+// (16 stores per wave and tile instead of 32, 12 000 -> 6 000 cycles).
+// Image: 256-byte rows, 16-byte chunk c of row r at slot c ^ r (both the writes -- 8 consecutive rows at one chunk index -- and the
+// reads -- the four 16-lane groups of ds_read_b128 -- are conflict-free).  Wave-private, LDS operations of a wave execute in order:
+// no workgroup barrier.
+template <int MT, typename Acc, typename Finish>
+__device__ __forceinline__ void staged_rows(unsigned char *stage, const Acc &acc, int lane, Finish &&finish) {
+    const int fr = lane & 15, fq = lane >> 4;
+    const int rr = lane >> 3, c0 = 2 * (lane & 7);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) *reinterpret_cast<f32x4 *>(stage + fr * 256 + (((nt * 4 + fq) ^ fr) << 4)) = acc[nt][mt];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int r = 8 * j + rr;
+            const f32x4 lo = *reinterpret_cast<const f32x4 *>(stage + r * 256 + ((c0 ^ r) << 4));
+            const f32x4 hi = *reinterpret_cast<const f32x4 *>(stage + r * 256 + (((c0 + 1) ^ r) << 4));
+            finish(mt * 16 + r, c0 * 4, lo, hi);
+        }
+        __builtin_amdgcn_wave_barrier();  // the next fragment row's writes stay behind these reads
+    }
+}
+
+constexpr int STAGED_ROWS_LDS = 8 * 4096;  // 8 waves
+
 }  // namespace hive_mfma

@@ -142,6 +142,36 @@ __device__ __forceinline__ void stage_group(const bf16 *__restrict__ src, int ld
     __builtin_amdgcn_global_load_lds((const void *)g, (__attribute__((address_space(3))) void *)(tile + grp * 1024), 16, 0, 0);
 }
 
+// Epilogue of the A.W^T GEMM tiles (EPI_BIAS / _GELU / _RESIDUAL): bias, GELU or residual in f32, one rounding to bf16; through the
+// wave's 4 KiB of LDS (mfma_pipe.hpp staged_rows) so that the residual loads and the stores are 16 bytes per lane on whole lines.
+template <int EPI, int MT>
+__device__ __forceinline__ void gemm_store_rows(const GemmParams &p, const f32x4 (&acc)[4][MT], int m_base, int n_base, unsigned char *stage, int lane) {
+    const int n = n_base + (lane & 7) * 8;
+    const float4 b0 = *reinterpret_cast<const float4 *>(p.bias + n), b1 = *reinterpret_cast<const float4 *>(p.bias + n + 4);
+    hive_mfma::staged_rows<MT>(stage, acc, lane, [&](int r, int, const f32x4 &lo, const f32x4 &hi) {
+        const int m = m_base + r;
+        if (m >= p.M) return;
+        float o[8] = {lo[0] + b0.x, lo[1] + b0.y, lo[2] + b0.z, lo[3] + b0.w, hi[0] + b1.x, hi[1] + b1.y, hi[2] + b1.z, hi[3] + b1.w};
+        if (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) {
+                const f32x2 g = gelu_exact2(f32x2{o[j], o[j + 1]});
+                o[j] = g.x;
+                o[j + 1] = g.y;
+            }
+        }
+        if (EPI == EPI_BIAS_RESIDUAL) {
+            const bf16x8 rs = *reinterpret_cast<const bf16x8 *>(p.residual + (size_t)m * p.ldc + n);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] += (float)rs[j];
+        }
+        bf16x8 ov;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ov[j] = (bf16)o[j];
+        *reinterpret_cast<bf16x8 *>(p.C + (size_t)m * p.ldc + n) = ov;
+    });
+}
+
 // C tile = TM x 128, K-step 64, TM/32 waves (each a 64 x 64 sub-tile = 4 x 4 MFMA 16x16x32 accumulators), an
 // NST-stage LDS ring filled by LDS-DMA, ONE raw s_barrier per K-step.
 //   NST = 3: stages kt+1 and kt+2 in flight while kt is multiplied, counted s_waitcnt vmcnt (never 0 in the loop);
@@ -155,7 +185,7 @@ __device__ __forceinline__ void stage_group(const bf16 *__restrict__ src, int ld
 // EPI_QKV here means "v^T tile": orientation A.W^T and the transposed store; q|k columns use EPI_BIAS.
 template <int EPI, int TM, int NST>
 __global__ __launch_bounds__(TM * 2, 1) void gemm_kernel(GemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // NST stages x (A tile TM x 64, W tile 128 x 64)
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // NST stages x (A tile TM x 64, W tile 128 x 64) + 4 KiB per wave for the epilogue
     constexpr int NWAVES = TM / 32;
     constexpr int A_GROUPS = TM / 8, GROUPS = A_GROUPS + 16, PER_WAVE = GROUPS / NWAVES;
     constexpr int STAGE_BYTES = GROUPS * 1024;
@@ -213,36 +243,8 @@ __global__ __launch_bounds__(TM * 2, 1) void gemm_kernel(GemmParams p) {
     }
 
     // epilogue
-    if (!VT) {
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            const int n = n0 + wc * 64 + nt * 16 + fq * 4;
-            const float4 b = *reinterpret_cast<const float4 *>(p.bias + n);
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const int m = m0 + wr * 64 + mt * 16 + fr;
-                if (m < p.M) {
-                    float o[4] = {acc[nt][mt][0] + b.x, acc[nt][mt][1] + b.y, acc[nt][mt][2] + b.z, acc[nt][mt][3] + b.w};
-                    if (EPI == EPI_BIAS_GELU) {
-#pragma unroll
-                        for (int j = 0; j < 4; j += 2) {
-                            const f32x2 g = gelu_exact2(f32x2{o[j], o[j + 1]});
-                            o[j] = g.x;
-                            o[j + 1] = g.y;
-                        }
-                    }
-                    if (EPI == EPI_BIAS_RESIDUAL) {
-                        const bf16x4 rs = *reinterpret_cast<const bf16x4 *>(p.residual + (size_t)m * p.ldc + n);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) o[j] += (float)rs[j];
-                    }
-                    bf16x4 ov;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) ov[j] = (bf16)o[j];
-                    *reinterpret_cast<bf16x4 *>(p.C + (size_t)m * p.ldc + n) = ov;
-                }
-            }
-        }
+    if constexpr (!VT) {
+        gemm_store_rows<EPI, 4>(p, acc, m0 + wr * 64, n0 + wc * 64, lds + NST * STAGE_BYTES + wave * 4096, lane);
     } else {
         // v^T[b][h][c][token]: a lane owns 4 consecutive tokens (rows m) of one channel (col n)
 #pragma unroll
@@ -277,9 +279,21 @@ __global__ __launch_bounds__(TM * 2, 1) void gemm_kernel(GemmParams p) {
 // (the operand stream, not the MFMAs or LDS, bounds that one: DESIGN.md section 5.3).  Two 64-KiB LDS-DMA stages.
 constexpr int T256 = 256, T256_STAGE = 2 * T256 / 8 * 1024;
 
+#ifdef HIVE_GEMM_STAMPS  // tuning builds only (make stamps): per-workgroup phase clocks of gemm256_kernel, read back by tools/probe_gemm_stamps.py
+__device__ unsigned long long g_stamps[8 * 8192];
+extern "C" int hive_debug_read_stamps(void *host, size_t bytes) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), bytes, 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
+}
+#define HIVE_STAMP(i) do { if (tid == 0 && blockIdx.x < 8192) g_stamps[blockIdx.x * 8 + (i)] = clock64(); } while (0)
+#define HIVE_STAMP_ADD(i, v) do { if (tid == 0 && blockIdx.x < 8192) g_stamps[blockIdx.x * 8 + (i)] = (v); } while (0)
+#else
+#define HIVE_STAMP(i) do { } while (0)
+#define HIVE_STAMP_ADD(i, v) do { } while (0)
+#endif
+
 template <int EPI>
 __global__ __launch_bounds__(512, 1) void gemm256_kernel(GemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // 2 stages x (A tile 256 x 64, W tile 256 x 64)
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // 2 stages x (A tile 256 x 64, W tile 256 x 64) + 8 x 4 KiB for the epilogue
     constexpr int A_GROUPS = T256 / 8, GROUPS = 2 * A_GROUPS, PER_WAVE = GROUPS / 8;
     static_assert(EPI != EPI_QKV, "the transposed v^T store stays with the 128-row kernel (N = 768)");
     const int tid = threadIdx.x, lane = tid & 63;
@@ -306,47 +320,37 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(GemmParams p) {
         for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int KT = p.K / BK;
+    HIVE_STAMP(0);
 #pragma unroll
     for (int j = 0; j < PER_WAVE; ++j) issue_piece(0, 0, j);
     const int fr = lane & 15, fq = lane >> 4;
+#ifdef HIVE_GEMM_STAMPS
+    unsigned long long waited = 0;
+#endif
     for (int kt = 0; kt < KT; ++kt) {
+#ifdef HIVE_GEMM_STAMPS
+        const unsigned long long w0 = clock64();
+#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();  // everyone's stage kt landed; everyone finished reading stage kt - 1
+#ifdef HIVE_GEMM_STAMPS
+        if (kt == 0) HIVE_STAMP(1); else waited += clock64() - w0;
+#endif
         const int nk = min(kt + 1, KT - 1);  // next stage (past the end: the last one again), issued between the MFMA slots
         const unsigned char *a_t = lds + (kt & 1) * T256_STAGE, *w_t = a_t + A_GROUPS * 1024;
         hive_mfma::kstep64<8, false>(a_t, w_t, wr * 128, wc * 64, fr, fq, acc, PER_WAVE, [&](int j) { issue_piece(nk, (kt + 1) & 1, j); });
     }
+    HIVE_STAMP(2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the redundant last stage
+    HIVE_STAMP(3);
+    HIVE_STAMP_ADD(6, waited);
 
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-        const int n = n0 + wc * 64 + nt * 16 + fq * 4;
-        const float4 b = *reinterpret_cast<const float4 *>(p.bias + n);
-#pragma unroll
-        for (int mt = 0; mt < 8; ++mt) {
-            const int m = m0 + wr * 128 + mt * 16 + fr;
-            if (m < p.M) {
-                float o[4] = {acc[nt][mt][0] + b.x, acc[nt][mt][1] + b.y, acc[nt][mt][2] + b.z, acc[nt][mt][3] + b.w};
-                if (EPI == EPI_BIAS_GELU) {
-#pragma unroll
-                    for (int j = 0; j < 4; j += 2) {
-                        const f32x2 g = gelu_exact2(f32x2{o[j], o[j + 1]});
-                        o[j] = g.x;
-                        o[j + 1] = g.y;
-                    }
-                }
-                if (EPI == EPI_BIAS_RESIDUAL) {
-                    const bf16x4 rs = *reinterpret_cast<const bf16x4 *>(p.residual + (size_t)m * p.ldc + n);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] += (float)rs[j];
-                }
-                bf16x4 ov;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) ov[j] = (bf16)o[j];
-                *reinterpret_cast<bf16x4 *>(p.C + (size_t)m * p.ldc + n) = ov;
-            }
-        }
-    }
+    gemm_store_rows<EPI, 8>(p, acc, m0 + wr * 128, n0 + wc * 64, lds + 2 * T256_STAGE + wave * 4096, lane);
+    HIVE_STAMP(4);
+#ifdef HIVE_GEMM_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    HIVE_STAMP(5);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -599,11 +603,11 @@ static int launch_layernorm(hive_ctx *ctx, const bf16 *x, const float *g, const 
 }
 
 constexpr int GEMM_TM = 128, GEMM_NST = 2;
-constexpr size_t GEMM_LDS = (size_t)GEMM_NST * (GEMM_TM / 8 + 16) * 1024;
+constexpr size_t GEMM_LDS = (size_t)GEMM_NST * (GEMM_TM / 8 + 16) * 1024 + (GEMM_TM / 32) * 4096;  // the stages + 4 KiB per wave for the epilogue: 80 KiB, two workgroups per CU
 
 static int launch_gemm256(hive_ctx *ctx, int epi, const GemmParams &p) {
     const dim3 grid((unsigned)(((p.M + T256 - 1) / T256) * (p.N / T256))), block(512);
-    const size_t lds_bytes = 2 * T256_STAGE;
+    const size_t lds_bytes = 2 * T256_STAGE + hive_mfma::STAGED_ROWS_LDS;
     switch (epi) {
         case EPI_BIAS: hipLaunchKernelGGL((gemm256_kernel<EPI_BIAS>), grid, block, lds_bytes, ctx->stream, p); break;
         case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm256_kernel<EPI_BIAS_GELU>), grid, block, lds_bytes, ctx->stream, p); break;
@@ -658,9 +662,9 @@ static int ensure_gemm_attrs(hive_ctx *ctx) {
     HIVE_CHECK_HIP(ctx, (set_gemm_lds<EPI_BIAS_GELU>()));
     HIVE_CHECK_HIP(ctx, (set_gemm_lds<EPI_BIAS_RESIDUAL>()));
     HIVE_CHECK_HIP(ctx, (set_gemm_lds<EPI_QKV>()));
-    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)gemm256_kernel<EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * T256_STAGE));
-    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)gemm256_kernel<EPI_BIAS_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * T256_STAGE));
-    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)gemm256_kernel<EPI_BIAS_RESIDUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * T256_STAGE));
+    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)gemm256_kernel<EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * T256_STAGE + hive_mfma::STAGED_ROWS_LDS));
+    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)gemm256_kernel<EPI_BIAS_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * T256_STAGE + hive_mfma::STAGED_ROWS_LDS));
+    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)gemm256_kernel<EPI_BIAS_RESIDUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * T256_STAGE + hive_mfma::STAGED_ROWS_LDS));
     if (ctx->device < 64) g_gemm_attr_set[ctx->device] = true;
     return HIVE_OK;
 }
