@@ -52,13 +52,21 @@ struct ConvParams {
     int S, taps;        // kernel width (1 or 3), R * S
     int stride, pad_t, pad_l;  // input row of tap ky for output row oy: oy * stride + ky - pad_t
     int M;              // NB * Ho * Wo
+    float *gn_partial;  // GN kernels only: [M tile][2 images of the tile][sum, sum of squares][Cout] of the stored (rounded) outputs
 };
 
 // epilogue: through the wave's 4 KiB of LDS (mfma_pipe.hpp staged_rows) so that the residual loads and the stores are 16 bytes
 // per lane on whole 128-byte lines; a lane gets 8 consecutive output channels (always the same ones) of one pixel; everything in
 // f32, one rounding
-template <int MT>
-__device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x4 (&acc)[4][MT], int m_base, int n_base, unsigned char *stage, int lane) {
+//
+// GN (the ResNetV2 convolutions, each followed by a GroupNorm): the statistics pass of that GroupNorm is folded in.  The lane adds
+// the outputs it stores (after the rounding: the values the GroupNorm will read) and their squares per channel, separately for the
+// two images a tile of TM <= Ho Wo rows can touch (rows below / from `boundary`); the 8 lanes that share its channels are added by
+// xor-shuffles, the waves of the tile through LDS in wave order -- a fixed order, run-to-run identical -- and the tile's row of
+// `gn_partial` is written.  hive_nhwc_group_norm_stats (dpt_ops.hip) finishes from there: no pass over the tensor for statistics.
+template <int MT, bool GN>
+__device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x4 (&acc)[4][MT], int m_base, int n_base, unsigned char *stage, int lane,
+                                              int boundary, float (&gsum)[2][8], float (&gsq)[2][8]) {
     const int n = n_base + (lane & 7) * 8;
     float b[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (p.bias) {
@@ -91,6 +99,17 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x4 (&acc)[
 #pragma unroll
         for (int j = 0; j < 8; ++j) ov[j] = (bf16)o[j];
         *reinterpret_cast<bf16x8 *>(p.out + o_off) = ov;
+        if (GN) {
+            const bool second = m >= boundary;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float v = (float)ov[j], v0 = second ? 0.f : v, v1 = second ? v : 0.f;
+                gsum[0][j] += v0;
+                gsum[1][j] += v1;
+                gsq[0][j] += v0 * v0;
+                gsq[1][j] += v1 * v1;
+            }
+        }
         if (p.out_relu) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) ov[j] = (bf16)fmaxf(o[j], 0.0f);
@@ -101,7 +120,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x4 (&acc)[
 
 constexpr int BK = 64;
 
-template <int TM, int TN>
+template <int TM, int TN, bool GN>
 __global__ __launch_bounds__(512, 1) void conv_kernel(ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // 2 stages x (A tile TM x 64, W tile TN x 64) + 8 x 4 KiB for the epilogue
     constexpr int A_GROUPS = TM / 8, A_PW = A_GROUPS / 8;  // 1 KiB groups of the A tile, and how many each wave stages
@@ -212,7 +231,47 @@ __global__ __launch_bounds__(512, 1) void conv_kernel(ConvParams p) {
             hive_mfma::kstep64<MT, false>(a_t, w_t, wr * RW, wc * 64, fr, fq, acc, PER_WAVE, [&](int j) { issue_piece(T, buf ^ 1, is_tap, is_cc, j); });
             buf ^= 1;
         }
-        conv_epilogue<MT>(p, acc, em0 + wr * RW, en0 + wc * 64, lds + 2 * STAGE_BYTES + wave * 4096, lane);
+        unsigned char *stage = lds + 2 * STAGE_BYTES + wave * 4096;
+        float gsum[2][8], gsq[2][8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) gsum[0][j] = gsum[1][j] = gsq[0][j] = gsq[1][j] = 0.f;
+        const int hw = p.Ho * p.Wo, boundary = (em0 / hw + 1) * hw;  // first row of the tile's second image
+        conv_epilogue<MT, GN>(p, acc, em0 + wr * RW, en0 + wc * 64, stage, lane, boundary, gsum, gsq);
+        if (GN) {
+            // the 8 lanes with the same channels (lane bits 3..5), then the WM waves of the tile in wave order
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    float a = gsum[h][j], q = gsq[h][j];
+#pragma unroll
+                    for (int off = 8; off < 64; off <<= 1) {
+                        a += __shfl_xor(a, off);
+                        q += __shfl_xor(q, off);
+                    }
+                    gsum[h][j] = a;
+                    gsq[h][j] = q;
+                }
+            float *wsum = reinterpret_cast<float *>(stage);  // [image h][sum, sq][64 channels of this wave]
+            if (lane < 8) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        wsum[(h * 2 + 0) * 64 + lane * 8 + j] = gsum[h][j];
+                        wsum[(h * 2 + 1) * 64 + lane * 8 + j] = gsq[h][j];
+                    }
+            }
+            __syncthreads();
+            const int tile_m = em0 / TM;
+            for (int t = tid; t < 4 * TN; t += 512) {
+                const int hq = t / TN, ch = t - hq * TN, cw = ch >> 6, c = ch & 63;
+                float a = 0.f;
+#pragma unroll
+                for (int w = 0; w < WM; ++w) a += reinterpret_cast<const float *>(lds + 2 * STAGE_BYTES + (w * WN + cw) * 4096)[hq * 64 + c];
+                p.gn_partial[((size_t)tile_m * 4 + hq) * p.Cout + en0 + ch] = a;
+            }
+        }
         if (!has_next) break;
         tl += per_xcd;
     }
@@ -225,19 +284,25 @@ bool g_conv_attr_set[64] = {};
 
 int ensure_conv_attrs(hive_ctx *ctx) {
     if (ctx->device < 64 && g_conv_attr_set[ctx->device]) return HIVE_OK;
-    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)conv_kernel<256, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds(256, 256)));
-    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)conv_kernel<256, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds(256, 128)));
-    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)conv_kernel<256, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds(256, 64)));
-    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)conv_kernel<128, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds(128, 256)));
-    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)conv_kernel<128, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds(128, 128)));
+    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)conv_kernel<256, 256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds(256, 256)));
+    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)conv_kernel<256, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds(256, 256)));
+    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)conv_kernel<256, 128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds(256, 128)));
+    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)conv_kernel<256, 128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds(256, 128)));
+    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)conv_kernel<256, 64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds(256, 64)));
+    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)conv_kernel<256, 64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds(256, 64)));
+    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)conv_kernel<128, 256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds(128, 256)));
+    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)conv_kernel<128, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds(128, 256)));
+    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)conv_kernel<128, 128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds(128, 128)));
+    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)conv_kernel<128, 128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds(128, 128)));
     if (ctx->device < 64) g_conv_attr_set[ctx->device] = true;
     return HIVE_OK;
 }
 
 int launch_conv(hive_ctx *ctx, const char *what, const void *d_x, int dtype, int N, int H, int W, int C_in, int C_out, int R, int stride, int pad_t,
                        int pad_l, int Ho, int Wo, const void *d_w, const void *d_bias, int relu, const void *d_residual, const void *d_residual2,
-                       void *d_out, void *d_out_relu) {
+                       void *d_out, void *d_out_relu, void *d_gn_partial = nullptr, long long gn_partial_floats = 0, int *gn_tile_rows = nullptr) {
     HIVE_REQUIRE(ctx, d_x && d_w && d_out, "%s: NULL argument", what);
+    if (gn_tile_rows) *gn_tile_rows = 0;
     HIVE_REQUIRE(ctx, dtype == HIVE_BF16, "%s: bf16 only", what);
     HIVE_REQUIRE(ctx, N > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && (long long)N * H * W < (1ll << 31) && (long long)N * Ho * Wo < (1ll << 31),
                  "%s: bad sizes %d x %d x %d -> %d x %d", what, N, H, W, Ho, Wo);
@@ -274,20 +339,35 @@ int launch_conv(hive_ctx *ctx, const char *what, const void *d_x, int dtype, int
     const int tn = C_out % 256 == 0 ? 256 : (C_out % 128 == 0 ? 128 : 64);
     // 256 output pixels per tile, or 128 where that would leave CUs without a tile (30 x 40 and 15 x 20 maps: 113 / 29 tiles of 256)
     const int tm = (tn >= 128 && (long long)((p.M + 255) / 256) * (C_out / tn) < ctx->num_cus) ? 128 : 256;
+    // GroupNorm statistics from the epilogue: a tile may touch two images at most (tm <= Ho Wo); smaller maps keep the stand-alone pass
+    if (d_gn_partial && gn_tile_rows && (long long)Ho * Wo >= tm) {
+        HIVE_REQUIRE(ctx, (long long)((p.M + tm - 1) / tm) * 4 * C_out <= gn_partial_floats, "%s: gn_partial holds %lld floats, %lld needed", what,
+                     gn_partial_floats, (long long)((p.M + tm - 1) / tm) * 4 * C_out);
+        p.gn_partial = (float *)d_gn_partial;
+        *gn_tile_rows = tm;
+    }
     // persistent workgroups, one per CU, a multiple of 8 so that every XCD gets the same number
     const long long tiles = (long long)((p.M + tm - 1) / tm) * (C_out / tn);
     const dim3 grid((unsigned)std::min<long long>((tiles + 7) / 8 * 8, (long long)ctx->num_cus / 8 * 8));
     const size_t lds = (size_t)conv_lds(tm, tn);
+#define HIVE_CONV_LAUNCH(TM_, TN_)                                                                                   \
+    do {                                                                                                             \
+        if (p.gn_partial)                                                                                            \
+            hipLaunchKernelGGL((conv_kernel<TM_, TN_, true>), grid, dim3(512), lds, ctx->stream, p);                 \
+        else                                                                                                         \
+            hipLaunchKernelGGL((conv_kernel<TM_, TN_, false>), grid, dim3(512), lds, ctx->stream, p);                \
+    } while (0)
     if (tm == 256 && tn == 256)
-        hipLaunchKernelGGL((conv_kernel<256, 256>), grid, dim3(512), lds, ctx->stream, p);
+        HIVE_CONV_LAUNCH(256, 256);
     else if (tm == 256 && tn == 128)
-        hipLaunchKernelGGL((conv_kernel<256, 128>), grid, dim3(512), lds, ctx->stream, p);
+        HIVE_CONV_LAUNCH(256, 128);
     else if (tm == 256)
-        hipLaunchKernelGGL((conv_kernel<256, 64>), grid, dim3(512), lds, ctx->stream, p);
+        HIVE_CONV_LAUNCH(256, 64);
     else if (tn == 256)
-        hipLaunchKernelGGL((conv_kernel<128, 256>), grid, dim3(512), lds, ctx->stream, p);
+        HIVE_CONV_LAUNCH(128, 256);
     else
-        hipLaunchKernelGGL((conv_kernel<128, 128>), grid, dim3(512), lds, ctx->stream, p);
+        HIVE_CONV_LAUNCH(128, 128);
+#undef HIVE_CONV_LAUNCH
     HIVE_CHECK_HIP(ctx, hipGetLastError());
     return HIVE_OK;
 }
@@ -302,6 +382,18 @@ extern "C" int hive_nhwc_conv3x3(hive_ctx *ctx, const void *d_x, int dtype, int 
     HIVE_REQUIRE(ctx, C_out % 128 == 0, "nhwc_conv3x3: need C_out %% 128 == 0, got %d", C_out);
     HIVE_REQUIRE(ctx, d_out != d_x && d_out_relu != d_x, "nhwc_conv3x3: the output must not alias the input (3 x 3 halo)");
     return launch_conv(ctx, "nhwc_conv3x3", d_x, dtype, N, H, W, C_in, C_out, 3, 1, 1, 1, H, W, d_w, d_bias, relu, d_residual, d_residual2, d_out, d_out_relu);
+}
+
+extern "C" int64_t hive_nhwc_conv_gn_partial_floats(int64_t n_px, int C_out) { return (n_px / 128 + 1) * 4 * (int64_t)C_out; }
+
+extern "C" int hive_nhwc_conv_gn(hive_ctx *ctx, const void *d_x, int dtype, int N, int H, int W, int C_in, int C_out, int kernel, int stride, int pad_top,
+                                 int pad_left, int H_out, int W_out, const void *d_w, const void *d_bias, int relu, const void *d_residual,
+                                 const void *d_residual2, void *d_out, void *d_out_relu, void *d_gn_partial, int64_t gn_partial_floats, int *gn_tile_rows) {
+    HIVE_ENTER(ctx);
+    if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
+    HIVE_REQUIRE(ctx, d_gn_partial && gn_tile_rows, "nhwc_conv_gn: NULL argument");
+    return launch_conv(ctx, "nhwc_conv_gn", d_x, dtype, N, H, W, C_in, C_out, kernel, stride, pad_top, pad_left, H_out, W_out, d_w, d_bias, relu, d_residual,
+                       d_residual2, d_out, d_out_relu, d_gn_partial, gn_partial_floats, gn_tile_rows);
 }
 
 extern "C" int hive_nhwc_conv(hive_ctx *ctx, const void *d_x, int dtype, int N, int H, int W, int C_in, int C_out, int kernel, int stride, int pad_top,

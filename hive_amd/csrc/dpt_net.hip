@@ -79,6 +79,8 @@ namespace {
 struct Map {  // a channels-last activation [N][H][W][C]
     bf16 *p;
     int H, W, C;
+    float *gn = nullptr;  // GroupNorm statistics of the tensor, per tile of gn_tm rows, left by the convolution that wrote it
+    int gn_tm = 0;        // (hive_nhwc_conv_gn); 0: none, the GroupNorm makes its own pass
 };
 
 #define DPT_TRY(expr)              \
@@ -99,7 +101,7 @@ int run_forward(hive_dpt *d, bool dry, const uint8_t *d_rgb, int B, int H, int W
     };
     auto same_out = [](int i, int s) { return (i + s - 1) / s; };
     auto conv = [&](const Map &x, const std::string &wname, const char *bias_name, int cout, int k, int stride, bool same_pad, int relu, const bf16 *res1,
-                    const bf16 *res2, bool want_relu_copy, Map *out, Map *out_relu) -> int {
+                    const bf16 *res2, bool want_relu_copy, Map *out, Map *out_relu, bool gn_stats = false) -> int {
         int pt, pl, oh, ow;
         if (same_pad) {  // timm StdConv2dSame: TensorFlow "SAME", the odd pixel at the bottom / right
             oh = same_out(x.H, stride);
@@ -113,10 +115,15 @@ int run_forward(hive_dpt *d, bool dry, const uint8_t *d_rgb, int B, int H, int W
         }
         *out = Map{d->alloc((size_t)B * oh * ow * cout), oh, ow, cout};
         if (out_relu) *out_relu = Map{want_relu_copy ? d->alloc((size_t)B * oh * ow * cout) : nullptr, oh, ow, cout};
+        const int64_t gn_floats = gn_stats ? hive_nhwc_conv_gn_partial_floats((int64_t)B * oh * ow, cout) : 0;
+        if (gn_stats) out->gn = (float *)d->alloc((size_t)gn_floats * 2);
         if (dry) return HIVE_OK;
         const void *wp, *bp = nullptr;
         DPT_TRY(need(wname, &wp));
         if (bias_name) DPT_TRY(need(bias_name, &bp));
+        if (gn_stats)  // the ResNetV2 convolutions: the GroupNorm behind each gets its statistics from this epilogue
+            return hive_nhwc_conv_gn(ctx, x.p, HIVE_BF16, B, x.H, x.W, x.C, cout, k, stride, pt, pl, oh, ow, wp, bp, relu, res1, res2, out->p,
+                                     out_relu ? out_relu->p : nullptr, out->gn, gn_floats, &out->gn_tm);
         return hive_nhwc_conv(ctx, x.p, HIVE_BF16, B, x.H, x.W, x.C, cout, k, stride, pt, pl, oh, ow, wp, bp, relu, res1, res2, out->p,
                               out_relu ? out_relu->p : nullptr);
     };
@@ -126,7 +133,7 @@ int run_forward(hive_dpt *d, bool dry, const uint8_t *d_rgb, int B, int H, int W
         const void *g, *b;
         DPT_TRY(need(prefix + ".weight", &g));
         DPT_TRY(need(prefix + ".bias", &b));
-        return hive_nhwc_group_norm(ctx, x.p, HIVE_BF16, B, x.H * x.W, x.C, 32, g, b, d->cfg.gn_eps, residual, relu, out->p);
+        return hive_nhwc_group_norm_stats(ctx, x.p, HIVE_BF16, B, x.H * x.W, x.C, 32, g, b, d->cfg.gn_eps, residual, relu, out->p, x.gn, x.gn_tm);
     };
 
     // ---- pre-processing + ResNetV2 stem -----------------------------------------------------------------------------------
@@ -152,14 +159,14 @@ int run_forward(hive_dpt *d, bool dry, const uint8_t *d_rgb, int B, int H, int W
             const int cout = chans[s], mid = cout / 4, stride = (blk == 0 && s > 0) ? 2 : 1;
             Map shortcut = feat, t, u;
             if (blk == 0) {
-                DPT_TRY(conv(feat, pre + "downsample.conv.weight", nullptr, cout, 1, stride, true, 0, nullptr, nullptr, false, &t, nullptr));
+                DPT_TRY(conv(feat, pre + "downsample.conv.weight", nullptr, cout, 1, stride, true, 0, nullptr, nullptr, false, &t, nullptr, true));
                 DPT_TRY(group_norm(t, pre + "downsample.norm", nullptr, 0, &shortcut));
             }
-            DPT_TRY(conv(feat, pre + "conv1.weight", nullptr, mid, 1, 1, true, 0, nullptr, nullptr, false, &t, nullptr));
+            DPT_TRY(conv(feat, pre + "conv1.weight", nullptr, mid, 1, 1, true, 0, nullptr, nullptr, false, &t, nullptr, true));
             DPT_TRY(group_norm(t, pre + "norm1", nullptr, 1, &u));
-            DPT_TRY(conv(u, pre + "conv2.weight", nullptr, mid, 3, stride, true, 0, nullptr, nullptr, false, &t, nullptr));
+            DPT_TRY(conv(u, pre + "conv2.weight", nullptr, mid, 3, stride, true, 0, nullptr, nullptr, false, &t, nullptr, true));
             DPT_TRY(group_norm(t, pre + "norm2", nullptr, 1, &u));
-            DPT_TRY(conv(u, pre + "conv3.weight", nullptr, cout, 1, 1, true, 0, nullptr, nullptr, false, &t, nullptr));
+            DPT_TRY(conv(u, pre + "conv3.weight", nullptr, cout, 1, 1, true, 0, nullptr, nullptr, false, &t, nullptr, true));
             DPT_TRY(group_norm(t, pre + "norm3", shortcut.p, 1, &feat));  // relu(norm3(.) + shortcut)
         }
         if (s < 2) hook[s] = feat;

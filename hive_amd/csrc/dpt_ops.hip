@@ -48,7 +48,21 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const T *__restrict__ x
     const int p0 = slab * per, p1 = min(p0 + per, HW);
     float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const T *base = x + (size_t)n * HW * C + v * 8;
-    for (int p = p0 + pp; p < p1; p += PP) {
+    // four loads in flight per thread (one per trip left the kernel latency-bound at 3.6 TB/s); the adds keep the pixel order
+    int p = p0 + pp;
+    for (; p + 3 * PP < p1; p += 4 * PP) {
+        float f[4][8];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) load8(base + (size_t)(p + u * PP) * C, f[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                s[j] += f[u][j];
+                q[j] += f[u][j] * f[u][j];
+            }
+    }
+    for (; p < p1; p += PP) {
         float f[8];
         load8(base + (size_t)p * C, f);
 #pragma unroll
@@ -108,6 +122,45 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float *__restric
     }
 }
 
+// stage 2 when the producing convolution's epilogue already summed its tiles (csrc/conv.hip, GN): partial[tile][h][sum, sq][C] with
+// h = 0 for the rows of the tile's first image, 1 for the rows past that image's end (TM <= HW: two images at most).  Same
+// reduction as above over the tiles that overlap sample n.
+__global__ __launch_bounds__(256) void gn_finalize_tiles_kernel(const float *__restrict__ partial, int C, int G, int TM, int HW, float eps,
+                                                                float *__restrict__ stats, int total) {
+    __shared__ double red[8];
+    const int i = blockIdx.x;  // i = n * G + g
+    if (i >= total) return;
+    const int n = i / G, g = i % G, cpg = C / G;
+    const long long r0 = (long long)n * HW, r1 = r0 + HW - 1;
+    const int t0 = (int)(r0 / TM), nt = (int)(r1 / TM) - t0 + 1;
+    double s = 0.0, q = 0.0;
+    for (int e = threadIdx.x; e < nt * cpg; e += 256) {
+        const int t = t0 + e / cpg, c = e % cpg;
+        const int h = ((long long)t * TM) / HW == n ? 0 : 1;  // is n the image of the tile's first row?
+        const float *ps = partial + (((size_t)t * 2 + h) * 2) * C + g * cpg + c;
+        s += (double)ps[0];
+        q += (double)ps[C];
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        s += __shfl_xor(s, off);
+        q += __shfl_xor(q, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        red[threadIdx.x >> 6] = s;
+        red[4 + (threadIdx.x >> 6)] = q;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s = ((red[0] + red[1]) + red[2]) + red[3];
+        q = ((red[4] + red[5]) + red[6]) + red[7];
+        const double cnt = (double)HW * cpg;
+        const double mean = s / cnt;
+        const double var = fmax(q / cnt - mean * mean, 0.0);
+        stats[2 * i] = (float)mean;
+        stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
+
 // stage 3: y = (x - mean) * rstd * gamma + beta  [+ residual]  [ReLU].  grid (blocks, N)
 template <typename T>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const T *__restrict__ x, const T *__restrict__ gamma, const T *__restrict__ beta,
@@ -131,15 +184,11 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T *__restrict__ x, 
         }
     }
     const size_t off = (size_t)n * HW * C + v * 8;
-    for (int p = blockIdx.x * PP + pp; p < HW; p += gridDim.x * PP) {
-        float f[8];
-        load8(x + off + (size_t)p * C, f);
+    auto finish = [&](int p, float (&f)[8], const float (&r)[8]) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) f[j] = f[j] * a[j] + b[j];
         if (residual) {
             // the reference rounds the normalised value to the tensor type before the add (separate ops)
-            float r[8];
-            load8(residual + off + (size_t)p * C, r);
 #pragma unroll
             for (int j = 0; j < 8; ++j) f[j] = (float)(T)f[j] + r[j];
         }
@@ -148,6 +197,26 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T *__restrict__ x, 
             for (int j = 0; j < 8; ++j) f[j] = fmaxf(f[j], 0.f);
         }
         store8(out + off + (size_t)p * C, f);
+    };
+    // four pixels per trip: the loads of all four are in flight together (one per trip: 3.5 TB/s, latency-bound)
+    const int step = gridDim.x * PP;
+    int p = blockIdx.x * PP + pp;
+    for (; p + 3 * step < HW; p += 4 * step) {
+        float f[4][8], r[4][8];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) load8(x + off + (size_t)(p + u * step) * C, f[u]);
+        if (residual) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) load8(residual + off + (size_t)(p + u * step) * C, r[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) finish(p + u * step, f[u], r[u]);
+    }
+    for (; p < HW; p += step) {
+        float f[8], r[8];
+        load8(x + off + (size_t)p * C, f);
+        if (residual) load8(residual + off + (size_t)p * C, r);
+        finish(p, f, r);
     }
 }
 
@@ -160,18 +229,16 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T *__restrict__ x, 
 template <typename T>
 __global__ __launch_bounds__(256) void upsample2x_kernel(const T *__restrict__ in, const T *__restrict__ bias, T *__restrict__ out, int N, int H,
                                                          int W, int C) {
+    // grid (x-blocks over OW * C / 8, OH, N): no 64-bit index arithmetic per element (the linear-index form of round 1 spent more on
+    // its divisions than on the interpolation: 2.3 TB/s)
     const int VC = C >> 3;
     const int OH = 2 * H, OW = 2 * W;
-    const size_t total = (size_t)N * OH * OW * VC;
     const float sh = OH > 1 ? (float)(H - 1) / (float)(OH - 1) : 0.f;
     const float sw = OW > 1 ? (float)(W - 1) / (float)(OW - 1) : 0.f;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int v = (int)(i % VC);
-        size_t r = i / VC;
-        const int ox = (int)(r % OW);
-        r /= OW;
-        const int oy = (int)(r % OH);
-        const int n = (int)(r / OH);
+    const int oy = blockIdx.y, n = blockIdx.z;
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < OW * VC; t += gridDim.x * 256) {
+        const int ox = t / VC, v = t - ox * VC;
+        const size_t i = ((size_t)n * OH + oy) * OW * VC + t;
         const float fy = sh * (float)oy, fx = sw * (float)ox;
         const int y0 = (int)fy, x0 = (int)fx;
         const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
@@ -245,34 +312,54 @@ static bool pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
 
 extern "C" {
 
-int hive_nhwc_group_norm(hive_ctx *ctx, const void *d_x, int dtype, int N, int HW, int C, int G, const void *d_gamma,
-                         const void *d_beta, float eps, const void *d_residual, int relu, void *d_out) {
-    HIVE_ENTER(ctx);
-    if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
+static int group_norm_impl(hive_ctx *ctx, const void *d_x, int dtype, int N, int HW, int C, int G, const void *d_gamma, const void *d_beta, float eps,
+                           const void *d_residual, int relu, void *d_out, const void *d_gn_partial, int gn_tile_rows) {
     HIVE_REQUIRE(ctx, d_x && d_gamma && d_beta && d_out, "group_norm: NULL argument");
     HIVE_REQUIRE(ctx, N > 0 && HW > 0 && C >= 8 && C <= 2048 && pow2(C) && G > 0 && C % G == 0,
                  "group_norm: need C a power of two in [8, 2048] and C %% G == 0 (N=%d HW=%d C=%d G=%d)", N, HW, C, G);
     HIVE_REQUIRE(ctx, dtype == HIVE_BF16 || dtype == HIVE_F16, "group_norm: dtype must be HIVE_F16 or HIVE_BF16");
+    const bool from_tiles = d_gn_partial && gn_tile_rows > 0;
+    HIVE_REQUIRE(ctx, !from_tiles || gn_tile_rows <= HW, "group_norm_stats: tiles of %d rows on samples of %d", gn_tile_rows, HW);
     const int VC = C / 8, PP = 256 / VC;
     const int slabs = std::max(1, std::min(64, std::min(HW / (4 * PP) + 1, (ctx->num_cus * 8 + N - 1) / N)));
-    const size_t partial_floats = (size_t)N * slabs * 2 * C, stats_floats = (size_t)N * G * 2;
+    const size_t partial_floats = from_tiles ? 0 : (size_t)N * slabs * 2 * C, stats_floats = (size_t)N * G * 2;
     int rc = hive_reserve_device(ctx, &ctx->d_scratch, &ctx->scratch_bytes, (partial_floats + stats_floats) * sizeof(float));
     if (rc) return rc;
     float *partial = (float *)ctx->d_scratch, *stats = partial + partial_floats;
     const dim3 g1(slabs, N), g3(std::max(1, std::min((HW + PP - 1) / PP, (ctx->num_cus * 8 + N - 1) / N)), N);
+    if (from_tiles)
+        hipLaunchKernelGGL(gn_finalize_tiles_kernel, dim3(N * G), dim3(256), 0, ctx->stream, (const float *)d_gn_partial, C, G, gn_tile_rows, HW, eps, stats, N * G);
     if (dtype == HIVE_BF16) {
-        hipLaunchKernelGGL(gn_partial_kernel<bf16>, g1, dim3(256), 0, ctx->stream, (const bf16 *)d_x, HW, C, slabs, partial);
-        hipLaunchKernelGGL(gn_finalize_kernel, dim3(N * G), dim3(256), 0, ctx->stream, partial, C, G, slabs, HW, eps, stats, N * G);
+        if (!from_tiles) {
+            hipLaunchKernelGGL(gn_partial_kernel<bf16>, g1, dim3(256), 0, ctx->stream, (const bf16 *)d_x, HW, C, slabs, partial);
+            hipLaunchKernelGGL(gn_finalize_kernel, dim3(N * G), dim3(256), 0, ctx->stream, partial, C, G, slabs, HW, eps, stats, N * G);
+        }
         hipLaunchKernelGGL(gn_apply_kernel<bf16>, g3, dim3(256), 0, ctx->stream, (const bf16 *)d_x, (const bf16 *)d_gamma, (const bf16 *)d_beta,
                            stats, (const bf16 *)d_residual, (bf16 *)d_out, HW, C, G, relu);
     } else {
-        hipLaunchKernelGGL(gn_partial_kernel<_Float16>, g1, dim3(256), 0, ctx->stream, (const _Float16 *)d_x, HW, C, slabs, partial);
-        hipLaunchKernelGGL(gn_finalize_kernel, dim3(N * G), dim3(256), 0, ctx->stream, partial, C, G, slabs, HW, eps, stats, N * G);
+        if (!from_tiles) {
+            hipLaunchKernelGGL(gn_partial_kernel<_Float16>, g1, dim3(256), 0, ctx->stream, (const _Float16 *)d_x, HW, C, slabs, partial);
+            hipLaunchKernelGGL(gn_finalize_kernel, dim3(N * G), dim3(256), 0, ctx->stream, partial, C, G, slabs, HW, eps, stats, N * G);
+        }
         hipLaunchKernelGGL(gn_apply_kernel<_Float16>, g3, dim3(256), 0, ctx->stream, (const _Float16 *)d_x, (const _Float16 *)d_gamma,
                            (const _Float16 *)d_beta, stats, (const _Float16 *)d_residual, (_Float16 *)d_out, HW, C, G, relu);
     }
     HIVE_CHECK_HIP(ctx, hipGetLastError());
     return HIVE_OK;
+}
+
+int hive_nhwc_group_norm(hive_ctx *ctx, const void *d_x, int dtype, int N, int HW, int C, int G, const void *d_gamma,
+                         const void *d_beta, float eps, const void *d_residual, int relu, void *d_out) {
+    HIVE_ENTER(ctx);
+    if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
+    return group_norm_impl(ctx, d_x, dtype, N, HW, C, G, d_gamma, d_beta, eps, d_residual, relu, d_out, nullptr, 0);
+}
+
+int hive_nhwc_group_norm_stats(hive_ctx *ctx, const void *d_x, int dtype, int N, int HW, int C, int G, const void *d_gamma, const void *d_beta,
+                               float eps, const void *d_residual, int relu, void *d_out, const void *d_gn_partial, int gn_tile_rows) {
+    HIVE_ENTER(ctx);
+    if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
+    return group_norm_impl(ctx, d_x, dtype, N, HW, C, G, d_gamma, d_beta, eps, d_residual, relu, d_out, d_gn_partial, gn_tile_rows);
 }
 
 int hive_nhwc_bias_act(hive_ctx *ctx, const void *d_x, int dtype, int64_t n_px, int C, const void *d_bias, int relu,
@@ -300,8 +387,8 @@ int hive_nhwc_upsample2x(hive_ctx *ctx, const void *d_in, const void *d_bias, in
     if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
     HIVE_REQUIRE(ctx, d_in && d_out, "upsample2x: NULL argument");
     HIVE_REQUIRE(ctx, N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "upsample2x: need C %% 8 == 0 (N=%d H=%d W=%d C=%d)", N, H, W, C);
-    const size_t total = (size_t)N * 4 * H * W * (C / 8);
-    const dim3 grid((unsigned)std::min<size_t>((total + 255) / 256, (size_t)ctx->num_cus * 32));
+    HIVE_REQUIRE(ctx, 2 * H <= 65535 && N <= 65535, "upsample2x: H %d / N %d too large for the launch grid", H, N);
+    const dim3 grid((unsigned)((2 * W * (C / 8) + 255) / 256), (unsigned)(2 * H), (unsigned)N);
     if (dtype == HIVE_BF16)
         hipLaunchKernelGGL(upsample2x_kernel<bf16>, grid, dim3(256), 0, ctx->stream, (const bf16 *)d_in, (const bf16 *)d_bias, (bf16 *)d_out, N, H, W, C);
     else if (dtype == HIVE_F16)

@@ -71,7 +71,7 @@ class StdConv2dSame(nn.Conv2d):
 
     def forward(self, x):
         if self.engine == "hip" and dpt_ops.conv_eligible(x, self):
-            return dpt_ops.conv2d(x, self, weight=self.standardized_weight(), same_pad=True)
+            return dpt_ops.conv2d(x, self, weight=self.standardized_weight(), same_pad=True, gn_stats=True)  # a GroupNorm follows every StdConv2dSame
         if self.engine == "hip" and dpt_ops.stem_conv_eligible(x, self):
             return dpt_ops.stem_conv(x, self, self.standardized_weight())
         ih, iw = x.shape[-2:]
@@ -94,7 +94,7 @@ class GroupNormAct(nn.GroupNorm):
     def forward(self, x, residual=None):
         """relu?(group_norm(x) (+ residual)); with a residual the ReLU is always applied (bottleneck tail)."""
         return dpt_ops.group_norm_act(x, self.num_groups, self.weight, self.bias, self.eps, relu=self.apply_act or residual is not None,
-                                      residual=residual, engine=self.engine)
+                                      residual=residual, engine=self.engine, stats=getattr(x, "hive_gn_stats", None))
 
 
 class MaxPool2dSame(nn.Module):

@@ -17,8 +17,9 @@ def _code(dtype):
     return _lib.BF16 if dtype == torch.bfloat16 else _lib.F16
 
 
-def group_norm_act(x, num_groups, weight, bias, eps, relu=True, residual=None, engine="torch"):
-    """relu?(group_norm(x) (+ residual)).  x: [N, C, H, W]."""
+def group_norm_act(x, num_groups, weight, bias, eps, relu=True, residual=None, engine="torch", stats=None):
+    """relu?(group_norm(x) (+ residual)).  x: [N, C, H, W].  ``stats``: the (partial sums, tile rows) the convolution that wrote
+    ``x`` left (``conv2d(..., gn_stats=True)``): the statistics pass over ``x`` is skipped."""
     c = x.shape[1]
     if engine == "hip" and _hip_eligible(x) and (c & (c - 1)) == 0 and c <= 2048 and weight.dtype == x.dtype:
         if residual is not None:
@@ -27,8 +28,10 @@ def group_norm_act(x, num_groups, weight, bias, eps, relu=True, residual=None, e
         n, _, h, w = x.shape
         out = torch.empty_like(x)  # preserves channels_last
         ctx = _lib.default_context(x.device.index or 0)
-        ctx.check(ctx.lib.hive_nhwc_group_norm(ctx.handle, x.data_ptr(), _code(x.dtype), n, h * w, c, num_groups, weight.data_ptr(),
-                                               bias.data_ptr(), float(eps), _lib.ptr(residual), int(bool(relu)), out.data_ptr()))
+        partial, tile_rows = stats if stats is not None else (None, 0)
+        ctx.check(ctx.lib.hive_nhwc_group_norm_stats(ctx.handle, x.data_ptr(), _code(x.dtype), n, h * w, c, num_groups, weight.data_ptr(),
+                                                     bias.data_ptr(), float(eps), _lib.ptr(residual), int(bool(relu)), out.data_ptr(),
+                                                     _lib.ptr(partial), int(tile_rows)))
         return out
     y = F.group_norm(x, num_groups, weight, bias, eps)
     if residual is not None:
@@ -99,9 +102,11 @@ def conv_eligible(x, conv):
             and conv.weight.dtype == torch.bfloat16 and x.shape[1] == conv.in_channels and conv.padding[0] == conv.padding[1] and conv.padding[0] < k[0])
 
 
-def conv2d(x, conv, weight=None, same_pad=False, relu=False, residual=None, residual2=None, also_relu=False, with_bias=True):
+def conv2d(x, conv, weight=None, same_pad=False, relu=False, residual=None, residual2=None, also_relu=False, with_bias=True, gn_stats=False):
     """relu?(conv(x) (+ bias) (+ residuals)) through hive_nhwc_conv (see ``conv_eligible``).  ``weight``: use this tensor
-    instead of ``conv.weight`` (the standardised weight of a StdConv2dSame), [C_out, C_in, k, k] in channels-last memory format."""
+    instead of ``conv.weight`` (the standardised weight of a StdConv2dSame), [C_out, C_in, k, k] in channels-last memory format.
+    ``gn_stats``: also leave the per-tile channel sums of the output for the GroupNorm that follows (hive_nhwc_conv_gn); they ride
+    on the returned tensor as ``out.hive_gn_stats = (partial, tile_rows)`` for ``group_norm_act(..., stats=)``."""
     n, _, ih, iw = x.shape
     k, st, pt, pl, oh, ow = conv_geometry(conv, ih, iw, same_pad)
     w = weight if weight is not None else _conv3x3_weight(conv)
@@ -113,9 +118,18 @@ def conv2d(x, conv, weight=None, same_pad=False, relu=False, residual=None, resi
         assert r is None or (r.shape == out.shape and r.dtype == out.dtype and r.is_contiguous(memory_format=torch.channels_last))
     bias = conv.bias if (with_bias and conv.bias is not None) else None
     ctx = _lib.default_context(x.device.index or 0)
-    ctx.check(ctx.lib.hive_nhwc_conv(ctx.handle, x.data_ptr(), _lib.BF16, n, ih, iw, conv.in_channels, conv.out_channels, k, st, pt, pl, oh, ow,
-                                     w.data_ptr(), _lib.ptr(bias), int(bool(relu)), _lib.ptr(residual), _lib.ptr(residual2), out.data_ptr(),
-                                     _lib.ptr(out_relu)))
+    if gn_stats:
+        import ctypes
+        partial = torch.empty(int(ctx.lib.hive_nhwc_conv_gn_partial_floats(n * oh * ow, conv.out_channels)), dtype=torch.float32, device=x.device)
+        tile_rows = ctypes.c_int(0)
+        ctx.check(ctx.lib.hive_nhwc_conv_gn(ctx.handle, x.data_ptr(), _lib.BF16, n, ih, iw, conv.in_channels, conv.out_channels, k, st, pt, pl, oh, ow,
+                                            w.data_ptr(), _lib.ptr(bias), int(bool(relu)), _lib.ptr(residual), _lib.ptr(residual2), out.data_ptr(),
+                                            _lib.ptr(out_relu), partial.data_ptr(), partial.numel(), ctypes.byref(tile_rows)))
+        out.hive_gn_stats = (partial, tile_rows.value)
+    else:
+        ctx.check(ctx.lib.hive_nhwc_conv(ctx.handle, x.data_ptr(), _lib.BF16, n, ih, iw, conv.in_channels, conv.out_channels, k, st, pt, pl, oh, ow,
+                                         w.data_ptr(), _lib.ptr(bias), int(bool(relu)), _lib.ptr(residual), _lib.ptr(residual2), out.data_ptr(),
+                                         _lib.ptr(out_relu)))
     return (out, out_relu) if also_relu else out
 
 

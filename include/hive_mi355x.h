@@ -345,6 +345,21 @@ int hive_nhwc_conv(hive_ctx *ctx, const void *d_x, int dtype, int N, int H, int 
                    int pad_top, int pad_left, int H_out, int W_out, const void *d_w, const void *d_bias, int relu,
                    const void *d_residual, const void *d_residual2, void *d_out, void *d_out_relu);
 
+/* The same convolution with the statistics pass of the GroupNorm that follows it (timm ResNetV2: `norm(conv(x))` behind every
+ * convolution of the hybrid backbone) folded into the epilogue: per tile of *gn_tile_rows output pixels (all C_out channels) the sum
+ * and the sum of squares of the stored outputs, per channel, split between the two samples the tile may touch, are left in
+ * d_gn_partial (float, >= hive_nhwc_conv_gn_partial_floats(N * H_out * W_out, C_out) elements).  *gn_tile_rows = 0 when the map is
+ * smaller than a tile: nothing was written and the GroupNorm makes its own pass.  hive_nhwc_group_norm_stats = hive_nhwc_group_norm
+ * taking its statistics from there (d_gn_partial NULL or gn_tile_rows 0: identical to hive_nhwc_group_norm). */
+int64_t hive_nhwc_conv_gn_partial_floats(int64_t n_px, int C_out);
+int hive_nhwc_conv_gn(hive_ctx *ctx, const void *d_x, int dtype, int N, int H, int W, int C_in, int C_out, int kernel, int stride,
+                      int pad_top, int pad_left, int H_out, int W_out, const void *d_w, const void *d_bias, int relu,
+                      const void *d_residual, const void *d_residual2, void *d_out, void *d_out_relu, void *d_gn_partial,
+                      int64_t gn_partial_floats, int *gn_tile_rows);
+int hive_nhwc_group_norm_stats(hive_ctx *ctx, const void *d_x, int dtype, int N, int HW, int C, int G, const void *d_gamma,
+                               const void *d_beta, float eps, const void *d_residual, int relu, void *d_out,
+                               const void *d_gn_partial, int gn_tile_rows);
+
 /* ResNetV2 stem of the hybrid backbone (timm 0.5.4 ResNetV2.stem, reached from DPTDepthModel.forward): the 7 x 7 stride-2
  * weight-standardised convolution 3 -> 64 with TensorFlow "SAME" padding on the channels-last frame d_x [N][H][W][3] ->
  * d_out [N][ceil(H/2)][ceil(W/2)][64]; d_w = the standardised weights as [64][7][32] ((kx, c) of a kernel row padded from 21 to

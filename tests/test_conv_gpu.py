@@ -174,3 +174,68 @@ def test_stem_conv_and_maxpool_match_torch(gpu_ctx, n, h, w):
     got_p = pool(y)
     assert got_p.shape == ref_p.shape and got_p.is_contiguous(memory_format=torch.channels_last)
     assert torch.equal(got_p.float(), ref_p), "max pooling is exact"
+
+
+@pytest.mark.parametrize("n,cin,cout,k,stride,h,w", [
+    (3, 64, 256, 1, 1, 20, 24),     # HW = 480: the 256-row tiles straddle the samples; 256 output channels (one N tile)
+    (2, 256, 64, 1, 1, 40, 56),     # 64 output channels: 8 waves of 32 rows
+    (5, 128, 128, 3, 2, 47, 61),    # stride-2 3 x 3 "SAME" (conv2 of a stage's first block), odd sizes, ragged last tile
+    (2, 256, 512, 1, 1, 30, 40),    # two N tiles write disjoint channel ranges of the tile rows
+    (40, 64, 64, 1, 1, 48, 64),     # M = 122 880: more tiles than CUs (persistent workgroups run several epilogues)
+    (4, 64, 128, 3, 1, 9, 13),      # HW = 117 < a tile: no statistics from the epilogue, the GroupNorm makes its own pass
+])
+def test_conv_epilogue_group_norm_statistics(gpu_ctx, n, cin, cout, k, stride, h, w):
+    """hive_nhwc_conv_gn: the per-tile channel sums the epilogue leaves equal the sums over the stored output, and the GroupNorm that
+    takes its statistics from them equals the GroupNorm that makes its own pass (statistics: f32 sums in another order; the
+    normalised bf16 outputs may differ by one rounding in a few places)."""
+    from hive_amd.dpt import ops
+    from hive_amd.dpt.models import StdConv2dSame
+    g = torch.Generator(device="cpu").manual_seed(n * 1000 + cout)
+    conv = StdConv2dSame(cin, cout, k, stride=stride)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g))
+    conv = conv.to(memory_format=torch.channels_last).to(torch.bfloat16).cuda().eval()
+    x = (torch.randn(n, cin, h, w, generator=g) + 0.3).bfloat16().cuda().contiguous(memory_format=torch.channels_last)
+    assert ops.conv_eligible(x, conv)
+    wstd = conv.standardized_weight()
+    plain = ops.conv2d(x, conv, weight=wstd, same_pad=True)
+    out = ops.conv2d(x, conv, weight=wstd, same_pad=True, gn_stats=True)
+    assert torch.equal(out, plain), "the statistics must not change the convolution"
+    partial, tile_rows = out.hive_gn_stats
+    hw = out.shape[2] * out.shape[3]
+    if hw < 128:
+        assert tile_rows == 0
+    else:
+        assert tile_rows in (128, 256) and tile_rows <= hw
+        rows = out.permute(0, 2, 3, 1).reshape(-1, cout).float()  # [M][C] in memory order
+        m = rows.shape[0]
+        n_tiles = (m + tile_rows - 1) // tile_rows
+        got = partial[: n_tiles * 4 * cout].view(n_tiles, 2, 2, cout).double()
+        # per sample: the tiles' first-image halves of the tiles starting in it + the second halves of the tile straddling into it
+        ref_s = rows.double().view(n, hw, cout).sum(1)
+        ref_q = (rows.double() ** 2).view(n, hw, cout).sum(1)
+        acc_s = torch.zeros_like(ref_s)
+        acc_q = torch.zeros_like(ref_q)
+        for t in range(n_tiles):
+            first = (t * tile_rows) // hw
+            acc_s[first] += got[t, 0, 0]
+            acc_q[first] += got[t, 0, 1]
+            if first + 1 < n:
+                acc_s[first + 1] += got[t, 1, 0]
+                acc_q[first + 1] += got[t, 1, 1]
+            else:
+                assert got[t, 1].abs().max().item() == 0.0
+        assert torch.allclose(acc_s, ref_s, rtol=1e-5, atol=1e-2), (acc_s - ref_s).abs().max().item()
+        assert torch.allclose(acc_q, ref_q, rtol=1e-5, atol=1e-2), (acc_q - ref_q).abs().max().item()
+    gamma = (torch.rand(cout, generator=g) + 0.5).bfloat16().cuda()
+    beta = (torch.randn(cout, generator=g) * 0.2).bfloat16().cuda()
+    res = torch.randn(out.shape, generator=g).bfloat16().cuda().contiguous(memory_format=torch.channels_last)
+    for residual in (None, res):
+        own = ops.group_norm_act(plain, 32, gamma, beta, 1e-5, relu=True, residual=residual, engine="hip")
+        fused = ops.group_norm_act(out, 32, gamma, beta, 1e-5, relu=True, residual=residual, engine="hip", stats=out.hive_gn_stats)
+        diff = (own.float() - fused.float()).abs()
+        assert diff.max().item() <= 2 ** -7 * max(own.float().abs().max().item(), 1.0)
+        assert (diff > 0).float().mean().item() < 2e-3, "more than a few one-rounding differences"
+    again = ops.conv2d(x, conv, weight=wstd, same_pad=True, gn_stats=True)
+    used = ((out.numel() // cout + tile_rows - 1) // tile_rows) * 4 * cout if tile_rows else 0
+    assert torch.equal(again.hive_gn_stats[0][:used], partial[:used]), "the epilogue sums are run-to-run identical"

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""profiles/<tag>_steady_step.csv: per-step kernel time of the bench in steady state = (stats of the 30-step
-run - stats of the 10-step run) / 20, from tools/steady_profile.sh."""
+"""profiles/<tag>_steady_step.csv: per-step kernel time of the bench in steady state = (stats of the 16-step
+run - stats of the 6-step run) / 10 (64 frames per step), from tools/steady_profile.sh."""
 import csv, glob, os, sys
 tag = sys.argv[1]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,12 +10,12 @@ def load(s):
     for r in csv.DictReader(open(max(fs, key=os.path.getmtime))):
         d[r["Name"]] = (int(r["Calls"]), float(r["TotalDurationNs"]))
     return d
-a, b = load(10), load(30)
+a, b = load(6), load(16)
 rows = []
 for n, (c, t) in b.items():
     c0, t0 = a.get(n, (0, 0.0))
     if c - c0 > 0:
-        rows.append((n, (c - c0) / 20.0, (t - t0) / 20.0 / 1e3))
+        rows.append((n, (c - c0) / 10.0, (t - t0) / 10.0 / 1e3))
 rows.sort(key=lambda r: -r[2])
 tot = sum(r[2] for r in rows)
 out = os.path.join(root, "profiles", f"{tag}_steady_step.csv")
