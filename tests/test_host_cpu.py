@@ -109,7 +109,7 @@ def test_capi_library_exports_every_declared_symbol():
     """The library loads on a CPU-only box and exports exactly what include/hive_mi355x.h declares."""
     from hive_amd import _lib
     header = open(os.path.join(ROOT, "include", "hive_mi355x.h")).read()
-    declared = set(re.findall(r"^(?:int|const char \*)\s*\*?(hive_[a-z0-9_]+)\s*\(", header, flags=re.M))
+    declared = set(re.findall(r"^(?:int|int64_t|const char \*)\s*\*?(hive_[a-z0-9_]+)\s*\(", header, flags=re.M))
     assert declared, "no declarations parsed"
     assert os.path.exists(_lib.LIB_PATH), "build first: python -c 'import __graft_entry__ as g; g.build()'"
     lib = ctypes.CDLL(_lib.LIB_PATH)
