@@ -26,6 +26,9 @@
 // stage take 2550+ cycles to arrive against 2048 cycles of MFMA -- per-workgroup clocks (tools/probe_gemm_stamps.py) show 2100 busy +
 // 800 waiting cycles per K-step.  Also tried and taken out: start delays that de-phase the persistent workgroups (so that their
 // epilogues' stores do not hit HBM together): no change where the delay is free (workgroups with one tile fewer), slower elsewhere.
+// And a timing experiment that settles what a smarter A path could buy (an LDS-resident pixel window re-used by the 9 taps): with
+// three quarters of the A pieces simply not issued the 3 x 3 convolutions run at 1144 instead of 1118 TFLOP/s -- the operand
+// stream is not what the K-step waits for.
 #include "hive_internal.hpp"
 #include "mfma_pipe.hpp"
 

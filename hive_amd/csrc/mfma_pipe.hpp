@@ -59,6 +59,66 @@ __device__ __forceinline__ void kstep64(const unsigned char *a_t, const unsigned
     for (int j = SLOTS; j < n_pieces; ++j) issue(j);  // more pieces than slots (narrow tiles)
 }
 
+// The same K-step ROTATED ACROSS THE BARRIER.  With one s_barrier per K-step and all 8 waves (two per SIMD) behind it, every wave
+// starts its step with an exposed LDS round trip (its first fragments cannot be read before the stage is known to have landed), both
+// waves of a SIMD at the same moment: the MFMA pipe idles.  KPipe holds the MFMAs of the step's LAST `DEFER` slots back (their
+// fragments are in registers), and the next step, after the barrier, first issues its fragment reads (`begin`), then runs the
+// held-back MFMAs under that latency (`flush`), then its own slots (`body`).  Per tile: begin/body for the first step, barrier +
+// begin/flush/body for the others, one flush before the epilogue.
+template <int MT, bool SWAP>
+struct KPipe {
+    static constexpr int SLOTS = 2 * MT, DEFER = 2, D = 3;
+    static constexpr int WPS = MT >= 4 ? 1 : 4 / MT;
+    static_assert(MT == 2 || MT == 4 || MT == 8, "A fragments per wave");
+    bf16x8 ring[4], wfr[2][4];  // slot sl uses ring[sl & 3]; the deferred slots SLOTS - 2, SLOTS - 1 sit in ring[2], ring[3]
+    const unsigned char *a_t, *w_t;
+    int a_row0, w_row0, fr, fq;
+
+    __device__ __forceinline__ bf16x8 rd_a(int sl) const { return *reinterpret_cast<const bf16x8 *>(a_t + swz(a_row0 + (sl % MT) * 16 + fr, (sl / MT) * 4 + fq)); }
+    __device__ __forceinline__ bf16x8 rd_w(int sub, int t) const { return *reinterpret_cast<const bf16x8 *>(w_t + swz(w_row0 + t * 16 + fr, sub * 4 + fq)); }
+    template <typename Acc>
+    __device__ __forceinline__ void mfma_slot(int sl, Acc &acc) {
+        const int sub = sl / MT, mt = sl % MT;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            if (SWAP)
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ring[sl & 3], wfr[sub][nt], acc[mt][nt], 0, 0, 0);
+            else
+                acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[sub][nt], ring[sl & 3], acc[nt][mt], 0, 0, 0);
+        }
+    }
+    // right behind the barrier: point at the new stage and issue its first reads (W of sub-step 0, A of slots 0 and 1)
+    __device__ __forceinline__ void begin(const unsigned char *a_tile, const unsigned char *w_tile) {
+        a_t = a_tile;
+        w_t = w_tile;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) wfr[0][t] = rd_w(0, t);
+        ring[0] = rd_a(0);
+        ring[1] = rd_a(1);
+    }
+    // the MFMAs held back from the previous step (fragments in ring[2], ring[3], wfr[1])
+    template <typename Acc>
+    __device__ __forceinline__ void flush(Acc &acc) {
+#pragma unroll
+        for (int sl = SLOTS - DEFER; sl < SLOTS; ++sl) mfma_slot(sl, acc);
+    }
+    template <typename Acc, typename Issue>
+    __device__ __forceinline__ void body(Acc &acc, int n_pieces, Issue &&issue) {
+        ring[2] = rd_a(2);
+#pragma unroll
+        for (int sl = 0; sl < SLOTS - DEFER; ++sl) {
+            if (sl + D < SLOTS) ring[(sl + D) & 3] = rd_a(sl + D);
+            if (sl < 4 / WPS) {
+#pragma unroll
+                for (int k = 0; k < WPS; ++k) wfr[1][sl * WPS + k] = rd_w(1, sl * WPS + k);
+            }
+            mfma_slot(sl, acc);
+            if (sl < n_pieces) issue(sl);
+        }
+        for (int j = SLOTS - DEFER; j < n_pieces; ++j) issue(j);
+    }
+};
+
 // Epilogue of the SWAP = false accumulators through LDS.  In the MFMA layout a lane owns 4 consecutive W rows (output columns) of
 // one A row, so a direct store writes 16 rows x 32 bytes per wave-instruction, 8 bytes per lane.  A CU's vector-memory path takes a
 // wave-instruction every 40-47 cycles whatever its width (per-workgroup clocks, tools/probe_gemm_stamps.py: 23 000 cycles for the

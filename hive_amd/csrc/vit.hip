@@ -277,6 +277,14 @@ __global__ __launch_bounds__(TM * 2, 1) void gemm_kernel(GemmParams p) {
 // Large-M variant: C tile 256 x 256, K-step 64, EIGHT waves as 2 (M) x 4 (N), each a 128 x 64 sub-tile (8 x 4 MFMA
 // 16x16x32 accumulators, 128 VGPRs: two waves per SIMD).  Half the L2 operand bytes per flop of the 128 x 128 tile
 // (the operand stream, not the MFMAs or LDS, bounds that one: DESIGN.md section 5.3).  Two 64-KiB LDS-DMA stages.
+//
+// What the K-step costs, measured (tools/probe_gemm_stamps.py: per-workgroup clocks; timing builds with parts of the loop removed):
+// 2700-2750 shader cycles against 2048 of MFMA issue.  Without the LDS-DMA stream the same loop (MFMAs, fragment reads, barrier) runs
+// 4096^3 at 1478 TFLOP/s instead of 1230-1290 (hipBLASLt: 1470); without the barrier as well, 1506.  It is not the pieces' latency:
+// a wave's own pieces have landed when it reaches the barrier (vmcnt wait: 10 % of its waiting), and a FOUR-stage ring of 32-deep
+// steps (stages issued three steps ahead, counted vmcnt -- built, bit-identical results, 1241 vs 1280) is no faster; issuing the
+// pieces later in the step is slower (1290 -> 1180 -> 1156 for a start at slot 0 / 3 / 6), two per slot marginally faster.  What
+// did help: the rotated K-step of mfma_pipe.hpp (KPipe: +2-5 %) and the epilogue through LDS (+10-20 % at K = 768).
 constexpr int T256 = 256, T256_STAGE = 2 * T256 / 8 * 1024;
 
 #ifdef HIVE_GEMM_STAMPS  // tuning builds only (make stamps): per-workgroup phase clocks of gemm256_kernel, read back by tools/probe_gemm_stamps.py
@@ -325,25 +333,34 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(GemmParams p) {
     for (int j = 0; j < PER_WAVE; ++j) issue_piece(0, 0, j);
     const int fr = lane & 15, fq = lane >> 4;
 #ifdef HIVE_GEMM_STAMPS
-    unsigned long long waited = 0;
+    unsigned long long waited = 0, waited_vm = 0;
 #endif
+    hive_mfma::KPipe<8, false> pipe;
+    pipe.a_row0 = wr * 128, pipe.w_row0 = wc * 64, pipe.fr = fr, pipe.fq = fq;
     for (int kt = 0; kt < KT; ++kt) {
 #ifdef HIVE_GEMM_STAMPS
         const unsigned long long w0 = clock64();
 #endif
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // (lgkmcnt: the held-back slots' fragment reads of stage kt - 1)
+#ifdef HIVE_GEMM_STAMPS
+        const unsigned long long w1 = clock64();
+#endif
         __builtin_amdgcn_s_barrier();  // everyone's stage kt landed; everyone finished reading stage kt - 1
 #ifdef HIVE_GEMM_STAMPS
-        if (kt == 0) HIVE_STAMP(1); else waited += clock64() - w0;
+        if (kt == 0) HIVE_STAMP(1); else waited += clock64() - w0, waited_vm += w1 - w0;
 #endif
         const int nk = min(kt + 1, KT - 1);  // next stage (past the end: the last one again), issued between the MFMA slots
         const unsigned char *a_t = lds + (kt & 1) * T256_STAGE, *w_t = a_t + A_GROUPS * 1024;
-        hive_mfma::kstep64<8, false>(a_t, w_t, wr * 128, wc * 64, fr, fq, acc, PER_WAVE, [&](int j) { issue_piece(nk, (kt + 1) & 1, j); });
+        pipe.begin(a_t, w_t);
+        if (kt > 0) pipe.flush(acc);  // the previous step's last slots, under the latency of this step's first reads
+        pipe.body(acc, PER_WAVE, [&](int j) { issue_piece(nk, (kt + 1) & 1, j); });
     }
+    pipe.flush(acc);
     HIVE_STAMP(2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the redundant last stage
     HIVE_STAMP(3);
     HIVE_STAMP_ADD(6, waited);
+    HIVE_STAMP_ADD(7, waited_vm);
 
     gemm_store_rows<EPI, 8>(p, acc, m0 + wr * 128, n0 + wc * 64, lds + 2 * T256_STAGE + wave * 4096, lane);
     HIVE_STAMP(4);

@@ -23,6 +23,6 @@ for (M, N, K, epi) in [(29184, 3072, 768, 1), (29184, 1536, 768, 0), (19456, 768
     t0 = st[:, 0].min()
     med = lambda x: float(np.median(x))
     print(f"M={M} N={N} K={K} epi={epi}: {us:.1f} us, {n_wg} workgroups, K stages {K // 64}")
-    print(f"   prologue fill {med(st[:,1]-st[:,0]):8.0f} | K loop {med(st[:,2]-st[:,1]):8.0f} (waiting {med(st[:,6]):8.0f}) | drain {med(st[:,3]-st[:,2]):6.0f} | "
+    print(f"   prologue fill {med(st[:,1]-st[:,0]):8.0f} | K loop {med(st[:,2]-st[:,1]):8.0f} (waiting {med(st[:,6]):8.0f}, of it vmcnt {med(st[:,7]):8.0f}) | drain {med(st[:,3]-st[:,2]):6.0f} | "
           f"epilogue issue {med(st[:,4]-st[:,3]):8.0f} | stores land {med(st[:,5]-st[:,4]):8.0f} | whole {med(st[:,5]-st[:,0]):8.0f} ticks")
     print(f"   kernel span {st[:,5].max()-t0} ticks for {us:.1f} us -> {(st[:,5].max()-t0)/us:.1f} ticks/us; start spread: p50 {med(st[:,0]-t0):.0f} p99 {np.percentile(st[:,0]-t0, 99):.0f}")
