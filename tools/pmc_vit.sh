@@ -4,7 +4,7 @@
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmcvit_$1
 rm -rf $OUT && mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-P="python3 $GRAFT_REPO_ROOT/bench.py --timed-only --steps 2 --warmup 1 --batch ${2:-24}"
+P="python3 $GRAFT_REPO_ROOT/bench.py --timed-only --steps 2 --warmup 1 --batch ${2:-64}"
 $P > $OUT/warm.log 2>&1
 pass() { n=$1; shift; timeout -k 10 300 rocprofv3 --pmc "$@" --output-format csv -d $OUT/p$n -- $P > $OUT/p$n.log 2>&1 || echo "pass $n failed"; }
 pass A SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE SQ_WAVES
@@ -12,9 +12,11 @@ pass B SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTI
 pass C SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INST_CYCLES_VMEM_RD
 python3 - <<PY
 import csv, glob, collections, json
-kernels = {"gemm_kernel<0": "gemm q|k (bias)", "gemm_kernel<1": "gemm fc1 + GELU (128 x 128 tiles)", "gemm_kernel<2": "gemm proj / fc2 + residual",
-           "gemm_kernel<3": "gemm v^T", "gemm256_kernel<1": "gemm fc1 + GELU (256 x 256 tiles)", "attention_kernel": "attention", "head_conv_kernel": "fused depth head",
-           "conv3x3_kernel<256>": "conv 3x3 -> 256 (decoder RCUs, layer_rn)", "conv3x3_kernel<128>": "conv 3x3 256 -> 128 (output_conv[0])"}
+kernels = {"gemm256_kernel<0": "gemm q|k (bias; 256 x 256 tiles)", "gemm256_kernel<1": "gemm fc1 + GELU (256 x 256 tiles)", "gemm256_kernel<2": "gemm proj / fc2 + residual (256 x 256 tiles)",
+           "gemm_kernel<0": "gemm (bias; 128 x 128 tiles)", "gemm_kernel<1": "gemm + GELU (128 x 128 tiles)", "gemm_kernel<2": "gemm + residual (128 x 128 tiles)",
+           "gemm_kernel<3": "gemm v^T", "attention_kernel": "attention", "head_conv_kernel": "fused depth head",
+           "conv_kernel<256, 256, false>": "conv -> 256-channel tiles (decoder RCUs, layer_rn)", "conv_kernel<256, 256, true>": "conv + GroupNorm statistics (ResNetV2, 256-channel tiles)",
+           "conv_kernel<256, 128, false>": "conv 3x3 256 -> 128 (output_conv[0])"}
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("$OUT/p?/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):

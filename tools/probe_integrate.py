@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Quick probe: integrate-kernel time at 512^3 on the bench scene (HIP events), N_upd, GB/s."""
+"""Quick probe: integrate-kernel time on the room scene (HIP events), N_upd, GB/s: 512^3 / VGA by default."""
 import argparse
 import os
 import sys
@@ -15,9 +15,12 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--frames", type=int, default=30)
 ap.add_argument("--voxel", type=float, default=0.01)
 ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--height", type=int, default=480)
+ap.add_argument("--width", type=int, default=640, help="--height 1080 --width 1920 --voxel 0.005: BASELINE config 4 (1024^3)")
+ap.add_argument("--no-mesh", action="store_true")
 args = ap.parse_args()
 
-seq = synthetic.make_sequence(num_frames=args.frames, yaw_step_deg=360.0 / args.frames)
+seq = synthetic.make_sequence(num_frames=args.frames, height=args.height, width=args.width, yaw_step_deg=360.0 / args.frames)
 ctx = _lib.default_context(0)
 vol = fusion.TSDFVolume(synthetic.room_bounds(), args.voxel, ctx=ctx)
 color = torch.from_numpy(seq["color"]).cuda()
@@ -37,6 +40,8 @@ for rep in range(args.reps):
     alg = (24.0 * np.mean(n_upd) + 8.0 * H * W)
     print(f"rep {rep}: {n} launches, kernel avg {ms / n * 1e3:.1f} us, wall/frame {wall / args.frames * 1e3:.3f} ms, "
           f"algorithmic {alg / 1e6:.1f} MB/frame -> {alg / (ms / n * 1e-3) / 1e9:.1f} GB/s")
+if args.no_mesh:
+    sys.exit(0)
 t0 = time.time()
 verts, faces, norms, colors = vol.get_mesh()
 print(f"mesh: {len(verts)} verts, {len(faces)} faces in {time.time() - t0:.3f} s (incl. D2H)")

@@ -7,6 +7,12 @@ src, dst = os.path.join(root, "gpurun_out", "prof_r02"), os.path.join(root, "pro
 stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)
 if stats:
     shutil.copy(max(stats, key=os.path.getmtime), os.path.join(dst, "r02_kernel_stats.csv"))
+stats = glob.glob(os.path.join(src, "trace_1024", "**", "*kernel_stats.csv"), recursive=True)
+if stats:
+    shutil.copy(max(stats, key=os.path.getmtime), os.path.join(dst, "r02_kernel_stats_1024cubed_1080p.csv"))
+    log = os.path.join(src, "trace_1024.log")
+    if os.path.exists(log):
+        shutil.copy(log, os.path.join(dst, "r02_probe_1024cubed_1080p.log"))
 def mean_counter(sub, counter):
     vals = []
     for f in glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True):
