@@ -95,6 +95,8 @@ SIGNATURES = {
     "hive_nhwc_conv_gn_partial_floats": (c_int64, [c_int64, c_int]),
     "hive_nhwc_conv_gn": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                   c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, P(c_int)]),
+    "hive_nhwc_conv_gn_apply": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int,
+                                        c_void_p, c_void_p, c_float, c_void_p, c_int, c_void_p, c_void_p, c_int64, P(c_int)]),
     "hive_nhwc_group_norm_stats": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_int,
                                            c_void_p, c_void_p, c_int]),
     "hive_resnet_stem_conv": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),

@@ -56,6 +56,11 @@ struct ConvParams {
     int stride, pad_t, pad_l;  // input row of tap ky for output row oy: oy * stride + ky - pad_t
     int M;              // NB * Ho * Wo
     float *gn_partial;  // GN kernels only: [M tile][2 images of the tile][sum, sum of squares][Cout] of the stored (rounded) outputs
+    int stats_only;     // GN == 1: nothing is stored but gn_partial (first pass of hive_nhwc_conv_gn_apply)
+    // GN == 2 (second pass): out = relu?(bf16(gn(bf16(conv))) + residual) with the (mean, rstd) of gn_stats[sample * gn_G + group]
+    const float *gn_stats;
+    const bf16 *gn_gamma, *gn_beta;
+    int gn_G, gn_cpg;   // groups, channels per group (>= 8: a lane's 8 channels share a group)
 };
 
 // epilogue: through the wave's 4 KiB of LDS (mfma_pipe.hpp staged_rows) so that the residual loads and the stores are 16 bytes
@@ -67,15 +72,34 @@ struct ConvParams {
 // two images a tile of TM <= Ho Wo rows can touch (rows below / from `boundary`); the 8 lanes that share its channels are added by
 // xor-shuffles, the waves of the tile through LDS in wave order -- a fixed order, run-to-run identical -- and the tile's row of
 // `gn_partial` is written.  hive_nhwc_group_norm_stats (dpt_ops.hip) finishes from there: no pass over the tensor for statistics.
-template <int MT, bool GN>
+// y = x * (rstd * gamma) + (beta - mean * (rstd * gamma)) with every operation rounded on its own, as gn_apply_kernel (dpt_ops.hip, built
+// with -ffp-contract=off) computes it (HIP's __fmul_rn / __fadd_rn are plain operators and contract to an FMA in this file)
+__device__ __forceinline__ float gn_affine_exact(float x, float rstd, float gamma, float beta, float mean) {
+#pragma clang fp contract(off)
+    const float a = rstd * gamma;
+    const float b = beta - mean * a;
+    return x * a + b;
+}
+
+template <int MT, int GN>
 __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x4 (&acc)[4][MT], int m_base, int n_base, unsigned char *stage, int lane,
-                                              int boundary, float (&gsum)[2][8], float (&gsq)[2][8]) {
+                                              int boundary, bool straddles, float (&gsum)[2][8], float (&gsq)[2][8]) {
     const int n = n_base + (lane & 7) * 8;
     float b[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (p.bias) {
         const bf16x8 bv = *reinterpret_cast<const bf16x8 *>(p.bias + n);
 #pragma unroll
         for (int j = 0; j < 8; ++j) b[j] = (float)bv[j];
+    }
+    float ggam[8], gbet[8], gmean[2] = {0.f, 0.f}, grstd[2] = {0.f, 0.f};
+    if (GN == 2) {
+        const bf16x8 gv = *reinterpret_cast<const bf16x8 *>(p.gn_gamma + n), bv = *reinterpret_cast<const bf16x8 *>(p.gn_beta + n);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ggam[j] = (float)gv[j], gbet[j] = (float)bv[j];
+        const int hw = p.Ho * p.Wo, img0 = boundary / hw - 1, n_img = p.M / hw, g = n / p.gn_cpg;
+        const float *st = p.gn_stats + ((size_t)img0 * p.gn_G + g) * 2;
+        gmean[0] = st[0], grstd[0] = st[1];
+        if (img0 + 1 < n_img) gmean[1] = st[2 * p.gn_G], grstd[1] = st[2 * p.gn_G + 1];
     }
     hive_mfma::staged_rows<MT>(stage, acc, lane, [&](int r, int, const f32x4 &lo, const f32x4 &hi) {
         const int m = m_base + r;
@@ -84,33 +108,63 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x4 (&acc)[
         float o[8];
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] = lo[j] + b[j], o[4 + j] = hi[j] + b[4 + j];
-        if (p.res1) {
+        if (GN != 2 && p.res1) {
             const bf16x8 rs = *reinterpret_cast<const bf16x8 *>(p.res1 + o_off);
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] += (float)rs[j];
         }
-        if (p.res2) {
+        if (GN != 2 && p.res2) {
             const bf16x8 rs = *reinterpret_cast<const bf16x8 *>(p.res2 + o_off);
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] += (float)rs[j];
         }
-        if (p.relu) {
+        if (GN != 2 && p.relu) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = fmaxf(o[j], 0.0f);
         }
         bf16x8 ov;
 #pragma unroll
         for (int j = 0; j < 8; ++j) ov[j] = (bf16)o[j];
-        *reinterpret_cast<bf16x8 *>(p.out + o_off) = ov;
-        if (GN) {
+        if (GN == 2) {
+            // the GroupNorm behind this convolution, applied to the ROUNDED output with gn_apply_kernel's operations in its order
+            // (no contraction: bit-identical to the separate pass), then the block's shortcut and ReLU
             const bool second = m >= boundary;
+            const float mean = second ? gmean[1] : gmean[0], rstd = second ? grstd[1] : grstd[0];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float v = (float)ov[j], v0 = second ? 0.f : v, v1 = second ? v : 0.f;
-                gsum[0][j] += v0;
-                gsum[1][j] += v1;
-                gsq[0][j] += v0 * v0;
-                gsq[1][j] += v1 * v1;
+            for (int j = 0; j < 8; ++j) o[j] = gn_affine_exact((float)ov[j], rstd, ggam[j], gbet[j], mean);
+            if (p.res1) {
+                const bf16x8 rs = *reinterpret_cast<const bf16x8 *>(p.res1 + o_off);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (float)(bf16)o[j] + (float)rs[j];
+            }
+            if (p.relu) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = fmaxf(o[j], 0.0f);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ov[j] = (bf16)o[j];
+            *reinterpret_cast<bf16x8 *>(p.out + o_off) = ov;
+            return;
+        }
+        if (GN != 1 || !p.stats_only) *reinterpret_cast<bf16x8 *>(p.out + o_off) = ov;
+        if (GN == 1) {
+            if (!straddles) {  // (workgroup-uniform) the whole tile lies in one sample: one set of sums
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float v = (float)ov[j];
+                    gsum[0][j] += v;
+                    gsq[0][j] += v * v;
+                }
+            } else {
+                const bool second = m >= boundary;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float v = (float)ov[j], v0 = second ? 0.f : v, v1 = second ? v : 0.f;
+                    gsum[0][j] += v0;
+                    gsum[1][j] += v1;
+                    gsq[0][j] += v0 * v0;
+                    gsq[1][j] += v1 * v1;
+                }
             }
         }
         if (p.out_relu) {
@@ -123,7 +177,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x4 (&acc)[
 
 constexpr int BK = 64;
 
-template <int TM, int TN, bool GN>
+template <int TM, int TN, int GN>
 __global__ __launch_bounds__(512, 1) void conv_kernel(ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // 2 stages x (A tile TM x 64, W tile TN x 64) + 8 x 4 KiB for the epilogue
     constexpr int A_GROUPS = TM / 8, A_PW = A_GROUPS / 8;  // 1 KiB groups of the A tile, and how many each wave stages
@@ -239,13 +293,15 @@ __global__ __launch_bounds__(512, 1) void conv_kernel(ConvParams p) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) gsum[0][j] = gsum[1][j] = gsq[0][j] = gsq[1][j] = 0.f;
         const int hw = p.Ho * p.Wo, boundary = (em0 / hw + 1) * hw;  // first row of the tile's second image
-        conv_epilogue<MT, GN>(p, acc, em0 + wr * RW, en0 + wc * 64, stage, lane, boundary, gsum, gsq);
-        if (GN) {
+        const bool straddles = boundary < em0 + TM && boundary < p.M;  // the tile reaches into a second sample
+        conv_epilogue<MT, GN>(p, acc, em0 + wr * RW, en0 + wc * 64, stage, lane, boundary, straddles, gsum, gsq);
+        if (GN == 1) {
             // the 8 lanes with the same channels (lane bits 3..5), then the WM waves of the tile in wave order
 #pragma unroll
             for (int j = 0; j < 8; ++j)
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
+                    if (h == 1 && !straddles) continue;  // all zero
                     float a = gsum[h][j], q = gsq[h][j];
 #pragma unroll
                     for (int off = 8; off < 64; off <<= 1) {
@@ -287,23 +343,26 @@ bool g_conv_attr_set[64] = {};
 
 int ensure_conv_attrs(hive_ctx *ctx) {
     if (ctx->device < 64 && g_conv_attr_set[ctx->device]) return HIVE_OK;
-    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)conv_kernel<256, 256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds(256, 256)));
-    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)conv_kernel<256, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds(256, 256)));
-    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)conv_kernel<256, 128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds(256, 128)));
-    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)conv_kernel<256, 128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds(256, 128)));
-    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)conv_kernel<256, 64, false>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds(256, 64)));
-    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)conv_kernel<256, 64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds(256, 64)));
-    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)conv_kernel<128, 256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds(128, 256)));
-    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)conv_kernel<128, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds(128, 256)));
-    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)conv_kernel<128, 128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds(128, 128)));
-    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)conv_kernel<128, 128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds(128, 128)));
+    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)conv_kernel<256, 256, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds(256, 256)));
+    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)conv_kernel<256, 256, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds(256, 256)));
+    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)conv_kernel<256, 128, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds(256, 128)));
+    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)conv_kernel<256, 128, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds(256, 128)));
+    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)conv_kernel<256, 64, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds(256, 64)));
+    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)conv_kernel<256, 64, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds(256, 64)));
+    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)conv_kernel<128, 256, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds(128, 256)));
+    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)conv_kernel<128, 256, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds(128, 256)));
+    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)conv_kernel<128, 128, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds(128, 128)));
+    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)conv_kernel<128, 128, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds(128, 128)));
+    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)conv_kernel<256, 256, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds(256, 256)));
+    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)conv_kernel<128, 256, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds(128, 256)));
     if (ctx->device < 64) g_conv_attr_set[ctx->device] = true;
     return HIVE_OK;
 }
 
 int launch_conv(hive_ctx *ctx, const char *what, const void *d_x, int dtype, int N, int H, int W, int C_in, int C_out, int R, int stride, int pad_t,
                        int pad_l, int Ho, int Wo, const void *d_w, const void *d_bias, int relu, const void *d_residual, const void *d_residual2,
-                       void *d_out, void *d_out_relu, void *d_gn_partial = nullptr, long long gn_partial_floats = 0, int *gn_tile_rows = nullptr) {
+                       void *d_out, void *d_out_relu, void *d_gn_partial = nullptr, long long gn_partial_floats = 0, int *gn_tile_rows = nullptr,
+                       const ConvParams *gn_mode = nullptr) {  // gn_mode: stats_only / gn_stats .. gn_cpg of the two-pass GroupNorm convolution
     HIVE_REQUIRE(ctx, d_x && d_w && d_out, "%s: NULL argument", what);
     if (gn_tile_rows) *gn_tile_rows = 0;
     HIVE_REQUIRE(ctx, dtype == HIVE_BF16, "%s: bf16 only", what);
@@ -342,6 +401,14 @@ int launch_conv(hive_ctx *ctx, const char *what, const void *d_x, int dtype, int
     const int tn = C_out % 256 == 0 ? 256 : (C_out % 128 == 0 ? 128 : 64);
     // 256 output pixels per tile, or 128 where that would leave CUs without a tile (30 x 40 and 15 x 20 maps: 113 / 29 tiles of 256)
     const int tm = (tn >= 128 && (long long)((p.M + 255) / 256) * (C_out / tn) < ctx->num_cus) ? 128 : 256;
+    if (gn_mode) {
+        p.stats_only = gn_mode->stats_only;
+        p.gn_stats = gn_mode->gn_stats;
+        p.gn_gamma = gn_mode->gn_gamma;
+        p.gn_beta = gn_mode->gn_beta;
+        p.gn_G = gn_mode->gn_G;
+        p.gn_cpg = gn_mode->gn_cpg;
+    }
     // GroupNorm statistics from the epilogue: a tile may touch two images at most (tm <= Ho Wo); smaller maps keep the stand-alone pass
     if (d_gn_partial && gn_tile_rows && (long long)Ho * Wo >= tm) {
         HIVE_REQUIRE(ctx, (long long)((p.M + tm - 1) / tm) * 4 * C_out <= gn_partial_floats, "%s: gn_partial holds %lld floats, %lld needed", what,
@@ -356,11 +423,16 @@ int launch_conv(hive_ctx *ctx, const char *what, const void *d_x, int dtype, int
 #define HIVE_CONV_LAUNCH(TM_, TN_)                                                                                   \
     do {                                                                                                             \
         if (p.gn_partial)                                                                                            \
-            hipLaunchKernelGGL((conv_kernel<TM_, TN_, true>), grid, dim3(512), lds, ctx->stream, p);                 \
+            hipLaunchKernelGGL((conv_kernel<TM_, TN_, 1>), grid, dim3(512), lds, ctx->stream, p);                    \
         else                                                                                                         \
-            hipLaunchKernelGGL((conv_kernel<TM_, TN_, false>), grid, dim3(512), lds, ctx->stream, p);                \
+            hipLaunchKernelGGL((conv_kernel<TM_, TN_, 0>), grid, dim3(512), lds, ctx->stream, p);                    \
     } while (0)
-    if (tm == 256 && tn == 256)
+    if (p.gn_stats) {  // second pass of hive_nhwc_conv_gn_apply: C_out % 256 == 0 (checked there)
+        if (tm == 256)
+            hipLaunchKernelGGL((conv_kernel<256, 256, 2>), grid, dim3(512), lds, ctx->stream, p);
+        else
+            hipLaunchKernelGGL((conv_kernel<128, 256, 2>), grid, dim3(512), lds, ctx->stream, p);
+    } else if (tm == 256 && tn == 256)
         HIVE_CONV_LAUNCH(256, 256);
     else if (tm == 256 && tn == 128)
         HIVE_CONV_LAUNCH(256, 128);
@@ -397,6 +469,47 @@ extern "C" int hive_nhwc_conv_gn(hive_ctx *ctx, const void *d_x, int dtype, int 
     HIVE_REQUIRE(ctx, d_gn_partial && gn_tile_rows, "nhwc_conv_gn: NULL argument");
     return launch_conv(ctx, "nhwc_conv_gn", d_x, dtype, N, H, W, C_in, C_out, kernel, stride, pad_top, pad_left, H_out, W_out, d_w, d_bias, relu, d_residual,
                        d_residual2, d_out, d_out_relu, d_gn_partial, gn_partial_floats, gn_tile_rows);
+}
+
+// out = relu?(GroupNorm(conv(x)) + residual) WITHOUT the convolution's output ever reaching memory: the convolution runs twice.  Pass 1
+// keeps only the per-tile channel sums of its (rounded) outputs; (mean, rstd) per (sample, group) follow; pass 2 recomputes the tile
+// and normalises it in the epilogue.  Worth it where the output is wider than the input -- the ResNetV2 bottlenecks' expanding 1 x 1
+// convolutions (conv3: C -> 4 C, and the stage's downsample convolution): per element of the 4 C-wide tensor the separate sequence
+// moves write + read (statistics, now folded) + read + write, this one a single write, at the price of reading the C-wide input twice.
+extern "C" int hive_nhwc_conv_gn_apply(hive_ctx *ctx, const void *d_x, int dtype, int N, int H, int W, int C_in, int C_out, int kernel, int stride,
+                                       int pad_top, int pad_left, int H_out, int W_out, const void *d_w, int G, const void *d_gamma, const void *d_beta,
+                                       float eps, const void *d_residual, int relu, void *d_out, void *d_scratch, int64_t scratch_floats, int *fused) {
+    HIVE_ENTER(ctx);
+    if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
+    HIVE_REQUIRE(ctx, d_gamma && d_beta && d_scratch && fused, "nhwc_conv_gn_apply: NULL argument");
+    *fused = 0;
+    const long long hw = (long long)H_out * W_out;
+    // eligible: whole 256-channel tiles, a lane's 8 channels inside one group, a tile inside two samples
+    if (G <= 0 || C_out % 256 != 0 || C_out % G != 0 || (C_out / G) % 8 != 0 || hw < 256) return HIVE_OK;
+    const int64_t partial_floats = hive_nhwc_conv_gn_partial_floats((int64_t)N * hw, C_out);
+    HIVE_REQUIRE(ctx, scratch_floats >= partial_floats + 2ll * N * G, "nhwc_conv_gn_apply: scratch holds %lld floats, %lld needed", (long long)scratch_floats,
+                 (long long)(partial_floats + 2ll * N * G));
+    float *partial = (float *)d_scratch, *stats = partial + partial_floats;
+    ConvParams mode{};
+    mode.stats_only = 1;
+    int tile_rows = 0;
+    int rc = launch_conv(ctx, "nhwc_conv_gn_apply", d_x, dtype, N, H, W, C_in, C_out, kernel, stride, pad_top, pad_left, H_out, W_out, d_w, nullptr, 0, nullptr,
+                         nullptr, d_out, nullptr, partial, partial_floats, &tile_rows, &mode);
+    if (rc) return rc;
+    HIVE_REQUIRE(ctx, tile_rows > 0, "nhwc_conv_gn_apply: no statistics from a %lld-pixel map", hw);
+    rc = hive_gn_finalize_tiles(ctx, partial, N, (int)hw, C_out, G, tile_rows, eps, stats);
+    if (rc) return rc;
+    mode.stats_only = 0;
+    mode.gn_stats = stats;
+    mode.gn_gamma = (const bf16 *)d_gamma;
+    mode.gn_beta = (const bf16 *)d_beta;
+    mode.gn_G = G;
+    mode.gn_cpg = C_out / G;
+    rc = launch_conv(ctx, "nhwc_conv_gn_apply", d_x, dtype, N, H, W, C_in, C_out, kernel, stride, pad_top, pad_left, H_out, W_out, d_w, nullptr, relu, d_residual,
+                     nullptr, d_out, nullptr, nullptr, 0, nullptr, &mode);
+    if (rc) return rc;
+    *fused = 1;
+    return HIVE_OK;
 }
 
 extern "C" int hive_nhwc_conv(hive_ctx *ctx, const void *d_x, int dtype, int N, int H, int W, int C_in, int C_out, int kernel, int stride, int pad_top,

@@ -127,6 +127,29 @@ int run_forward(hive_dpt *d, bool dry, const uint8_t *d_rgb, int B, int H, int W
         return hive_nhwc_conv(ctx, x.p, HIVE_BF16, B, x.H, x.W, x.C, cout, k, stride, pt, pl, oh, ow, wp, bp, relu, res1, res2, out->p,
                               out_relu ? out_relu->p : nullptr);
     };
+    // conv + GroupNorm (+ shortcut + ReLU) of a bottleneck's expanding 1 x 1 convolutions as the two-pass operation; falls back to the pair
+    auto conv_norm = [&](const Map &x, const std::string &wname, const std::string &norm_prefix, int cout, int stride, const bf16 *residual, int relu,
+                         Map *out) -> int {
+        const int oh = same_out(x.H, stride), ow = same_out(x.W, stride);
+        const int64_t scratch_floats = hive_nhwc_conv_gn_partial_floats((int64_t)B * oh * ow, cout) + 2ll * B * 32;
+        float *scratch = (float *)d->alloc((size_t)scratch_floats * 2);
+        *out = Map{d->alloc((size_t)B * oh * ow * cout), oh, ow, cout};
+        const bool eligible = cout % 256 == 0 && (cout / 32) % 8 == 0 && (long long)oh * ow >= 256;  // hive_nhwc_conv_gn_apply's conditions
+        Map t{eligible ? nullptr : d->alloc((size_t)B * oh * ow * cout), oh, ow, cout};               // the pair's intermediate: small maps only
+        if (dry) return HIVE_OK;
+        const void *wp, *g, *b;
+        DPT_TRY(need(wname, &wp));
+        DPT_TRY(need(norm_prefix + ".weight", &g));
+        DPT_TRY(need(norm_prefix + ".bias", &b));
+        int fused = 0;
+        DPT_TRY(hive_nhwc_conv_gn_apply(ctx, x.p, HIVE_BF16, B, x.H, x.W, x.C, cout, 1, stride, 0, 0, oh, ow, wp, 32, g, b, d->cfg.gn_eps, residual, relu, out->p,
+                                        scratch, scratch_floats, &fused));
+        if (fused) return HIVE_OK;
+        if (eligible) return hive_fail(ctx, HIVE_ERR_INVALID, "hive_dpt: conv + GroupNorm of '%s' was not fused", wname.c_str());
+        DPT_TRY(hive_nhwc_conv_gn(ctx, x.p, HIVE_BF16, B, x.H, x.W, x.C, cout, 1, stride, 0, 0, oh, ow, wp, nullptr, 0, nullptr, nullptr, t.p, nullptr, scratch,
+                                  scratch_floats, &t.gn_tm));
+        return hive_nhwc_group_norm_stats(ctx, t.p, HIVE_BF16, B, oh * ow, cout, 32, g, b, d->cfg.gn_eps, residual, relu, out->p, scratch, t.gn_tm);
+    };
     auto group_norm = [&](const Map &x, const std::string &prefix, const bf16 *residual, int relu, Map *out) -> int {
         *out = Map{d->alloc((size_t)B * x.H * x.W * x.C), x.H, x.W, x.C};
         if (dry) return HIVE_OK;
@@ -158,16 +181,12 @@ int run_forward(hive_dpt *d, bool dry, const uint8_t *d_rgb, int B, int H, int W
             const std::string pre = bb + "stages." + std::to_string(s) + ".blocks." + std::to_string(blk) + ".";
             const int cout = chans[s], mid = cout / 4, stride = (blk == 0 && s > 0) ? 2 : 1;
             Map shortcut = feat, t, u;
-            if (blk == 0) {
-                DPT_TRY(conv(feat, pre + "downsample.conv.weight", nullptr, cout, 1, stride, true, 0, nullptr, nullptr, false, &t, nullptr, true));
-                DPT_TRY(group_norm(t, pre + "downsample.norm", nullptr, 0, &shortcut));
-            }
+            if (blk == 0) DPT_TRY(conv_norm(feat, pre + "downsample.conv.weight", pre + "downsample.norm", cout, stride, nullptr, 0, &shortcut));
             DPT_TRY(conv(feat, pre + "conv1.weight", nullptr, mid, 1, 1, true, 0, nullptr, nullptr, false, &t, nullptr, true));
             DPT_TRY(group_norm(t, pre + "norm1", nullptr, 1, &u));
             DPT_TRY(conv(u, pre + "conv2.weight", nullptr, mid, 3, stride, true, 0, nullptr, nullptr, false, &t, nullptr, true));
             DPT_TRY(group_norm(t, pre + "norm2", nullptr, 1, &u));
-            DPT_TRY(conv(u, pre + "conv3.weight", nullptr, cout, 1, 1, true, 0, nullptr, nullptr, false, &t, nullptr, true));
-            DPT_TRY(group_norm(t, pre + "norm3", shortcut.p, 1, &feat));  // relu(norm3(.) + shortcut)
+            DPT_TRY(conv_norm(u, pre + "conv3.weight", pre + "norm3", cout, 1, shortcut.p, 1, &feat));  // relu(norm3(conv3(.)) + shortcut)
         }
         if (s < 2) hook[s] = feat;
     }

@@ -310,6 +310,12 @@ __global__ __launch_bounds__(256) void bias_act_kernel(const T *__restrict__ x, 
 
 static bool pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
 
+int hive_gn_finalize_tiles(hive_ctx *ctx, const float *d_partial, int N, int HW, int C, int G, int tile_rows, float eps, float *d_stats) {
+    hipLaunchKernelGGL(gn_finalize_tiles_kernel, dim3(N * G), dim3(256), 0, ctx->stream, d_partial, C, G, tile_rows, HW, eps, d_stats, N * G);
+    HIVE_CHECK_HIP(ctx, hipGetLastError());
+    return HIVE_OK;
+}
+
 extern "C" {
 
 static int group_norm_impl(hive_ctx *ctx, const void *d_x, int dtype, int N, int HW, int C, int G, const void *d_gamma, const void *d_beta, float eps,

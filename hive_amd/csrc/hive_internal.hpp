@@ -91,6 +91,8 @@ int hive_reserve_device(hive_ctx *ctx, void **ptr, size_t *cur, size_t bytes);
 // copies `bytes` from host memory to device memory `dst` through the pinned ring; returns once the
 // host buffer may be reused by the caller
 int hive_upload(hive_ctx *ctx, void *dst, const void *src, size_t bytes);
+// dpt_ops.hip: (mean, rstd) per (sample, group) from the per-tile channel sums a GN convolution epilogue left (conv.hip)
+int hive_gn_finalize_tiles(hive_ctx *ctx, const float *d_partial, int N, int HW, int C, int G, int tile_rows, float eps, float *d_stats);
 // event helpers for kernel timing
 int hive_time_begin(hive_ctx *ctx);
 int hive_time_end(hive_ctx *ctx);

@@ -115,6 +115,15 @@ class MaxPool2dSame(nn.Module):
         return F.max_pool2d(x, self.k, self.s)
 
 
+def _conv_norm(conv, norm, x, residual=None):
+    """The expanding 1 x 1 convolutions of a bottleneck with their GroupNorm (+ shortcut + ReLU) as one two-pass operation
+    (hive_nhwc_conv_gn_apply), or None: not the hip engine / not eligible."""
+    if conv.engine != "hip" or norm.engine != "hip" or not dpt_ops.conv_eligible(x, conv):
+        return None
+    return dpt_ops.conv_gn_act(x, conv, norm, weight=conv.standardized_weight(), same_pad=True, relu=norm.apply_act or residual is not None,
+                               residual=residual)
+
+
 class DownsampleConv(nn.Module):
     def __init__(self, in_chs, out_chs, stride):
         super().__init__()
@@ -122,7 +131,8 @@ class DownsampleConv(nn.Module):
         self.norm = GroupNormAct(out_chs, apply_act=False)
 
     def forward(self, x):
-        return self.norm(self.conv(x))
+        y = _conv_norm(self.conv, self.norm, x)
+        return y if y is not None else self.norm(self.conv(x))
 
 
 class Bottleneck(nn.Module):
@@ -143,7 +153,8 @@ class Bottleneck(nn.Module):
         shortcut = x if self.downsample is None else self.downsample(x)
         x = self.norm1(self.conv1(x))
         x = self.norm2(self.conv2(x))
-        return self.norm3(self.conv3(x), residual=shortcut)  # relu(norm3(.) + shortcut)
+        y = _conv_norm(self.conv3, self.norm3, x, residual=shortcut)
+        return y if y is not None else self.norm3(self.conv3(x), residual=shortcut)  # relu(norm3(.) + shortcut)
 
 
 class ResNetStage(nn.Module):

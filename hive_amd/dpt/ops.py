@@ -133,6 +133,31 @@ def conv2d(x, conv, weight=None, same_pad=False, relu=False, residual=None, resi
     return (out, out_relu) if also_relu else out
 
 
+def conv_gn_act(x, conv, norm, weight=None, same_pad=False, relu=True, residual=None):
+    """relu?(group_norm(conv(x)) (+ residual)) through hive_nhwc_conv_gn_apply (the convolution's output never reaches memory), or
+    None where that is not eligible (the caller then runs ``conv2d`` + ``group_norm_act``).  ``norm``: the nn.GroupNorm."""
+    import ctypes
+    if not (conv_eligible(x, conv) and conv.bias is None and norm.weight.dtype == x.dtype):
+        return None
+    n, _, ih, iw = x.shape
+    k, st, pt, pl, oh, ow = conv_geometry(conv, ih, iw, same_pad)
+    cout, g = conv.out_channels, norm.num_groups
+    if cout % 256 or cout % g or (cout // g) % 8 or oh * ow < 256:
+        return None
+    w = weight if weight is not None else _conv3x3_weight(conv)
+    if not w.is_contiguous(memory_format=torch.channels_last):
+        w = w.contiguous(memory_format=torch.channels_last)
+    out = torch.empty((n, cout, oh, ow), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    assert residual is None or (residual.shape == out.shape and residual.dtype == out.dtype and residual.is_contiguous(memory_format=torch.channels_last))
+    ctx = _lib.default_context(x.device.index or 0)
+    scratch = torch.empty(int(ctx.lib.hive_nhwc_conv_gn_partial_floats(n * oh * ow, cout)) + 2 * n * g, dtype=torch.float32, device=x.device)
+    fused = ctypes.c_int(0)
+    ctx.check(ctx.lib.hive_nhwc_conv_gn_apply(ctx.handle, x.data_ptr(), _lib.BF16, n, ih, iw, conv.in_channels, cout, k, st, pt, pl, oh, ow, w.data_ptr(), g,
+                                              norm.weight.data_ptr(), norm.bias.data_ptr(), float(norm.eps), _lib.ptr(residual), int(bool(relu)),
+                                              out.data_ptr(), scratch.data_ptr(), scratch.numel(), ctypes.byref(fused)))
+    return out if fused.value else None
+
+
 _stem_weights = {}  # id(conv) -> (stamp, [64][7][32] weights)
 
 

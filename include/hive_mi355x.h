@@ -360,6 +360,17 @@ int hive_nhwc_group_norm_stats(hive_ctx *ctx, const void *d_x, int dtype, int N,
                                const void *d_beta, float eps, const void *d_residual, int relu, void *d_out,
                                const void *d_gn_partial, int gn_tile_rows);
 
+/* d_out = relu?( GroupNorm_G(conv(x); gamma, beta, eps) (+ d_residual) ) with the convolution's own output never written: the
+ * bottleneck tails of timm's ResNetV2 (`norm3(conv3(x))` + shortcut + ReLU, and `downsample.norm(downsample.conv(x))`).  The
+ * convolution runs twice -- per-tile channel sums first, then normalisation in the epilogue -- which pays where C_out > C_in.
+ * Results are bit-identical to hive_nhwc_conv_gn followed by hive_nhwc_group_norm_stats.  d_scratch: float,
+ * >= hive_nhwc_conv_gn_partial_floats(N * H_out * W_out, C_out) + 2 * N * G elements.  *fused = 0: not eligible (needs
+ * C_out % 256 == 0, (C_out / G) % 8 == 0, H_out * W_out >= 256), nothing was done and the caller runs the separate sequence. */
+int hive_nhwc_conv_gn_apply(hive_ctx *ctx, const void *d_x, int dtype, int N, int H, int W, int C_in, int C_out, int kernel,
+                            int stride, int pad_top, int pad_left, int H_out, int W_out, const void *d_w, int G,
+                            const void *d_gamma, const void *d_beta, float eps, const void *d_residual, int relu, void *d_out,
+                            void *d_scratch, int64_t scratch_floats, int *fused);
+
 /* ResNetV2 stem of the hybrid backbone (timm 0.5.4 ResNetV2.stem, reached from DPTDepthModel.forward): the 7 x 7 stride-2
  * weight-standardised convolution 3 -> 64 with TensorFlow "SAME" padding on the channels-last frame d_x [N][H][W][3] ->
  * d_out [N][ceil(H/2)][ceil(W/2)][64]; d_w = the standardised weights as [64][7][32] ((kx, c) of a kernel row padded from 21 to

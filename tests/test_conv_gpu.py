@@ -239,3 +239,43 @@ def test_conv_epilogue_group_norm_statistics(gpu_ctx, n, cin, cout, k, stride, h
     again = ops.conv2d(x, conv, weight=wstd, same_pad=True, gn_stats=True)
     used = ((out.numel() // cout + tile_rows - 1) // tile_rows) * 4 * cout if tile_rows else 0
     assert torch.equal(again.hive_gn_stats[0][:used], partial[:used]), "the epilogue sums are run-to-run identical"
+
+
+@pytest.mark.parametrize("n,cin,cout,stride,h,w,with_residual", [
+    (3, 64, 256, 1, 20, 24, True),      # conv3 of a stage-1 block: tiles straddle the samples
+    (2, 256, 1024, 1, 30, 40, True),    # four N tiles
+    (5, 256, 512, 2, 47, 61, False),    # the downsample convolution of a stage: stride 2, no shortcut, no ReLU
+    (40, 64, 256, 1, 48, 64, True),     # more tiles than CUs
+    (2, 64, 256, 1, 9, 13, True),       # smaller than a tile: not fused (None)
+    (2, 64, 128, 1, 20, 24, True),      # 128 output channels: not fused
+])
+def test_conv_group_norm_two_pass_equals_the_pair(gpu_ctx, n, cin, cout, stride, h, w, with_residual):
+    """hive_nhwc_conv_gn_apply (convolution twice, its output never stored) is bit-identical to conv -> GroupNorm with the
+    epilogue's statistics, and within bf16 rounding of float32 torch."""
+    from hive_amd.dpt import ops
+    from hive_amd.dpt.models import GroupNormAct, StdConv2dSame
+    g = torch.Generator(device="cpu").manual_seed(cout + h)
+    conv = StdConv2dSame(cin, cout, 1, stride=stride)
+    norm = GroupNormAct(cout, apply_act=False)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g))
+        norm.weight.copy_(torch.rand(cout, generator=g) + 0.5)
+        norm.bias.copy_(torch.randn(cout, generator=g) * 0.2)
+    conv = conv.to(memory_format=torch.channels_last).to(torch.bfloat16).cuda().eval()
+    norm = norm.to(torch.bfloat16).cuda().eval()
+    x = (torch.randn(n, cin, h, w, generator=g) + 0.3).bfloat16().cuda().contiguous(memory_format=torch.channels_last)
+    wstd = conv.standardized_weight()
+    t = ops.conv2d(x, conv, weight=wstd, same_pad=True, gn_stats=True)
+    res = torch.randn(t.shape, generator=g).bfloat16().cuda().contiguous(memory_format=torch.channels_last) if with_residual else None
+    relu = with_residual
+    pair = ops.group_norm_act(t, 32, norm.weight, norm.bias, norm.eps, relu=relu, residual=res, engine="hip", stats=t.hive_gn_stats)
+    fused = ops.conv_gn_act(x, conv, norm, weight=wstd, same_pad=True, relu=relu, residual=res)
+    if t.shape[2] * t.shape[3] < 256 or cout % 256:
+        assert fused is None
+        return
+    assert fused is not None and torch.equal(fused, pair)
+    ref = F.group_norm(F.conv2d(x.float(), wstd.float(), None, stride), 32, norm.weight.float(), norm.bias.float(), norm.eps)
+    if res is not None:
+        ref = F.relu(ref + res.float())
+    err = (fused.float() - ref).abs().max().item()
+    assert err <= 0.04 * max(ref.abs().max().item(), 1.0), err
