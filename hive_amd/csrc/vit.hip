@@ -382,6 +382,12 @@ struct AttnParams {
 constexpr int ATT_KV = 64;  // keys per tile
 constexpr float ATT_DEFER = 8.0f / (0.125f * 1.44269504088896340736f);  // raw-score margin = 8 in the log2 domain
 
+__device__ __forceinline__ float max3_raw(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * ATT_KV * 128];  // 2 stages x (K tile, V^T tile)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -448,9 +454,18 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
                 for (int i = 0; i < 16; ++i)
                     if (key0 + kb * 32 + (i & 3) + 8 * (i >> 2) >= p.N) sacc[kb][i] = -INFINITY;
         }
-        float m_tile = fmaxf(sacc[0][0], sacc[1][0]);
+        // v_max3_f32 by hand: fmaxf() makes the compiler canonicalise every MFMA result first (one v_max_f32 x, x, x per score:
+        // 50 v_max + 8 v_max3 per tile where 16 v_max3 do; the softmax VALU work, not the MFMAs, bounds this kernel)
+        float m_tile = max3_raw(sacc[0][0], sacc[1][0], sacc[0][1]);
+        m_tile = max3_raw(m_tile, sacc[1][1], sacc[0][2]);
 #pragma unroll
-        for (int i = 1; i < 16; ++i) m_tile = fmaxf(m_tile, fmaxf(sacc[0][i], sacc[1][i]));
+        for (int i = 2; i < 16; i += 2) {
+            m_tile = max3_raw(m_tile, sacc[1][i], sacc[0][i + 1]);
+            if (i + 2 < 16)
+                m_tile = max3_raw(m_tile, sacc[1][i + 1], sacc[0][i + 2]);
+            else
+                m_tile = max3_raw(m_tile, sacc[1][i + 1], sacc[1][i + 1]);
+        }
         m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32));
         // deferred maximum: the running maximum m_run only moves when some query of the wave exceeds it by
         // more than ATT_DEFER (probabilities then stay below 2^(c * ATT_DEFER) = 2^8 -- harmless in f32 / bf16),
