@@ -105,6 +105,8 @@ struct GemmParams {
     int M, N, K, ldc;
     int Np, H;           // EPI_QKV: tokens per image (padded), heads
     int n_split;         // EPI_QKV: columns >= n_split are V columns
+    int q_cols;          // EPI_BIAS: columns < q_cols (a multiple of 8) are multiplied by q_scale after the bias (the q part of q|k)
+    float q_scale;
 };
 
 constexpr int BN = 128, BK = 64;
@@ -152,6 +154,10 @@ __device__ __forceinline__ void gemm_store_rows(const GemmParams &p, const f32x4
         const int m = m_base + r;
         if (m >= p.M) return;
         float o[8] = {lo[0] + b0.x, lo[1] + b0.y, lo[2] + b0.z, lo[3] + b0.w, hi[0] + b1.x, hi[1] + b1.y, hi[2] + b1.z, hi[3] + b1.w};
+        if (EPI == EPI_BIAS && n < p.q_cols) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] *= p.q_scale;
+        }
         if (EPI == EPI_BIAS_GELU) {
 #pragma unroll
             for (int j = 0; j < 8; j += 2) {
@@ -372,15 +378,14 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(GemmParams p) {
 
 // ------------------------------------------------------------------------------------------------
 struct AttnParams {
-    const bf16 *qk;  // [B*Np][2D]
+    const bf16 *qk;  // [B*Np][2D]; q pre-multiplied by head_dim^-0.5 * log2(e) (hive_vit_qkv)
     const bf16 *vT;  // [B][H][64][Np]
     bf16 *out;       // [B*Np][D]
     int B, H, N, Np, D;
-    float scale_log2e;  // head_dim^-0.5 * log2(e)
 };
 
 constexpr int ATT_KV = 64;  // keys per tile
-constexpr float ATT_DEFER = 8.0f / (0.125f * 1.44269504088896340736f);  // raw-score margin = 8 in the log2 domain
+constexpr float ATT_DEFER = 8.0f;  // margin of the deferred maximum, in the scores' (base-2 exponent) units
 
 __device__ __forceinline__ float max3_raw(float a, float b, float c) {
     float r;
@@ -435,8 +440,11 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
         if (t + 1 < n_tiles) issue_tile(t + 1, stage ^ 1);  // that buffer was last read in tile t-1, before its barrier
         const unsigned char *k_t = lds + stage * 2 * ATT_KV * 128, *v_t = k_t + ATT_KV * 128;
         // S^T[key][q] for 64 keys x 32 queries: rows (keys) in registers, query on the lane
+        // q is pre-scaled, so the products are the softmax's base-2 exponents; the accumulators start at -m (the running maximum of
+        // this lane's query), so they come out of the MFMAs already shifted: p = exp2(acc) -- no multiply-subtract per score
+        const float m_used = t == 0 ? 0.f : m_run;
         f32x16 sacc[2];
-        for (int i = 0; i < 16; ++i) sacc[0][i] = sacc[1][i] = 0.f;
+        for (int i = 0; i < 16; ++i) sacc[0][i] = sacc[1][i] = -m_used;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -444,7 +452,6 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
                 const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(k_t + swz(kb * 32 + lq, ks * 2 + hh));
                 sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[kb], 0, 0, 0);
             }
-        // online softmax in base 2 on the raw scores: p = exp2(c * (s - m)), c = log2(e) / 8.
         // key row of register i: 32 kb + (i & 3) + 8 (i >> 2) + 4 hh.  Keys >= N exist only in the last tile.
         if (t == n_tiles - 1) {
             const int key0 = t * ATT_KV + 4 * hh;
@@ -466,29 +473,31 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
             else
                 m_tile = max3_raw(m_tile, sacc[1][i + 1], sacc[1][i + 1]);
         }
-        m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32));
-        // deferred maximum: the running maximum m_run only moves when some query of the wave exceeds it by
-        // more than ATT_DEFER (probabilities then stay below 2^(c * ATT_DEFER) = 2^8 -- harmless in f32 / bf16),
-        // so the rescale of the O accumulators is skipped for almost every tile.  Any m gives the same softmax.
-        if (__any(m_tile > m_run + ATT_DEFER)) {
-            const float m_new = fmaxf(m_run, m_tile);
-            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * p.scale_log2e);  // 0 for the first tile
+        m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32));  // the tile's maximum RELATIVE to m_used
+        // deferred maximum: the running maximum only moves when some query of the wave exceeds it by more than ATT_DEFER
+        // (probabilities then stay below 2^8 -- harmless in f32 / bf16), so the rescale of the O accumulators and the re-shift of
+        // the scores are skipped for almost every tile.  Any m gives the same softmax.
+        if (t == 0 || __any(m_tile > ATT_DEFER)) {
+            const float m_new = t == 0 ? m_tile : fmaxf(m_run, m_used + m_tile);
+            const float delta = m_new - m_used;
+            const float alpha = t == 0 ? 0.f : __builtin_amdgcn_exp2f(m_run - m_new);
             m_run = m_new;
             l_run *= alpha;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 oacc[0][i] *= alpha;
                 oacc[1][i] *= alpha;
+                sacc[0][i] -= delta;
+                sacc[1][i] -= delta;
             }
         }
-        const float mc = m_run * p.scale_log2e;
         float l_tile = 0.f;
         bf16x8 pf[2][2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[kb][i], p.scale_log2e, -mc));
+                const float e = __builtin_amdgcn_exp2f(sacc[kb][i]);
                 l_tile += e;
                 pf[kb][i >> 3][i & 7] = (bf16)e;
             }
@@ -753,6 +762,8 @@ int hive_vit_qkv(hive_ctx *ctx, const void *x, const void *W, const float *bias,
     p.N = 2 * D;
     p.K = D;
     p.ldc = 2 * D;
+    p.q_cols = D;  // q leaves the GEMM in the softmax's base-2 exponent units: (x Wq + b) * head_dim^-0.5 * log2(e), rounded once
+    p.q_scale = 0.125f * 1.44269504088896340736f;
     if ((rc = launch_gemm(ctx, EPI_BIAS, p))) return rc;
     // v columns: transposed store into vT [B][H][64][Np]
     GemmParams pv{};
@@ -785,7 +796,6 @@ int hive_vit_attention(hive_ctx *ctx, const void *qk, const void *vT, void *out,
     p.N = N;
     p.Np = Np;
     p.D = D;
-    p.scale_log2e = 0.125f * 1.44269504088896340736f;
     return launch_attention(ctx, p);
 }
 

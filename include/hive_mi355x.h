@@ -269,12 +269,14 @@ int hive_vit_layernorm(hive_ctx *ctx, const void *x, const float *gamma, const f
 /* C = epilogue(A[M][K] W[N][K]^T + bias): epilogue 0 = none, 1 = GELU (erf), 2 = + residual[M][N] */
 int hive_vit_linear(hive_ctx *ctx, const void *A, const void *W, const float *bias, const void *residual,
                     void *C, int M, int N, int K, int epilogue);
-/* qkv projection of x [B*Np][D] (Np a multiple of 64): q|k -> qk [B*Np][2D], v -> vT [B][H][64][Np].  vT is an operand
- * layout private to hive_vit_attention: along its last axis the token quads 4..7 and 8..11 of every group of 16 are swapped
+/* qkv projection of x [B*Np][D] (Np a multiple of 64): q|k -> qk [B*Np][2D], v -> vT [B][H][64][Np].  Both are operands
+ * private to hive_vit_attention: q is stored multiplied by head_dim^-0.5 * log2(e) (in f32, before the one rounding to bf16), so
+ * the attention's score products are base-2 exponents; vT is laid out for its fragment reads: along its last axis the token quads 4..7 and 8..11 of every group of 16 are swapped
  * (token t is stored at t with bits 2 and 3 exchanged), which makes the attention's V fragments single 16-byte LDS reads. */
 int hive_vit_qkv(hive_ctx *ctx, const void *x, const void *W, const float *bias, void *qk, void *vT,
                  int B, int Np, int D, int H);
-/* softmax(q k^T / 8) v over the first N keys of each image -> out [B*Np][D]; Np = N rounded up to a multiple of 64 */
+/* softmax(q k^T / 8) v over the first N keys of each image -> out [B*Np][D]; Np = N rounded up to a multiple of 64; qk, vT as
+ * hive_vit_qkv writes them (q pre-scaled: the kernel evaluates exp2(q' k^T - max)) */
 int hive_vit_attention(hive_ctx *ctx, const void *qk, const void *vT, void *out, int B, int N, int Np,
                        int D, int H);
 

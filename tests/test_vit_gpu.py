@@ -102,7 +102,10 @@ def test_qkv_and_attention(gpu_ctx, B, N):
     vT = torch.empty(B, H, 64, Np, device="cuda", dtype=torch.bfloat16)
     gpu_ctx.check(gpu_ctx.lib.hive_vit_qkv(gpu_ctx.handle, x.data_ptr(), W.data_ptr(), bias.data_ptr(), qk.data_ptr(), vT.data_ptr(), B, Np, D, H))
     ref_qkv = x.float().reshape(B * Np, D) @ W.float().t() + bias
-    _close(qk, ref_qkv[:, :2 * D], "q|k")
+    c = 0.125 * 1.4426950408889634  # q is stored in the softmax's base-2 exponent units: q * head_dim^-0.5 * log2(e)
+    ref_qk = ref_qkv[:, :2 * D].clone()
+    ref_qk[:, :D] *= c
+    _close(qk, ref_qk, "q|k")
     ref_v = ref_qkv[:, 2 * D:].reshape(B, Np, H, 64).permute(0, 2, 3, 1)
     # v^T is stored with token quads 4..7 and 8..11 of every 16 swapped (bits 2 and 3 of the token index exchanged): undo it
     tok = torch.arange(Np, device="cuda")
@@ -115,7 +118,7 @@ def test_qkv_and_attention(gpu_ctx, B, N):
     q = qk[:, :D].float().reshape(B, Np, H, 64).permute(0, 2, 1, 3)[:, :, :N]
     k = qk[:, D:].float().reshape(B, Np, H, 64).permute(0, 2, 1, 3)[:, :, :N]
     v = vT_tokens.float().permute(0, 1, 3, 2)[:, :, :N]
-    attn = torch.softmax(q @ k.transpose(-1, -2) * 0.125, dim=-1)
+    attn = torch.softmax(q @ k.transpose(-1, -2) * 0.6931471805599453, dim=-1)  # exp2(q' k^T) with the stored q' = c q
     ref = (attn @ v).permute(0, 2, 1, 3).reshape(B, N, D)
     _close(out.reshape(B, Np, D)[:, :N], ref, "attention")
 
