@@ -430,6 +430,8 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
     f32x16 oacc[2];
     for (int i = 0; i < 16; ++i) oacc[0][i] = oacc[1][i] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
+    f32x16 neg_m;  // -m_run in every element (0 before the first tile)
+    for (int i = 0; i < 16; ++i) neg_m[i] = 0.f;
 
     const int n_tiles = p.Np / ATT_KV;
     issue_tile(0, 0);
@@ -442,18 +444,20 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
         // S^T[key][q] for 64 keys x 32 queries: rows (keys) in registers, query on the lane
         // q is pre-scaled, so the products are the softmax's base-2 exponents; the accumulators start at -m (the running maximum of
         // this lane's query), so they come out of the MFMAs already shifted: p = exp2(acc) -- no multiply-subtract per score
+        // (-m sits in 16 registers of its own, rewritten only when the maximum moves, and is the C operand of each chain's first MFMA:
+        // no per-tile initialisation of the 32 accumulators)
         const float m_used = t == 0 ? 0.f : m_run;
         f32x16 sacc[2];
-        for (int i = 0; i < 16; ++i) sacc[0][i] = sacc[1][i] = -m_used;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
                 const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(k_t + swz(kb * 32 + lq, ks * 2 + hh));
-                sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[kb], 0, 0, 0);
+                sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], ks == 0 ? neg_m : sacc[kb], 0, 0, 0);
             }
         // key row of register i: 32 kb + (i & 3) + 8 (i >> 2) + 4 hh.  Keys >= N exist only in the last tile.
         if (t == n_tiles - 1) {
+            asm volatile("; pad keys: last tile only" ::: "memory");  // keeps this a branch (if-converted it is 31 v_cndmask in EVERY tile)
             const int key0 = t * ATT_KV + 4 * hh;
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
@@ -489,6 +493,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
                 oacc[1][i] *= alpha;
                 sacc[0][i] -= delta;
                 sacc[1][i] -= delta;
+                neg_m[i] = -m_new;
             }
         }
         float l_tile = 0.f;
@@ -519,16 +524,28 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
     }
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = 1.0f / l_tot;
-    if (q_row < p.Np) {
-        bf16 *o = p.out + (row0 + q_row) * p.D + head * 64;
+    // O leaves through LDS (the K / V stages are free: the loop's last barrier is behind every wave): in the accumulator layout a lane
+    // owns 4 consecutive channels of its query, so a direct store is 32 rows x 16 bytes per instruction (8 per wave, store-issue
+    // bound); turned around in the wave's private 4 KiB -- [query][64 channels], 16-byte chunk c of row r at slot c ^ (r & 7) -- the
+    // wave stores 4 x (8 rows x 128 contiguous bytes).
+    unsigned char *ot = lds + wave * 4096;
 #pragma unroll
-        for (int db = 0; db < 2; ++db)
+    for (int db = 0; db < 2; ++db)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                bf16x4 ov;
-                for (int j = 0; j < 4; ++j) ov[j] = (bf16)(oacc[db][4 * g + j] * inv);
-                *reinterpret_cast<bf16x4 *>(o + db * 32 + 8 * g + 4 * hh) = ov;
-            }
+        for (int g = 0; g < 4; ++g) {
+            bf16x4 ov;
+            for (int j = 0; j < 4; ++j) ov[j] = (bf16)(oacc[db][4 * g + j] * inv);
+            *reinterpret_cast<bf16x4 *>(ot + lq * 128 + (((4 * db + g) ^ (lq & 7)) << 4) + 8 * hh) = ov;  // channels 32 db + 8 g + 4 hh ..+3
+        }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = 8 * j + (lane >> 3), c = lane & 7;
+        const bf16x8 row = *reinterpret_cast<const bf16x8 *>(ot + r * 128 + ((c ^ (r & 7)) << 4));
+        const int q = qb * 128 + wave * 32 + r;
+        if (q < p.Np) *reinterpret_cast<bf16x8 *>(p.out + (row0 + q) * p.D + head * 64 + 8 * c) = row;
     }
 }
 
