@@ -252,23 +252,41 @@ __global__ __launch_bounds__(TM * 2, 1) void gemm_kernel(GemmParams p) {
     if constexpr (!VT) {
         gemm_store_rows<EPI, 4>(p, acc, m0 + wr * 64, n0 + wc * 64, lds + NST * STAGE_BYTES + wave * 4096, lane);
     } else {
-        // v^T[b][h][c][token]: a lane owns 4 consecutive tokens (rows m) of one channel (col n)
+        // v^T[b][h][c][token]: the wave's 64 tokens x 64 channels are one head of one image (Np % 64 == 0): 64 rows of 128 contiguous
+        // bytes.  A lane owns 4 consecutive tokens of one channel, so a direct store is 16 rows x 32 bytes per instruction; instead
+        // the block is turned around in the wave's 4 KiB of LDS, 32 channels at a time ([channel][64 token slots] bf16, 16-byte chunk c
+        // of row r at c ^ (r & 7)) and leaves as 8 rows x 128 bytes per instruction.  vt_slot exchanges bits 2 and 3 of the token
+        // index = the two bits of fq: the lane's quad stays contiguous.
+        unsigned char *ot = lds + NST * STAGE_BYTES + wave * 4096;
+        const int mw = m0 + wr * 64;  // M = B Np is a multiple of 64: the block is inside or outside as a whole
+        const int fqs = ((fq & 1) << 1) | (fq >> 1);
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            const int n = n0 + wc * 64 + nt * 16 + fr;  // column of the V block
-            const float b = p.bias[n];
-            const int head = n >> 6, ch = n & 63;
+        for (int half = 0; half < 2; ++half) {
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const int m = m0 + wr * 64 + mt * 16 + fq * 4;  // multiple of 4; Np is a multiple of 64
-                if (m < p.M) {
-                    const int img = m / p.Np, tok = vt_slot(m % p.Np);
+            for (int ntl = 0; ntl < 2; ++ntl) {
+                const int nt = half * 2 + ntl, row = ntl * 16 + fr;
+                const float b = p.bias[n0 + wc * 64 + nt * 16 + fr];
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
                     bf16x4 ov;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) ov[j] = (bf16)(acc[mt][nt][j] + b);
-                    *reinterpret_cast<bf16x4 *>(p.vT + (((size_t)img * p.H + head) * 64 + ch) * p.Np + tok) = ov;
+                    *reinterpret_cast<bf16x4 *>(ot + row * 128 + (((mt * 2 + (fqs >> 1)) ^ (row & 7)) << 4) + (fqs & 1) * 8) = ov;
                 }
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (mw < p.M) {
+                const int img = mw / p.Np, tok0 = mw - img * p.Np, head = (n0 + wc * 64) >> 6;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = 8 * i + (lane >> 3), c = lane & 7;
+                    const bf16x8 o8 = *reinterpret_cast<const bf16x8 *>(ot + row * 128 + ((c ^ (row & 7)) << 4));
+                    *reinterpret_cast<bf16x8 *>(p.vT + (((size_t)img * p.H + head) * 64 + half * 32 + row) * p.Np + tok0 + 8 * c) = o8;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();  // the second half's writes stay behind these reads
         }
     }
     if (!has_next) break;
