@@ -130,10 +130,15 @@ struct KPipe {
 // Image: 256-byte rows, 16-byte chunk c of row r at slot c ^ r (both the writes -- 8 consecutive rows at one chunk index -- and the
 // reads -- the four 16-lane groups of ds_read_b128 -- are conflict-free).  Wave-private, LDS operations of a wave execute in order:
 // no workgroup barrier.
-template <int MT, typename Acc, typename Finish>
-__device__ __forceinline__ void staged_rows(unsigned char *stage, const Acc &acc, int lane, Finish &&finish) {
+// `pre(mt, j)` (optional) is called one fragment row AHEAD of `finish(row, col, lo, hi, mt, j)`: the place to issue the global loads
+// (residual rows) that finish will consume, so that they fly during the previous fragment row's turn-around instead of being
+// waited for in front of every store.
+template <int MT, typename Acc, typename Pre, typename Finish>
+__device__ __forceinline__ void staged_rows(unsigned char *stage, const Acc &acc, int lane, Pre &&pre, Finish &&finish) {
     const int fr = lane & 15, fq = lane >> 4;
     const int rr = lane >> 3, c0 = 2 * (lane & 7);
+    pre(0, 0);
+    pre(0, 1);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -141,15 +146,24 @@ __device__ __forceinline__ void staged_rows(unsigned char *stage, const Acc &acc
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (mt + 1 < MT) {
+            pre(mt + 1, 0);
+            pre(mt + 1, 1);
+        }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int r = 8 * j + rr;
             const f32x4 lo = *reinterpret_cast<const f32x4 *>(stage + r * 256 + ((c0 ^ r) << 4));
             const f32x4 hi = *reinterpret_cast<const f32x4 *>(stage + r * 256 + (((c0 + 1) ^ r) << 4));
-            finish(mt * 16 + r, c0 * 4, lo, hi);
+            finish(mt * 16 + r, c0 * 4, lo, hi, mt, j);
         }
         __builtin_amdgcn_wave_barrier();  // the next fragment row's writes stay behind these reads
     }
+}
+
+template <int MT, typename Acc, typename Finish>
+__device__ __forceinline__ void staged_rows(unsigned char *stage, const Acc &acc, int lane, Finish &&finish) {
+    staged_rows<MT>(stage, acc, lane, [](int, int) {}, [&](int r, int c, const f32x4 &lo, const f32x4 &hi, int, int) { finish(r, c, lo, hi); });
 }
 
 constexpr int STAGED_ROWS_LDS = 8 * 4096;  // 8 waves

@@ -148,32 +148,41 @@ __device__ __forceinline__ void stage_group(const bf16 *__restrict__ src, int ld
 // wave's 4 KiB of LDS (mfma_pipe.hpp staged_rows) so that the residual loads and the stores are 16 bytes per lane on whole lines.
 template <int EPI, int MT>
 __device__ __forceinline__ void gemm_store_rows(const GemmParams &p, const f32x4 (&acc)[4][MT], int m_base, int n_base, unsigned char *stage, int lane) {
-    const int n = n_base + (lane & 7) * 8;
+    const int n = n_base + (lane & 7) * 8, rr = lane >> 3;
     const float4 b0 = *reinterpret_cast<const float4 *>(p.bias + n), b1 = *reinterpret_cast<const float4 *>(p.bias + n + 4);
-    hive_mfma::staged_rows<MT>(stage, acc, lane, [&](int r, int, const f32x4 &lo, const f32x4 &hi) {
+    // residual rows: loaded one fragment row ahead (two register sets), not in front of each store.  The residual may BE the output
+    // (x += proj(...)): every element is read by the lane that later writes it, rows of fragment row mt + 1 are read before rows of
+    // mt are written -- no hazard, but the compiler cannot know, so the order is set by hand.
+    bf16x8 rs[2][2];
+    auto pre = [&](int mt, int j) {
+        if (EPI == EPI_BIAS_RESIDUAL) {
+            const int m = min(m_base + mt * 16 + 8 * j + rr, p.M - 1);
+            rs[mt & 1][j] = *reinterpret_cast<const bf16x8 *>(p.residual + (size_t)m * p.ldc + n);
+        }
+    };
+    hive_mfma::staged_rows<MT>(stage, acc, lane, pre, [&](int r, int, const f32x4 &lo, const f32x4 &hi, int mt, int j) {
         const int m = m_base + r;
         if (m >= p.M) return;
         float o[8] = {lo[0] + b0.x, lo[1] + b0.y, lo[2] + b0.z, lo[3] + b0.w, hi[0] + b1.x, hi[1] + b1.y, hi[2] + b1.z, hi[3] + b1.w};
         if (EPI == EPI_BIAS && n < p.q_cols) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] *= p.q_scale;
+            for (int k = 0; k < 8; ++k) o[k] *= p.q_scale;
         }
         if (EPI == EPI_BIAS_GELU) {
 #pragma unroll
-            for (int j = 0; j < 8; j += 2) {
-                const f32x2 g = gelu_exact2(f32x2{o[j], o[j + 1]});
-                o[j] = g.x;
-                o[j + 1] = g.y;
+            for (int k = 0; k < 8; k += 2) {
+                const f32x2 g = gelu_exact2(f32x2{o[k], o[k + 1]});
+                o[k] = g.x;
+                o[k + 1] = g.y;
             }
         }
         if (EPI == EPI_BIAS_RESIDUAL) {
-            const bf16x8 rs = *reinterpret_cast<const bf16x8 *>(p.residual + (size_t)m * p.ldc + n);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] += (float)rs[j];
+            for (int k = 0; k < 8; ++k) o[k] += (float)rs[mt & 1][j][k];
         }
         bf16x8 ov;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) ov[j] = (bf16)o[j];
+        for (int k = 0; k < 8; ++k) ov[k] = (bf16)o[k];
         *reinterpret_cast<bf16x8 *>(p.C + (size_t)m * p.ldc + n) = ov;
     });
 }
