@@ -345,13 +345,21 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(GemmParams p) {
     const int tiles_n = p.N / T256;
     const int m0 = (tile / tiles_n) * T256, n0 = (tile % tiles_n) * T256;
 
+    // LDS-DMA addressing, hoisted: piece j of this wave (group g = wave + 8 j: j < 4 an A group, else a W group; 8 rows x 128 B) reads
+    // [uniform panel base + 128 kt] + [per-lane byte offset of (row, swizzled chunk)], and the per-lane part does not depend on kt --
+    // 8 registers computed once instead of a clamp, two 64-bit multiply-adds and three 64-bit adds per piece and K-step (~90 VALU
+    // instructions per wave and step beside its 64 MFMAs).
+    unsigned piece_off[PER_WAVE];
+#pragma unroll
+    for (int j = 0; j < PER_WAVE; ++j) {
+        const int g = wave + j * 8, row = (g & (A_GROUPS - 1)) * 8 + (lane >> 3), chunk = (lane & 7) ^ ((row >> 1) & 7);
+        const int rel = j < PER_WAVE / 2 ? min(row, p.M - 1 - m0) : min(row, p.N - 1 - n0);  // rows past the end: the last row again (never stored)
+        piece_off[j] = (unsigned)rel * (unsigned)p.K * 2u + (unsigned)chunk * 16u;
+    }
+    const char *a_panel = reinterpret_cast<const char *>(p.A + (size_t)m0 * p.K), *w_panel = reinterpret_cast<const char *>(p.W + (size_t)n0 * p.K);
     auto issue_piece = [&](int kt, int stage, int j) {
-        unsigned char *st = lds + stage * T256_STAGE;
-        const int g = wave + j * 8;
-        if (g < A_GROUPS)
-            stage_group(p.A, p.K, m0, p.M - 1, kt * BK, st, g, lane);
-        else
-            stage_group(p.W, p.K, n0, p.N - 1, kt * BK, st + A_GROUPS * 1024, g - A_GROUPS, lane);
+        const char *g = (j < PER_WAVE / 2 ? a_panel : w_panel) + (size_t)kt * (BK * 2) + piece_off[j];
+        __builtin_amdgcn_global_load_lds((const void *)g, (__attribute__((address_space(3))) void *)(lds + stage * T256_STAGE + (wave + j * 8) * 1024), 16, 0, 0);
     };
 
     f32x4 acc[4][8];  // acc[nt][mt] = W_frag . A_frag^T : rows = n, cols = m
