@@ -317,7 +317,12 @@ __global__ __launch_bounds__(TM * 2, 1) void gemm_kernel(GemmParams p) {
 // a wave's own pieces have landed when it reaches the barrier (vmcnt wait: 10 % of its waiting), and a FOUR-stage ring of 32-deep
 // steps (stages issued three steps ahead, counted vmcnt -- built, bit-identical results, 1241 vs 1280) is no faster; issuing the
 // pieces later in the step is slower (1290 -> 1180 -> 1156 for a start at slot 0 / 3 / 6), two per slot marginally faster.  What
-// did help: the rotated K-step of mfma_pipe.hpp (KPipe: +2-5 %) and the epilogue through LDS (+10-20 % at K = 768).
+// did help: the rotated K-step of mfma_pipe.hpp (KPipe: +2-5 %) and the epilogue through LDS (+10-20 % at K = 768).  The decisive
+// timing build: every piece still issued and still writing its 1 KiB into LDS, but all reading the SAME 128 bytes -- 1670 TFLOP/s.
+// So neither the issue of the LDS-DMA instructions, nor their address arithmetic (hoisted out of the loop since: +1-2 %), nor the LDS
+// writes cost the 20 %: fetching 64 KiB of distinct lines per 2048 MFMA cycles and CU from L2 does (32 B/clk/CU wanted, ~26 B/clk
+// delivered with all 256 CUs streaming: tools/ubench/ldsdma.hip).  At 256 x 256 x 64 the tile is L2-bandwidth-bound; a larger tile does
+// not fit the register file.
 constexpr int T256 = 256, T256_STAGE = 2 * T256 / 8 * 1024;
 
 #ifdef HIVE_GEMM_STAMPS  // tuning builds only (make stamps): per-workgroup phase clocks of gemm256_kernel, read back by tools/probe_gemm_stamps.py
