@@ -116,6 +116,7 @@ int hive_ctx_create(int device_id, void *stream, hive_ctx **out) {
         }
     }
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_scalars, 64 * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMemset(ctx->d_scalars, 0, 64 * sizeof(unsigned));  // the TSDF scalar blocks start cleared (tsdf.hip prepare_frame)
     if (e == hipSuccess) e = hipMalloc(&ctx->d_zeros, 256);
     if (e == hipSuccess) e = hipMemset(ctx->d_zeros, 0, 256);
     if (e != hipSuccess) {

@@ -40,8 +40,11 @@ struct FrameParams {
 // atomicMax per workgroup).  VEC = false is the scalar fallback for unaligned / ragged images.
 template <bool VEC>
 __global__ __launch_bounds__(256) void pack_frame_kernel(const float *__restrict__ depth, const uint8_t *__restrict__ color,
-                                                         int n, uint2 *__restrict__ out, unsigned *max_bits) {
+                                                         int n, uint2 *__restrict__ out, unsigned *max_bits, unsigned *zero_next) {
     __shared__ unsigned wave_max[4];
+    // the NEXT frame's scalar block (max depth, update count, work-list length) is cleared here instead of by a memset launch per
+    // frame: the blocks alternate, and this kernel runs after every kernel of the frame that used that block last (stream order)
+    if (blockIdx.x == 0 && threadIdx.x < 8) zero_next[threadIdx.x] = 0u;
     const int i = (blockIdx.x * 256 + threadIdx.x) * (VEC ? 4 : 1);
     // max over non-negative floats == max over their bit patterns; NaN / negatives are ignored (treated as 0)
     unsigned bits = 0;
@@ -621,6 +624,9 @@ static int fill_volume(hive_tsdf *v) {
     return HIVE_OK;
 }
 
+// the scalar block of the frame in flight: d_scalars[0..7] or d_scalars[48..55]
+static inline unsigned *tsdf_scalars(hive_ctx *ctx) { return ctx->d_scalars + (ctx->tsdf_scalars ? 48 : 0); }
+
 static int prepare_frame(hive_tsdf *v, const uint8_t *color, const float *depth, int H, int W, int mem,
                          const uint8_t **d_color, const float **d_depth) {
     hive_ctx *ctx = v->ctx;
@@ -640,15 +646,17 @@ static int prepare_frame(hive_tsdf *v, const uint8_t *color, const float *depth,
     }
     int rc = hive_reserve_device(ctx, &ctx->d_frame, &ctx->frame_bytes, npx * sizeof(uint2));
     if (rc) return rc;
-    // [0] max depth bits, [2..3] n_updated, [4] work-list length
-    HIVE_CHECK_HIP(ctx, hipMemsetAsync(ctx->d_scalars, 0, 32, ctx->stream));
+    // scalar block of this frame: [0] max depth bits, [2..3] n_updated, [4] work-list length.  Two blocks alternate (both zero after
+    // hive_ctx_create); the pack kernel of a frame clears the block of the next one.
+    ctx->tsdf_scalars ^= 1;
+    unsigned *mine = tsdf_scalars(ctx), *next = ctx->d_scalars + (ctx->tsdf_scalars ? 0 : 48);
     const bool vec = npx % 4 == 0 && ((uintptr_t)*d_depth % 16 == 0) && ((uintptr_t)*d_color % 4 == 0);
     if (vec)
         hipLaunchKernelGGL(pack_frame_kernel<true>, dim3((unsigned)((npx / 4 + 255) / 256)), dim3(256), 0, ctx->stream, *d_depth,
-                           *d_color, (int)npx, (uint2 *)ctx->d_frame, ctx->d_scalars);
+                           *d_color, (int)npx, (uint2 *)ctx->d_frame, mine, next);
     else
         hipLaunchKernelGGL(pack_frame_kernel<false>, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, ctx->stream, *d_depth,
-                           *d_color, (int)npx, (uint2 *)ctx->d_frame, ctx->d_scalars);
+                           *d_color, (int)npx, (uint2 *)ctx->d_frame, mine, next);
     HIVE_CHECK_HIP(ctx, hipGetLastError());
     return HIVE_OK;
 }
@@ -679,8 +687,8 @@ static int launch_integrate(hive_tsdf *v, float *accum, int H, int W, const floa
     p.H = H;
     p.W = W;
     p.frame = (const uint2 *)ctx->d_frame;
-    p.max_depth_bits = ctx->d_scalars;
-    p.n_updated = (unsigned long long *)(ctx->d_scalars + 2);
+    p.max_depth_bits = tsdf_scalars(ctx);
+    p.n_updated = (unsigned long long *)(tsdf_scalars(ctx) + 2);
     const long long rows = (long long)p.X * p.Y;
     float *a0 = ACCUM ? accum : v->d_tsdf;
     const bool vec = (p.Z % 4 == 0) && (((uintptr_t)a0 | (uintptr_t)v->d_weight | (uintptr_t)v->d_color) % 16 == 0);
@@ -690,7 +698,7 @@ static int launch_integrate(hive_tsdf *v, float *accum, int H, int W, const floa
     int rc = hive_reserve_device(ctx, &ctx->d_scratch, &ctx->scratch_bytes, max_items * sizeof(WorkItem));
     if (rc) return rc;
     WorkItem *items = (WorkItem *)ctx->d_scratch;
-    unsigned *n_items = ctx->d_scalars + 4;
+    unsigned *n_items = tsdf_scalars(ctx) + 4;
     const dim3 wl_grid((unsigned)((rows + 1023) / 1024));
     if (vec)
         hipLaunchKernelGGL(build_worklist_kernel<4>, wl_grid, dim3(1024), 0, ctx->stream, p, items, n_items);
@@ -876,7 +884,7 @@ int hive_tsdf_integrate(hive_tsdf *vol, const uint8_t *color, const float *depth
     vol->n_verts = vol->n_faces = -1;
     if (n_updated) {
         unsigned long long n = 0;
-        HIVE_CHECK_HIP(ctx, hipMemcpyAsync(&n, ctx->d_scalars + 2, sizeof(n), hipMemcpyDeviceToHost, ctx->stream));
+        HIVE_CHECK_HIP(ctx, hipMemcpyAsync(&n, tsdf_scalars(ctx) + 2, sizeof(n), hipMemcpyDeviceToHost, ctx->stream));
         HIVE_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
         *n_updated = n;
     }
