@@ -99,6 +99,8 @@ SIGNATURES = {
                                         c_void_p, c_void_p, c_float, c_void_p, c_int, c_void_p, c_void_p, c_int64, P(c_int)]),
     "hive_nhwc_group_norm_stats": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_int,
                                            c_void_p, c_void_p, c_int]),
+    "hive_patch_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "hive_nhwc_pixel_shuffle_bias": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "hive_resnet_stem_conv": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "hive_nhwc_maxpool3x3s2": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "hive_dpt_create": (c_int, [c_void_p, c_void_p, c_void_p, c_int, P(c_void_p)]),

@@ -308,6 +308,54 @@ __global__ __launch_bounds__(256) void bias_act_kernel(const T *__restrict__ x, 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Patch embedding of ViT-L/16 (timm PatchEmbed: Conv2d(3, D, 16, 16)) as a GEMM: the P x P x C patch of output token (n, gy, gx) is
+// copied into row m of a [tokens][P P C] matrix in (ky, kx, c) order -- the order of the weight tensor in channels-last memory
+// format -- and hive_vit_linear does the rest.  A kernel row of a patch is P C contiguous values of the channels-last frame.
+template <typename T>
+__global__ __launch_bounds__(256) void patch_rows_kernel(const T *__restrict__ x, T *__restrict__ out, int N, int H, int W, int C, int P) {
+    const int gh = H / P, gw = W / P, row_vals = P * C;        // values per kernel row of a patch
+    const long long total = (long long)N * gh * gw * P;         // one (token, ky) pair per work item
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int ky = (int)(i % P);
+        const long long m = i / P;
+        const int gx = (int)(m % gw), gy = (int)((m / gw) % gh), n = (int)(m / ((long long)gw * gh));
+        const T *src = x + (((long long)n * H + gy * P + ky) * W + (long long)gx * P) * C;
+        T *dst = out + (m * P + ky) * row_vals;
+        if (row_vals % 8 == 0 && ((uintptr_t)src % 16 == 0)) {
+            for (int v = 0; v < row_vals; v += 8) *reinterpret_cast<uint4 *>(dst + v) = *reinterpret_cast<const uint4 *>(src + v);
+        } else {
+            for (int v = 0; v < row_vals; ++v) dst[v] = src[v];
+        }
+    }
+}
+
+// ConvTranspose2d with kernel == stride == s (DPT-Large's reassemble stages 1 and 2): the transposed convolution is a 1 x 1 convolution
+// to s s C channels ((dy, dx, co) order) followed by this scatter: in [N H W][s s C] -> out [N][s H][s W][C] (+ bias[co]).
+template <typename T>
+__global__ __launch_bounds__(256) void pixel_shuffle_bias_kernel(const T *__restrict__ in, const T *__restrict__ bias, T *__restrict__ out, int N, int H,
+                                                                  int W, int C, int s) {
+    const int VC = C >> 3;
+    const long long total = (long long)N * H * W * s * s * VC;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int v = (int)(i % VC);
+        long long r = i / VC;
+        const int dx = (int)(r % s);
+        r /= s;
+        const int dy = (int)(r % s);
+        r /= s;  // r = input pixel (n, y, x)
+        const int xx = (int)(r % W), yy = (int)((r / W) % H), n = (int)(r / ((long long)W * H));
+        float f[8], b[8];
+        load8(in + i * 8, f);  // in is [pixel][dy][dx][C]: exactly the order of i
+        if (bias) {
+            load8(bias + v * 8, b);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] += b[j];
+        }
+        store8(out + ((((long long)n * H * s + (long long)yy * s + dy) * W * s) + (long long)xx * s + dx) * C + v * 8, f);
+    }
+}
+
 static bool pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
 
 int hive_gn_finalize_tiles(hive_ctx *ctx, const float *d_partial, int N, int HW, int C, int G, int tile_rows, float eps, float *d_stats) {
@@ -401,6 +449,43 @@ int hive_nhwc_upsample2x(hive_ctx *ctx, const void *d_in, const void *d_bias, in
         hipLaunchKernelGGL(upsample2x_kernel<_Float16>, grid, dim3(256), 0, ctx->stream, (const _Float16 *)d_in, (const _Float16 *)d_bias, (_Float16 *)d_out, N, H, W, C);
     else
         return hive_fail(ctx, HIVE_ERR_INVALID, "upsample2x: dtype must be HIVE_F16 or HIVE_BF16");
+    HIVE_CHECK_HIP(ctx, hipGetLastError());
+    return HIVE_OK;
+}
+
+int hive_patch_rows(hive_ctx *ctx, const void *d_x, int dtype, int N, int H, int W, int C, int patch, void *d_out) {
+    HIVE_ENTER(ctx);
+    if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
+    HIVE_REQUIRE(ctx, d_x && d_out, "patch_rows: NULL argument");
+    HIVE_REQUIRE(ctx, N > 0 && C > 0 && patch > 0 && H >= patch && W >= patch && H % patch == 0 && W % patch == 0,
+                 "patch_rows: need H, W multiples of the patch size (N=%d H=%d W=%d C=%d patch=%d)", N, H, W, C, patch);
+    const long long total = (long long)N * (H / patch) * (W / patch) * patch;
+    const dim3 grid((unsigned)std::min<long long>((total + 255) / 256, (long long)ctx->num_cus * 32));
+    if (dtype == HIVE_BF16)
+        hipLaunchKernelGGL(patch_rows_kernel<bf16>, grid, dim3(256), 0, ctx->stream, (const bf16 *)d_x, (bf16 *)d_out, N, H, W, C, patch);
+    else if (dtype == HIVE_F16)
+        hipLaunchKernelGGL(patch_rows_kernel<_Float16>, grid, dim3(256), 0, ctx->stream, (const _Float16 *)d_x, (_Float16 *)d_out, N, H, W, C, patch);
+    else
+        return hive_fail(ctx, HIVE_ERR_INVALID, "patch_rows: dtype must be HIVE_F16 or HIVE_BF16");
+    HIVE_CHECK_HIP(ctx, hipGetLastError());
+    return HIVE_OK;
+}
+
+int hive_nhwc_pixel_shuffle_bias(hive_ctx *ctx, const void *d_in, const void *d_bias, int dtype, int N, int H, int W, int C, int s, void *d_out) {
+    HIVE_ENTER(ctx);
+    if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
+    HIVE_REQUIRE(ctx, d_in && d_out && d_in != d_out, "pixel_shuffle_bias: NULL or aliasing argument");
+    HIVE_REQUIRE(ctx, N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && s > 0 && s <= 8, "pixel_shuffle_bias: need C %% 8 == 0, 1 <= s <= 8 (N=%d H=%d W=%d C=%d s=%d)", N,
+                 H, W, C, s);
+    const long long total = (long long)N * H * W * s * s * (C / 8);
+    const dim3 grid((unsigned)std::min<long long>((total + 255) / 256, (long long)ctx->num_cus * 32));
+    if (dtype == HIVE_BF16)
+        hipLaunchKernelGGL(pixel_shuffle_bias_kernel<bf16>, grid, dim3(256), 0, ctx->stream, (const bf16 *)d_in, (const bf16 *)d_bias, (bf16 *)d_out, N, H, W, C, s);
+    else if (dtype == HIVE_F16)
+        hipLaunchKernelGGL(pixel_shuffle_bias_kernel<_Float16>, grid, dim3(256), 0, ctx->stream, (const _Float16 *)d_in, (const _Float16 *)d_bias, (_Float16 *)d_out,
+                           N, H, W, C, s);
+    else
+        return hive_fail(ctx, HIVE_ERR_INVALID, "pixel_shuffle_bias: dtype must be HIVE_F16 or HIVE_BF16");
     HIVE_CHECK_HIP(ctx, hipGetLastError());
     return HIVE_OK;
 }

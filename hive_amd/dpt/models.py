@@ -469,6 +469,8 @@ class DPT(nn.Module):
         """An nn.Conv2d of the reassemble / embedding stages: the hand-written kernel where it applies (1 x 1, 3 x 3 stride 2)."""
         if self.engine == "hip" and isinstance(layer, nn.Conv2d) and not isinstance(layer, nn.ConvTranspose2d) and dpt_ops.conv_eligible(x, layer):
             return dpt_ops.conv2d(x, layer)
+        if self.engine == "hip" and dpt_ops.conv_transpose_eligible(x, layer):  # DPT-Large: ConvTranspose2d(k = s) as conv 1 x 1 + scatter
+            return dpt_ops.conv_transpose(x, layer)
         return layer(x)
 
     def forward_backbone(self, x, stages=None):
@@ -480,9 +482,13 @@ class DPT(nn.Module):
 
         def reassemble(tap, post):
             # readout projection -> [B, D, gh, gw] -> the stage's convolutions (isl-org/DPT forward_vit)
-            y = post[1](post[0](tap)).reshape(b, -1, gh, gw)
-            if cl:
-                y = y.contiguous(memory_format=torch.channels_last)
+            y = post[0](tap)  # [b, gh gw, D]
+            if cl and y.is_contiguous():
+                y = y.view(b, gh, gw, -1).permute(0, 3, 1, 2)  # the token matrix IS the channels-last map: no transposing copies
+            else:
+                y = post[1](y).reshape(b, -1, gh, gw)
+                if cl:
+                    y = y.contiguous(memory_format=torch.channels_last)
             for layer in post[3:]:
                 y = self._conv(layer, y)
             return y
@@ -494,7 +500,10 @@ class DPT(nn.Module):
             feat = vit.patch_embed.backbone.stages[2](layer_2)
         else:
             feat = x
-        tokens = self._conv(vit.patch_embed.proj, feat).flatten(2).transpose(1, 2)
+        if self.engine == "hip" and not p.hybrid and dpt_ops.patch_embed_eligible(feat, vit.patch_embed.proj):
+            tokens = dpt_ops.patch_embed(feat, vit.patch_embed.proj)  # ViT-L/16: the 16 x 16 / 16 convolution as rows + GEMM
+        else:
+            tokens = self._conv(vit.patch_embed.proj, feat).flatten(2).transpose(1, 2)
         tokens = torch.cat((vit.cls_token.expand(b, -1, -1).to(tokens.dtype), tokens), dim=1)
         tokens = tokens + vit.resize_pos_embed(gh, gw).to(tokens.dtype)
         taps = self._run_blocks(tokens)

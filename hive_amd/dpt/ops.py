@@ -158,6 +158,64 @@ def conv_gn_act(x, conv, norm, weight=None, same_pad=False, relu=True, residual=
     return out if fused.value else None
 
 
+_derived = {}  # (id(layer), what) -> (stamp, tensors): weights re-laid-out for the kernels, rebuilt when the parameter changes
+
+
+def _cached(layer, what, params, build):
+    stamp = tuple((p.data_ptr(), p._version, p.dtype, p.device) for p in params)
+    hit = _derived.get((id(layer), what))
+    if hit is None or hit[0] != stamp:
+        with torch.no_grad():
+            hit = _derived[(id(layer), what)] = (stamp, build())
+    return hit[1]
+
+
+def patch_embed_eligible(x, conv):
+    k = conv.kernel_size
+    return (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last) and type(conv) is torch.nn.Conv2d
+            and k[0] == k[1] and tuple(conv.stride) == tuple(k) and tuple(conv.padding) == (0, 0) and conv.groups == 1 and conv.weight.dtype == torch.bfloat16
+            and x.shape[2] % k[0] == 0 and x.shape[3] % k[0] == 0 and (k[0] * k[0] * conv.in_channels) % 64 == 0 and conv.out_channels % 128 == 0)
+
+
+def patch_embed(x, conv):
+    """timm ``PatchEmbed.proj`` (Conv2d(C, D, P, P)) -> tokens [N, (H/P)(W/P), D]: hive_patch_rows + the hand-written GEMM."""
+    n, c, h, w = x.shape
+    p, d = conv.kernel_size[0], conv.out_channels
+    wmat, bias = _cached(conv, "patch", (conv.weight, conv.bias) if conv.bias is not None else (conv.weight,), lambda: (
+        conv.weight.permute(0, 2, 3, 1).reshape(d, p * p * c).contiguous(),
+        (conv.bias.float() if conv.bias is not None else torch.zeros(d, device=x.device)).contiguous()))
+    m = n * (h // p) * (w // p)
+    cols = torch.empty((m, p * p * c), dtype=x.dtype, device=x.device)
+    out = torch.empty((n, (h // p) * (w // p), d), dtype=x.dtype, device=x.device)
+    ctx = _lib.default_context(x.device.index or 0)
+    ctx.check(ctx.lib.hive_patch_rows(ctx.handle, x.data_ptr(), _lib.BF16, n, h, w, c, p, cols.data_ptr()))
+    ctx.check(ctx.lib.hive_vit_linear(ctx.handle, cols.data_ptr(), wmat.data_ptr(), bias.data_ptr(), None, out.data_ptr(), m, d, p * p * c, 0))
+    return out
+
+
+def conv_transpose_eligible(x, layer):
+    k = layer.kernel_size
+    return (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)
+            and isinstance(layer, torch.nn.ConvTranspose2d) and k[0] == k[1] and tuple(layer.stride) == tuple(k) and tuple(layer.padding) == (0, 0)
+            and tuple(layer.output_padding) == (0, 0) and layer.groups == 1 and tuple(layer.dilation) == (1, 1) and layer.weight.dtype == torch.bfloat16
+            and layer.in_channels % 64 == 0 and layer.out_channels % 64 == 0 and k[0] <= 8)
+
+
+def conv_transpose(x, layer):
+    """ConvTranspose2d with kernel == stride (DPT-Large's reassemble stages): a 1 x 1 convolution to s s C_out channels in (dy, dx, co)
+    order (hive_nhwc_conv) and the scatter + bias of hive_nhwc_pixel_shuffle_bias."""
+    n, cin, h, w = x.shape
+    s_, cout = layer.kernel_size[0], layer.out_channels
+    wmat = _cached(layer, "convT", (layer.weight,), lambda: layer.weight.permute(2, 3, 1, 0).reshape(s_ * s_ * cout, cin).contiguous())  # [(dy, dx, co)][ci]
+    tmp = torch.empty((n * h * w, s_ * s_ * cout), dtype=x.dtype, device=x.device)
+    out = torch.empty((n, cout, h * s_, w * s_), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    ctx = _lib.default_context(x.device.index or 0)
+    ctx.check(ctx.lib.hive_nhwc_conv(ctx.handle, x.data_ptr(), _lib.BF16, n, h, w, cin, s_ * s_ * cout, 1, 1, 0, 0, h, w, wmat.data_ptr(), None, 0, None, None,
+                                     tmp.data_ptr(), None))
+    ctx.check(ctx.lib.hive_nhwc_pixel_shuffle_bias(ctx.handle, tmp.data_ptr(), _lib.ptr(layer.bias), _lib.BF16, n, h, w, cout, s_, out.data_ptr()))
+    return out
+
+
 _stem_weights = {}  # id(conv) -> (stamp, [64][7][32] weights)
 
 

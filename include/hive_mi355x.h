@@ -373,6 +373,17 @@ int hive_nhwc_conv_gn_apply(hive_ctx *ctx, const void *d_x, int dtype, int N, in
                             const void *d_gamma, const void *d_beta, float eps, const void *d_residual, int relu, void *d_out,
                             void *d_scratch, int64_t scratch_floats, int *fused);
 
+/* DPT-Large (timm vit_large_patch16_384, `DPTDepthModel(backbone="vitl16_384")`) pieces that are not plain convolutions of
+ * hive_nhwc_conv:
+ *   hive_patch_rows: the patch embedding Conv2d(C, D, P, P) as a GEMM -- the channels-last frame d_x [N][H][W][C] is rearranged into
+ *     d_out [N (H/P) (W/P)][P P C] ((ky, kx, c) order = the weight tensor in channels-last memory format); hive_vit_linear with that
+ *     weight and the bias then yields the tokens.
+ *   hive_nhwc_pixel_shuffle_bias: ConvTranspose2d(C, C, s, s) (reassemble stages 1 and 2) = a 1 x 1 convolution to s s C channels in
+ *     (dy, dx, co) order (hive_nhwc_conv) followed by this scatter d_in [N H W][s s C] -> d_out [N][s H][s W][C] (+ d_bias[co]). */
+int hive_patch_rows(hive_ctx *ctx, const void *d_x, int dtype, int N, int H, int W, int C, int patch, void *d_out);
+int hive_nhwc_pixel_shuffle_bias(hive_ctx *ctx, const void *d_in, const void *d_bias, int dtype, int N, int H, int W, int C, int s,
+                                 void *d_out);
+
 /* ResNetV2 stem of the hybrid backbone (timm 0.5.4 ResNetV2.stem, reached from DPTDepthModel.forward): the 7 x 7 stride-2
  * weight-standardised convolution 3 -> 64 with TensorFlow "SAME" padding on the channels-last frame d_x [N][H][W][3] ->
  * d_out [N][ceil(H/2)][ceil(W/2)][64]; d_w = the standardised weights as [64][7][32] ((kx, c) of a kernel row padded from 21 to

@@ -279,3 +279,37 @@ def test_conv_group_norm_two_pass_equals_the_pair(gpu_ctx, n, cin, cout, stride,
         ref = F.relu(ref + res.float())
     err = (fused.float() - ref).abs().max().item()
     assert err <= 0.04 * max(ref.abs().max().item(), 1.0), err
+
+
+def test_patch_embed_and_conv_transpose_match_torch(gpu_ctx):
+    """DPT-Large's non-standard convolutions through the hand-written kernels: the 16 x 16 / 16 patch embedding (hive_patch_rows +
+    the GEMM) and ConvTranspose2d with kernel == stride 4 and 2 (1 x 1 convolution + hive_nhwc_pixel_shuffle_bias), against float32 torch."""
+    from hive_amd.dpt import ops
+    g = torch.Generator(device="cpu").manual_seed(11)
+    x = torch.randn(2, 3, 96, 160, generator=g).bfloat16().cuda().contiguous(memory_format=torch.channels_last)
+    pe = nn.Conv2d(3, 1024, 16, 16)
+    with torch.no_grad():
+        pe.weight.copy_(torch.randn(pe.weight.shape, generator=g) * 0.05)
+        pe.bias.copy_(torch.randn(1024, generator=g) * 0.1)
+    pe = pe.to(memory_format=torch.channels_last).to(torch.bfloat16).cuda()
+    assert ops.patch_embed_eligible(x, pe)
+    tok = ops.patch_embed(x, pe)
+    ref = F.conv2d(x.float(), pe.weight.float(), pe.bias.float(), 16).flatten(2).transpose(1, 2)
+    assert tok.shape == ref.shape == (2, 60, 1024)
+    assert (tok.float() - ref).abs().max().item() <= 2 ** -7 * ref.abs().max().item() + 1e-3
+    with torch.no_grad():
+        pe.bias.add_(1.0)  # the derived weights follow a parameter update
+    assert (ops.patch_embed(x, pe).float() - (ref + 1.0)).abs().max().item() <= 2 ** -6 * (ref.abs().max().item() + 1.0)
+    for cin, s in ((256, 4), (512, 2)):
+        y = torch.randn(2, cin, 6, 10, generator=g).bfloat16().cuda().contiguous(memory_format=torch.channels_last)
+        ct = nn.ConvTranspose2d(cin, cin, s, s, 0, bias=True)
+        with torch.no_grad():
+            ct.weight.copy_(torch.randn(ct.weight.shape, generator=g) * (1.0 / cin) ** 0.5)
+            ct.bias.copy_(torch.randn(cin, generator=g) * 0.2)
+        ct = ct.to(torch.bfloat16).cuda()
+        assert ops.conv_transpose_eligible(y, ct)
+        out = ops.conv_transpose(y, ct)
+        ref = F.conv_transpose2d(y.float(), ct.weight.float(), ct.bias.float(), s)
+        assert out.shape == ref.shape and out.is_contiguous(memory_format=torch.channels_last)
+        # the 1 x 1 convolution's result is rounded to bf16 before the bias is added (two roundings)
+        assert (out.float() - ref).abs().max().item() <= 2 ** -6 * ref.abs().max().item() + 1e-3
