@@ -313,3 +313,32 @@ def test_patch_embed_and_conv_transpose_match_torch(gpu_ctx):
         assert out.shape == ref.shape and out.is_contiguous(memory_format=torch.channels_last)
         # the 1 x 1 convolution's result is rounded to bf16 before the bias is added (two roundings)
         assert (out.float() - ref).abs().max().item() <= 2 ** -6 * ref.abs().max().item() + 1e-3
+
+
+def test_new_entry_points_reject_bad_arguments(gpu_ctx):
+    """Argument checks of the round-2 additions come back as HiveError (never a launch on bad shapes)."""
+    import ctypes
+    from hive_amd import _lib
+    lib, h = gpu_ctx.lib, gpu_ctx.handle
+    x = torch.zeros(1, 64, 16, 16, device="cuda", dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = torch.zeros(256, 64, 1, 1, device="cuda", dtype=torch.bfloat16)
+    out = torch.zeros(1, 256, 16, 16, device="cuda", dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    small = torch.zeros(16, device="cuda")
+    tile_rows, fused = ctypes.c_int(-1), ctypes.c_int(-1)
+    with pytest.raises(_lib.HiveError, match="gn_partial holds"):
+        gpu_ctx.check(lib.hive_nhwc_conv_gn(h, x.data_ptr(), _lib.BF16, 1, 16, 16, 64, 256, 1, 1, 0, 0, 16, 16, w.data_ptr(), None, 0, None, None, out.data_ptr(), None,
+                                            small.data_ptr(), small.numel(), ctypes.byref(tile_rows)))
+    g = torch.ones(256, device="cuda", dtype=torch.bfloat16)
+    with pytest.raises(_lib.HiveError, match="scratch holds"):
+        gpu_ctx.check(lib.hive_nhwc_conv_gn_apply(h, x.data_ptr(), _lib.BF16, 1, 16, 16, 64, 256, 1, 1, 0, 0, 16, 16, w.data_ptr(), 32, g.data_ptr(), g.data_ptr(), 1e-5,
+                                                  None, 1, out.data_ptr(), small.data_ptr(), small.numel(), ctypes.byref(fused)))
+    # not eligible (128 output channels): reported through *fused = 0, not as an error, and nothing is launched
+    w2 = torch.zeros(128, 64, 1, 1, device="cuda", dtype=torch.bfloat16)
+    gpu_ctx.check(lib.hive_nhwc_conv_gn_apply(h, x.data_ptr(), _lib.BF16, 1, 16, 16, 64, 128, 1, 1, 0, 0, 16, 16, w2.data_ptr(), 32, g.data_ptr(), g.data_ptr(), 1e-5,
+                                              None, 1, out.data_ptr(), small.data_ptr(), small.numel(), ctypes.byref(fused)))
+    assert fused.value == 0
+    frame = torch.zeros(1, 3, 40, 48, device="cuda", dtype=torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    with pytest.raises(_lib.HiveError, match="multiples of the patch size"):
+        gpu_ctx.check(lib.hive_patch_rows(h, frame.data_ptr(), _lib.BF16, 1, 40, 48, 3, 16, out.data_ptr()))
+    with pytest.raises(_lib.HiveError, match="pixel_shuffle_bias"):
+        gpu_ctx.check(lib.hive_nhwc_pixel_shuffle_bias(h, out.data_ptr(), None, _lib.BF16, 1, 4, 4, 12, 2, x.data_ptr()))
