@@ -159,73 +159,139 @@ int run_forward(hive_dpt *d, bool dry, const uint8_t *d_rgb, int B, int H, int W
         return hive_nhwc_group_norm_stats(ctx, x.p, HIVE_BF16, B, x.H * x.W, x.C, 32, g, b, d->cfg.gn_eps, residual, relu, out->p, x.gn, x.gn_tm);
     };
 
-    // ---- pre-processing + ResNetV2 stem -----------------------------------------------------------------------------------
-    bf16 *xin = d->alloc((size_t)B * H * W * 3);
-    Map s0{d->alloc((size_t)B * same_out(H, 2) * same_out(W, 2) * 64), same_out(H, 2), same_out(W, 2), 64};
-    if (!dry) {
-        DPT_TRY(hive_dpt_preprocess(ctx, d_rgb, (int64_t)B * H * W * 3, 0.5f, 0.5f, HIVE_BF16, xin));
-        const void *sw;
-        DPT_TRY(need(bb + "stem.conv.weight", &sw));
-        DPT_TRY(hive_resnet_stem_conv(ctx, xin, HIVE_BF16, B, H, W, sw, s0.p));
-    }
-    Map s1, feat;
-    DPT_TRY(group_norm(s0, bb + "stem.norm", nullptr, 1, &s1));
-    feat = Map{d->alloc((size_t)B * same_out(s1.H, 2) * same_out(s1.W, 2) * 64), same_out(s1.H, 2), same_out(s1.W, 2), 64};
-    if (!dry) DPT_TRY(hive_nhwc_maxpool3x3s2(ctx, s1.p, HIVE_BF16, B, s1.H, s1.W, 64, feat.p));
-
-    // ---- ResNetV2 stages: non pre-activation bottlenecks, GroupNorm behind every convolution ------------------------------
-    const int depths[3] = {3, 4, 9}, chans[3] = {256, 512, 1024};
-    Map hook[2];
-    for (int s = 0; s < 3; ++s) {
-        for (int blk = 0; blk < depths[s]; ++blk) {
-            const std::string pre = bb + "stages." + std::to_string(s) + ".blocks." + std::to_string(blk) + ".";
-            const int cout = chans[s], mid = cout / 4, stride = (blk == 0 && s > 0) ? 2 : 1;
-            Map shortcut = feat, t, u;
-            if (blk == 0) DPT_TRY(conv_norm(feat, pre + "downsample.conv.weight", pre + "downsample.norm", cout, stride, nullptr, 0, &shortcut));
-            DPT_TRY(conv(feat, pre + "conv1.weight", nullptr, mid, 1, 1, true, 0, nullptr, nullptr, false, &t, nullptr, true));
-            DPT_TRY(group_norm(t, pre + "norm1", nullptr, 1, &u));
-            DPT_TRY(conv(u, pre + "conv2.weight", nullptr, mid, 3, stride, true, 0, nullptr, nullptr, false, &t, nullptr, true));
-            DPT_TRY(group_norm(t, pre + "norm2", nullptr, 1, &u));
-            DPT_TRY(conv_norm(u, pre + "conv3.weight", pre + "norm3", cout, 1, shortcut.p, 1, &feat));  // relu(norm3(conv3(.)) + shortcut)
+    Map layer_1, layer_2, layer_3, layer_4;
+    auto hybrid_backbone = [&]() -> int {
+        // ---- pre-processing + ResNetV2 stem -----------------------------------------------------------------------------------
+        bf16 *xin = d->alloc((size_t)B * H * W * 3);
+        Map s0{d->alloc((size_t)B * same_out(H, 2) * same_out(W, 2) * 64), same_out(H, 2), same_out(W, 2), 64};
+        if (!dry) {
+            DPT_TRY(hive_dpt_preprocess(ctx, d_rgb, (int64_t)B * H * W * 3, 0.5f, 0.5f, HIVE_BF16, xin));
+            const void *sw;
+            DPT_TRY(need(bb + "stem.conv.weight", &sw));
+            DPT_TRY(hive_resnet_stem_conv(ctx, xin, HIVE_BF16, B, H, W, sw, s0.p));
         }
-        if (s < 2) hook[s] = feat;
-    }
-    const Map layer_1 = hook[0], layer_2 = hook[1];
+        Map s1, feat;
+        DPT_TRY(group_norm(s0, bb + "stem.norm", nullptr, 1, &s1));
+        feat = Map{d->alloc((size_t)B * same_out(s1.H, 2) * same_out(s1.W, 2) * 64), same_out(s1.H, 2), same_out(s1.W, 2), 64};
+        if (!dry) DPT_TRY(hive_nhwc_maxpool3x3s2(ctx, s1.p, HIVE_BF16, B, s1.H, s1.W, 64, feat.p));
 
-    // ---- patch projection, tokens, ViT blocks, readout ------------------------------------------------------------------------
-    const int gh = feat.H, gw = feat.W, n_patch = gh * gw, N = n_patch + 1, D = 768;
-    Map pe;
-    DPT_TRY(conv(feat, "pretrained.model.patch_embed.proj.weight", "pretrained.model.patch_embed.proj.bias", D, 1, 1, false, 0, nullptr, nullptr, false, &pe,
-                 nullptr));
-    bf16 *tokens = d->alloc((size_t)B * N * D), *tap3 = d->alloc((size_t)B * N * D), *tap4 = d->alloc((size_t)B * N * D);
-    bf16 *cat = d->alloc((size_t)B * n_patch * 2 * D);
-    Map map3{d->alloc((size_t)B * n_patch * D), gh, gw, D}, map4{d->alloc((size_t)B * n_patch * D), gh, gw, D};
-    if (!dry) {
-        const void *cls;
-        DPT_TRY(need("pretrained.model.cls_token", &cls));
-        const int blocks = (int)std::min<long long>(((long long)B * N * D / 8 + 255) / 256, (long long)ctx->num_cus * 16);
-        hipLaunchKernelGGL(assemble_tokens_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const bf16 *)pe.p, (const bf16 *)cls, (const bf16 *)d_pos, tokens, B,
-                           n_patch, D);
-        HIVE_CHECK_HIP(ctx, hipGetLastError());
-        const int taps[2] = {8, 11};
-        void *tap_out[2] = {tap3, tap4};
-        DPT_TRY(hive_vit_forward(d->vit, tokens, B, N, taps, 2, tap_out));
-        const bf16 *tap[2] = {tap3, tap4};
-        Map *maps[2] = {&map3, &map4};
-        for (int r = 0; r < 2; ++r) {
-            hipLaunchKernelGGL(readout_concat_kernel, dim3(blocks), dim3(256), 0, ctx->stream, tap[r], cat, B, n_patch, D);
+        // ---- ResNetV2 stages: non pre-activation bottlenecks, GroupNorm behind every convolution ------------------------------
+        const int depths[3] = {3, 4, 9}, chans[3] = {256, 512, 1024};
+        Map hook[2];
+        for (int s = 0; s < 3; ++s) {
+            for (int blk = 0; blk < depths[s]; ++blk) {
+                const std::string pre = bb + "stages." + std::to_string(s) + ".blocks." + std::to_string(blk) + ".";
+                const int cout = chans[s], mid = cout / 4, stride = (blk == 0 && s > 0) ? 2 : 1;
+                Map shortcut = feat, t, u;
+                if (blk == 0) DPT_TRY(conv_norm(feat, pre + "downsample.conv.weight", pre + "downsample.norm", cout, stride, nullptr, 0, &shortcut));
+                DPT_TRY(conv(feat, pre + "conv1.weight", nullptr, mid, 1, 1, true, 0, nullptr, nullptr, false, &t, nullptr, true));
+                DPT_TRY(group_norm(t, pre + "norm1", nullptr, 1, &u));
+                DPT_TRY(conv(u, pre + "conv2.weight", nullptr, mid, 3, stride, true, 0, nullptr, nullptr, false, &t, nullptr, true));
+                DPT_TRY(group_norm(t, pre + "norm2", nullptr, 1, &u));
+                DPT_TRY(conv_norm(u, pre + "conv3.weight", pre + "norm3", cout, 1, shortcut.p, 1, &feat));  // relu(norm3(conv3(.)) + shortcut)
+            }
+            if (s < 2) hook[s] = feat;
+        }
+        layer_1 = hook[0];
+        layer_2 = hook[1];
+
+        // ---- patch projection, tokens, ViT blocks, readout ------------------------------------------------------------------------
+        const int gh = feat.H, gw = feat.W, n_patch = gh * gw, N = n_patch + 1, D = 768;
+        Map pe;
+        DPT_TRY(conv(feat, "pretrained.model.patch_embed.proj.weight", "pretrained.model.patch_embed.proj.bias", D, 1, 1, false, 0, nullptr, nullptr, false, &pe,
+                     nullptr));
+        bf16 *tokens = d->alloc((size_t)B * N * D), *tap3 = d->alloc((size_t)B * N * D), *tap4 = d->alloc((size_t)B * N * D);
+        bf16 *cat = d->alloc((size_t)B * n_patch * 2 * D);
+        Map map3{d->alloc((size_t)B * n_patch * D), gh, gw, D}, map4{d->alloc((size_t)B * n_patch * D), gh, gw, D};
+        if (!dry) {
+            const void *cls;
+            DPT_TRY(need("pretrained.model.cls_token", &cls));
+            const int blocks = (int)std::min<long long>(((long long)B * N * D / 8 + 255) / 256, (long long)ctx->num_cus * 16);
+            hipLaunchKernelGGL(assemble_tokens_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const bf16 *)pe.p, (const bf16 *)cls, (const bf16 *)d_pos, tokens, B,
+                               n_patch, D);
             HIVE_CHECK_HIP(ctx, hipGetLastError());
-            const std::string pre = std::string("pretrained.act_postprocess") + (r == 0 ? "3" : "4") + ".0.project.0.";
-            const void *rw, *rb;
-            DPT_TRY(need(pre + "weight", &rw));
-            DPT_TRY(need(pre + "bias", &rb));  // float32
-            DPT_TRY(hive_vit_linear(ctx, cat, rw, (const float *)rb, nullptr, maps[r]->p, B * n_patch, D, 2 * D, 1 /* GELU */));
+            const int taps[2] = {8, 11};
+            void *tap_out[2] = {tap3, tap4};
+            DPT_TRY(hive_vit_forward(d->vit, tokens, B, N, taps, 2, tap_out));
+            const bf16 *tap[2] = {tap3, tap4};
+            Map *maps[2] = {&map3, &map4};
+            for (int r = 0; r < 2; ++r) {
+                hipLaunchKernelGGL(readout_concat_kernel, dim3(blocks), dim3(256), 0, ctx->stream, tap[r], cat, B, n_patch, D);
+                HIVE_CHECK_HIP(ctx, hipGetLastError());
+                const std::string pre = std::string("pretrained.act_postprocess") + (r == 0 ? "3" : "4") + ".0.project.0.";
+                const void *rw, *rb;
+                DPT_TRY(need(pre + "weight", &rw));
+                DPT_TRY(need(pre + "bias", &rb));  // float32
+                DPT_TRY(hive_vit_linear(ctx, cat, rw, (const float *)rb, nullptr, maps[r]->p, B * n_patch, D, 2 * D, 1 /* GELU */));
+            }
         }
-    }
-    Map layer_3, layer_4, t4;
-    DPT_TRY(conv(map3, "pretrained.act_postprocess3.3.weight", "pretrained.act_postprocess3.3.bias", D, 1, 1, false, 0, nullptr, nullptr, false, &layer_3, nullptr));
-    DPT_TRY(conv(map4, "pretrained.act_postprocess4.3.weight", "pretrained.act_postprocess4.3.bias", D, 1, 1, false, 0, nullptr, nullptr, false, &t4, nullptr));
-    DPT_TRY(conv(t4, "pretrained.act_postprocess4.4.weight", "pretrained.act_postprocess4.4.bias", D, 3, 2, false, 0, nullptr, nullptr, false, &layer_4, nullptr));
+        Map t4;
+        DPT_TRY(conv(map3, "pretrained.act_postprocess3.3.weight", "pretrained.act_postprocess3.3.bias", D, 1, 1, false, 0, nullptr, nullptr, false, &layer_3, nullptr));
+        DPT_TRY(conv(map4, "pretrained.act_postprocess4.3.weight", "pretrained.act_postprocess4.3.bias", D, 1, 1, false, 0, nullptr, nullptr, false, &t4, nullptr));
+        DPT_TRY(conv(t4, "pretrained.act_postprocess4.4.weight", "pretrained.act_postprocess4.4.bias", D, 3, 2, false, 0, nullptr, nullptr, false, &layer_4, nullptr));
+        return HIVE_OK;
+    };
+    // ---- DPT-Large backbone (timm vit_large_patch16_384 as isl-org/DPT hooks it: blocks 5 / 11 / 17 / 23) -------------------------
+    // pre-processing -> 16 x 16 / 16 patch embedding (rows + GEMM) -> class token + position embedding -> 24 ViT blocks -> "project"
+    // readouts -> reassemble: 1x1 (+ ConvTranspose 4x4/4 | ConvTranspose 2x2/2 | nothing | 3x3/2) to 256 / 512 / 1024 / 1024 channels
+    auto large_backbone = [&]() -> int {
+        const int D = 1024, gh = H / 16, gw = W / 16, n_patch = gh * gw, N = n_patch + 1;
+        bf16 *xin = d->alloc((size_t)B * H * W * 3), *cols = d->alloc((size_t)B * n_patch * 768), *pe = d->alloc((size_t)B * n_patch * D);
+        bf16 *tokens = d->alloc((size_t)B * N * D), *cat = d->alloc((size_t)B * n_patch * 2 * D);
+        bf16 *tapb[4];
+        Map maps[4];
+        for (int r = 0; r < 4; ++r) {
+            tapb[r] = d->alloc((size_t)B * N * D);
+            maps[r] = Map{d->alloc((size_t)B * n_patch * D), gh, gw, D};
+        }
+        if (!dry) {
+            DPT_TRY(hive_dpt_preprocess(ctx, d_rgb, (int64_t)B * H * W * 3, 0.5f, 0.5f, HIVE_BF16, xin));
+            DPT_TRY(hive_patch_rows(ctx, xin, HIVE_BF16, B, H, W, 3, 16, cols));
+            const void *pw, *pb, *cls;
+            DPT_TRY(need("pretrained.model.patch_embed.proj.weight", &pw));    // [D][16][16][3] = [D][768]
+            DPT_TRY(need("pretrained.model.patch_embed.proj.bias.f32", &pb));
+            DPT_TRY(need("pretrained.model.cls_token", &cls));
+            DPT_TRY(hive_vit_linear(ctx, cols, pw, (const float *)pb, nullptr, pe, B * n_patch, D, 768, 0));
+            const int blocks = (int)std::min<long long>(((long long)B * N * D / 8 + 255) / 256, (long long)ctx->num_cus * 16);
+            hipLaunchKernelGGL(assemble_tokens_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const bf16 *)pe, (const bf16 *)cls, (const bf16 *)d_pos, tokens, B,
+                               n_patch, D);
+            HIVE_CHECK_HIP(ctx, hipGetLastError());
+            const int taps[4] = {5, 11, 17, 23};
+            void *tap_out[4] = {tapb[0], tapb[1], tapb[2], tapb[3]};
+            DPT_TRY(hive_vit_forward(d->vit, tokens, B, N, taps, 4, tap_out));
+            for (int r = 0; r < 4; ++r) {
+                hipLaunchKernelGGL(readout_concat_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const bf16 *)tapb[r], cat, B, n_patch, D);
+                HIVE_CHECK_HIP(ctx, hipGetLastError());
+                const std::string pre = "pretrained.act_postprocess" + std::to_string(r + 1) + ".0.project.0.";
+                const void *rw, *rb;
+                DPT_TRY(need(pre + "weight", &rw));
+                DPT_TRY(need(pre + "bias", &rb));  // float32
+                DPT_TRY(hive_vit_linear(ctx, cat, rw, (const float *)rb, nullptr, maps[r].p, B * n_patch, D, 2 * D, 1 /* GELU */));
+            }
+        }
+        // ConvTranspose2d(C, C, s, s) = 1 x 1 convolution to s s C channels ((dy, dx, co) rows of the re-laid-out weight) + scatter + bias
+        auto conv_transpose = [&](const Map &x, const std::string &prefix, int s_, Map *out) -> int {
+            Map tmp{d->alloc((size_t)B * x.H * x.W * s_ * s_ * x.C), x.H, x.W, s_ * s_ * x.C};
+            *out = Map{d->alloc((size_t)B * x.H * x.W * s_ * s_ * x.C), s_ * x.H, s_ * x.W, x.C};
+            if (dry) return HIVE_OK;
+            const void *wr, *bias;
+            DPT_TRY(need(prefix + ".weight.rows", &wr));
+            DPT_TRY(need(prefix + ".bias", &bias));
+            DPT_TRY(hive_nhwc_conv(ctx, x.p, HIVE_BF16, B, x.H, x.W, x.C, s_ * s_ * x.C, 1, 1, 0, 0, x.H, x.W, wr, nullptr, 0, nullptr, nullptr, tmp.p, nullptr));
+            return hive_nhwc_pixel_shuffle_bias(ctx, tmp.p, bias, HIVE_BF16, B, x.H, x.W, x.C, s_, out->p);
+        };
+        const std::string pp = "pretrained.act_postprocess";
+        Map t;
+        DPT_TRY(conv(maps[0], pp + "1.3.weight", (pp + "1.3.bias").c_str(), 256, 1, 1, false, 0, nullptr, nullptr, false, &t, nullptr));
+        DPT_TRY(conv_transpose(t, pp + "1.4", 4, &layer_1));
+        DPT_TRY(conv(maps[1], pp + "2.3.weight", (pp + "2.3.bias").c_str(), 512, 1, 1, false, 0, nullptr, nullptr, false, &t, nullptr));
+        DPT_TRY(conv_transpose(t, pp + "2.4", 2, &layer_2));
+        DPT_TRY(conv(maps[2], pp + "3.3.weight", (pp + "3.3.bias").c_str(), 1024, 1, 1, false, 0, nullptr, nullptr, false, &layer_3, nullptr));
+        DPT_TRY(conv(maps[3], pp + "4.3.weight", (pp + "4.3.bias").c_str(), 1024, 1, 1, false, 0, nullptr, nullptr, false, &t, nullptr));
+        return conv(t, pp + "4.4.weight", (pp + "4.4.bias").c_str(), 1024, 3, 2, false, 0, nullptr, nullptr, false, &layer_4, nullptr);
+    };
+
+    DPT_TRY(d->cfg.backbone == 0 ? hybrid_backbone() : large_backbone());
 
     // ---- decoder: layerN_rn, four RefineNet fusion blocks --------------------------------------------------------------------
     auto refinenet = [&](int n, const Map *path, const Map &lrn, const Map &lrn_relu, Map *out) -> int {
@@ -275,7 +341,8 @@ int hive_dpt_create(hive_ctx *ctx, const hive_dpt_config *config, const hive_dpt
     HIVE_ENTER(ctx);
     if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
     HIVE_REQUIRE(ctx, config && tensors && n_tensors > 0 && out, "hive_dpt_create: NULL argument");
-    HIVE_REQUIRE(ctx, config->backbone == 0, "hive_dpt_create: backbone %d (only 0 = vitb_rn50_384, the one HIVE instantiates)", config->backbone);
+    HIVE_REQUIRE(ctx, config->backbone == 0 || config->backbone == 1, "hive_dpt_create: backbone %d (0 = vitb_rn50_384, 1 = vitl16_384)", config->backbone);
+    const int vit_depth = config->backbone == 0 ? 12 : 24, vit_dim = config->backbone == 0 ? 768 : 1024, vit_heads = vit_dim / 64;
     *out = nullptr;
     hive_dpt *d = new hive_dpt();
     d->ctx = ctx;
@@ -283,10 +350,10 @@ int hive_dpt_create(hive_ctx *ctx, const hive_dpt_config *config, const hive_dpt
     for (int i = 0; i < n_tensors; ++i)
         if (tensors[i].name && tensors[i].data) d->w[tensors[i].name] = tensors[i].data;
     // the ViT engine over the table's block weights
-    std::vector<hive_vit_block_weights> blocks(12);
+    std::vector<hive_vit_block_weights> blocks(vit_depth);
     const char *fields[12] = {"norm1.weight", "norm1.bias", "attn.qkv.weight", "attn.qkv.bias", "attn.proj.weight", "attn.proj.bias",
                               "norm2.weight", "norm2.bias", "mlp.fc1.weight", "mlp.fc1.bias", "mlp.fc2.weight", "mlp.fc2.bias"};
-    for (int i = 0; i < 12; ++i) {
+    for (int i = 0; i < vit_depth; ++i) {
         const void **dst = reinterpret_cast<const void **>(&blocks[i]);
         for (int f = 0; f < 12; ++f) {
             const std::string name = "pretrained.model.blocks." + std::to_string(i) + "." + fields[f];
@@ -298,7 +365,7 @@ int hive_dpt_create(hive_ctx *ctx, const hive_dpt_config *config, const hive_dpt
             }
         }
     }
-    int rc = hive_vit_create(ctx, 12, 768, 12, 3072, config->ln_eps, blocks.data(), &d->vit);
+    int rc = hive_vit_create(ctx, vit_depth, vit_dim, vit_heads, 4 * vit_dim, config->ln_eps, blocks.data(), &d->vit);
     const void *b0 = d->get("scratch.output_conv.0.bias.f32");
     if (!rc && !b0) rc = hive_fail(ctx, HIVE_ERR_INVALID, "hive_dpt_create: tensor 'scratch.output_conv.0.bias.f32' missing from the table");
     if (rc) {

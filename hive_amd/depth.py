@@ -110,7 +110,7 @@ class DepthFusionStream:
 
     def __init__(self, model, volume, cam_intr, max_depth=10.0, accumulate=False, native=True):
         self.model = model
-        self.native = native  # run the network as one hive_dpt_forward call where it applies (bf16 hybrid, frame size % 32 == 0)
+        self.native = native  # run the network as one hive_dpt_forward call where it applies (bf16, frame size % 32 == 0)
         self.volume = volume
         self.K = np.ascontiguousarray(cam_intr, dtype=np.float32)
         self.max_depth = float(max_depth)
@@ -124,7 +124,7 @@ class DepthFusionStream:
     def depth(self, frames_u8):
         """[B, H, W, 3] uint8 (GPU) -> (depth_m f32 [B, H, W] after the hand-off, depth_mm int16-viewed-as-uint16)."""
         if (self.native and self.dtype == torch.bfloat16 and frames_u8.shape[1] % 32 == 0 and frames_u8.shape[2] % 32 == 0
-                and getattr(self.model, "engine", None) == "hip" and self.model.pretrained.hybrid):
+                and getattr(self.model, "engine", None) == "hip"):
             _, mm, m = self.model.forward_frames(frames_u8, max_depth=self.max_depth)  # ONE C-ABI call: hive_dpt_forward
             return m, mm
         x = preprocess_on_device(frames_u8, self.dtype)

@@ -1,5 +1,5 @@
 """Host side of the C-ABI network object (``hive_dpt_create / forward / destroy``, csrc/dpt_net.hip): builds the tensor table
-from a ``DPTDepthModel`` (hybrid backbone) -- standardised ResNet weights, channels-last convolution weights, bf16 matrices,
+from a ``DPTDepthModel`` (DPT-Hybrid or DPT-Large) -- standardised ResNet weights, channels-last convolution weights, bf16 matrices,
 f32 biases / LayerNorm parameters, as ``include/hive_mi355x.h`` documents -- and runs whole batches of uint8 frames through it:
 frames in HBM -> depth maps in HBM without a PyTorch operator in between.  No fallback: construction raises if the library or
 the device is missing."""
@@ -27,13 +27,11 @@ def parameter_stamp(model):
 
 class NativeDPT:
     def __init__(self, model, ctx=None):
-        """:param model: a ``hive_amd.dpt.models.DPTDepthModel`` (``vitb_rn50_384``) whose parameters live on an MI355X."""
+        """:param model: a ``hive_amd.dpt.models.DPTDepthModel`` (``vitb_rn50_384`` or ``vitl16_384``) whose parameters live on an MI355X."""
         from hive_amd.dpt.models import StdConv2dSame
         dev = next(model.parameters()).device
         if dev.type != "cuda":
             raise _lib.HiveError(_lib.ERR_DEVICE, "the native DPT network needs the model on an MI355X (model.cuda()); no CPU fallback")
-        if not model.pretrained.hybrid:
-            raise NotImplementedError("hive_dpt_* covers the hybrid backbone (the one the reference instantiates)")
         self.ctx = ctx or _lib.default_context(dev.index or 0)
         self.model = model
         self.stamp = parameter_stamp(model)
@@ -64,6 +62,9 @@ class NativeDPT:
                     add(name, p.detach().to(device=dev, dtype=bf).permute(2, 3, 0, 1))  # [ky][kx][32][128] for the fused head
                 elif name != "scratch.output_conv.4.weight":
                     add(name, conv_w(p))
+            elif isinstance(mod, nn.ConvTranspose2d) and leaf == "weight":  # DPT-Large reassemble: rows (dy, dx, co) of the 1 x 1 form
+                k, co = mod.kernel_size[0], mod.out_channels
+                add(name + ".rows", p.detach().to(device=dev, dtype=bf).permute(2, 3, 1, 0).reshape(k * k * co, mod.in_channels))
             elif isinstance(mod, nn.Linear) and leaf == "weight":
                 add(name, p.to(device=dev, dtype=bf))
             elif isinstance(mod, (nn.Linear, nn.LayerNorm)):  # GEMM biases and LayerNorm affine parameters: float32
@@ -74,7 +75,9 @@ class NativeDPT:
                 add(name, p.to(device=dev, dtype=bf))
         head = model.scratch.output_conv
         add("scratch.output_conv.0.bias.f32", head[0].bias.to(device=dev, dtype=f32))
-        cfg = _Config(0, float(model.scale), float(model.shift), int(bool(model.invert)), int(isinstance(head[5], nn.ReLU)), 1e-5,
+        if not model.pretrained.hybrid:  # the 16 x 16 / 16 patch embedding runs as a GEMM: float32 bias
+            add("pretrained.model.patch_embed.proj.bias.f32", model.pretrained.model.patch_embed.proj.bias.to(device=dev, dtype=f32))
+        cfg = _Config(0 if model.pretrained.hybrid else 1, float(model.scale), float(model.shift), int(bool(model.invert)), int(isinstance(head[5], nn.ReLU)), 1e-5,
                       float(model.pretrained.model.blocks[0].norm1.eps))
         b3, w1 = head[2].bias.detach().float().cpu(), head[4].weight.detach().float().reshape(-1).cpu()
         for i in range(32):

@@ -411,21 +411,28 @@ int hive_nhwc_maxpool3x3s2(hive_ctx *ctx, const void *d_x, int dtype, int N, int
  *   scratch.output_conv.0.weight [128][3][3][256]; scratch.output_conv.0.bias.f32 (f32 [128]); scratch.output_conv.2.weight as
  *   [ky][kx][32][128]; the last two layers' host values go in the config (head_b3 = output_conv.2.bias, head_w1 / head_b1 = output_conv.4).
  * All convolution weights are [C_out][ky][kx][C_in] (= the PyTorch tensor in channels-last memory format).  The pointers must
- * stay valid for the life of the handle. */
+ * stay valid for the life of the handle.
+ * backbone 1 (DPT-Large, `dpt_large-midas-2f21e586.pt`: no ResNet; 24 blocks of width 1024, hooks 5 / 11 / 17 / 23) differs in:
+ *   pretrained.model.patch_embed.proj.weight [1024][16][16][3] (the GEMM's [1024][768]), ...proj.bias.f32 (f32 [1024]), cls_token [1024];
+ *   blocks.I.* with 768 -> 1024, 3072 -> 4096 (I = 0 .. 23); act_postprocess{1..4}.0.project.0.{weight [1024][2048], bias f32};
+ *   act_postprocess1.3.* [256][1][1][1024], act_postprocess1.4.weight.rows [4 4 256][256] = ConvTranspose2d(256, 256, 4, 4).weight
+ *   permuted to ((dy, dx, co), ci), act_postprocess1.4.bias; act_postprocess2.3.* [512][1][1][1024], act_postprocess2.4.weight.rows
+ *   [2 2 512][512], .bias; act_postprocess3.3.* [1024][1][1][1024]; act_postprocess4.3.* likewise, act_postprocess4.4.* [1024][3][3][1024];
+ *   scratch.layer{1..4}_rn.weight with C_in = 256 / 512 / 1024 / 1024. */
 typedef struct hive_dpt hive_dpt;
 typedef struct hive_dpt_tensor {
     const char *name;
     const void *data;
 } hive_dpt_tensor;
 typedef struct hive_dpt_config {
-    int backbone;                 /* 0 = vitb_rn50_384 (DPT-Hybrid: the one HIVE instantiates) */
+    int backbone;                 /* 0 = vitb_rn50_384 (DPT-Hybrid: the one HIVE instantiates), 1 = vitl16_384 (DPT-Large) */
     float scale, shift;           /* depth = 1 / max(scale * x + shift, 1e-8) when invert */
     int invert, non_negative;
     float gn_eps, ln_eps;         /* 1e-5 (GroupNorm), 1e-6 (timm ViT LayerNorm) */
     float head_b3[32], head_w1[32], head_b1;
 } hive_dpt_config;
 int hive_dpt_create(hive_ctx *ctx, const hive_dpt_config *config, const hive_dpt_tensor *tensors, int n_tensors, hive_dpt **out);
-/* d_rgb u8 [B][H][W][3] (H, W multiples of 32), d_pos_embed bf16 [(H/16)(W/16) + 1][768] = the position embedding resized to this
+/* d_rgb u8 [B][H][W][3] (H, W multiples of 32), d_pos_embed bf16 [(H/16)(W/16) + 1][768 | 1024] = the position embedding resized to this
  * token grid (dpt `_resize_pos_embed`: evaluated once per frame size by the host binding).  Outputs [B][H][W], any may be NULL (not
  * all): d_depth f32 metres; d_out_mm = uint16(depth * 1000); d_out_m = mm / 1000 with > max_depth -> 0. */
 int hive_dpt_forward(hive_dpt *dpt, const uint8_t *d_rgb, int B, int H, int W, const void *d_pos_embed, float *d_depth, float max_depth,

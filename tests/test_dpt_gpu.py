@@ -268,3 +268,24 @@ def test_native_network_object_equals_python_orchestration(gpu_ctx):
     assert hip.native() is not nat and not torch.equal(d2, d_c), "a parameter update must rebuild the native network"
     with pytest.raises(Exception):
         hip.forward_frames(frames[:, :90], max_depth=10.0)  # 90 rows: not a multiple of 32
+
+
+def test_native_network_object_dpt_large(gpu_ctx):
+    """hive_dpt_create(backbone = 1): DPT-Large (vitl16_384) as one C-ABI object -- patch embedding as rows + GEMM, 24 blocks, four
+    readouts, ConvTranspose reassembly -- bit-identical to the Python orchestration of the same kernels, at two frame sizes."""
+    from dpt_weights import seeded_init
+    from hive_amd import depth as depth_mod
+    from hive_amd.dpt.models import DPTDepthModel
+    ref = DPTDepthModel(path=None, scale=0.000305, shift=0.1378, invert=True, backbone="vitl16_384", engine="hip").eval()
+    seeded_init(ref, seed=7)
+    hip = ref.to(memory_format=torch.channels_last).to(torch.bfloat16).cuda()
+    rng = np.random.default_rng(3)
+    for (b, h, w) in ((2, 96, 160), (1, 480, 864)):
+        frames = torch.from_numpy(rng.integers(0, 256, (b, h, w, 3), dtype=np.uint8)).cuda()
+        with torch.no_grad():
+            d_py, mm_py, m_py = hip(depth_mod.preprocess_on_device(frames, torch.bfloat16), handoff=(10.0,))
+            d_c, mm_c, m_c = hip.forward_frames(frames, max_depth=10.0)
+        assert d_c.shape == (b, h, w) and torch.isfinite(d_c).all()
+        assert float(d_c.max() - d_c.min()) > 0.5, "the seeded weights must give a depth range"
+        assert torch.equal(d_c, d_py), f"depth differs by up to {float((d_c - d_py).abs().max()) * 1000:.3f} mm"
+        assert torch.equal(mm_c, mm_py) and torch.equal(m_c, m_py)
