@@ -416,6 +416,81 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(GemmParams p) {
 #endif
 }
 
+// The same tile as PERSISTENT workgroups (one per CU, XCD-aware runs of tiles as in csrc/conv.hip): the K-steps of a workgroup's tiles
+// form one stream, the first stage of the next tile is issued during the last K-step of the current one and lands under its epilogue.
+template <int EPI>
+__global__ __launch_bounds__(512, 1) void gemm256p_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    constexpr int A_GROUPS = T256 / 8, GROUPS = 2 * A_GROUPS, PER_WAVE = GROUPS / 8;
+    static_assert(EPI != EPI_QKV, "the transposed v^T store stays with the 128-row kernel");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int tiles_n = p.N / T256, n_tiles = ((p.M + T256 - 1) / T256) * tiles_n;
+    const int xcd = blockIdx.x & 7, per_xcd = gridDim.x >> 3, tq = n_tiles >> 3, tr = n_tiles & 7;
+    const int run0 = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq, run_n = tq + (xcd < tr ? 1 : 0);
+    int tl = blockIdx.x >> 3;
+    if (tl >= run_n) return;  // (whole workgroup)
+    int m0, n0;
+    unsigned piece_off[PER_WAVE];
+    const char *a_panel, *w_panel;
+    auto setup = [&](int tile) {
+        m0 = (tile / tiles_n) * T256;
+        n0 = (tile % tiles_n) * T256;
+#pragma unroll
+        for (int j = 0; j < PER_WAVE; ++j) {
+            const int g = wave + j * 8, row = (g & (A_GROUPS - 1)) * 8 + (lane >> 3), chunk = (lane & 7) ^ ((row >> 1) & 7);
+            const int rel = j < PER_WAVE / 2 ? min(row, p.M - 1 - m0) : min(row, p.N - 1 - n0);
+            piece_off[j] = (unsigned)rel * (unsigned)p.K * 2u + (unsigned)chunk * 16u;
+        }
+        a_panel = reinterpret_cast<const char *>(p.A + (size_t)m0 * p.K);
+        w_panel = reinterpret_cast<const char *>(p.W + (size_t)n0 * p.K);
+    };
+    auto issue_piece = [&](int kt, int stage, int j) {
+        const char *g = (j < PER_WAVE / 2 ? a_panel : w_panel) + (size_t)kt * (BK * 2) + piece_off[j];
+        __builtin_amdgcn_global_load_lds((const void *)g, (__attribute__((address_space(3))) void *)(lds + stage * T256_STAGE + (wave + j * 8) * 1024), 16, 0, 0);
+    };
+    const int KT = p.K / BK;
+    setup(run0 + tl);
+#pragma unroll
+    for (int j = 0; j < PER_WAVE; ++j) issue_piece(0, 0, j);
+    hive_mfma::KPipe<8, false> pipe;
+    pipe.a_row0 = wr * 128, pipe.w_row0 = wc * 64, pipe.fr = lane & 15, pipe.fq = lane >> 4;
+    int buf = 0;
+    for (;;) {
+        const bool has_next = tl + per_xcd < run_n;
+        const int em0 = m0, en0 = n0;
+        f32x4 acc[4][8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int kt = 0; kt < KT; ++kt) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            int nk = kt + 1;
+            if (nk == KT) {
+                if (has_next) {
+                    setup(run0 + tl + per_xcd);  // this tile's last stage is in LDS: its offsets are not needed any more
+                    nk = 0;
+                } else {
+                    nk = KT - 1;  // the last stage again, into the buffer nobody reads any more
+                }
+            }
+            const unsigned char *a_t = lds + buf * T256_STAGE, *w_t = a_t + A_GROUPS * 1024;
+            pipe.begin(a_t, w_t);
+            if (kt > 0) pipe.flush(acc);
+            pipe.body(acc, PER_WAVE, [&](int j) { issue_piece(nk, buf ^ 1, j); });
+            buf ^= 1;
+        }
+        pipe.flush(acc);
+        gemm_store_rows<EPI, 8>(p, acc, em0 + wr * 128, en0 + wc * 64, lds + 2 * T256_STAGE + wave * 4096, lane);
+        if (!has_next) break;
+        tl += per_xcd;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 // ------------------------------------------------------------------------------------------------
 struct AttnParams {
     const bf16 *qk;  // [B*Np][2D]; q pre-multiplied by head_dim^-0.5 * log2(e) (hive_vit_qkv)
@@ -706,6 +781,20 @@ constexpr size_t GEMM_LDS = (size_t)GEMM_NST * (GEMM_TM / 8 + 16) * 1024 + (GEMM
 static int launch_gemm256(hive_ctx *ctx, int epi, const GemmParams &p) {
     const dim3 grid((unsigned)(((p.M + T256 - 1) / T256) * (p.N / T256))), block(512);
     const size_t lds_bytes = 2 * T256_STAGE + hive_mfma::STAGED_ROWS_LDS;
+    // persistent workgroups by default (+2-4 % where a workgroup gets more than one tile: the next tile's first fill is hidden);
+    // HIVE_GEMM_PERSIST=0 selects the one-tile-per-workgroup kernel, the one the phase clocks of `make stamps` instrument
+    static const char *persist = getenv("HIVE_GEMM_PERSIST");
+    if (!(persist && persist[0] == '0')) {
+        const dim3 pgrid((unsigned)std::min<long long>(((long long)grid.x + 7) / 8 * 8, (long long)ctx->num_cus / 8 * 8));
+        switch (epi) {
+            case EPI_BIAS: hipLaunchKernelGGL((gemm256p_kernel<EPI_BIAS>), pgrid, block, lds_bytes, ctx->stream, p); break;
+            case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm256p_kernel<EPI_BIAS_GELU>), pgrid, block, lds_bytes, ctx->stream, p); break;
+            case EPI_BIAS_RESIDUAL: hipLaunchKernelGGL((gemm256p_kernel<EPI_BIAS_RESIDUAL>), pgrid, block, lds_bytes, ctx->stream, p); break;
+            default: return hive_fail(ctx, HIVE_ERR_INVALID, "gemm: unknown epilogue %d", epi);
+        }
+        HIVE_CHECK_HIP(ctx, hipGetLastError());
+        return HIVE_OK;
+    }
     switch (epi) {
         case EPI_BIAS: hipLaunchKernelGGL((gemm256_kernel<EPI_BIAS>), grid, block, lds_bytes, ctx->stream, p); break;
         case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm256_kernel<EPI_BIAS_GELU>), grid, block, lds_bytes, ctx->stream, p); break;
@@ -761,8 +850,11 @@ static int ensure_gemm_attrs(hive_ctx *ctx) {
     HIVE_CHECK_HIP(ctx, (set_gemm_lds<EPI_BIAS_RESIDUAL>()));
     HIVE_CHECK_HIP(ctx, (set_gemm_lds<EPI_QKV>()));
     HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)gemm256_kernel<EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * T256_STAGE + hive_mfma::STAGED_ROWS_LDS));
+    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)gemm256p_kernel<EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * T256_STAGE + hive_mfma::STAGED_ROWS_LDS));
     HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)gemm256_kernel<EPI_BIAS_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * T256_STAGE + hive_mfma::STAGED_ROWS_LDS));
+    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)gemm256p_kernel<EPI_BIAS_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * T256_STAGE + hive_mfma::STAGED_ROWS_LDS));
     HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)gemm256_kernel<EPI_BIAS_RESIDUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * T256_STAGE + hive_mfma::STAGED_ROWS_LDS));
+    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)gemm256p_kernel<EPI_BIAS_RESIDUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * T256_STAGE + hive_mfma::STAGED_ROWS_LDS));
     if (ctx->device < 64) g_gemm_attr_set[ctx->device] = true;
     return HIVE_OK;
 }

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Where a gemm256_kernel workgroup spends its cycles (tuning build: `make -C hive_amd/csrc stamps`, run with
-HIVE_AMD_LIB=hive_amd/lib/libhive_stamps.so HIVE_GEMM_TILE=256).  Per shape: median over workgroups of
+HIVE_AMD_LIB=hive_amd/lib/libhive_stamps.so HIVE_GEMM_TILE=256 HIVE_GEMM_PERSIST=0).  Per shape: median over workgroups of
 prologue fill | K loop (of which waiting for the next stage) | drain | epilogue issue | store drain, in clock64() ticks."""
 import ctypes, os, sys, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
