@@ -808,12 +808,12 @@ static int launch_gemm256(hive_ctx *ctx, int epi, const GemmParams &p) {
 static int launch_gemm(hive_ctx *ctx, int epi, const GemmParams &p) {
     // 256 x 256 tiles (half the operand bytes per flop: 690-970 TFLOP/s against 510-680 for the 128-row tiles on the ViT shapes)
     // wherever they fill the chip: one workgroup per CU, so what matters is how full the last round of tiles is -- at M = 29184,
-    // N = 768 there are 342 tiles for 256 CUs (67 %: 412-685 TFLOP/s), at M = 19456 228 (89 %: 970); below 80 % the persistent
+    // N = 768 there are 342 tiles for 256 CUs (67 %), at M = 19456 228 (89 %: 970 TFLOP/s), at M = 9728 114 (44 %); below 60 % the persistent
     // 128-row tiles (two workgroups per CU, 1368 tiles for 512 slots) win.
     static const char *force = getenv("HIVE_GEMM_TILE");  // "256" / "128": tuning override
     const long long tiles256 = (long long)((p.M + T256 - 1) / T256) * (p.N / T256);
     const long long rounds = (tiles256 + ctx->num_cus - 1) / ctx->num_cus;
-    const bool fills = tiles256 * 5 >= rounds * ctx->num_cus * 4;  // >= 80 % of the CU slots of its rounds
+    const bool fills = tiles256 * 5 >= rounds * ctx->num_cus * 3;  // >= 60 % of the CU slots of its rounds (67 %: 635 / 763 vs 612 / 705 TFLOP/s for proj / fc2 at M = 29184; 44 %: 655 vs 858)
     if (epi != EPI_QKV && p.N % T256 == 0 && ((force && force[0] == '2') || (!force && fills))) return launch_gemm256(ctx, epi, p);
     // persistent workgroups: two per CU (64 KiB of LDS each), a multiple of 8 so that every XCD gets the same number
     const long long tiles = (long long)((p.M + GEMM_TM - 1) / GEMM_TM) * (p.N / BN);
