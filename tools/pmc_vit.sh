@@ -12,7 +12,7 @@ pass B SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTI
 pass C SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INST_CYCLES_VMEM_RD
 python3 - <<PY
 import csv, glob, collections, json
-kernels = {"gemm256_kernel<0": "gemm q|k (bias; 256 x 256 tiles)", "gemm256_kernel<1": "gemm fc1 + GELU (256 x 256 tiles)", "gemm256_kernel<2": "gemm proj / fc2 + residual (256 x 256 tiles)",
+kernels = {"gemm256p_kernel<0": "gemm q|k (bias; 256 x 256 tiles)", "gemm256p_kernel<1": "gemm fc1 + GELU (256 x 256 tiles)", "gemm256p_kernel<2": "gemm proj / fc2 + residual (256 x 256 tiles)",
            "gemm_kernel<0": "gemm (bias; 128 x 128 tiles)", "gemm_kernel<1": "gemm + GELU (128 x 128 tiles)", "gemm_kernel<2": "gemm + residual (128 x 128 tiles)",
            "gemm_kernel<3": "gemm v^T", "attention_kernel": "attention", "head_conv_kernel": "fused depth head",
            "conv_kernel<256, 256, 0>": "conv -> 256-channel tiles (decoder RCUs, layer_rn)", "conv_kernel<256, 256, 1>": "conv + GroupNorm statistics (ResNetV2, 256-channel tiles)",
