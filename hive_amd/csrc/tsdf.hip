@@ -20,6 +20,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <type_traits>
 
 struct FrameParams {
@@ -559,6 +560,200 @@ __global__ __launch_bounds__(256) void integrate_kernel(FrameParams p, const Wor
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// SEVERAL FRAMES PER LAUNCH (hive_tsdf_integrate_batch on device frames).  Consecutive frames of a sequence see almost the same part
+// of the volume, and a voxel's update depends on its own state only: a trip loads its voxels ONCE, applies frames 0 .. nf - 1 to the
+// registers in sequence order -- the same operations in the same order as nf launches, so the result is bit-identical -- and stores
+// them once.  Per frame the gather role, the LDS exchange and the tests are those of integrate_kernel; the volume is loaded by a lane
+// at the first frame that updates one of its voxels.  The work list is built over the UNION of the frames' clipped intervals (every
+// voxel still runs every frame's exact tests).  What this buys: the volume traffic of nf frames for the price of one, the step
+// becomes bound by the per-frame arithmetic (the single-frame kernel keeps its SIMDs 56 % busy).
+constexpr int MAXF = 4;
+struct MultiParams {
+    FrameParams f[MAXF];  // the per-frame fields (R, T, frame, max_depth_bits) differ; the rest is the same in all
+    int nf;
+};
+
+template <int VPT>
+__global__ __launch_bounds__(1024) void build_worklist_multi_kernel(MultiParams mp, WorkItem *__restrict__ items, unsigned *n_items) {
+    __shared__ unsigned wave_sum[16];
+    __shared__ unsigned block_base;
+    constexpr int CHUNK = SEG_LANES * VPT;
+    const FrameParams &p = mp.f[0];
+    const long long row = (long long)blockIdx.x * 1024 + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned n_chunks = 0;
+    int zstart = 0, z1 = 0, x = 0, y = 0;
+    if (row < (long long)p.X * p.Y) {
+        x = (int)(row / p.Y);
+        y = (int)(row % p.Y);
+        int lo = p.Z, hi = 0;
+#pragma unroll
+        for (int f = 0; f < MAXF; ++f)
+            if (f < mp.nf) {
+                const FrameParams &q = mp.f[f];
+                const float tx = (q.ox + (float)(x + q.x_off) * q.vs) - q.T[0];
+                const float ty = (q.oy + (float)y * q.vs) - q.T[1];
+                const float ax = q.R[0] * tx + q.R[3] * ty;
+                const float ay = q.R[1] * tx + q.R[4] * ty;
+                const float az = q.R[2] * tx + q.R[5] * ty;
+                const float far_z = __uint_as_float(*q.max_depth_bits) + q.trunc;
+                const RowClip clip = clip_row(q, ax, ay, az, far_z);
+                if (clip.z1 > clip.z0) {
+                    lo = min(lo, clip.z0);
+                    hi = max(hi, clip.z1);
+                }
+            }
+        if (hi > lo) {
+            zstart = (lo / VPT) * VPT;
+            z1 = hi;
+            n_chunks = (unsigned)((z1 - zstart + CHUNK - 1) / CHUNK);
+        }
+    }
+    unsigned inc = n_chunks;
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned o = (unsigned)__shfl_up((int)inc, off);
+        if (lane >= off) inc += o;
+    }
+    if (lane == 63) wave_sum[wave] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned total = 0;
+        for (int w = 0; w < 16; ++w) {
+            const unsigned s = wave_sum[w];
+            wave_sum[w] = total;
+            total += s;
+        }
+        block_base = total ? atomicAdd(n_items, total) : 0u;
+    }
+    __syncthreads();
+    const unsigned slot = block_base + wave_sum[wave] + inc - n_chunks;
+    for (unsigned c = 0; c < n_chunks; ++c) {
+        WorkItem it;
+        it.xy = (unsigned)x | ((unsigned)y << 16);
+        it.zz = (unsigned)(zstart + (int)c * CHUNK) | ((unsigned)z1 << 16);
+        items[slot + c] = it;
+    }
+}
+
+template <int RM>
+__global__ __launch_bounds__(256) void integrate_multi_kernel(MultiParams mp, const WorkItem *__restrict__ items, const unsigned *__restrict__ n_items_ptr,
+                                                              float *__restrict__ v0, float *__restrict__ v1, float *__restrict__ v2) {
+    constexpr int VPT = 4, PER_WAVE = 64 / SEG_LANES, SEG_VOX = SEG_LANES * 4;
+    typedef ItemShape<VPT> Sh;
+    typedef typename Sh::V V;
+    __shared__ uint2 xchg[4 * PER_WAVE * SEG_VOX];
+    const int lane = threadIdx.x & 63;
+    const int seg = lane / SEG_LANES, sl = lane % SEG_LANES;
+    const unsigned n_items = *n_items_ptr;
+    const unsigned n_trips = (n_items + PER_WAVE - 1) / PER_WAVE;
+    const unsigned stride = gridDim.x * 4;
+    const FrameParams &p0 = mp.f[0];
+    const float trunc_rcp = refined_rcp(p0.trunc);
+    for (unsigned trip = blockIdx.x * 4 + (threadIdx.x >> 6); trip < n_trips; trip += stride) {
+        const unsigned ii = trip * PER_WAVE + (unsigned)seg;
+        WorkItem item;
+        item.xy = item.zz = 0u;
+        if (ii < n_items) item = items[ii];
+        const int x = (int)(item.xy & 0xffffu), y = (int)(item.xy >> 16);
+        const int zseg = (int)(item.zz & 0xffffu);
+        const int zb = zseg + sl * VPT;
+        const bool live = zb < (int)(item.zz >> 16);
+        const long long idx = ((long long)x * p0.Y + y) * p0.Z + zb;
+        float t[VPT], w[VPT], c[VPT];
+        bool loaded = false;
+        uint2 *mine = xchg + ((threadIdx.x >> 6) * PER_WAVE + seg) * SEG_VOX;
+#pragma unroll 1  // one frame's parameters in scalar registers at a time (unrolled, the four sets spill 160 SGPRs)
+        for (int f = 0; f < mp.nf; ++f) {
+            const FrameParams &p = mp.f[f];
+            const float tx = (p.ox + (float)(x + p.x_off) * p.vs) - p.T[0];
+            const float ty = (p.oy + (float)y * p.vs) - p.T[1];
+            const float ax = p.R[0] * tx + p.R[3] * ty;
+            const float ay = p.R[1] * tx + p.R[4] * ty;
+            const float az = p.R[2] * tx + p.R[5] * ty;
+            // gather role: voxels zseg + SEG_LANES k + sl, k = 0 .. 3
+            uint2 tex[4];
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                V cz;
+                int pix[Sh::NV];
+                voxel_pixels<RM, V, Sh::NV, SEG_LANES>(p, ax, ay, az, zseg + sl + 2 * SEG_LANES * g, cz, pix);
+#pragma unroll
+                for (int i = 0; i < Sh::NV; ++i) {
+                    uint2 tx2 = p.frame[max(pix[i], 0)];
+                    if (pix[i] < 0) tx2.x = 0u;
+                    tex[g * Sh::NV + i] = tx2;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) mine[SEG_LANES * k + sl] = tex[k];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const uint4 lo = *reinterpret_cast<const uint4 *>(mine + 4 * sl);
+            const uint4 hi = *reinterpret_cast<const uint4 *>(mine + 4 * sl + 2);
+            const float depth_v[VPT] = {__uint_as_float(lo.x), __uint_as_float(lo.z), __uint_as_float(hi.x), __uint_as_float(hi.z)};
+            const unsigned rgb[VPT] = {lo.y, lo.w, hi.y, hi.w};
+            __builtin_amdgcn_wave_barrier();  // the next frame's writes stay behind these reads
+            V cam_z[Sh::NG], dist[Sh::NG];
+#pragma unroll
+            for (int g = 0; g < Sh::NG; ++g) cam_z[g] = voxel_cam_z<V, Sh::NV>(p, az, zb + g * Sh::NV);
+            bool ok[VPT];
+            bool any = false;
+#pragma unroll
+            for (int g = 0; g < Sh::NG; ++g) {
+                V depth;
+#pragma unroll
+                for (int i = 0; i < Sh::NV; ++i) v_set(depth, i, depth_v[g * Sh::NV + i]);
+                const V diff = depth - cam_z[g];
+                dist[g] = v_min(v_splat(1.0f, diff), div_exact(diff, v_splat(p.trunc, diff), v_splat(trunc_rcp, diff)));
+#pragma unroll
+                for (int i = 0; i < Sh::NV; ++i) {
+                    const int j = g * Sh::NV + i;
+                    ok[j] = live && (v_get(depth, i) != 0.0f) && !(v_get(diff, i) < -p.trunc);
+                    any = any || ok[j];
+                }
+            }
+            if (any) {
+                if (!loaded) {  // the lane's first frame with an update: its voxels come in now and stay in registers
+                    vol_load4(t, v0 + idx);
+                    vol_load4(w, v1 + idx);
+                    vol_load4(c, v2 + idx);
+                    loaded = true;
+                }
+#pragma unroll
+                for (int g = 0; g < Sh::NG; ++g) {
+                    V tv, wv, cv;
+                    unsigned rg[Sh::NV];
+                    bool okg[Sh::NV];
+#pragma unroll
+                    for (int i = 0; i < Sh::NV; ++i) {
+                        const int j = g * Sh::NV + i;
+                        v_set(tv, i, t[j]);
+                        v_set(wv, i, w[j]);
+                        v_set(cv, i, c[j]);
+                        rg[i] = rgb[j];
+                        okg[i] = ok[j];
+                    }
+                    update_voxels<RM, V, Sh::NV>(tv, wv, cv, dist[g], rg, okg, p.obs_w);
+#pragma unroll
+                    for (int i = 0; i < Sh::NV; ++i) {
+                        const int j = g * Sh::NV + i;
+                        t[j] = v_get(tv, i);
+                        w[j] = v_get(wv, i);
+                        c[j] = v_get(cv, i);
+                    }
+                }
+            }
+        }
+        if (loaded) {
+            vol_store4(v0 + idx, t);
+            vol_store4(v1 + idx, w);
+            vol_store4(v2 + idx, c);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void fill3_kernel(float *__restrict__ a, float *__restrict__ b, float *__restrict__ c,
                                                     long long n, float va, float vb, float vc) {
     const long long stride = (long long)gridDim.x * 256 * 4;
@@ -661,11 +856,7 @@ static int prepare_frame(hive_tsdf *v, const uint8_t *color, const float *depth,
     return HIVE_OK;
 }
 
-template <bool ACCUM>
-static int launch_integrate(hive_tsdf *v, float *accum, int H, int W, const float K[9], const double pose[16],
-                            float obs_weight, bool count) {
-    hive_ctx *ctx = v->ctx;
-    FrameParams p;
+static void fill_frame_params(hive_tsdf *v, int H, int W, const float K[9], const double pose[16], float obs_weight, FrameParams &p) {
     for (int r = 0; r < 3; ++r) {
         for (int c = 0; c < 3; ++c) p.R[3 * r + c] = (float)pose[4 * r + c];
         p.T[r] = (float)pose[4 * r + 3];
@@ -686,6 +877,57 @@ static int launch_integrate(hive_tsdf *v, float *accum, int H, int W, const floa
     p.Z = (int)v->dim[2];
     p.H = H;
     p.W = W;
+}
+
+// nf (2 .. MAXF) device-resident frames in ONE sweep (integrate_multi_kernel): nf pack launches, one work list over the union of the
+// frames' clips, one integrate launch.  Scalars: d_scalars[56 + f] = max depth of frame f, [60] = work-list length.
+static int launch_integrate_multi(hive_tsdf *v, int nf, const uint8_t *color, const float *depth, int H, int W, const float K[9], const double *poses,
+                                  float obs_weight) {
+    hive_ctx *ctx = v->ctx;
+    const size_t npx = (size_t)H * W;
+    int rc = hive_reserve_device(ctx, &ctx->d_frame, &ctx->frame_bytes, (size_t)nf * npx * sizeof(uint2));
+    if (rc) return rc;
+    unsigned *sc = ctx->d_scalars + 56;
+    HIVE_CHECK_HIP(ctx, hipMemsetAsync(sc, 0, 8 * sizeof(unsigned), ctx->stream));
+    unsigned *idle_block = ctx->d_scalars + (ctx->tsdf_scalars ? 0 : 48);  // the single-frame path's next block: cleared anyway
+    MultiParams mp;
+    mp.nf = nf;
+    for (int f = 0; f < nf; ++f) {
+        uint2 *packed = (uint2 *)ctx->d_frame + (size_t)f * npx;
+        hipLaunchKernelGGL(pack_frame_kernel<true>, dim3((unsigned)((npx / 4 + 255) / 256)), dim3(256), 0, ctx->stream, depth + f * npx, color + f * npx * 3,
+                           (int)npx, packed, sc + f, idle_block);
+        fill_frame_params(v, H, W, K, poses + 16 * (size_t)f, obs_weight, mp.f[f]);
+        mp.f[f].frame = packed;
+        mp.f[f].max_depth_bits = sc + f;
+        mp.f[f].n_updated = nullptr;
+    }
+    for (int f = nf; f < MAXF; ++f) mp.f[f] = mp.f[0];
+    HIVE_CHECK_HIP(ctx, hipGetLastError());
+    const FrameParams &p = mp.f[0];
+    const long long rows = (long long)p.X * p.Y;
+    const long long seg = SEG_LANES * 4;
+    const size_t max_items = (size_t)rows * (size_t)((p.Z + seg - 1) / seg);
+    if ((rc = hive_reserve_device(ctx, &ctx->d_scratch, &ctx->scratch_bytes, max_items * sizeof(WorkItem)))) return rc;
+    WorkItem *items = (WorkItem *)ctx->d_scratch;
+    unsigned *n_items = sc + 4;
+    hipLaunchKernelGGL(build_worklist_multi_kernel<4>, dim3((unsigned)((rows + 1023) / 1024)), dim3(1024), 0, ctx->stream, mp, items, n_items);
+    const long long max_trips = (long long)((max_items + 64 / SEG_LANES - 1) / (64 / SEG_LANES));
+    const dim3 grid((unsigned)std::min<long long>((long long)ctx->num_cus * 8 * HIVE_GRID_MULT, (max_trips + 3) / 4)), block(256);
+    if ((rc = hive_time_begin(ctx))) return rc;
+    if (v->round_mode)
+        hipLaunchKernelGGL((integrate_multi_kernel<1>), grid, block, 0, ctx->stream, mp, items, n_items, v->d_tsdf, v->d_weight, v->d_color);
+    else
+        hipLaunchKernelGGL((integrate_multi_kernel<0>), grid, block, 0, ctx->stream, mp, items, n_items, v->d_tsdf, v->d_weight, v->d_color);
+    HIVE_CHECK_HIP(ctx, hipGetLastError());
+    return hive_time_end(ctx);
+}
+
+template <bool ACCUM>
+static int launch_integrate(hive_tsdf *v, float *accum, int H, int W, const float K[9], const double pose[16],
+                            float obs_weight, bool count) {
+    hive_ctx *ctx = v->ctx;
+    FrameParams p;
+    fill_frame_params(v, H, W, K, pose, obs_weight, p);
     p.frame = (const uint2 *)ctx->d_frame;
     p.max_depth_bits = tsdf_scalars(ctx);
     p.n_updated = (unsigned long long *)(tsdf_scalars(ctx) + 2);
@@ -898,11 +1140,23 @@ int hive_tsdf_integrate_batch(hive_tsdf *vol, int n, const uint8_t *color, const
     if (rc) return rc;
     HIVE_REQUIRE(vol->ctx, n >= 0, "integrate_batch: n must be >= 0");
     const size_t npx = (size_t)H * W;
-    for (int f = 0; f < n; ++f) {
-        const uint8_t *d_color;
-        const float *d_depth;
-        if ((rc = prepare_frame(vol, color + f * npx * 3, depth + f * npx, H, W, mem, &d_color, &d_depth))) return rc;
-        if ((rc = launch_integrate<false>(vol, nullptr, H, W, K, cam_poses + 16 * (size_t)f, obs_weight, false))) return rc;
+    // device-resident frames on the vector path: groups of up to MAXF consecutive frames per sweep (bit-identical to one sweep each)
+    static const char *frames_env = getenv("HIVE_TSDF_FRAMES_PER_LAUNCH");  // "1": the single-frame kernel (tuning / A-B)
+    const int group = frames_env ? std::max(1, std::min(MAXF, atoi(frames_env))) : MAXF;
+    const bool multi = mem == HIVE_MEM_DEVICE && group > 1 && vol->dim[2] % 4 == 0 && npx % 4 == 0 && ((uintptr_t)depth % 16 == 0) && ((uintptr_t)color % 4 == 0) &&
+                       (npx * 3) % 4 == 0 && (((uintptr_t)vol->d_tsdf | (uintptr_t)vol->d_weight | (uintptr_t)vol->d_color) % 16 == 0);
+    int f = 0;
+    while (f < n) {
+        const int nf = multi ? std::min(group, n - f) : 1;
+        if (nf > 1) {
+            if ((rc = launch_integrate_multi(vol, nf, color + f * npx * 3, depth + f * npx, H, W, K, cam_poses + 16 * (size_t)f, obs_weight))) return rc;
+        } else {
+            const uint8_t *d_color;
+            const float *d_depth;
+            if ((rc = prepare_frame(vol, color + f * npx * 3, depth + f * npx, H, W, mem, &d_color, &d_depth))) return rc;
+            if ((rc = launch_integrate<false>(vol, nullptr, H, W, K, cam_poses + 16 * (size_t)f, obs_weight, false))) return rc;
+        }
+        f += nf;
     }
     vol->n_verts = vol->n_faces = -1;
     return HIVE_OK;

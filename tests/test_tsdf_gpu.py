@@ -284,3 +284,44 @@ def test_exact_slab_fusion_single_rank_and_device_volume_copies(gpu_ctx, oracle_
     verts, faces, _, _ = full.get_mesh()
     o_verts, o_faces, _, _ = ora.get_mesh()
     assert np.array_equal(faces, o_faces) and np.array_equal(verts, o_verts)
+
+
+@pytest.mark.parametrize("round_mode", [0, 1])
+def test_multi_frame_sweep_is_bit_identical(gpu_ctx, oracle_lib, round_mode):
+    """hive_tsdf_integrate_batch on device frames fuses up to four consecutive frames per sweep (volume loaded and stored once,
+    frames applied to the registers in order): bit-identical to one sweep per frame and to the oracle -- 7 frames (groups of 4 + 3)
+    into 128^3, both rounding modes, then at the benchmark's size against the single-frame kernel."""
+    import torch
+    from hive_amd import fusion, synthetic
+    seq = synthetic.make_sequence(num_frames=7, height=120, width=160, yaw_step_deg=17.0, seed=5)
+    ora = oracle_lib.TSDFVolume(synthetic.room_bounds(), 0.04, round_mode=round_mode)
+    for i in range(7):
+        ora.integrate(seq["color"][i], seq["depth"][i], seq["K"], seq["poses"][i], obs_weight=1.0 + 0.5 * (i % 2))
+    color_d, depth_d = torch.from_numpy(seq["color"]).cuda(), torch.from_numpy(seq["depth"]).cuda()
+    fused = fusion.TSDFVolume(synthetic.room_bounds(), 0.04, ctx=gpu_ctx, round_mode=round_mode)
+    one = fusion.TSDFVolume(synthetic.room_bounds(), 0.04, ctx=gpu_ctx, round_mode=round_mode)
+    # obs_weight is per call: two batches with different weights, frames interleaved as in the oracle loop above
+    for i in range(7):
+        one.integrate(color_d[i], depth_d[i], seq["K"], seq["poses"][i], obs_weight=1.0 + 0.5 * (i % 2))
+    ora2 = oracle_lib.TSDFVolume(synthetic.room_bounds(), 0.04, round_mode=round_mode)
+    for i in range(7):
+        ora2.integrate(seq["color"][i], seq["depth"][i], seq["K"], seq["poses"][i])
+    fused.integrate_batch(color_d, depth_d, seq["K"], seq["poses"])
+    _volumes_equal(one, ora)
+    _volumes_equal(fused, ora2)
+
+
+def test_multi_frame_sweep_full_size(gpu_ctx):
+    """The same at 640 x 480 into 512^3: six consecutive frames of the bench sequence, fused sweep vs six single sweeps."""
+    import torch
+    from hive_amd import fusion, synthetic
+    seq = synthetic.make_sequence(num_frames=6, yaw_step_deg=2.4)
+    color_d, depth_d = torch.from_numpy(seq["color"]).cuda(), torch.from_numpy(seq["depth"]).cuda()
+    fused = fusion.TSDFVolume(synthetic.room_bounds(), 0.01, ctx=gpu_ctx)
+    one = fusion.TSDFVolume(synthetic.room_bounds(), 0.01, ctx=gpu_ctx)
+    fused.integrate_batch(color_d, depth_d, seq["K"], seq["poses"])
+    for i in range(6):
+        one.integrate(color_d[i], depth_d[i], seq["K"], seq["poses"][i])
+    for a, b in zip(fused.device_tensors(), one.device_tensors()):
+        assert torch.equal(a, b)
+    assert float(fused.device_tensors()[1].max()) == 6.0
