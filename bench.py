@@ -257,8 +257,11 @@ def main():
                 k_ms, k_n = k_ms + ms, k_n + n
         return float(np.mean(n_upd)), float(np.mean(leg_ms)), (k_ms / max(k_n, 1) * 1e3, k_n)
 
-    def roofline(n_upd_mean, launch_us, traffic_key):
-        alg = 24.0 * n_upd_mean + 8.0 * H * W  # 3 volumes read + written for every updated voxel + one read of depth / colour
+    def roofline(n_upd_mean, launch_us, traffic_key, frames_per_launch):
+        # SURVEY 8(d)'s per-frame figure: 3 volumes read + written for every updated voxel + one read of depth / colour -- times the
+        # frames one launch integrates (hive_tsdf_integrate_batch sweeps up to 4 consecutive frames at once: the volume is loaded and
+        # stored once for all of them, so the bytes that actually move (`traffic`) are FEWER than this figure)
+        alg = (24.0 * n_upd_mean + 8.0 * H * W) * frames_per_launch
         achieved = alg / (launch_us * 1e-6) / 1e9
         traffic = None
         tf = os.path.join(ROOT, "profiles", "integrate_traffic.json")
@@ -267,8 +270,8 @@ def main():
                 traffic = json.load(open(tf)).get(traffic_key)
             except Exception:
                 traffic = None
-        return {"kernel": "integrate_kernel", "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                "traffic": traffic, "algorithmic_bytes_per_launch": alg, "avg_launch_us": launch_us, "n_upd_mean": n_upd_mean,
+        return {"kernel": "integrate_multi_kernel" if frames_per_launch > 1 else "integrate_kernel", "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                "traffic": traffic, "algorithmic_bytes_per_launch": alg, "frames_per_launch": frames_per_launch, "avg_launch_us": launch_us, "n_upd_mean": n_upd_mean,
                 "n_upd_fraction": n_upd_mean / (volume.num_voxels * (world if exact else 1))}
 
     with torch.no_grad():
@@ -279,7 +282,8 @@ def main():
         else:
             timed_sets = [job_frames(args.warmup + s, 1)[0] for s in range(args.steps)]
         n_upd_dpt, leg_dpt, _ = measure(timed_sets, lambda fr, ids: stream.depth(fr)[0])
-        main_roof = roofline(n_upd_dpt, kernel_ms / max(n_launch, 1) * 1e3, "hbm_bytes_per_launch")
+        frames_timed = sum(len(ids) for ids in timed_sets)  # frames this rank integrated in the timed region
+        main_roof = roofline(n_upd_dpt, kernel_ms / max(n_launch, 1) * 1e3, "hbm_bytes_per_launch", frames_timed / max(n_launch, 1))
         main_roof["launches"] = n_launch
         main_roof["tsdf_leg_us_per_frame"] = leg_dpt * 1e3
         # the room scene: the same integrate on the ray-cast (analytic) depth of the sequence -- real depth variation, a
@@ -287,7 +291,7 @@ def main():
         room_ids = list(range(0, T, max(1, T // 30)))[:30]
         volume.reset()
         n_upd_room, leg_room, (us_room, n_room) = measure([room_ids], lambda fr, ids: torch.from_numpy(seq["depth"][ids]).to(device), time_kernel=True)
-        room_roof = roofline(n_upd_room, us_room, "hbm_bytes_per_launch_room")
+        room_roof = roofline(n_upd_room, us_room, "hbm_bytes_per_launch_room", len(room_ids) / max(n_room, 1))
         room_roof["launches"] = n_room
         room_roof["tsdf_leg_us_per_frame"] = leg_room * 1e3
         room_roof["scene"] = "analytic ray-cast depth of the same trajectory (surface inside the volume), 30 frames"

@@ -115,8 +115,8 @@ int hive_ctx_create(int device_id, void *stream, hive_ctx **out) {
             ctx->stream = (hipStream_t)stream;  // NULL = the default stream
         }
     }
-    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_scalars, 64 * sizeof(unsigned));
-    if (e == hipSuccess) e = hipMemset(ctx->d_scalars, 0, 64 * sizeof(unsigned));  // the TSDF scalar blocks start cleared (tsdf.hip prepare_frame)
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_scalars, 128 * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMemset(ctx->d_scalars, 0, 128 * sizeof(unsigned));  // the TSDF scalar blocks start cleared (tsdf.hip prepare_frame)
     if (e == hipSuccess) e = hipMalloc(&ctx->d_zeros, 256);
     if (e == hipSuccess) e = hipMemset(ctx->d_zeros, 0, 256);
     if (e != hipSuccess) {

@@ -568,7 +568,10 @@ __global__ __launch_bounds__(256) void integrate_kernel(FrameParams p, const Wor
 // at the first frame that updates one of its voxels.  The work list is built over the UNION of the frames' clipped intervals (every
 // voxel still runs every frame's exact tests).  What this buys: the volume traffic of nf frames for the price of one, the step
 // becomes bound by the per-frame arithmetic (the single-frame kernel keeps its SIMDs 56 % busy).
-constexpr int MAXF = 4;
+#ifndef HIVE_TSDF_MAXF
+#define HIVE_TSDF_MAXF 4
+#endif
+constexpr int MAXF = HIVE_TSDF_MAXF;
 struct MultiParams {
     FrameParams f[MAXF];  // the per-frame fields (R, T, frame, max_depth_bits) differ; the rest is the same in all
     int nf;
@@ -880,15 +883,15 @@ static void fill_frame_params(hive_tsdf *v, int H, int W, const float K[9], cons
 }
 
 // nf (2 .. MAXF) device-resident frames in ONE sweep (integrate_multi_kernel): nf pack launches, one work list over the union of the
-// frames' clips, one integrate launch.  Scalars: d_scalars[56 + f] = max depth of frame f, [60] = work-list length.
+// frames' clips, one integrate launch.
 static int launch_integrate_multi(hive_tsdf *v, int nf, const uint8_t *color, const float *depth, int H, int W, const float K[9], const double *poses,
                                   float obs_weight) {
     hive_ctx *ctx = v->ctx;
     const size_t npx = (size_t)H * W;
     int rc = hive_reserve_device(ctx, &ctx->d_frame, &ctx->frame_bytes, (size_t)nf * npx * sizeof(uint2));
     if (rc) return rc;
-    unsigned *sc = ctx->d_scalars + 56;
-    HIVE_CHECK_HIP(ctx, hipMemsetAsync(sc, 0, 8 * sizeof(unsigned), ctx->stream));
+    unsigned *sc = ctx->d_scalars + 64;  // [64 + f] = max depth of frame f, [64 + MAXF] = work-list length
+    HIVE_CHECK_HIP(ctx, hipMemsetAsync(sc, 0, (MAXF + 1) * sizeof(unsigned), ctx->stream));
     unsigned *idle_block = ctx->d_scalars + (ctx->tsdf_scalars ? 0 : 48);  // the single-frame path's next block: cleared anyway
     MultiParams mp;
     mp.nf = nf;
@@ -909,7 +912,7 @@ static int launch_integrate_multi(hive_tsdf *v, int nf, const uint8_t *color, co
     const size_t max_items = (size_t)rows * (size_t)((p.Z + seg - 1) / seg);
     if ((rc = hive_reserve_device(ctx, &ctx->d_scratch, &ctx->scratch_bytes, max_items * sizeof(WorkItem)))) return rc;
     WorkItem *items = (WorkItem *)ctx->d_scratch;
-    unsigned *n_items = sc + 4;
+    unsigned *n_items = sc + MAXF;
     hipLaunchKernelGGL(build_worklist_multi_kernel<4>, dim3((unsigned)((rows + 1023) / 1024)), dim3(1024), 0, ctx->stream, mp, items, n_items);
     const long long max_trips = (long long)((max_items + 64 / SEG_LANES - 1) / (64 / SEG_LANES));
     const dim3 grid((unsigned)std::min<long long>((long long)ctx->num_cus * 8 * HIVE_GRID_MULT, (max_trips + 3) / 4)), block(256);

@@ -20,5 +20,5 @@ done
 # 3. BASELINE config 4's TSDF side: 1920 x 1080 frames into 1024^3 (5 mm), kernel trace                -> gpurun_out/prof_r02/trace_1024
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_1024 -- python3 $GRAFT_REPO_ROOT/tools/probe_integrate.py --height 1080 --width 1920 --voxel 0.005 --frames 6 --reps 2 --no-mesh > $OUT/trace_1024.log 2>&1 || echo "1024 trace failed"
 find $OUT/trace_1024 -name "*kernel_trace.csv" -delete
-for f in $(find $OUT -name "*counter_collection.csv"); do (head -1 $f; grep integrate_kernel $f) > $f.tmp && mv $f.tmp $f; done
+for f in $(find $OUT -name "*counter_collection.csv"); do (head -1 $f; grep -E "integrate_kernel|integrate_multi_kernel" $f) > $f.tmp && mv $f.tmp $f; done
 du -sh $OUT; echo profile done

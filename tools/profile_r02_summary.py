@@ -18,11 +18,11 @@ def mean_counter(sub, counter):
     for f in glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
             name = row["Kernel_Name"]
-            timed = "false, false" in name or "Lb0ELb0E" in name  # COUNT = false, ACCUM = false: the timed variant
-            if row["Counter_Name"] == counter and "integrate_kernel" in name and timed:
+            timed = "false, false" in name or "Lb0ELb0E" in name or "integrate_multi_kernel" in name  # the timed variants (no COUNT, no ACCUM)
+            if row["Counter_Name"] == counter and ("integrate_kernel" in name or "integrate_multi_kernel" in name) and timed:
                 vals.append(float(row["Counter_Value"]))
     return (sum(vals) / len(vals), len(vals)) if vals else (None, 0)
-out = {"kernel": "integrate_kernel<4, RM, COUNT=false, ACCUM=false>", "correction": "reads = 2 x FETCH_SIZE (gfx950 tallies the 128-B requests of a 16 B/lane stream at 64 B), writes = WRITE_SIZE; KiB"}
+out = {"kernel": "integrate_multi_kernel<RM> (up to 4 frames per launch) / integrate_kernel<4, RM, COUNT=false, ACCUM=false>", "correction": "reads = 2 x FETCH_SIZE (gfx950 tallies the 128-B requests of a 16 B/lane stream at 64 B), writes = WRITE_SIZE; KiB"}
 traffic = {"source": "profiles/r02_integrate_pmc.json"}
 for scene, key in (("bench", "hbm_bytes_per_launch"), ("room", "hbm_bytes_per_launch_room")):
     fetch, nf = mean_counter(f"pmc_fetch_{scene}", "FETCH_SIZE")
