@@ -43,6 +43,11 @@ template <bool VEC>
 __global__ __launch_bounds__(256) void pack_frame_kernel(const float *__restrict__ depth, const uint8_t *__restrict__ color,
                                                          int n, uint2 *__restrict__ out, unsigned *max_bits, unsigned *zero_next) {
     __shared__ unsigned wave_max[4];
+    // blockIdx.y = frame of a batch (launch_integrate_multi): frames are n pixels apart in all three buffers, one max-depth slot each
+    depth += (size_t)blockIdx.y * n;
+    color += (size_t)blockIdx.y * n * 3;
+    out += (size_t)blockIdx.y * n;
+    max_bits += blockIdx.y;
     // the NEXT frame's scalar block (max depth, update count, work-list length) is cleared here instead of by a memset launch per
     // frame: the blocks alternate, and this kernel runs after every kernel of the frame that used that block last (stream order)
     if (blockIdx.x == 0 && threadIdx.x < 8) zero_next[threadIdx.x] = 0u;
@@ -895,10 +900,10 @@ static int launch_integrate_multi(hive_tsdf *v, int nf, const uint8_t *color, co
     unsigned *idle_block = ctx->d_scalars + (ctx->tsdf_scalars ? 0 : 48);  // the single-frame path's next block: cleared anyway
     MultiParams mp;
     mp.nf = nf;
+    hipLaunchKernelGGL(pack_frame_kernel<true>, dim3((unsigned)((npx / 4 + 255) / 256), (unsigned)nf), dim3(256), 0, ctx->stream, depth, color, (int)npx,
+                       (uint2 *)ctx->d_frame, sc, idle_block);  // all nf frames in one launch
     for (int f = 0; f < nf; ++f) {
         uint2 *packed = (uint2 *)ctx->d_frame + (size_t)f * npx;
-        hipLaunchKernelGGL(pack_frame_kernel<true>, dim3((unsigned)((npx / 4 + 255) / 256)), dim3(256), 0, ctx->stream, depth + f * npx, color + f * npx * 3,
-                           (int)npx, packed, sc + f, idle_block);
         fill_frame_params(v, H, W, K, poses + 16 * (size_t)f, obs_weight, mp.f[f]);
         mp.f[f].frame = packed;
         mp.f[f].max_depth_bits = sc + f;
