@@ -118,7 +118,8 @@ int hive_tsdf_integrate(hive_tsdf *vol, const uint8_t *color, const float *depth
                         const float K[9], const double cam_pose[16], float obs_weight,
                         int mem, uint64_t *n_updated);
 /* n frames back to back (frame f at color + f*H*W*3, depth + f*H*W, poses + f*16), in order:
- * identical results to n calls of hive_tsdf_integrate. */
+ * identical results (bit for bit) to n calls of hive_tsdf_integrate.  Device-resident frames are swept up to four
+ * consecutive frames per launch: a voxel is loaded once, the frames are applied to it in order, it is stored once. */
 int hive_tsdf_integrate_batch(hive_tsdf *vol, int n, const uint8_t *color, const float *depth,
                               int H, int W, const float K[9], const double *cam_poses,
                               float obs_weight, int mem);
