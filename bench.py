@@ -6,7 +6,7 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-The job: K * B frames of the seeded 150-frame synthetic sequence (wrapping), B = --batch (64).  A step = one batch of B
+The job: K * B frames of the seeded 150-frame synthetic sequence (wrapping), B = --batch (96).  A step = one batch of B
 frames: uint8 frames start in PINNED HOST memory and are uploaded inside the timed region (double-buffered on a copy stream,
 SURVEY.md 8d) -> preprocess -> DPT-Hybrid (random-init weights of the real architecture, bf16, HIP engine) -> f32 depth tail
 + uint16-mm hand-off -> TSDF integrate.
@@ -39,7 +39,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=64, help="frames per step (measured: 24 -> 857, 48 -> 904, 64 -> 931, 96 -> 938 frames/s)")
+    ap.add_argument("--batch", type=int, default=96, help="frames per step (final code: 64 -> 1074, 96 -> 1104, 128 -> 1102 frames/s on one box)")
     ap.add_argument("--frames", type=int, default=150, help="length of the synthetic sequence")
     ap.add_argument("--voxel", type=float, default=0.01, help="0.01 -> 512^3 over the 5.12 m volume")
     ap.add_argument("--engine", default="hip", choices=["hip", "torch"], help="'torch' = PyTorch-op ViT blocks (comparison only)")
