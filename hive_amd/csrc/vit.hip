@@ -422,7 +422,7 @@ template <int EPI>
 __global__ __launch_bounds__(512, 1) void gemm256p_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr int A_GROUPS = T256 / 8, GROUPS = 2 * A_GROUPS, PER_WAVE = GROUPS / 8;
-    static_assert(EPI != EPI_QKV, "the transposed v^T store stays with the 128-row kernel");
+    constexpr bool VT = (EPI == EPI_QKV);  // the v columns of the QKV projection: orientation A.W^T (a lane owns 4 consecutive TOKENS of one channel)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
@@ -454,17 +454,17 @@ __global__ __launch_bounds__(512, 1) void gemm256p_kernel(GemmParams p) {
     setup(run0 + tl);
 #pragma unroll
     for (int j = 0; j < PER_WAVE; ++j) issue_piece(0, 0, j);
-    hive_mfma::KPipe<8, false> pipe;
+    hive_mfma::KPipe<8, VT> pipe;
     pipe.a_row0 = wr * 128, pipe.w_row0 = wc * 64, pipe.fr = lane & 15, pipe.fq = lane >> 4;
     int buf = 0;
     for (;;) {
         const bool has_next = tl + per_xcd < run_n;
         const int em0 = m0, en0 = n0;
-        f32x4 acc[4][8];
+        f32x4 acc[VT ? 8 : 4][VT ? 4 : 8];  // [nt][mt], or [mt][nt] for the v^T tiles
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < (VT ? 8 : 4); ++i)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < (VT ? 4 : 8); ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int kt = 0; kt < KT; ++kt) {
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -484,7 +484,46 @@ __global__ __launch_bounds__(512, 1) void gemm256p_kernel(GemmParams p) {
             buf ^= 1;
         }
         pipe.flush(acc);
-        gemm_store_rows<EPI, 8>(p, acc, em0 + wr * 128, en0 + wc * 64, lds + 2 * T256_STAGE + wave * 4096, lane);
+        if constexpr (!VT) {
+            gemm_store_rows<EPI, 8>(p, acc, em0 + wr * 128, en0 + wc * 64, lds + 2 * T256_STAGE + wave * 4096, lane);
+        } else {
+            // v^T[b][h][c][token]: the wave's 128 tokens x 64 channels are two 64-token blocks of one head (Np % 64 == 0), each 64 rows of
+            // 128 contiguous bytes; turned around in the wave's 4 KiB of LDS, 64 tokens x 32 channels at a time (see gemm_kernel's v^T path)
+            unsigned char *ot = lds + 2 * T256_STAGE + wave * 4096;
+            const int fr = lane & 15, fq = lane >> 4, fqs = ((fq & 1) << 1) | (fq >> 1);
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+                const int mw = em0 + wr * 128 + blk * 64;
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+#pragma unroll
+                    for (int ntl = 0; ntl < 2; ++ntl) {
+                        const int nt = half * 2 + ntl, row = ntl * 16 + fr;
+                        const float bv = p.bias[en0 + wc * 64 + nt * 16 + fr];
+#pragma unroll
+                        for (int mtl = 0; mtl < 4; ++mtl) {
+                            bf16x4 ov;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) ov[j] = (bf16)(acc[blk * 4 + mtl][nt][j] + bv);
+                            *reinterpret_cast<bf16x4 *>(ot + row * 128 + (((mtl * 2 + (fqs >> 1)) ^ (row & 7)) << 4) + (fqs & 1) * 8) = ov;
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    if (mw < p.M) {
+                        const int img = mw / p.Np, tok0 = mw - img * p.Np, head = (en0 + wc * 64) >> 6;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int row = 8 * i + (lane >> 3), c = lane & 7;
+                            const bf16x8 o8 = *reinterpret_cast<const bf16x8 *>(ot + row * 128 + ((c ^ (row & 7)) << 4));
+                            *reinterpret_cast<bf16x8 *>(p.vT + (((size_t)img * p.H + head) * 64 + half * 32 + row) * p.Np + tok0 + 8 * c) = o8;
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+        }
         if (!has_next) break;
         tl += per_xcd;
     }
@@ -790,6 +829,7 @@ static int launch_gemm256(hive_ctx *ctx, int epi, const GemmParams &p) {
             case EPI_BIAS: hipLaunchKernelGGL((gemm256p_kernel<EPI_BIAS>), pgrid, block, lds_bytes, ctx->stream, p); break;
             case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm256p_kernel<EPI_BIAS_GELU>), pgrid, block, lds_bytes, ctx->stream, p); break;
             case EPI_BIAS_RESIDUAL: hipLaunchKernelGGL((gemm256p_kernel<EPI_BIAS_RESIDUAL>), pgrid, block, lds_bytes, ctx->stream, p); break;
+            case EPI_QKV: hipLaunchKernelGGL((gemm256p_kernel<EPI_QKV>), pgrid, block, lds_bytes, ctx->stream, p); break;
             default: return hive_fail(ctx, HIVE_ERR_INVALID, "gemm: unknown epilogue %d", epi);
         }
         HIVE_CHECK_HIP(ctx, hipGetLastError());
@@ -814,7 +854,9 @@ static int launch_gemm(hive_ctx *ctx, int epi, const GemmParams &p) {
     const long long tiles256 = (long long)((p.M + T256 - 1) / T256) * (p.N / T256);
     const long long rounds = (tiles256 + ctx->num_cus - 1) / ctx->num_cus;
     const bool fills = tiles256 * 5 >= rounds * ctx->num_cus * 3;  // >= 60 % of the CU slots of its rounds (67 %: 635 / 763 vs 612 / 705 TFLOP/s for proj / fc2 at M = 29184; 44 %: 655 vs 858)
-    if (epi != EPI_QKV && p.N % T256 == 0 && ((force && force[0] == '2') || (!force && fills))) return launch_gemm256(ctx, epi, p);
+    static const char *persist_env = getenv("HIVE_GEMM_PERSIST");
+    const bool one_tile_kernel = persist_env && persist_env[0] == '0';  // that kernel has no v^T epilogue
+    if ((epi != EPI_QKV || !one_tile_kernel) && p.N % T256 == 0 && ((force && force[0] == '2') || (!force && fills))) return launch_gemm256(ctx, epi, p);
     // persistent workgroups: two per CU (64 KiB of LDS each), a multiple of 8 so that every XCD gets the same number
     const long long tiles = (long long)((p.M + GEMM_TM - 1) / GEMM_TM) * (p.N / BN);
     const dim3 grid((unsigned)std::min<long long>((tiles + 7) / 8 * 8, (long long)(2 * ctx->num_cus) / 8 * 8)), block(GEMM_TM * 2);
@@ -855,6 +897,7 @@ static int ensure_gemm_attrs(hive_ctx *ctx) {
     HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)gemm256p_kernel<EPI_BIAS_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * T256_STAGE + hive_mfma::STAGED_ROWS_LDS));
     HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)gemm256_kernel<EPI_BIAS_RESIDUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * T256_STAGE + hive_mfma::STAGED_ROWS_LDS));
     HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)gemm256p_kernel<EPI_BIAS_RESIDUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * T256_STAGE + hive_mfma::STAGED_ROWS_LDS));
+    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)gemm256p_kernel<EPI_QKV>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * T256_STAGE + hive_mfma::STAGED_ROWS_LDS));
     if (ctx->device < 64) g_gemm_attr_set[ctx->device] = true;
     return HIVE_OK;
 }
