@@ -14,7 +14,7 @@ python3 - <<PY
 import csv, glob, collections, json
 kernels = {"gemm256p_kernel<0": "gemm q|k (bias; 256 x 256 tiles)", "gemm256p_kernel<1": "gemm fc1 + GELU (256 x 256 tiles)", "gemm256p_kernel<2": "gemm proj / fc2 + residual (256 x 256 tiles)",
            "gemm_kernel<0": "gemm (bias; 128 x 128 tiles)", "gemm_kernel<1": "gemm + GELU (128 x 128 tiles)", "gemm_kernel<2": "gemm + residual (128 x 128 tiles)",
-           "gemm_kernel<3": "gemm v^T", "attention_kernel": "attention", "head_conv_kernel": "fused depth head",
+           "gemm256p_kernel<3>": "gemm v^T (256 x 256 tiles)", "gemm_kernel<3": "gemm v^T (128 x 128 tiles)", "attention_kernel": "attention", "head_conv_kernel": "fused depth head",
            "conv_kernel<256, 256, 0>": "conv -> 256-channel tiles (decoder RCUs, layer_rn)", "conv_kernel<256, 256, 1>": "conv + GroupNorm statistics (ResNetV2, 256-channel tiles)",
            "conv_kernel<256, 256, 2>": "conv + GroupNorm apply, second pass (ResNetV2 conv3 / downsample)", "conv_kernel<256, 128, 0>": "conv 3x3 256 -> 128 (output_conv[0])"}
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
