@@ -229,40 +229,65 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T *__restrict__ x, 
 template <typename T>
 __global__ __launch_bounds__(256) void upsample2x_kernel(const T *__restrict__ in, const T *__restrict__ bias, T *__restrict__ out, int N, int H,
                                                          int W, int C) {
-    // grid (x-blocks over OW * C / 8, OH, N): no 64-bit index arithmetic per element (the linear-index form of round 1 spent more on
-    // its divisions than on the interpolation: 2.3 TB/s)
+    // A thread produces a 2 x 2 block of output pixels (8 channels) from the 3 x 3 input pixels it can touch: 9 loads per 4 stores
+    // instead of 16 -- the kernel is bound by the L1 path of its gathers, not by HBM (a fill of its output alone runs twice as fast).
+    // Source rows of output rows 2k, 2k + 1: y0(2k) = ya and y0(2k + 1) = ya + dy with dy in {0, 1} (the scale is below 1/2), so both
+    // pairs (y0, y1 = min(y0 + 1, H - 1)) lie in r_i = min(ya + i, H - 1), i = 0..2; columns likewise.  Every output is evaluated with
+    // the formula above on the same operands as the one-pixel form: bit-identical.
+    // grid (x-blocks over W * C / 8, H, N)
     const int VC = C >> 3;
     const int OH = 2 * H, OW = 2 * W;
     const float sh = OH > 1 ? (float)(H - 1) / (float)(OH - 1) : 0.f;
     const float sw = OW > 1 ? (float)(W - 1) / (float)(OW - 1) : 0.f;
-    const int oy = blockIdx.y, n = blockIdx.z;
-    for (int t = blockIdx.x * 256 + threadIdx.x; t < OW * VC; t += gridDim.x * 256) {
-        const int ox = t / VC, v = t - ox * VC;
-        const size_t i = ((size_t)n * OH + oy) * OW * VC + t;
-        const float fy = sh * (float)oy, fx = sw * (float)ox;
-        const int y0 = (int)fy, x0 = (int)fx;
-        const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
-        const float h1 = fy - (float)y0, h0 = 1.f - h1, w1 = fx - (float)x0, w0 = 1.f - w1;
-        const T *b = in + (size_t)n * H * W * C + v * 8;
-        float v00[8], v01[8], v10[8], v11[8], o[8];
-        load8(b + ((size_t)y0 * W + x0) * C, v00);
-        load8(b + ((size_t)y0 * W + x1) * C, v01);
-        load8(b + ((size_t)y1 * W + x0) * C, v10);
-        load8(b + ((size_t)y1 * W + x1) * C, v11);
+    const int k = blockIdx.y, n = blockIdx.z;
+    const float fy0 = sh * (float)(2 * k), fy1 = sh * (float)(2 * k + 1);
+    const int ya = (int)fy0, yb = (int)fy1;
+    const bool dy = yb != ya;  // (uniform)
+    const float hy1[2] = {fy0 - (float)ya, fy1 - (float)yb};
+    const int r1 = min(ya + 1, H - 1), r2 = min(ya + 2, H - 1);
+    float bb[8];
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < W * VC; t += gridDim.x * 256) {
+        const int j = t / VC, v = t - j * VC;
+        const float fx0 = sw * (float)(2 * j), fx1 = sw * (float)(2 * j + 1);
+        const int xa = (int)fx0, xb = (int)fx1;
+        const bool dx = xb != xa;
+        const float wx1[2] = {fx0 - (float)xa, fx1 - (float)xb};
+        const int c1 = min(xa + 1, W - 1), c2 = min(xa + 2, W - 1);
+        const T *base = in + (size_t)n * H * W * C + v * 8;
+        const int rows[3] = {ya, r1, r2}, cols[3] = {xa, c1, c2};
+        float B[3][3][8];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) load8(base + ((size_t)rows[i] * W + cols[q]) * C, B[i][q]);
         if (bias) {
-            float bb[8];
             load8(bias + v * 8, bb);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                v00[j] = (float)(T)(v00[j] + bb[j]);
-                v01[j] = (float)(T)(v01[j] + bb[j]);
-                v10[j] = (float)(T)(v10[j] + bb[j]);
-                v11[j] = (float)(T)(v11[j] + bb[j]);
-            }
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) B[i][q][e] = (float)(T)(B[i][q][e] + bb[e]);
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = h0 * (w0 * v00[j] + w1 * v01[j]) + h1 * (w0 * v10[j] + w1 * v11[j]);
-        store8(out + i * 8, o);
+        for (int a = 0; a < 2; ++a) {
+            const float h1 = hy1[a], h0 = 1.f - h1;
+            const bool sy = a == 1 && dy;  // rows (sy, sy + 1) of the block
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const float w1 = wx1[b], w0 = 1.f - w1;
+                const bool sx = b == 1 && dx;
+                float o[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float t0 = sy ? B[1][0][e] : B[0][0][e], t1 = sy ? B[1][1][e] : B[0][1][e], t2 = sy ? B[1][2][e] : B[0][2][e];
+                    const float u0 = sy ? B[2][0][e] : B[1][0][e], u1 = sy ? B[2][1][e] : B[1][1][e], u2 = sy ? B[2][2][e] : B[1][2][e];
+                    const float v00 = sx ? t1 : t0, v01 = sx ? t2 : t1, v10 = sx ? u1 : u0, v11 = sx ? u2 : u1;
+                    o[e] = h0 * (w0 * v00 + w1 * v01) + h1 * (w0 * v10 + w1 * v11);
+                }
+                store8(out + ((((size_t)n * OH + 2 * k + a) * OW) + 2 * j + b) * C + v * 8, o);
+            }
+        }
     }
 }
 
@@ -441,8 +466,8 @@ int hive_nhwc_upsample2x(hive_ctx *ctx, const void *d_in, const void *d_bias, in
     if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
     HIVE_REQUIRE(ctx, d_in && d_out, "upsample2x: NULL argument");
     HIVE_REQUIRE(ctx, N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "upsample2x: need C %% 8 == 0 (N=%d H=%d W=%d C=%d)", N, H, W, C);
-    HIVE_REQUIRE(ctx, 2 * H <= 65535 && N <= 65535, "upsample2x: H %d / N %d too large for the launch grid", H, N);
-    const dim3 grid((unsigned)((2 * W * (C / 8) + 255) / 256), (unsigned)(2 * H), (unsigned)N);
+    HIVE_REQUIRE(ctx, H <= 65535 && N <= 65535, "upsample2x: H %d / N %d too large for the launch grid", H, N);
+    const dim3 grid((unsigned)((W * (C / 8) + 255) / 256), (unsigned)H, (unsigned)N);  // a thread per 2 x 2 output pixels x 8 channels
     if (dtype == HIVE_BF16)
         hipLaunchKernelGGL(upsample2x_kernel<bf16>, grid, dim3(256), 0, ctx->stream, (const bf16 *)d_in, (const bf16 *)d_bias, (bf16 *)d_out, N, H, W, C);
     else if (dtype == HIVE_F16)
