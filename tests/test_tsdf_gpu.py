@@ -325,3 +325,26 @@ def test_multi_frame_sweep_full_size(gpu_ctx):
     for a, b in zip(fused.device_tensors(), one.device_tensors()):
         assert torch.equal(a, b)
     assert float(fused.device_tensors()[1].max()) == 6.0
+
+
+def test_multi_frame_sweep_on_x_slabs(gpu_ctx, oracle_lib, small_sequence):
+    """The fused sweep on x-slab volumes (what the bit-exact multi-GPU mode runs): device frames through integrate_batch into
+    three uneven slabs == the oracle's whole volume, bit for bit."""
+    import torch
+    from hive_amd import fusion, synthetic
+    seq = small_sequence
+    bounds, voxel = synthetic.room_bounds(), 0.0641  # 80^3
+    ora = oracle_lib.TSDFVolume(bounds, voxel)
+    n = seq["depth"].shape[0]
+    for i in range(n):
+        ora.integrate(seq["color"][i], seq["depth"][i], seq["K"], seq["poses"][i])
+    color_d, depth_d = torch.from_numpy(seq["color"]).cuda(), torch.from_numpy(seq["depth"]).cuda()
+    X = int(ora._vol_dim[0])
+    cuts = [0, 27, 28, X]
+    parts = []
+    for a, b in zip(cuts, cuts[1:]):
+        slab = fusion.TSDFVolume(bounds, voxel, ctx=gpu_ctx, x_range=(a, b))
+        slab.integrate_batch(color_d, depth_d, seq["K"], seq["poses"])
+        parts.append(slab.get_volume(with_weight=True))
+    for k, ref in enumerate((ora._tsdf, ora._color, ora._weight)):
+        assert np.array_equal(np.concatenate([p[k] for p in parts], axis=0), ref)
