@@ -40,7 +40,10 @@ def test_layernorm(gpu_ctx, M, D):
 @pytest.mark.parametrize("M,N,K,epi", [(1216, 768, 768, 0), (1216, 3072, 768, 1), (1216, 768, 3072, 2), (200, 128, 64, 0),
                                         (129, 256, 128, 2), (2432, 2304, 768, 0),
                                         # wide N with >= 256 tiles of 256 x 256: the 8-wave 256-tile kernel, incl. a ragged last row tile
-                                        (5632, 3072, 768, 1), (7300, 2304, 768, 2), (5600, 3072, 128, 0)])
+                                        (5632, 3072, 768, 1), (7300, 2304, 768, 2), (5600, 3072, 128, 0),
+                                        # enough 256 x 256 tiles to fill >= 60 % of the CU slots: the persistent 256-tile kernel, several tiles per
+                                        # workgroup, ragged last row tiles
+                                        (14000, 768, 3072, 2), (30000, 1536, 768, 0), (20001, 3072, 768, 1)])
 def test_linear_epilogues(gpu_ctx, M, N, K, epi):
     import torch
     torch.manual_seed(1)
@@ -57,6 +60,10 @@ def test_linear_epilogues(gpu_ctx, M, N, K, epi):
     if epi == 2:
         ref = ref + res.float()
     _close(C, ref, f"linear epi={epi}")
+    if epi == 2:  # the residual stream is updated in place in the model (x += proj(...)): same result
+        inplace = res.clone()
+        gpu_ctx.check(gpu_ctx.lib.hive_vit_linear(gpu_ctx.handle, A.data_ptr(), W.data_ptr(), bias.data_ptr(), inplace.data_ptr(), inplace.data_ptr(), M, N, K, epi))
+        assert torch.equal(inplace, C)
 
 
 def test_linear_asymmetric_identity(gpu_ctx):
