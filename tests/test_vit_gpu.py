@@ -89,7 +89,7 @@ def test_linear_rejects_bad_shapes(gpu_ctx):
         gpu_ctx.check(gpu_ctx.lib.hive_vit_linear(gpu_ctx.handle, t.data_ptr(), t.data_ptr(), f.data_ptr(), None, t.data_ptr(), 128, 128, 64, 2))
 
 
-@pytest.mark.parametrize("B,N", [(1, 1201), (2, 77), (1, 64), (3, 130)])
+@pytest.mark.parametrize("B,N", [(1, 1201), (2, 77), (1, 64), (3, 130), (24, 1201)])  # 24 x 1216 rows: q|k and v^T on the persistent 256-tile kernel
 def test_qkv_and_attention(gpu_ctx, B, N):
     """qkv projection (q|k row-major, v transposed) + softmax(q k^T / 8) v, incl. ragged N (key masking),
     and a spiked key row that forces the online-softmax rescale branch."""
