@@ -272,7 +272,10 @@ def main():
                 traffic = None
         return {"kernel": "integrate_multi_kernel" if frames_per_launch > 1 else "integrate_kernel", "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                 "traffic": traffic, "algorithmic_bytes_per_launch": alg, "frames_per_launch": frames_per_launch, "avg_launch_us": launch_us, "n_upd_mean": n_upd_mean,
-                "n_upd_fraction": n_upd_mean / (volume.num_voxels * (world if exact else 1))}
+                "n_upd_fraction": n_upd_mean / (volume.num_voxels * (world if exact else 1)),
+                "note": ("up to 4 consecutive frames per launch share ONE load / store of the volume (bit-identical to one sweep per frame): achieved = "
+                         "SURVEY 8(d)'s per-frame bytes x frames_per_launch / avg_launch_us, i.e. useful bytes per second; traffic = PMC bytes that "
+                         "actually moved per launch") if frames_per_launch > 1 else "one frame per launch"}
 
     with torch.no_grad():
         if exact:
