@@ -38,8 +38,9 @@ for rep in range(args.reps):
     n, ms = ctx.kernel_time_total()
     ctx.set_timing(False)
     alg = (24.0 * np.mean(n_upd) + 8.0 * H * W)
-    print(f"rep {rep}: {n} launches, kernel avg {ms / n * 1e3:.1f} us, wall/frame {wall / args.frames * 1e3:.3f} ms, "
-          f"algorithmic {alg / 1e6:.1f} MB/frame -> {alg / (ms / n * 1e-3) / 1e9:.1f} GB/s")
+    fpl = args.frames / n  # frames per launch (integrate_batch sweeps up to 4 consecutive device frames at once)
+    print(f"rep {rep}: {n} launches ({fpl:.2f} frames each), kernel avg {ms / n * 1e3:.1f} us = {ms / args.frames * 1e3:.1f} us/frame, wall/frame {wall / args.frames * 1e3:.3f} ms, "
+          f"algorithmic {alg / 1e6:.1f} MB/frame -> {alg * fpl / (ms / n * 1e-3) / 1e9:.1f} GB/s")
 if args.no_mesh:
     sys.exit(0)
 t0 = time.time()
