@@ -979,6 +979,11 @@ static int launch_integrate(hive_tsdf *v, float *accum, int H, int W, const floa
     return hive_time_end(ctx);
 }
 
+static double voxel_extent(const hive_tsdf *v) {  // longest side of the whole grid in metres
+    const double gx = (double)v->grid_dim0, gy = (double)v->dim[1], gz = (double)v->dim[2];
+    return std::max(gx, std::max(gy, gz)) * (double)v->voxel_size;
+}
+
 static int check_frame_args(hive_tsdf *vol, const void *color, const void *depth, int H, int W, const float *K,
                             const double *pose, int mem) {
     if (!vol) return hive_fail(nullptr, HIVE_ERR_INVALID, "vol is NULL");
@@ -1153,9 +1158,28 @@ int hive_tsdf_integrate_batch(hive_tsdf *vol, int n, const uint8_t *color, const
     const int group = frames_env ? std::max(1, std::min(MAXF, atoi(frames_env))) : MAXF;
     const bool multi = mem == HIVE_MEM_DEVICE && group > 1 && vol->dim[2] % 4 == 0 && npx % 4 == 0 && ((uintptr_t)depth % 16 == 0) && ((uintptr_t)color % 4 == 0) &&
                        (npx * 3) % 4 == 0 && (((uintptr_t)vol->d_tsdf | (uintptr_t)vol->d_weight | (uintptr_t)vol->d_color) % 16 == 0);
+    // Fusing pays when the frames look at (almost) the same voxels -- consecutive frames of a video; frames far apart share little and
+    // every voxel of the union still runs every frame's tests.  Measured on the room scene (640 x 480 into 512^3, us per frame: alone |
+    // pairs | fours): 2.4 degrees apart 90 | 70 | 62; 12 degrees 90 | - | 75; 15 degrees 85 | 77 | 82; 20 degrees 85 | 81 | 93; 30 degrees
+    // 85 | 80 | 96; 45 degrees 85 | 85 | 122.  A group therefore grows only while the optical axis stays within 36 degrees of its FIRST
+    // frame's (and the camera within a quarter of the volume's longest side).
+    const double max_side = voxel_extent(vol);
+    static const char *cos_env = getenv("HIVE_TSDF_FUSE_COS");  // tuning: cosine of the largest angle to the group's first frame
+    const double fuse_cos = cos_env ? atof(cos_env) : 0.809017;  // cos 36 deg
+    static const char *dist_env = getenv("HIVE_TSDF_FUSE_DIST");  // tuning: camera distance to the group's first frame, in longest volume sides
+    const double fuse_dist = dist_env ? atof(dist_env) : 0.25;
+    auto fusable = [&](int a, int b) {
+        const double *pa = cam_poses + 16 * (size_t)a, *pb = cam_poses + 16 * (size_t)b;
+        const double dot = pa[2] * pb[2] + pa[6] * pb[6] + pa[10] * pb[10];
+        const double na = sqrt(pa[2] * pa[2] + pa[6] * pa[6] + pa[10] * pa[10]), nb = sqrt(pb[2] * pb[2] + pb[6] * pb[6] + pb[10] * pb[10]);
+        const double dx = pa[3] - pb[3], dy = pa[7] - pb[7], dz = pa[11] - pb[11];
+        return dot >= fuse_cos * na * nb && dx * dx + dy * dy + dz * dz <= fuse_dist * fuse_dist * max_side * max_side;
+    };
     int f = 0;
     while (f < n) {
-        const int nf = multi ? std::min(group, n - f) : 1;
+        int nf = 1;
+        if (multi)
+            while (nf < group && f + nf < n && fusable(f, f + nf)) ++nf;
         if (nf > 1) {
             if ((rc = launch_integrate_multi(vol, nf, color + f * npx * 3, depth + f * npx, H, W, K, cam_poses + 16 * (size_t)f, obs_weight))) return rc;
         } else {
