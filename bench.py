@@ -260,7 +260,7 @@ def main():
     def roofline(n_upd_mean, launch_us, traffic_key, frames_per_launch):
         # SURVEY 8(d)'s per-frame figure: 3 volumes read + written for every updated voxel + one read of depth / colour -- times the
         # frames one launch integrates (hive_tsdf_integrate_batch sweeps up to 4 consecutive frames at once: the volume is loaded and
-        # stored once for all of them, so the bytes that actually move (`traffic`) are FEWER than this figure)
+        # stored once for all of them: a quarter of the writes; `traffic` is the PMC figure of the same launch)
         alg = (24.0 * n_upd_mean + 8.0 * H * W) * frames_per_launch
         achieved = alg / (launch_us * 1e-6) / 1e9
         traffic = None
@@ -274,8 +274,8 @@ def main():
                 "traffic": traffic, "algorithmic_bytes_per_launch": alg, "frames_per_launch": frames_per_launch, "avg_launch_us": launch_us, "n_upd_mean": n_upd_mean,
                 "n_upd_fraction": n_upd_mean / (volume.num_voxels * (world if exact else 1)),
                 "note": ("up to 4 consecutive frames per launch share ONE load / store of the volume (bit-identical to one sweep per frame): achieved = "
-                         "SURVEY 8(d)'s per-frame bytes x frames_per_launch / avg_launch_us, i.e. useful bytes per second; traffic = PMC bytes that "
-                         "actually moved per launch") if frames_per_launch > 1 else "one frame per launch"}
+                         "SURVEY 8(d)'s per-frame bytes x frames_per_launch / avg_launch_us, i.e. useful bytes per second; traffic = 2 x FETCH_SIZE + "
+                         "WRITE_SIZE per launch (PMC; the fetches include texel gathers served by the Infinity Cache)") if frames_per_launch > 1 else "one frame per launch"}
 
     with torch.no_grad():
         if exact:

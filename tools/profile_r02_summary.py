@@ -15,7 +15,8 @@ if stats:
         shutil.copy(log, os.path.join(dst, "r02_probe_1024cubed_1080p.log"))
 def mean_counter(sub, counter):
     vals = []
-    for f in glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True):
+    files = glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True)
+    for f in sorted(files, key=os.path.getmtime)[-1:]:  # the newest run only (gpurun merges into gpurun_out without deleting older runs)
         for row in csv.DictReader(open(f)):
             name = row["Kernel_Name"]
             timed = "false, false" in name or "Lb0ELb0E" in name or "integrate_multi_kernel" in name  # the timed variants (no COUNT, no ACCUM)
