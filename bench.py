@@ -8,7 +8,8 @@
 
 The job: K * B frames of the seeded 150-frame synthetic sequence (wrapping), B = --batch (96).  A step = one batch of B
 frames: uint8 frames start in PINNED HOST memory and are uploaded inside the timed region (double-buffered on a copy stream,
-SURVEY.md 8d) -> preprocess -> DPT-Hybrid (random-init weights of the real architecture, bf16, HIP engine) -> f32 depth tail
+SURVEY.md 8d) -> preprocess -> DPT-Hybrid (seeded random weights of the real architecture: depth maps of 1-7 m, so the TSDF scene
+has surfaces inside the volume; bf16 or --dtype fp16, HIP engine) -> f32 depth tail
 + uint16-mm hand-off -> TSDF integrate.
 
 N > 1 (BASELINE configs[2]: the SAME sequence frame-sharded; `--scaling strong`, default): the K * B frames are split in
@@ -45,20 +46,24 @@ def parse_args():
     ap.add_argument("--engine", default="hip", choices=["hip", "torch"], help="'torch' = PyTorch-op ViT blocks (comparison only)")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"], help="N > 1: shard the same job (strong) or repeat it per rank (weak)")
     ap.add_argument("--merge", default="sum", choices=["sum", "exact"], help="N > 1: how the shared volume is merged")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"], help="16-bit type of the network (north_star: bf16; the reference runs fp16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--timed-only", action="store_true", help="profiling runs: skip the untimed roofline measurements behind the timed region")
     return ap.parse_args()
 
 
 def cpu_baseline(seq, voxel, K):
-    """The CPU path timed on this box's host cores, on a bounded sample of the same workload: the numpy
-    port of the integrate step (bit-identical arithmetic to the C oracle; numpy runs it on ONE thread) on one 640 x 480
-    frame into the same 512^3 volume, and the fp32 torch-CPU DPT-Hybrid on two frames (after one warm-up, all cores)."""
+    """The CPU path timed on this box's host cores, on a bounded sample of the same workload: the fp32 torch-CPU DPT-Hybrid on
+    two frames (after one warm-up) and the C oracle's integrate -- the restatement of the reference library's loop, its x planes
+    spread over the same cores with OpenMP, as the library's own CPU fallback is `numba @njit(parallel=True)` -- on three 640 x 480
+    frames into the same 512^3 volume.  Both legs use every core the process may run on; the count is in `cores`."""
     import oracle
     from hive_amd import synthetic
+    from hive_amd.dpt.init import seeded_init
     from hive_amd.dpt.models import DPTDepthModel
-    threads = torch.get_num_threads()
-    model = DPTDepthModel(path=None, scale=0.000305, shift=0.1378, invert=True, engine="torch").eval()
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    model = seeded_init(DPTDepthModel(path=None, scale=0.000305, shift=0.1378, invert=True, engine="torch"), seed=1234).eval()
     x = torch.from_numpy(seq["color"][:1].astype(np.float32) / 255.0 * 2.0 - 1.0).permute(0, 3, 1, 2).contiguous()
     with torch.no_grad():
         model(x)
@@ -67,15 +72,18 @@ def cpu_baseline(seq, voxel, K):
             depth = model(x)
         t_dpt = (time.time() - t0) / 2
     depth_np = depth[0].numpy().astype(np.float32)
+    depth_np = np.where(depth_np > 10.0, 0.0, np.trunc(depth_np * 1000.0) / 1000.0).astype(np.float32)  # the uint16-mm hand-off
+    threads = oracle.set_threads(cores)
     ora = oracle.TSDFVolume(synthetic.room_bounds(), voxel)
-    tsdf, weight, color = ora._tsdf, ora._weight, ora._color
+    n_frames, n_upd = 3, 0
     t0 = time.time()
-    n_upd = oracle.integrate_numpy(tsdf, weight, color, ora._vol_origin, ora._voxel_size, np.float32(ora._trunc_margin), seq["color"][0],
-                                   depth_np, K, seq["poses"][0], round_mode=ora.round_mode)
-    t_tsdf = time.time() - t0
-    return {"value": 1.0 / (t_dpt + t_tsdf), "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": f"2 frames DPT-Hybrid fp32 torch-CPU ({threads} threads, {t_dpt:.2f} s/frame) + 1 frame numpy TSDF integrate "
-                      f"into {'x'.join(str(int(d)) for d in ora._vol_dim)} (numpy: 1 thread, {t_tsdf:.2f} s/frame, N_upd {n_upd})"}
+    for i in range(n_frames):
+        ora.integrate(seq["color"][i], depth_np, K, seq["poses"][i])
+        n_upd += ora.last_n_updated
+    t_tsdf = (time.time() - t0) / n_frames
+    return {"value": 1.0 / (t_dpt + t_tsdf), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"2 frames DPT-Hybrid fp32 torch-CPU ({torch.get_num_threads()} threads, {t_dpt:.2f} s/frame) + {n_frames} frames C-oracle TSDF integrate "
+                      f"into {'x'.join(str(int(d)) for d in ora._vol_dim)} (OpenMP, {threads} threads, {t_tsdf:.2f} s/frame, mean N_upd {n_upd // n_frames})"}
 
 
 class FrameFeeder:
@@ -142,7 +150,10 @@ def main():
     frames_host = torch.from_numpy(seq["color"]).pin_memory()  # uint8 [T, H, W, 3]
 
     ctx = _lib.default_context(dev_index)
-    model = depth_mod.build_model(None, device=device, dtype=torch.bfloat16, engine=args.engine)
+    net_dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
+    # seeded non-degenerate weights (hive_amd/dpt/init.py): PyTorch's default initialisation predicts a constant 7.25 m, i.e. a
+    # TSDF scene with no surface (free space only); these give depth maps of 1-7 m with surfaces inside the volume
+    model = depth_mod.build_model(None, device=device, dtype=net_dtype, engine=args.engine, init_seed=1234)
     if exact:
         merger = hdist.ExactSlabFusion(synthetic.room_bounds(), args.voxel, ctx=ctx)
         volume = merger.slab
@@ -234,20 +245,29 @@ def main():
         return
 
     # ---- untimed: what the timed launches processed --------------------------------------------------------------------
-    # N_upd of EVERY frame this rank integrated in the timed region (depends on depth + pose only, not on the volume state)
+    # A measurement volume of the same shape in caller-owned storage (its weight plane is read directly).  Per frame: N_upd, from the
+    # counting variant of the single-frame kernel.  Per sweep: N_union = voxels updated by ANY frame of the sweep = weights that moved
+    # across the launch (every update adds obs_weight > 0).  Both depend on depth + pose only, not on the volume's state.
+    x_range = merger.x_ranges[rank] if exact else None
+    n_vox = volume.num_voxels
+    storage = tuple(torch.empty(n_vox, dtype=torch.float32, device=device) for _ in range(3))
+    mvol = fusion.TSDFVolume(synthetic.room_bounds(), args.voxel, ctx=ctx, storage=storage, x_range=x_range)
+    w_plane = storage[1]
+
     def measure(frame_sets, depth_of, time_kernel=False):
-        """(mean N_upd, ms per frame of the TSDF leg = pack + work list + sweep, [mean sweep-kernel us, launches])."""
-        n_upd, leg_ms, k_ms, k_n = [], [], 0.0, 0
+        """Over all frames: per-frame N_upd, per-sweep (frames, N_union), ms per frame of the TSDF leg (pack + work list + sweep), and
+        with time_kernel the HIP-event time of the sweep launches."""
+        n_upd, sweeps, leg_ms, k_ms, k_n = [], [], [], 0.0, 0
         for ids in frame_sets:
             fr = torch.from_numpy(seq["color"][ids]).to(device)
             depth_m = depth_of(fr, ids)
-            for j, i in enumerate(ids):  # the counting variant of the kernel (one atomic per wave): never timed
-                n_upd.append(volume.integrate(fr[j], depth_m[j], K, poses[i], return_n_updated=True))
+            for j, i in enumerate(ids):
+                n_upd.append(mvol.integrate(fr[j], depth_m[j], K, poses[i], return_n_updated=True))
             if time_kernel:
                 ctx.set_timing(True)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            volume.integrate_batch(fr, depth_m, K, poses[ids])  # per frame, back to back
+            mvol.integrate_batch(fr, depth_m, K, poses[ids])  # as the timed job runs it
             e1.record()
             e1.synchronize()
             leg_ms.append(e0.elapsed_time(e1) / len(ids))
@@ -255,27 +275,51 @@ def main():
                 n, ms = ctx.kernel_time_total()
                 ctx.set_timing(False)
                 k_ms, k_n = k_ms + ms, k_n + n
-        return float(np.mean(n_upd)), float(np.mean(leg_ms)), (k_ms / max(k_n, 1) * 1e3, k_n)
+            a = 0
+            for nf in mvol.last_batch_groups():  # the same sweeps again, one call each, with the weight plane compared across the launch
+                before = w_plane.clone()
+                mvol.integrate_batch(fr[a:a + nf], depth_m[a:a + nf], K, poses[ids[a:a + nf]])
+                assert mvol.last_batch_groups() == [nf]
+                sweeps.append((nf, int((w_plane != before).sum().item())))
+                a += nf
+        return n_upd, sweeps, float(np.mean(leg_ms)), (k_ms / max(k_n, 1) * 1e3, k_n)
 
-    def roofline(n_upd_mean, launch_us, traffic_key, frames_per_launch):
-        # SURVEY 8(d)'s per-frame figure: 3 volumes read + written for every updated voxel + one read of depth / colour -- times the
-        # frames one launch integrates (hive_tsdf_integrate_batch sweeps up to 4 consecutive frames at once: the volume is loaded and
-        # stored once for all of them: a quarter of the writes; `traffic` is the PMC figure of the same launch)
-        alg = (24.0 * n_upd_mean + 8.0 * H * W) * frames_per_launch
+    def load_profile(name):
+        try:
+            return json.load(open(os.path.join(ROOT, "profiles", name)))
+        except Exception:
+            return None
+
+    def roofline(n_upd, sweeps, launch_us, scene_key):
+        """HBM roofline of the sweep kernel.  Bytes a launch MUST move: every voxel updated by any of its frames is read and written
+        once in three float planes (24 B x N_union) + one read of each frame's depth and colour (8 B x H x W x frames).  SURVEY 8(d)'s
+        per-frame figure (24 N_upd + 8 H W, one sweep per frame) times the frames of the launch is what the same work costs unfused;
+        it is reported separately as `serial_equivalent`: it is not a bandwidth and may exceed the HBM peak."""
+        frames = sum(nf for nf, _ in sweeps)
+        fpl = frames / max(len(sweeps), 1)
+        n_union = float(np.mean([u for _, u in sweeps]))
+        n_upd_mean = float(np.mean(n_upd))
+        alg = 24.0 * n_union + 8.0 * H * W * fpl
+        serial = (24.0 * n_upd_mean + 8.0 * H * W) * fpl
         achieved = alg / (launch_us * 1e-6) / 1e9
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "integrate_traffic.json")
-        if os.path.exists(tf):
-            try:
-                traffic = json.load(open(tf)).get(traffic_key)
-            except Exception:
-                traffic = None
-        return {"kernel": "integrate_multi_kernel" if frames_per_launch > 1 else "integrate_kernel", "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                "traffic": traffic, "algorithmic_bytes_per_launch": alg, "frames_per_launch": frames_per_launch, "avg_launch_us": launch_us, "n_upd_mean": n_upd_mean,
-                "n_upd_fraction": n_upd_mean / (volume.num_voxels * (world if exact else 1)),
-                "note": ("up to 4 consecutive frames per launch share ONE load / store of the volume (bit-identical to one sweep per frame): achieved = "
-                         "SURVEY 8(d)'s per-frame bytes x frames_per_launch / avg_launch_us, i.e. useful bytes per second; traffic = 2 x FETCH_SIZE + "
-                         "WRITE_SIZE per launch (PMC; the fetches include texel gathers served by the Infinity Cache)") if frames_per_launch > 1 else "one frame per launch"}
+        out = {"kernel": "integrate_multi_kernel" if fpl > 1 else "integrate_kernel", "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+               "frac": achieved / 8000.0, "traffic": None, "algorithmic_bytes_per_launch": alg, "frames_per_launch": fpl, "avg_launch_us": launch_us,
+               "us_per_frame": launch_us / fpl, "n_union_mean": n_union, "n_upd_mean": n_upd_mean, "n_upd_fraction": n_upd_mean / n_vox,
+               "serial_equivalent": {"bytes_per_launch": serial, "gbs": serial / (launch_us * 1e-6) / 1e9,
+                                     "note": "SURVEY 8(d)'s one-sweep-per-frame bytes (24 N_upd + 8 H W) x frames per launch / avg_launch_us: what the fusion saves, not a bandwidth"}}
+        pmc = load_profile("r03_integrate_pmc.json")
+        if pmc and scene_key in pmc:
+            t = pmc[scene_key]
+            out["traffic"] = t.get("hbm_bytes_per_launch")
+            out["traffic_detail"] = {k: t.get(k) for k in ("read_bytes_lo", "read_bytes_hi", "write_bytes", "launches", "note") if k in t}
+            v = t.get("valu")
+            if v:  # the limiter the counters name: VALU issue.  A wave64 f32 VALU instruction holds its SIMD for 4 cycles (packed: 2 results in the same 4)
+                issue_us = v["SQ_INSTS_VALU"] * 4.0 / 1024.0 / (v["clock_ghz"] * 1e3)
+                out["valu_issue"] = {"insts_per_launch": v["SQ_INSTS_VALU"], "cycles_per_inst": 4, "simds": 1024, "clock_ghz": v["clock_ghz"], "min_us": issue_us,
+                                     "frac_of_launch": issue_us / launch_us, "simd_busy_valu": v.get("simd_busy_valu"),
+                                     "note": "profiles/r03_integrate_pmc.json (rocprofv3 --pmc of the same kernel and scene); min_us = instructions x 4 cycles / 1024 SIMDs at the measured clock"}
+                out["limiter"] = "valu-issue" if issue_us / launch_us > achieved / 6300.0 else "hbm"
+        return out
 
     with torch.no_grad():
         if exact:
@@ -284,20 +328,56 @@ def main():
             timed_sets = batches(job_frames(args.warmup, args.steps)[0])
         else:
             timed_sets = [job_frames(args.warmup + s, 1)[0] for s in range(args.steps)]
-        n_upd_dpt, leg_dpt, _ = measure(timed_sets, lambda fr, ids: stream.depth(fr)[0])
-        frames_timed = sum(len(ids) for ids in timed_sets)  # frames this rank integrated in the timed region
-        main_roof = roofline(n_upd_dpt, kernel_ms / max(n_launch, 1) * 1e3, "hbm_bytes_per_launch", frames_timed / max(n_launch, 1))
+        n_upd_dpt, sweeps_dpt, leg_dpt, _ = measure(timed_sets, lambda fr, ids: stream.depth(fr)[0])
+        main_roof = roofline(n_upd_dpt, sweeps_dpt, kernel_ms / max(n_launch, 1) * 1e3, "bench")
         main_roof["launches"] = n_launch
         main_roof["tsdf_leg_us_per_frame"] = leg_dpt * 1e3
-        # the room scene: the same integrate on the ray-cast (analytic) depth of the sequence -- real depth variation, a
-        # surface inside the volume; the DPT-fed scene above has random-weight depth (nearly constant, free space only)
-        room_ids = list(range(0, T, max(1, T // 30)))[:30]
-        volume.reset()
-        n_upd_room, leg_room, (us_room, n_room) = measure([room_ids], lambda fr, ids: torch.from_numpy(seq["depth"][ids]).to(device), time_kernel=True)
-        room_roof = roofline(n_upd_room, us_room, "hbm_bytes_per_launch_room", len(room_ids) / max(n_room, 1))
+        main_roof["scene"] = "DPT-Hybrid depth (seeded weights) of the timed frames"
+        # the room scene: the same integrate on the ray-cast (analytic) depth of the sequence: CONSECUTIVE frames (2.4 degrees apart,
+        # sweeps of four, as in the timed job), the walls of the room as the surface
+        room_ids = list(range(min(32, T)))
+        mvol.reset()
+        n_upd_room, sweeps_room, leg_room, (us_room, n_room) = measure([room_ids], lambda fr, ids: torch.from_numpy(seq["depth"][ids]).to(device), time_kernel=True)
+        room_roof = roofline(n_upd_room, sweeps_room, us_room, "room")
         room_roof["launches"] = n_room
         room_roof["tsdf_leg_us_per_frame"] = leg_room * 1e3
-        room_roof["scene"] = "analytic ray-cast depth of the same trajectory (surface inside the volume), 30 frames"
+        room_roof["scene"] = f"analytic ray-cast depth of the same trajectory (the room's walls inside the volume), frames 0..{len(room_ids) - 1} consecutively"
+
+        # ---- DPT alone: MFMA roofline of the network (hive_dpt_forward on one step's batch, HIP events on the compute stream) ---------
+        from hive_amd.dpt.models import count_flops
+        fr = torch.from_numpy(seq["color"][[j % T for j in range(len(timed_sets[0]))]]).to(device)
+        stream.depth(fr)
+        reps = 3
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            stream.depth(fr)
+        e1.record()
+        e1.synchronize()
+        dpt_ms = e0.elapsed_time(e1) / reps
+        flops = count_flops(H, W)
+        tflops = flops["total"] * fr.shape[0] / (dpt_ms * 1e-3) / 1e12
+        dpt_roof = {"kernel": "hive_dpt_forward (190 launches: MFMA GEMM / attention / implicit-GEMM convolutions + glue)", "bound": "mfma", "achieved": tflops, "peak": 2500.0,
+                    "unit": "TFLOP/s", "frac": tflops / 2500.0, "dtype": args.dtype, "flops_per_frame": flops["total"], "frames": int(fr.shape[0]), "ms_per_batch": dpt_ms,
+                    "ms_per_frame": dpt_ms / fr.shape[0], "note": "algorithmic FLOPs (2 x MACs, hive_amd.dpt.models.count_flops) x frames / time of the whole network, "
+                    "glue kernels included; per-kernel mfma_busy: profiles/r03_mfma_pmc.json"}
+        busy = load_profile("r03_mfma_pmc.json")
+        if busy:
+            dpt_roof["mfma_busy"] = busy.get("mfma_busy")
+
+        # ---- marching cubes once, on the room volume (reported separately) ----------------------------------------------
+        mesh = None
+        if not exact:
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            n_v, n_f = mvol._extract()
+            e1.record()
+            e1.synchronize()
+            mc_bytes = 4.0 * n_vox + 36.0 * n_v + 12.0 * n_f + 4.0 * n_v
+            mesh = {"mesh_ms": e0.elapsed_time(e1), "vertices": n_v, "faces": n_f, "algorithmic_bytes": mc_bytes, "gbs": mc_bytes / (e0.elapsed_time(e1) * 1e-3) / 1e9,
+                    "note": "hive_tsdf_extract_mesh on the room volume after the 32 frames above (device side, incl. its two count read-backs); bytes = 4 N + 36 V + 12 F + 4 V (SURVEY 8d)"}
+    del mvol, storage, w_plane
 
     if rank != 0:
         return
@@ -316,18 +396,20 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "strong" if strong else "weak",
+        "scaling": None if world == 1 else ("strong" if strong else "weak"),
         "vs_baseline": None,
-        "dtype": "bf16",
+        "dtype": args.dtype,
         "data": "synthetic",
         "config": {
             "workload": f"synthetic {W}x{H}x{T} RGB (seeded room trajectory), host-resident uint8 frames uploaded in the timed region, DPT-Hybrid depth "
-                        f"(random-init weights, bf16, {args.engine} engine) + {dims} TSDF integrate, {B} frames/step" + merge_note,
+                        f"(seeded random weights: depth 1-7 m, {args.dtype}, {args.engine} engine) + {dims} TSDF integrate, {B} frames/step" + merge_note,
             "frames_per_step": B, "frames_total": total_frames, "image": [H, W], "volume": dims, "voxel_m": args.voxel,
-            "n_upd_mean": n_upd_dpt, "n_upd_fraction": main_roof["n_upd_fraction"], "merge": (args.merge if world > 1 else None),
+            "n_upd_mean": main_roof["n_upd_mean"], "n_upd_fraction": main_roof["n_upd_fraction"], "merge": (args.merge if world > 1 else None),
         },
         "roofline": main_roof,
         "roofline_room": room_roof,
+        "roofline_dpt": dpt_roof,
+        "mesh": mesh,
     }
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(seq, args.voxel, K)

@@ -47,6 +47,7 @@ SIGNATURES = {
                                     P(ctypes.c_uint64)]),
     "hive_tsdf_integrate_batch": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_float,
                                           c_int]),
+    "hive_tsdf_last_batch_groups": (c_int, [c_void_p, c_void_p, c_int, P(c_int)]),
     "hive_tsdf_get_volume": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "hive_tsdf_set_volume": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "hive_tsdf_extract_mesh": (c_int, [c_void_p, P(c_int64), P(c_int64)]),
@@ -58,6 +59,8 @@ SIGNATURES = {
     "hive_tsdf_accum_finalize": (c_int, [c_void_p, c_void_p]),
     "hive_tsdf_accum_finalize_to": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     "hive_tsdf_accum_from_volume": (c_int, [c_void_p, c_void_p]),
+    "hive_tsdf_accum_from_volume_sharded": (c_int, [c_void_p, c_void_p, c_int, c_int64]),
+    "hive_tsdf_set_volume_range": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     "hive_view_frustum": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "hive_view_frustum_batch": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "hive_depth_apply_mask": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),

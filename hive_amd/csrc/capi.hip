@@ -115,8 +115,9 @@ int hive_ctx_create(int device_id, void *stream, hive_ctx **out) {
             ctx->stream = (hipStream_t)stream;  // NULL = the default stream
         }
     }
-    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_scalars, 128 * sizeof(unsigned));
-    if (e == hipSuccess) e = hipMemset(ctx->d_scalars, 0, 128 * sizeof(unsigned));  // the TSDF scalar blocks start cleared (tsdf.hip prepare_frame)
+    // [0, 128): scalar blocks of the kernels; [128, 128 + 2048): HIVE_COUNT_SLOTS update counters, one per 128-byte line (tsdf.hip)
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_scalars, (128 + 2048) * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMemset(ctx->d_scalars, 0, (128 + 2048) * sizeof(unsigned));  // the TSDF scalar blocks start cleared (tsdf.hip prepare_frame)
     if (e == hipSuccess) e = hipMalloc(&ctx->d_zeros, 256);
     if (e == hipSuccess) e = hipMemset(ctx->d_zeros, 0, 256);
     if (e != hipSuccess) {

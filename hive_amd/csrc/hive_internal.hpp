@@ -113,6 +113,8 @@ struct hive_tsdf {
     // pixel / colour rounding of integrate, finalize and the mesh colour lookup of THIS volume (hive_round_mode):
     // a property of the volume, not of the context, so that two volumes of one thread may differ
     int round_mode = HIVE_ROUND_HALF_EVEN;
+    // frames per sweep of the most recent hive_tsdf_integrate_batch (1 = the single-frame kernel), in launch order
+    std::vector<int> last_groups;
     // mesh extraction results (device)
     int64_t n_verts = -1, n_faces = -1;
     float *d_verts = nullptr, *d_norms = nullptr, *d_verts_vox = nullptr;

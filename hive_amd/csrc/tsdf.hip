@@ -98,6 +98,7 @@ __global__ __launch_bounds__(256) void pack_frame_kernel(const float *__restrict
 #define HIVE_GRID_MULT 16
 #endif
 constexpr int SEG_LANES = HIVE_SEG_LANES;
+constexpr int COUNT_SLOTS = 64, COUNT_STRIDE = 16;  // update counters of the COUNT kernels: 64 x u64, 128 bytes apart (hive_ctx::d_scalars + 128)
 struct WorkItem {
     unsigned xy;  // x | y << 16
     unsigned zz;  // segment start z | interval end z << 16
@@ -560,8 +561,16 @@ __global__ __launch_bounds__(256) void integrate_kernel(FrameParams p, const Wor
         }
     }
     if (COUNT) {
+        // one atomic per WORKGROUP, spread over COUNT_SLOTS counters on separate 128-byte lines (summed on read-back): one same-address
+        // atomic per wave cost 863 us per frame at 512^3 against ~90 us for the sweep itself (profiles/r02_kernel_stats.csv)
+        __shared__ unsigned wave_cnt[4];
         for (int off = 32; off > 0; off >>= 1) n_upd += __shfl_xor((int)n_upd, off);
-        if (lane == 0 && n_upd) atomicAdd(p.n_updated, (unsigned long long)n_upd);
+        if (lane == 0) wave_cnt[threadIdx.x >> 6] = n_upd;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned total = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+            if (total) atomicAdd(p.n_updated + (size_t)(blockIdx.x % COUNT_SLOTS) * COUNT_STRIDE, (unsigned long long)total);
+        }
     }
 }
 
@@ -819,6 +828,29 @@ __global__ __launch_bounds__(256) void to_accum_kernel(const float *__restrict__
     }
 }
 
+// the same sums in the layout of ONE reduce-scatter: acc [world][5][chunk], voxel i in piece i / chunk at offset i % chunk; zeros past n
+__global__ __launch_bounds__(256) void to_accum_sharded_kernel(const float *__restrict__ tsdf, const float *__restrict__ weight,
+                                                               const float *__restrict__ color, long long n, long long chunk, long long total,
+                                                               float *__restrict__ acc) {
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+        const long long r = i / chunk, j = i - r * chunk;
+        float *o = acc + r * 5 * chunk + j;
+        float w = 0.f, t = 0.f;
+        unsigned c = 0u;
+        if (i < n) {
+            w = weight[i];
+            t = tsdf[i];
+            c = (unsigned)color[i];
+        }
+        o[0] = t * w;
+        o[chunk] = w;
+        o[2 * chunk] = (float)(c & 255u) * w;
+        o[3 * chunk] = (float)((c >> 8) & 255u) * w;
+        o[4 * chunk] = (float)(c >> 16) * w;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 static int fill_volume(hive_tsdf *v) {
     hive_ctx *ctx = v->ctx;
@@ -851,7 +883,7 @@ static int prepare_frame(hive_tsdf *v, const uint8_t *color, const float *depth,
     }
     int rc = hive_reserve_device(ctx, &ctx->d_frame, &ctx->frame_bytes, npx * sizeof(uint2));
     if (rc) return rc;
-    // scalar block of this frame: [0] max depth bits, [2..3] n_updated, [4] work-list length.  Two blocks alternate (both zero after
+    // scalar block of this frame: [0] max depth bits, [4] work-list length (update counters: d_scalars + 128).  Two blocks alternate (both zero after
     // hive_ctx_create); the pack kernel of a frame clears the block of the next one.
     ctx->tsdf_scalars ^= 1;
     unsigned *mine = tsdf_scalars(ctx), *next = ctx->d_scalars + (ctx->tsdf_scalars ? 0 : 48);
@@ -940,7 +972,8 @@ static int launch_integrate(hive_tsdf *v, float *accum, int H, int W, const floa
     fill_frame_params(v, H, W, K, pose, obs_weight, p);
     p.frame = (const uint2 *)ctx->d_frame;
     p.max_depth_bits = tsdf_scalars(ctx);
-    p.n_updated = (unsigned long long *)(tsdf_scalars(ctx) + 2);
+    p.n_updated = (unsigned long long *)(ctx->d_scalars + 128);
+    if (count) HIVE_CHECK_HIP(ctx, hipMemsetAsync(p.n_updated, 0, COUNT_SLOTS * COUNT_STRIDE * sizeof(unsigned long long), ctx->stream));
     const long long rows = (long long)p.X * p.Y;
     float *a0 = ACCUM ? accum : v->d_tsdf;
     const bool vec = (p.Z % 4 == 0) && (((uintptr_t)a0 | (uintptr_t)v->d_weight | (uintptr_t)v->d_color) % 16 == 0);
@@ -1140,9 +1173,11 @@ int hive_tsdf_integrate(hive_tsdf *vol, const uint8_t *color, const float *depth
     if ((rc = launch_integrate<false>(vol, nullptr, H, W, K, cam_pose, obs_weight, n_updated != nullptr))) return rc;
     vol->n_verts = vol->n_faces = -1;
     if (n_updated) {
-        unsigned long long n = 0;
-        HIVE_CHECK_HIP(ctx, hipMemcpyAsync(&n, tsdf_scalars(ctx) + 2, sizeof(n), hipMemcpyDeviceToHost, ctx->stream));
+        unsigned long long slots[COUNT_SLOTS * COUNT_STRIDE];
+        HIVE_CHECK_HIP(ctx, hipMemcpyAsync(slots, ctx->d_scalars + 128, sizeof(slots), hipMemcpyDeviceToHost, ctx->stream));
         HIVE_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        unsigned long long n = 0;
+        for (int i = 0; i < COUNT_SLOTS; ++i) n += slots[i * COUNT_STRIDE];
         *n_updated = n;
     }
     return HIVE_OK;
@@ -1177,6 +1212,7 @@ int hive_tsdf_integrate_batch(hive_tsdf *vol, int n, const uint8_t *color, const
         const double dx = pa[3] - pb[3], dy = pa[7] - pb[7], dz = pa[11] - pb[11];
         return dot >= fuse_cos * na * nb && dx * dx + dy * dy + dz * dz <= fuse_dist * fuse_dist * max_side * max_side;
     };
+    vol->last_groups.clear();
     int f = 0;
     while (f < n) {
         int nf = 1;
@@ -1190,9 +1226,18 @@ int hive_tsdf_integrate_batch(hive_tsdf *vol, int n, const uint8_t *color, const
             if ((rc = prepare_frame(vol, color + f * npx * 3, depth + f * npx, H, W, mem, &d_color, &d_depth))) return rc;
             if ((rc = launch_integrate<false>(vol, nullptr, H, W, K, cam_poses + 16 * (size_t)f, obs_weight, false))) return rc;
         }
+        vol->last_groups.push_back(nf);
         f += nf;
     }
     vol->n_verts = vol->n_faces = -1;
+    return HIVE_OK;
+}
+
+int hive_tsdf_last_batch_groups(hive_tsdf *vol, int *sizes, int capacity, int *n_groups) {
+    if (!vol) return hive_fail(nullptr, HIVE_ERR_INVALID, "vol is NULL");
+    HIVE_REQUIRE(vol->ctx, n_groups && capacity >= 0 && (sizes || capacity == 0), "last_batch_groups: bad arguments");
+    *n_groups = (int)vol->last_groups.size();
+    for (int i = 0; i < capacity && i < *n_groups; ++i) sizes[i] = vol->last_groups[i];
     return HIVE_OK;
 }
 
@@ -1249,6 +1294,34 @@ int hive_tsdf_accum_from_volume(hive_tsdf *v, float *d_accum) {
     const int blocks = (int)std::min<long long>((v->n + 255) / 256, 256 * 32);
     hipLaunchKernelGGL(to_accum_kernel, dim3(blocks), dim3(256), 0, ctx->stream, v->d_tsdf, v->d_weight, v->d_color, (long long)v->n, d_accum);
     HIVE_CHECK_HIP(ctx, hipGetLastError());
+    return HIVE_OK;
+}
+
+int hive_tsdf_accum_from_volume_sharded(hive_tsdf *v, float *d_out, int world, int64_t chunk) {
+    HIVE_ENTER(v ? v->ctx : nullptr);
+    if (!v) return hive_fail(nullptr, HIVE_ERR_INVALID, "vol is NULL");
+    hive_ctx *ctx = v->ctx;
+    HIVE_REQUIRE(ctx, d_out && world > 0 && chunk > 0 && (int64_t)world * chunk >= v->n, "accum_from_volume_sharded: need world * chunk >= %lld voxels (world %d, chunk %lld)",
+                 (long long)v->n, world, (long long)chunk);
+    const long long total = (long long)world * chunk;
+    const int blocks = (int)std::min<long long>((total + 255) / 256, 256 * 32);
+    hipLaunchKernelGGL(to_accum_sharded_kernel, dim3(blocks), dim3(256), 0, ctx->stream, v->d_tsdf, v->d_weight, v->d_color, (long long)v->n, (long long)chunk, total, d_out);
+    HIVE_CHECK_HIP(ctx, hipGetLastError());
+    return HIVE_OK;
+}
+
+int hive_tsdf_set_volume_range(hive_tsdf *v, int64_t first, int64_t count, const float *d_tsdf, const float *d_weight, const float *d_color) {
+    HIVE_ENTER(v ? v->ctx : nullptr);
+    if (!v) return hive_fail(nullptr, HIVE_ERR_INVALID, "vol is NULL");
+    hive_ctx *ctx = v->ctx;
+    HIVE_REQUIRE(ctx, first >= 0 && count >= 0 && first + count <= v->n, "set_volume_range: [%lld, %lld) outside the %lld voxels", (long long)first,
+                 (long long)(first + count), (long long)v->n);
+    if (count == 0) return HIVE_OK;
+    const size_t bytes = (size_t)count * sizeof(float);
+    if (d_tsdf) HIVE_CHECK_HIP(ctx, hipMemcpyAsync(v->d_tsdf + first, d_tsdf, bytes, hipMemcpyDefault, ctx->stream));
+    if (d_weight) HIVE_CHECK_HIP(ctx, hipMemcpyAsync(v->d_weight + first, d_weight, bytes, hipMemcpyDefault, ctx->stream));
+    if (d_color) HIVE_CHECK_HIP(ctx, hipMemcpyAsync(v->d_color + first, d_color, bytes, hipMemcpyDefault, ctx->stream));
+    v->n_verts = v->n_faces = -1;
     return HIVE_OK;
 }
 

@@ -10,20 +10,20 @@ from hive_amd import _lib
 from hive_amd.dpt import transforms as dpt_transforms
 from hive_amd.dpt.models import DPTDepthModel
 
-# The ResNet stem / RefineNet convolutions run on MIOpen.  Its find step times every applicable solver the
-# first time a shape is seen, including its naive reference convolution -- 0.1-1.4 s per call at 640 x 480
-# (30 s of a cold start).  That solver can never win, so it is taken out of the search.
-os.environ.setdefault("MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_FWD", "0")
-
 NET_W, NET_H = 640, 480  # hard-coded in the reference (dataset_adaptors.py:1363-1364)
 DPT_SCALE, DPT_SHIFT = 0.000305, 0.1378  # NYU fine-tuned DPT-Hybrid (dataset_adaptors.py:1368-1369)
 
 
-def build_model(weights_path=None, device="cuda", dtype=torch.bfloat16, engine="hip"):
+def build_model(weights_path=None, device="cuda", dtype=torch.bfloat16, engine="hip", init_seed=None):
     """DPT-Hybrid-NYU as the reference constructs it (dataset_adaptors.py:1366-1374, 1394-1401), in
-    channels-last 16-bit on the GPU.  ``weights_path=None`` gives a randomly initialised network."""
+    channels-last 16-bit on the GPU.  ``weights_path=None`` gives a randomly initialised network: PyTorch's default
+    initialisation (a constant ~7.25 m depth map), or, with ``init_seed``, the seeded non-degenerate weights of
+    ``hive_amd.dpt.init`` (depth maps spanning ~1-7 m -- what ``bench.py`` and the numerics tests use)."""
     model = DPTDepthModel(path=weights_path, scale=DPT_SCALE, shift=DPT_SHIFT, invert=True, backbone="vitb_rn50_384",
                           non_negative=True, enable_attention_hooks=False, engine=engine)
+    if weights_path is None and init_seed is not None:
+        from hive_amd.dpt.init import seeded_init
+        seeded_init(model, seed=init_seed)
     model.eval()
     model = model.to(memory_format=torch.channels_last)
     if dtype is not None:

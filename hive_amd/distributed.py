@@ -5,7 +5,8 @@ One process per GPU.  Frames are independent units for DPT, so rank r takes the 
 fuses its frames into its own volume and contributes the sums ``[num, w, r, g, b]`` (they commute, unlike
 running averages): either converted from its volumes at the end (``fuse_sharded(volume)``) or accumulated
 directly (``accum_integrate``); ONE all-reduce (RCCL over xGMI; ``backend="nccl"`` is RCCL on ROCm) over
-the 5 N floats merges them, after which every rank folds the sums into its volume.
+the 5 N floats merges them -- issued as ONE reduce-scatter + ONE all-gather (``fuse_sharded``) -- after which every rank holds the
+merged volume.
 
 Parity (stated): the merged tsdf equals the sequential running average up to float32 re-association
 (abs 1e-5), weights are exact (small integers), colours differ by at most 2 levels (the sequential
@@ -73,6 +74,12 @@ def _host_staged():
     return dist.is_initialized() and dist.get_backend() == "gloo"
 
 
+def _collective():
+    """Collectives are issued whenever a process group exists -- also a single-rank one (the one-GPU RCCL test runs the very
+    calls the 8-GPU job makes); without a group the helpers below copy locally."""
+    return dist.is_initialized()
+
+
 def _reduce_scatter(out, inp):
     if _host_staged() and inp.is_cuda:
         o, i = out.cpu(), inp.cpu()
@@ -92,8 +99,9 @@ def _all_gather(out, inp):
 
 
 class VoxelPartition:
-    """Equal, contiguous shares of a volume's N voxels over the ranks: rank r owns [r * chunk, r * chunk + count).  The planes
-    are padded to world * chunk elements so that reduce-scatter / all-gather see equal pieces."""
+    """Equal, contiguous shares of a volume's N voxels over the ranks: rank r owns [r * chunk, r * chunk + count_of(r)).  Buffers
+    that go through reduce-scatter / all-gather are laid out PIECE-major, ``[world][planes][chunk]``, so that each is ONE
+    collective over one contiguous tensor (a rank's piece holds all planes of its share)."""
 
     def __init__(self, n_voxels, world=None, rank=None, align=256):
         self.world = world if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
@@ -103,61 +111,77 @@ class VoxelPartition:
         self.chunk = -(-per // align) * align
         self.padded = self.chunk * self.world
         self.first = self.rank * self.chunk
-        self.count = max(0, min(self.chunk, self.n - self.first))
+        self.count = self.count_of(self.rank)
+
+    def count_of(self, rank):
+        return max(0, min(self.chunk, self.n - rank * self.chunk))
 
 
-def reduce_scatter_planes(accum, part):
-    """accum: float32 [5, part.padded] -> this rank's summed share [5, part.chunk].  One reduce-scatter per plane (a plane is
-    world equal pieces, in rank order).  Each GPU sends (W - 1) / W of a plane per plane -- over xGMI's point-to-point links
-    that is W - 1 concurrent transfers of 1 / W of the data each, instead of the two passes of an all-reduce."""
-    assert accum.dim() == 2 and accum.shape[1] == part.padded
-    out = torch.empty((accum.shape[0], part.chunk), dtype=accum.dtype, device=accum.device)
-    if part.world == 1:
-        out.copy_(accum)
-        return out
-    for p in range(accum.shape[0]):
-        _reduce_scatter(out[p], accum[p])
+def shard_layout(planes, part):
+    """planes [P, N] -> [world, P, chunk] (piece-major, zero past N): the generic (torch) form of what
+    ``hive_tsdf_accum_from_volume_sharded`` writes directly; used for raw accumulator tensors and by the CPU tests."""
+    p = planes.shape[0]
+    out = torch.zeros((part.world, p, part.chunk), dtype=planes.dtype, device=planes.device)
+    for r in range(part.world):
+        c = part.count_of(r)
+        if c:
+            out[r, :, :c] = planes[:, r * part.chunk:r * part.chunk + c]
     return out
 
 
-def all_gather_shares(full, part):
-    """full: [part.padded] with this rank's share already in place at [first, first + chunk): fills in everyone else's."""
-    assert full.dim() == 1 and full.numel() == part.padded
-    if part.world > 1:
-        _all_gather(full, full[part.first:part.first + part.chunk].clone() if _host_staged() else full[part.first:part.first + part.chunk])
-    return full
+def reduce_scatter_pieces(pieces, part):
+    """pieces [world, P, chunk] -> this rank's summed share [P, chunk]: ONE reduce-scatter.  Each GPU sends (W - 1) / W of the
+    buffer -- over xGMI's point-to-point links that is W - 1 concurrent transfers of 1 / W of the data each, instead of the two
+    passes of an all-reduce."""
+    assert pieces.dim() == 3 and pieces.shape[0] == part.world and pieces.shape[2] == part.chunk and pieces.is_contiguous()
+    out = torch.empty(tuple(pieces.shape[1:]), dtype=pieces.dtype, device=pieces.device)
+    if _collective():
+        _reduce_scatter(out.view(-1), pieces.view(-1))
+    else:
+        out.copy_(pieces[0])
+    return out
+
+
+def all_gather_pieces(mine, part):
+    """mine [P, chunk] (this rank's share of P result planes) -> [world, P, chunk] on every rank: ONE all-gather into a separate
+    output buffer (no aliasing of input and output)."""
+    assert mine.dim() == 2 and mine.shape[1] == part.chunk and mine.is_contiguous()
+    out = torch.empty((part.world,) + tuple(mine.shape), dtype=mine.dtype, device=mine.device)
+    if _collective():
+        _all_gather(out.view(-1), mine.view(-1))
+    else:
+        out[0].copy_(mine)
+    return out
 
 
 def fuse_sharded(volume, stream_or_accum=None):
-    """Merge the per-rank fusions into the shared static-scene volume, on every rank:
-    reduce-scatter of the 5 accumulator planes -> every rank folds ITS 1 / W of the voxels (`finalize_range`) -> all-gather of
-    the 3 result planes.  Against all-reduce + full finalize on every rank this moves 8 / 10 of the bytes
-    ((5 + 3) N (W - 1) / W instead of 2 x 5 N (W - 1) / W floats per GPU) and divides the finalize pass by W.
+    """Merge the per-rank fusions into the shared static-scene volume, on every rank, with TWO collectives:
+    ONE reduce-scatter of the 5 accumulator planes (piece-major ``[world][5][chunk]``) -> every rank folds ITS 1 / W of the
+    voxels (`accum_finalize_range`) -> ONE all-gather of the 3 result planes (``[world][3][chunk]``) -> the pieces are copied into
+    place.  Against all-reduce + full finalize on every rank this moves 8 / 10 of the bytes ((5 + 3) N (W - 1) / W instead of
+    2 x 5 N (W - 1) / W floats per GPU) and divides the finalize pass by W.
 
     ``stream_or_accum=None`` (what ``bench.py --gpus N`` does): every rank fused its own frames with the ordinary
     ``integrate`` (same kernel and cost as on one GPU); its volumes are converted to the sums
-    ``[tsdf * w, w, r * w, g * w, b * w]`` here.  Otherwise: the accumulators of a ``DepthFusionStream(accumulate=True)``
-    or a raw accumulator tensor filled with ``accum_integrate`` (sums of the raw observations, 40 B / voxel / frame)."""
+    ``[tsdf * w, w, r * w, g * w, b * w]`` straight into the piece-major buffer.  Otherwise: the accumulators of a
+    ``DepthFusionStream(accumulate=True)`` or a raw accumulator tensor filled with ``accum_integrate`` (sums of the raw
+    observations, 40 B / voxel / frame)."""
     n = volume.num_voxels
     part = VoxelPartition(n)
     accum = getattr(stream_or_accum, "accum", stream_or_accum)
-    planes = torch.empty((5, part.padded), dtype=torch.float32, device="cuda")
-    if part.padded > n:
-        planes[:, n:].zero_()
     if accum is None:
-        tight = torch.empty(5 * n, dtype=torch.float32, device="cuda")
-        volume.accum_from_volume(tight)
-        planes[:, :n].copy_(tight.view(5, n))
-        del tight
+        pieces = torch.empty((part.world, 5, part.chunk), dtype=torch.float32, device="cuda")
+        volume.accum_from_volume_sharded(pieces, part.world, part.chunk)
     else:
-        planes[:, :n].copy_(accum.view(5, n))
-    mine = reduce_scatter_planes(planes, part)
-    del planes
-    out = [torch.empty(part.padded, dtype=torch.float32, device="cuda") for _ in range(3)]  # tsdf, weight, colour
-    volume.accum_finalize_range(mine, part.chunk, part.count, [o[part.first:] for o in out])
-    for o in out:
-        all_gather_shares(o, part)
-    volume.set_volume_device(tsdf=out[0][:n], weight=out[1][:n], color=out[2][:n])
+        pieces = shard_layout(accum.view(5, n), part)
+    mine = reduce_scatter_pieces(pieces, part)  # [5, chunk]
+    del pieces
+    share = torch.zeros((3, part.chunk), dtype=torch.float32, device="cuda")  # tsdf, weight, colour of this rank's voxels
+    volume.accum_finalize_range(mine, part.chunk, part.count, [share[0], share[1], share[2]])
+    del mine
+    gathered = all_gather_pieces(share, part)  # [world, 3, chunk]
+    for r in range(part.world):
+        volume.set_volume_range(r * part.chunk, part.count_of(r), tsdf=gathered[r, 0], weight=gathered[r, 1], color=gathered[r, 2])
     return volume
 
 
@@ -172,11 +196,15 @@ def allgather_frames(local, counts):
     """local: this rank's frames [n_r, ...] (contiguous block of the sequence, rank order = sequence order); counts[r] = n_r.
     Returns all frames [sum(counts), ...] in sequence order on every rank."""
     world = len(counts)
-    if world == 1:
+    if not _collective():
+        assert world == 1
         return local
     most = max(counts)
-    padded = torch.zeros((most,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    padded[:local.shape[0]].copy_(local)
+    if local.shape[0] == most:
+        padded = local.contiguous()
+    else:
+        padded = torch.zeros((most,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        padded[:local.shape[0]].copy_(local)
     gathered = torch.empty((world * most,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     _all_gather(gathered, padded)
     if all(c == most for c in counts):
@@ -184,19 +212,22 @@ def allgather_frames(local, counts):
     return torch.cat([gathered[r * most:r * most + counts[r]] for r in range(world)], dim=0)
 
 
-def allgather_slabs(slab, x_ranges, row_elems):
-    """slab: this rank's [x1 - x0, Y, Z] (flattened or not); x_ranges[r] = (x0, x1) of rank r.  Returns the whole [X * Y * Z]
-    array on every rank."""
+def allgather_slabs(planes, x_ranges, row_elems):
+    """planes: this rank's slab of P planes, [P, (x1 - x0) * row_elems]; x_ranges[r] = (x0, x1) of rank r.  ONE all-gather of
+    piece-major ``[world][P][most]``; returns that buffer and the element count of every rank's slab."""
     world = len(x_ranges)
-    flat = slab.reshape(-1)
-    if world == 1:
-        return flat
-    most = max(b - a for a, b in x_ranges) * row_elems
-    padded = torch.zeros(most, dtype=flat.dtype, device=flat.device)
-    padded[:flat.numel()].copy_(flat)
-    gathered = torch.empty(world * most, dtype=flat.dtype, device=flat.device)
-    _all_gather(gathered, padded)
-    return torch.cat([gathered[r * most:r * most + (x_ranges[r][1] - x_ranges[r][0]) * row_elems] for r in range(world)])
+    counts = [(b - a) * row_elems for a, b in x_ranges]
+    most = max(counts)
+    p = planes.shape[0]
+    mine = torch.zeros((p, most), dtype=planes.dtype, device=planes.device)
+    mine[:, :planes.shape[1]].copy_(planes)
+    out = torch.empty((world, p, most), dtype=planes.dtype, device=planes.device)
+    if _collective():
+        _all_gather(out.view(-1), mine.view(-1))
+    else:
+        assert world == 1
+        out[0].copy_(mine)
+    return out, counts
 
 
 class ExactSlabFusion:
@@ -225,7 +256,7 @@ class ExactSlabFusion:
         from hive_amd import fusion
         row = self.dims[1] * self.dims[2]
         full = fusion.TSDFVolume(self.vol_bnds, self.voxel_size, ctx=self._ctx, **self._kwargs)
-        t, w, c = self.slab.device_tensors()
-        full.set_volume_device(tsdf=allgather_slabs(t, self.x_ranges, row), weight=allgather_slabs(w, self.x_ranges, row),
-                               color=allgather_slabs(c, self.x_ranges, row))
+        gathered, counts = allgather_slabs(torch.stack(self.slab.device_tensors()), self.x_ranges, row)  # [world][tsdf, weight, colour][most]
+        for r, (x0, _) in enumerate(self.x_ranges):
+            full.set_volume_range(x0 * row, counts[r], tsdf=gathered[r, 0], weight=gathered[r, 1], color=gathered[r, 2])
         return full

@@ -39,7 +39,13 @@ def group_norm_act(x, num_groups, weight, bias, eps, relu=True, residual=None, e
     return F.relu(y) if relu else y
 
 
-_cl_weights = {}  # id(conv) -> (stamp, channels-last weight): only for models that were not converted to channels_last
+def _module_cache(module):
+    """Derived (re-laid-out) weights live ON the module that owns the parameters: the cache dies with its owner and cannot be
+    hit by another object (a process-global dict keyed by id(module) can, once the id is recycled)."""
+    cache = module.__dict__.get("_hive_cache")
+    if cache is None:
+        cache = module.__dict__["_hive_cache"] = {}
+    return cache
 
 
 def _conv3x3_weight(conv):
@@ -49,9 +55,10 @@ def _conv3x3_weight(conv):
     if w.is_contiguous(memory_format=torch.channels_last):
         return w
     stamp = (w.data_ptr(), w._version)
-    hit = _cl_weights.get(id(conv))
+    cache = _module_cache(conv)
+    hit = cache.get("channels_last")
     if hit is None or hit[0] != stamp:
-        hit = _cl_weights[id(conv)] = (stamp, w.detach().contiguous(memory_format=torch.channels_last))
+        hit = cache["channels_last"] = (stamp, w.detach().contiguous(memory_format=torch.channels_last))
     return hit[1]
 
 
@@ -158,15 +165,14 @@ def conv_gn_act(x, conv, norm, weight=None, same_pad=False, relu=True, residual=
     return out if fused.value else None
 
 
-_derived = {}  # (id(layer), what) -> (stamp, tensors): weights re-laid-out for the kernels, rebuilt when the parameter changes
-
-
 def _cached(layer, what, params, build):
+    """Weights re-laid-out for the kernels, kept on ``layer`` and rebuilt when a parameter changes."""
     stamp = tuple((p.data_ptr(), p._version, p.dtype, p.device) for p in params)
-    hit = _derived.get((id(layer), what))
+    cache = _module_cache(layer)
+    hit = cache.get(what)
     if hit is None or hit[0] != stamp:
         with torch.no_grad():
-            hit = _derived[(id(layer), what)] = (stamp, build())
+            hit = cache[what] = (stamp, build())
     return hit[1]
 
 
@@ -216,9 +222,6 @@ def conv_transpose(x, layer):
     return out
 
 
-_stem_weights = {}  # id(conv) -> (stamp, [64][7][32] weights)
-
-
 def stem_conv_eligible(x, conv):
     return (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and x.shape[1] == 3 and x.is_contiguous(memory_format=torch.channels_last)
             and tuple(conv.kernel_size) == (7, 7) and tuple(conv.stride) == (2, 2) and conv.in_channels == 3 and conv.out_channels == 64
@@ -228,11 +231,12 @@ def stem_conv_eligible(x, conv):
 def stem_conv(x, conv, weight):
     """The 7 x 7 / 2 "SAME" stem convolution (csrc/stem.hip).  ``weight``: the standardised [64, 3, 7, 7] weights."""
     stamp = (weight.data_ptr(), weight._version)
-    hit = _stem_weights.get(id(conv))
+    cache = _module_cache(conv)
+    hit = cache.get("stem")
     if hit is None or hit[0] != stamp:
         w = torch.zeros((64, 7, 32), dtype=torch.bfloat16, device=weight.device)
         w[:, :, :21] = weight.detach().permute(0, 2, 3, 1).reshape(64, 7, 21)  # (ky, (kx, c)), a kernel row padded to 32
-        hit = _stem_weights[id(conv)] = (stamp, w.contiguous())
+        hit = cache["stem"] = (stamp, w.contiguous())
     n, _, h, w_ = x.shape
     out = torch.empty((n, 64, (h + 1) // 2, (w_ + 1) // 2), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
     ctx = _lib.default_context(x.device.index or 0)

@@ -155,6 +155,13 @@ class TSDFVolume:
         self._ctx.check(self._ctx.lib.hive_tsdf_integrate_batch(self._handle, depth.shape[0], ptr(color), ptr(depth), depth.shape[1],
                                                                 depth.shape[2], ptr(K), ptr(poses), float(obs_weight), mem))
 
+    def last_batch_groups(self):
+        """Frames per sweep of the most recent ``integrate_batch`` (1 = single-frame kernel), in launch order."""
+        sizes = (ctypes.c_int * 4096)()
+        n = ctypes.c_int(0)
+        self._ctx.check(self._ctx.lib.hive_tsdf_last_batch_groups(self._handle, ctypes.cast(sizes, ctypes.c_void_p), 4096, ctypes.byref(n)))
+        return [int(sizes[i]) for i in range(min(n.value, 4096))]
+
     def get_volume(self, with_weight=False):
         shape = tuple(int(v) for v in self._vol_dim)
         tsdf = np.empty(shape, np.float32)
@@ -241,6 +248,18 @@ class TSDFVolume:
         """planes = [tsdf * w, w, r * w, g * w, b * w] of this volume (a rank's contribution to the all-reduce)."""
         self._ctx.check(self._ctx.lib.hive_tsdf_accum_from_volume(self._handle, ptr(accum)))
 
+    def accum_from_volume_sharded(self, out, world, chunk):
+        """The same sums as float32 [world][5][chunk] (voxel i in piece i // chunk): the input of ONE reduce-scatter."""
+        self._ctx.follow_torch_stream()
+        self._ctx.check(self._ctx.lib.hive_tsdf_accum_from_volume_sharded(self._handle, ptr(out), int(world), int(chunk)))
+
+    def set_volume_range(self, first, count, tsdf=None, weight=None, color=None):
+        """Overwrite voxels [first, first + count) from device tensors of ``count`` float32 each (stream-ordered copies)."""
+        self._ctx.follow_torch_stream()
+        for a in (tsdf, weight, color):
+            assert a is None or (a.numel() >= count and str(a.dtype) == "torch.float32" and a.is_contiguous())
+        self._ctx.check(self._ctx.lib.hive_tsdf_set_volume_range(self._handle, int(first), int(count), ptr(tsdf), ptr(weight), ptr(color)))
+
     def accum_finalize(self, accum):
         self._ctx.check(self._ctx.lib.hive_tsdf_accum_finalize(self._handle, ptr(accum)))
 
@@ -289,10 +308,11 @@ class DeviceFrames:
         return int(self.depth.shape[0])
 
     @classmethod
-    def from_dataset(cls, dataset, frame_set, with_masks, device="cuda"):
+    def from_dataset(cls, dataset, frame_set, with_masks, device="cuda", with_color=True, staging=None):
         """Reads frame ``i`` of ``bg_rgb_dataset`` / ``bg_depth_dataset`` (/ ``mask_dataset``) once for every ``i`` in
         ``frame_set``, through pinned host buffers.  Poses: the dataset stores world-to-camera; the volume wants
-        camera-to-world (hive/fusion.py:50-51)."""
+        camera-to-world (hive/fusion.py:50-51).  ``with_color=False`` loads the depth maps only (the bounds pass of a chunked
+        run); ``staging``: a ``_Staging`` to reuse pinned / device buffers between chunks."""
         import torch
         frame_set = list(frame_set)
         assert len(frame_set) > 0, "empty frame set"
@@ -300,17 +320,18 @@ class DeviceFrames:
         first = np.asarray(dataset.bg_depth_dataset[frame_set[0]])
         h, w = first.shape
         n = len(frame_set)
-        color = torch.empty((n, h, w, 3), dtype=torch.uint8).pin_memory()
-        depth = torch.empty((n, h, w), dtype=torch.float32).pin_memory()
-        masks = torch.empty((n, h, w), dtype=torch.uint8).pin_memory() if with_masks else None
-        c_np, d_np = color.numpy(), depth.numpy()
+        staging = staging or _Staging(n, h, w, device)
+        color_h, depth_h, masks_h = staging.host(n, with_color, with_masks)
         for j, i in enumerate(frame_set):
-            d_np[j] = first if j == 0 else dataset.bg_depth_dataset[i]
-            c_np[j] = dataset.bg_rgb_dataset[i]
+            depth_h.numpy()[j] = first if j == 0 else dataset.bg_depth_dataset[i]
+            if with_color:
+                color_h.numpy()[j] = dataset.bg_rgb_dataset[i]
             if with_masks:
-                masks.numpy()[j] = dataset.mask_dataset[i]
-        to_dev = lambda t: None if t is None else t.to(device, non_blocking=True)
-        return cls(to_dev(color), to_dev(depth), poses, to_dev(masks))
+                masks_h.numpy()[j] = dataset.mask_dataset[i]
+        color, depth, masks = staging.upload(n, with_color, with_masks)
+        if not with_color:
+            color = torch.empty((n, h, w, 3), dtype=torch.uint8, device="meta")  # shape only: the bounds pass never reads colour
+        return cls(color, depth, poses, masks)
 
     def masked_depth(self, iterations, mode=MASK_BACKGROUND, instance_id=0, ctx=None):
         """Depth maps with the mask applied on the device: MASK_BACKGROUND = `depth[dilate(mask) > 0] = 0`
@@ -320,9 +341,68 @@ class DeviceFrames:
         ctx = ctx or _lib.default_context(self.depth.device.index or 0)
         out = torch.empty_like(self.depth)
         n, h, w = self.depth.shape
-        ctx.check(ctx.lib.hive_depth_apply_mask(ctx.handle, self.depth.data_ptr(), self.masks.data_ptr(), n, h, w, int(iterations),
-                                                int(mode), int(instance_id), out.data_ptr()))
+        for a in range(0, n, MAX_BATCH_FRAMES):
+            b = min(n, a + MAX_BATCH_FRAMES)
+            ctx.check(ctx.lib.hive_depth_apply_mask(ctx.handle, self.depth[a:b].data_ptr(), self.masks[a:b].data_ptr(), b - a, h, w, int(iterations),
+                                                    int(mode), int(instance_id), out[a:b].data_ptr()))
         return out
+
+
+class _Staging:
+    """Pinned host buffers + device buffers for up to ``capacity`` frames, reused from chunk to chunk (a chunked run keeps
+    ``capacity`` frames resident at most: 9 bytes per pixel pinned and on the device, whatever the length of the sequence).
+    The upload of a chunk is stream-ordered behind the kernels that read the previous chunk from the same device buffers; the
+    host buffers are refilled only after that upload has completed (``upload`` records an event, ``host`` waits for it)."""
+
+    def __init__(self, capacity, h, w, device="cuda"):
+        import torch
+        self.capacity, self.device = int(capacity), device
+        self.color_h = torch.empty((capacity, h, w, 3), dtype=torch.uint8).pin_memory()
+        self.depth_h = torch.empty((capacity, h, w), dtype=torch.float32).pin_memory()
+        self.masks_h = None
+        self.color_d = self.depth_d = self.masks_d = None
+        self.copied = None
+
+    def host(self, n, with_color, with_masks):
+        import torch
+        assert n <= self.capacity
+        if self.copied is not None:
+            self.copied.synchronize()  # the previous chunk's upload has left the pinned buffers
+        if with_masks and self.masks_h is None:
+            self.masks_h = torch.empty(tuple(self.depth_h.shape), dtype=torch.uint8).pin_memory()
+        return (self.color_h[:n] if with_color else None), self.depth_h[:n], (self.masks_h[:n] if with_masks else None)
+
+    def upload(self, n, with_color, with_masks):
+        import torch
+
+        def put(host, attr):
+            dev = getattr(self, attr)
+            if dev is None:
+                dev = torch.empty(tuple(host.shape), dtype=host.dtype, device=self.device)
+                setattr(self, attr, dev)
+            dev[:n].copy_(host[:n], non_blocking=True)
+            return dev[:n]
+        color = put(self.color_h, "color_d") if with_color else None
+        depth = put(self.depth_h, "depth_d")
+        masks = put(self.masks_h, "masks_d") if with_masks else None
+        self.copied = torch.cuda.Event()
+        self.copied.record()
+        return color, depth, masks
+
+
+def frame_chunks(dataset, frame_set, with_masks, chunk_frames, with_color=True):
+    """The frame set as ``DeviceFrames`` of at most ``chunk_frames`` frames each, in order, through ONE reused staging set."""
+    frame_set = list(frame_set)
+    staging = None
+    for a in range(0, len(frame_set), chunk_frames):
+        ids = frame_set[a:a + chunk_frames]
+        if staging is None:
+            h, w = np.asarray(dataset.bg_depth_dataset[ids[0]]).shape
+            staging = _Staging(min(chunk_frames, len(frame_set)), h, w)
+        yield DeviceFrames.from_dataset(dataset, ids, with_masks, with_color=with_color, staging=staging)
+
+
+MAX_BATCH_FRAMES = 32768  # hive_view_frustum_batch / hive_depth_apply_mask take the frame index from a 16-bit grid dimension
 
 
 def view_frusta(depth_ims, cam_intr, cam_poses, ctx=None):
@@ -338,16 +418,21 @@ def view_frusta(depth_ims, cam_intr, cam_poses, ctx=None):
     K = np.ascontiguousarray(cam_intr, dtype=np.float32).reshape(3, 3)
     poses = np.ascontiguousarray(cam_poses, dtype=np.float64).reshape(n, 4, 4)
     out = np.empty((n, 3, 5), np.float64)
-    ctx.check(ctx.lib.hive_view_frustum_batch(ctx.handle, ptr(depth), n, h, w, ptr(K), ptr(poses), mem, ptr(out)))
+    for a in range(0, n, MAX_BATCH_FRAMES):
+        b = min(n, a + MAX_BATCH_FRAMES)
+        ctx.check(ctx.lib.hive_view_frustum_batch(ctx.handle, ptr(depth[a:b]), b - a, h, w, ptr(K), ptr(poses[a:b]), mem, ptr(out[a:b])))
     return out
 
 
-def scene_bounds(frames: DeviceFrames, cam_intr, ctx=None) -> np.ndarray:
+def scene_bounds(frames, cam_intr, ctx=None) -> np.ndarray:
     """Axis-aligned bounds of the union of the view frusta of a frame set and the world origin -- the reference starts
-    from `zeros((3, 2))`, so the origin is always inside (hive/fusion.py:48, 60-61)."""
-    corners = view_frusta(frames.depth, cam_intr, frames.poses, ctx)  # (n, 3, 5)
-    lo = np.minimum(0.0, corners.min(axis=(0, 2)))
-    hi = np.maximum(0.0, corners.max(axis=(0, 2)))
+    from `zeros((3, 2))`, so the origin is always inside (hive/fusion.py:48, 60-61).  ``frames``: a ``DeviceFrames`` or an
+    iterable of them (the chunks of a long sequence: a running min / max, exact in any order)."""
+    lo, hi = np.zeros(3), np.zeros(3)
+    for chunk in ([frames] if isinstance(frames, DeviceFrames) else frames):
+        corners = view_frusta(chunk.depth, cam_intr, chunk.poses, ctx)  # (n, 3, 5)
+        lo = np.minimum(lo, corners.min(axis=(0, 2)))
+        hi = np.maximum(hi, corners.max(axis=(0, 2)))
     return np.stack([lo, hi], axis=1)
 
 
@@ -379,7 +464,14 @@ def _resolve_frames(dataset, num_frames, frame_set):
     return list(range(num_frames)) if frame_set is None else list(frame_set)
 
 
-def tsdf_fusion(dataset, options=None, num_frames=-1, frame_set: Optional[List[int]] = None, return_volume=False):
+# Frames kept resident at once by the drivers below.  Up to this many, the whole set is decoded ONCE and lives in HBM (bounds,
+# masking and integration all read it there).  Longer sequences stream through one reused staging set of this size in two passes,
+# as the reference walks its dataset twice (hive/fusion.py:53-61 and :113-124): 9 bytes per pixel pinned + 13 on the device per
+# resident frame, whatever the sequence length (2000 frames of 1080p no longer need 35 GB pinned + 50 GB of HBM).
+CHUNK_FRAMES = 256
+
+
+def tsdf_fusion(dataset, options=None, num_frames=-1, frame_set: Optional[List[int]] = None, return_volume=False, chunk_frames=None):
     """Static-scene reconstruction of a dataset (/root/reference/hive/fusion.py:79-134): bounds -> voxel size -> volume ->
     every frame of the set, dynamic objects masked out of the depth unless the dataset carries inpainted frames -> mesh.
 
@@ -393,17 +485,25 @@ def tsdf_fusion(dataset, options=None, num_frames=-1, frame_set: Optional[List[i
     options = options or BackgroundMeshOptions()
     frame_set = _resolve_frames(dataset, num_frames, frame_set)
     needs_masks = not dataset.has_inpainted_frame_data
-    frames = DeviceFrames.from_dataset(dataset, frame_set, with_masks=needs_masks)
-    voxel_size, volume_bounds = adjust_voxel_size(dataset, options, frame_set, frames=frames)
+    chunk_frames = int(chunk_frames or CHUNK_FRAMES)
+    if len(frame_set) <= chunk_frames:  # the whole set resident: one decode per frame
+        frames = DeviceFrames.from_dataset(dataset, frame_set, with_masks=needs_masks)
+        voxel_size, volume_bounds = adjust_voxel_size(dataset, options, frame_set, frames=frames)
+        chunks = [frames]
+    else:  # pass 1: depth maps only, running bounds; pass 2: everything, chunk by chunk, in sequence order
+        volume_bounds = scene_bounds(frame_chunks(dataset, frame_set, False, chunk_frames, with_color=False), dataset.camera_matrix)
+        voxel_size = voxel_size_for_budget(volume_bounds, options)
+        chunks = frame_chunks(dataset, frame_set, needs_masks, chunk_frames)
     tsdf_vol = TSDFVolume(volume_bounds, voxel_size=voxel_size)
-    depth = frames.masked_depth(options.depth_mask_dilation_iterations, MASK_BACKGROUND) if needs_masks else frames.depth
-    tsdf_vol.integrate_batch(frames.color, depth, dataset.camera_matrix, frames.poses, obs_weight=1.)
+    for frames in chunks:
+        depth = frames.masked_depth(options.depth_mask_dilation_iterations, MASK_BACKGROUND) if needs_masks else frames.depth
+        tsdf_vol.integrate_batch(frames.color, depth, dataset.camera_matrix, frames.poses, obs_weight=1.)
     verts, faces, norms, colors = tsdf_vol.get_mesh()
     mesh = make_mesh(vertices=verts, faces=faces, vertex_colors=colors, vertex_normals=norms)
     return (mesh, tsdf_vol) if return_volume else mesh
 
 
-def tsdf_fusion_fg_bg(dataset, options=None, num_frames=-1, frame_set: Optional[List[int]] = None, instance_id=0):
+def tsdf_fusion_fg_bg(dataset, options=None, num_frames=-1, frame_set: Optional[List[int]] = None, instance_id=0, chunk_frames=None):
     """Dynamic-object variant (BASELINE config 5): two volumes over the same bounds and voxel size from one resident frame
     set -- background = depth with the dilated instance masks zeroed (exactly ``tsdf_fusion``'s volume, from
     ``dataset.depth_dataset`` / ``rgb_dataset``), foreground = the complement (depth kept only on the undilated masks, or on
@@ -413,15 +513,21 @@ def tsdf_fusion_fg_bg(dataset, options=None, num_frames=-1, frame_set: Optional[
 
     options = options or BackgroundMeshOptions()
     frame_set = _resolve_frames(dataset, num_frames, frame_set)
-    frames = DeviceFrames.from_dataset(_RawFrames(dataset), frame_set, with_masks=True)
-    vol_bnds = scene_bounds(frames, dataset.camera_matrix)
+    raw = _RawFrames(dataset)
+    chunk_frames = int(chunk_frames or CHUNK_FRAMES)
+    if len(frame_set) <= chunk_frames:
+        chunks = [DeviceFrames.from_dataset(raw, frame_set, with_masks=True)]
+        vol_bnds = scene_bounds(chunks[0], dataset.camera_matrix)
+    else:
+        vol_bnds = scene_bounds(frame_chunks(raw, frame_set, False, chunk_frames, with_color=False), dataset.camera_matrix)
+        chunks = frame_chunks(raw, frame_set, True, chunk_frames)
     voxel_size = voxel_size_for_budget(vol_bnds, options)
-    volumes = {}
-    for name, mode, iterations in (("bg", MASK_BACKGROUND, options.depth_mask_dilation_iterations), ("fg", MASK_FOREGROUND, 0)):
-        vol = TSDFVolume(vol_bnds, voxel_size=voxel_size)
-        depth = frames.masked_depth(iterations, mode, instance_id if mode == MASK_FOREGROUND else 0)
-        vol.integrate_batch(frames.color, depth, dataset.camera_matrix, frames.poses, obs_weight=1.)
-        volumes[name] = vol
+    modes = (("bg", MASK_BACKGROUND, options.depth_mask_dilation_iterations), ("fg", MASK_FOREGROUND, 0))
+    volumes = {name: TSDFVolume(vol_bnds, voxel_size=voxel_size) for name, _, _ in modes}
+    for frames in chunks:  # both volumes from each resident chunk, in sequence order
+        for name, mode, iterations in modes:
+            depth = frames.masked_depth(iterations, mode, instance_id if mode == MASK_FOREGROUND else 0)
+            volumes[name].integrate_batch(frames.color, depth, dataset.camera_matrix, frames.poses, obs_weight=1.)
     return volumes
 
 

@@ -123,10 +123,17 @@ int hive_tsdf_integrate(hive_tsdf *vol, const uint8_t *color, const float *depth
 int hive_tsdf_integrate_batch(hive_tsdf *vol, int n, const uint8_t *color, const float *depth,
                               int H, int W, const float K[9], const double *cam_poses,
                               float obs_weight, int mem);
+/* How the most recent hive_tsdf_integrate_batch on this volume grouped its frames: *n_groups launches, sizes[i] frames in
+ * sweep i (1 = the single-frame kernel), in order; at most `capacity` sizes are written.  Diagnostic: the parity tests assert
+ * with it that the fused sweep really ran (the semantics are those of hive/fusion.py:113-124's serial loop either way). */
+int hive_tsdf_last_batch_groups(hive_tsdf *vol, int *sizes, int capacity, int *n_groups);
 /* TSDFVolume.get_volume(): copies tsdf and colour (and weight) out (any may be NULL).  The destinations / sources of
  * get_volume / set_volume may be host OR device memory (unified addressing decides the copy direction). */
 int hive_tsdf_get_volume(hive_tsdf *vol, float *h_tsdf, float *h_color, float *h_weight);
 int hive_tsdf_set_volume(hive_tsdf *vol, const float *h_tsdf, const float *h_color, const float *h_weight);
+/* Overwrite voxels [first, first + count) of the three planes from device (or host) arrays of `count` floats each (any may be
+ * NULL): how the pieces of an all-gather (a rank's share of the merged volume, or an x-slab) are put in place. */
+int hive_tsdf_set_volume_range(hive_tsdf *vol, int64_t first, int64_t count, const float *d_tsdf, const float *d_weight, const float *d_color);
 
 /* TSDFVolume.get_mesh() -- hive/fusion.py:127.  Two steps because the sizes are data dependent:
  * extract counts and builds the mesh on the device, copy_mesh copies it out.
@@ -143,6 +150,10 @@ int hive_tsdf_copy_mesh_voxel_coords(hive_tsdf *vol, float *verts_vox);
  * (The per-rank colours are already rounded per frame, so the merged colour can differ from the sequential one by the
  * same +-2 levels as with accum_integrate; tsdf and weight merge exactly up to float re-association.) */
 int hive_tsdf_accum_from_volume(hive_tsdf *vol, float *d_accum);
+/* The same sums laid out for ONE reduce-scatter over `world` ranks: d_out is float [world][5][chunk]; voxel i goes to piece
+ * i / chunk, offset i % chunk (world * chunk >= N; the tail past N is written as zeros).  Rank r's reduce-scatter output is then
+ * its [5][chunk] share, the input of hive_tsdf_accum_finalize_to with plane_stride = chunk. */
+int hive_tsdf_accum_from_volume_sharded(hive_tsdf *vol, float *d_out, int world, int64_t chunk);
 /* Frame-sharded fusion (BASELINE.json north_star): a rank accumulates
  * num = sum(w_i*dist_i), w = sum(w_i), rgb = sum(w_i*c_i) for its frames into 5 float planes
  * [5][X][Y][Z]; planes are summed across ranks (RCCL all-reduce by the caller), then folded

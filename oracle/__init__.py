@@ -42,6 +42,12 @@ def lib():
     return _lib
 
 
+def set_threads(n=0):
+    """Threads of the integrate loops (OpenMP over the x planes of the volume; the results do not depend on it: voxels are
+    independent).  ``n = 0`` keeps the OpenMP default (OMP_NUM_THREADS, else all cores).  Returns the count in effect."""
+    return int(lib().oracle_set_threads(int(n)))
+
+
 def _p(a):
     return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
 

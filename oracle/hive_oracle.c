@@ -32,6 +32,17 @@
 
 static inline float round_mode_f(float x, int mode) { return mode ? roundf(x) : rintf(x); }
 
+/* threads of the integrate loops (the only parallel region; every other function is serial): 0 = the OpenMP default */
+#ifdef _OPENMP
+#include <omp.h>
+int oracle_set_threads(int n) {
+    if (n > 0) omp_set_num_threads(n);
+    return omp_get_max_threads();
+}
+#else
+int oracle_set_threads(int n) { (void)n; return 1; }
+#endif
+
 /* ------------------------------------------------------------------------------------ */
 /* fusion.TSDFVolume.__init__ (call site hive/fusion.py:104): vol_dim = ceil((max-min)/voxel) */
 void oracle_tsdf_dims(const double vol_bnds[6], double voxel_size, int64_t vol_dim[3]) {
@@ -52,6 +63,8 @@ uint64_t oracle_tsdf_integrate(float *tsdf, float *weight, float *color, const i
     const float fx = K[0], fy = K[4], cx = K[2], cy = K[5];
     const int64_t X = vol_dim[0], Y = vol_dim[1], Z = vol_dim[2];
     uint64_t n_upd = 0;
+    /* voxels are independent: the x planes run on the host's cores (OMP_NUM_THREADS / oracle_set_threads); same bits as one thread */
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : n_upd)
     for (int64_t x = 0; x < X; ++x)
         for (int64_t y = 0; y < Y; ++y)
             for (int64_t z = 0; z < Z; ++z) {
@@ -108,6 +121,7 @@ uint64_t oracle_tsdf_accum_integrate(float *accum, const int64_t vol_dim[3], con
     const float fx = K[0], fy = K[4], cx = K[2], cy = K[5];
     const int64_t X = vol_dim[0], Y = vol_dim[1], Z = vol_dim[2], N = X * Y * Z;
     uint64_t n_upd = 0;
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : n_upd)
     for (int64_t x = 0; x < X; ++x)
         for (int64_t y = 0; y < Y; ++y)
             for (int64_t z = 0; z < Z; ++z) {

@@ -27,6 +27,14 @@ def small_sequence():
 
 
 @pytest.fixture(scope="session")
+def fusable_sequence():
+    """10 frames of the synthetic room at 120 x 160, 9 degrees apart: hive_tsdf_integrate_batch sweeps them in groups of
+    4 + 4 + 2 (a group grows while the optical axis stays within 36 degrees of its first frame's)."""
+    from hive_amd import synthetic
+    return synthetic.make_sequence(num_frames=10, height=120, width=160, yaw_step_deg=9.0, seed=77)
+
+
+@pytest.fixture(scope="session")
 def gpu_ctx():
     import torch
     if not torch.cuda.is_available():

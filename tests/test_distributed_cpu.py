@@ -89,8 +89,8 @@ def test_single_process_helpers_are_noops():
 
 
 def _worker_reduce_scatter(rank, world, port, out_path):
-    """fuse_sharded's collective shape with the oracle standing in for the HIP kernels: planes -> reduce-scatter -> fold own
-    share -> all-gather of the three result planes."""
+    """fuse_sharded's collective shape with the oracle standing in for the HIP kernels: piece-major planes -> ONE reduce-scatter
+    -> fold own share -> ONE all-gather of the three result planes."""
     sys.path.insert(0, ROOT)
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import ctypes
@@ -106,18 +106,18 @@ def _worker_reduce_scatter(rank, world, port, out_path):
     n = own._tsdf.size
     part = hdist.VoxelPartition(n, align=64)
     assert part.padded >= n and part.padded % world == 0 and part.chunk % 64 == 0
-    planes = torch.zeros((5, part.padded), dtype=torch.float32)
-    planes[:, :n] = torch.from_numpy(oracle.AccumVolume.planes_from_volume(own).reshape(5, n))
-    mine = hdist.reduce_scatter_planes(planes, part)
+    # piece-major [world][5][chunk]: what hive_tsdf_accum_from_volume_sharded writes on the GPU
+    pieces = hdist.shard_layout(torch.from_numpy(oracle.AccumVolume.planes_from_volume(own).reshape(5, n)), part)
+    mine = hdist.reduce_scatter_pieces(pieces, part)  # ONE reduce-scatter
     assert mine.shape == (5, part.chunk)
-    outs = [torch.zeros(part.padded, dtype=torch.float32) for _ in range(3)]
     share = [np.zeros(part.chunk, np.float32) for _ in range(3)]
     acc = np.ascontiguousarray(mine.numpy())
     oracle.lib().oracle_tsdf_accum_finalize(acc.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(part.chunk), share[0].ctypes.data_as(ctypes.c_void_p),
                                             share[1].ctypes.data_as(ctypes.c_void_p), share[2].ctypes.data_as(ctypes.c_void_p), own.round_mode)
-    for o, s in zip(outs, share):
-        o[part.first:part.first + part.chunk] = torch.from_numpy(s)
-        hdist.all_gather_shares(o, part)
+    gathered = hdist.all_gather_pieces(torch.from_numpy(np.stack(share)), part)  # ONE all-gather -> [world][3][chunk]
+    assert gathered.shape == (world, 3, part.chunk)
+    outs = [torch.cat([gathered[r, k, :part.count_of(r)] for r in range(world)]) for k in range(3)]
+    assert all(o.numel() == n for o in outs)
     if rank == 0:
         np.savez(out_path, tsdf=outs[0][:n].numpy(), weight=outs[1][:n].numpy(), color=outs[2][:n].numpy())
     torch.distributed.destroy_process_group()
@@ -171,7 +171,9 @@ def _worker_exact(rank, world, port, out_path):
     slabs = [torch.from_numpy(np.ascontiguousarray(a[x0:x1])) for a in (full._tsdf, full._weight, full._color)]
     poison = [torch.full_like(s, float("nan")) for s in slabs]  # what the other ranks hold is NOT available here
     del full
-    gathered = [hdist.allgather_slabs(s, x_ranges, Y * Z) for s in slabs]
+    pieces, counts = hdist.allgather_slabs(torch.stack([s.reshape(-1) for s in slabs]), x_ranges, Y * Z)  # ONE all-gather: [world][3][most]
+    assert counts == [(b - a) * Y * Z for a, b in x_ranges]
+    gathered = [torch.cat([pieces[r, k, :counts[r]] for r in range(world)]) for k in range(3)]
     assert all(g.numel() == X * Y * Z for g in gathered) and not any(torch.isnan(g).any() for g in gathered) and len(poison) == 3
     if rank == 1:
         np.savez(out_path, tsdf=gathered[0].numpy(), weight=gathered[1].numpy(), color=gathered[2].numpy(), dims=np.array([X, Y, Z]))

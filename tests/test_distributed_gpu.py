@@ -68,6 +68,49 @@ def test_rccl_collectives_on_accumulator_views(gpu_ctx, nccl_group):
         ora.integrate(seq["color"][i], seq["depth"][i], seq["K"], seq["poses"][i])
     assert np.array_equal(ora._tsdf, t_ref) and np.array_equal(ora._color, c_ref)
     assert np.array_equal(planes.cpu().numpy().reshape(5, *t_ref.shape), oracle.AccumVolume.planes_from_volume(ora))
+    # the piece-major form the merge sends (hive_tsdf_accum_from_volume_sharded) == the generic re-layout of those planes, for a
+    # partition into 3 uneven pieces
+    part3 = hdist.VoxelPartition(ref.num_voxels, world=3, rank=0, align=256)
+    pieces = torch.full((3, 5, part3.chunk), float("nan"), dtype=torch.float32, device="cuda")
+    ref.accum_from_volume_sharded(pieces, 3, part3.chunk)
+    assert torch.equal(pieces, hdist.shard_layout(planes.view(5, -1), part3))
     hdist.fuse_sharded(ref)
     t2, c2 = ref.get_volume()
     assert np.abs(t2 - t_ref).max() <= 1e-6 and np.array_equal(c2, c_ref)
+
+
+def test_rccl_runs_the_merge_collectives(gpu_ctx, nccl_group, monkeypatch):
+    """The collectives of both merge modes are ISSUED on RCCL with device tensors even at world size 1 (no short-circuit while a
+    process group exists): reduce_scatter_tensor + all_gather_into_tensor of `fuse_sharded`, and the all-gathers of
+    `ExactSlabFusion` (frames, slabs) -- counted by wrapping torch.distributed's entry points -- and the results are exact."""
+    import torch
+    import torch.distributed as tdist
+    from hive_amd import distributed as hdist, fusion, synthetic
+    calls = {"reduce_scatter_tensor": 0, "all_gather_into_tensor": 0}
+    for name in calls:
+        orig = getattr(tdist, name)
+
+        def wrapped(out, inp, *a, _orig=orig, _name=name, **k):
+            assert out.is_cuda and inp.is_cuda and out.data_ptr() != inp.data_ptr(), "collectives run on separate device buffers"
+            calls[_name] += 1
+            return _orig(out, inp, *a, **k)
+        monkeypatch.setattr(tdist, name, wrapped)
+    seq = synthetic.make_sequence(num_frames=6, height=120, width=160, yaw_step_deg=6.0)
+    color_d, depth_d = torch.from_numpy(seq["color"]).cuda(), torch.from_numpy(seq["depth"]).cuda()
+    bounds = synthetic.room_bounds()
+    ref = fusion.TSDFVolume(bounds, 0.04, ctx=gpu_ctx)
+    ref.integrate_batch(color_d, depth_d, seq["K"], seq["poses"])
+    want = [t.clone() for t in ref.device_tensors()]
+    # sum mode: one rank's volume through reduce-scatter -> finalize -> all-gather must come back (tsdf * w / w: within one ulp)
+    hdist.fuse_sharded(ref)
+    assert calls == {"reduce_scatter_tensor": 1, "all_gather_into_tensor": 1}
+    got = ref.device_tensors()
+    assert torch.equal(got[1], want[1]) and torch.equal(got[2], want[2]) and float((got[0] - want[0]).abs().max()) <= 1e-6
+    # exact mode: frames all-gathered (2 calls), slabs all-gathered (1 call), bit-identical
+    fus = hdist.ExactSlabFusion(bounds, 0.04, ctx=gpu_ctx)
+    fus.integrate(color_d, depth_d, seq["K"], seq["poses"], [6])
+    full = fus.gather()
+    assert calls == {"reduce_scatter_tensor": 1, "all_gather_into_tensor": 4}
+    assert fus.slab.last_batch_groups() == [4, 2]
+    for a, b in zip(full.device_tensors(), want):
+        assert torch.equal(a, b)

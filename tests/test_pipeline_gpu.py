@@ -213,6 +213,41 @@ def test_fg_bg_volumes_match_oracle(gpu_ctx, oracle_lib):
     assert np.array_equal(vol.get_volume()[0], o_bg._tsdf)
 
 
+def test_chunked_frame_streaming_equals_resident_set(gpu_ctx, oracle_lib):
+    """A frame set longer than the resident chunk (``chunk_frames``) streams through one reused staging set in two passes --
+    bounds (depth only), then masking + integration chunk by chunk -- and gives the same bounds, volumes and mesh, bit for bit, as
+    the resident path and as the oracle's frame-at-a-time loop (hive/fusion.py:113-124); 11 frames in chunks of 4 (4 + 4 + 3,
+    the chunk boundary cuts a fused sweep)."""
+    from hive_amd import fusion, synthetic
+    from hive_amd.options import BackgroundMeshOptions
+    n = 11
+    seq = synthetic.make_sequence(num_frames=n, height=60, width=80, yaw_step_deg=7.0)
+    masks = list(synthetic.ellipse_masks(n, 60, 80, num_objects=2, seed=3))
+    options = BackgroundMeshOptions(sdf_voxel_size=0.05, sdf_max_voxels=400_000, depth_mask_dilation_iterations=2)
+    _, whole = fusion.tsdf_fusion(FakeDataset(seq, masks), options, return_volume=True)
+    assert whole.last_batch_groups() == [4, 4, 3]
+    _, chunked = fusion.tsdf_fusion(FakeDataset(seq, masks), options, return_volume=True, chunk_frames=4)
+    assert chunked.last_batch_groups() == [3], "the last chunk holds frames 8..10"
+    o_voxel, o_bnds, o_vol = _oracle_fusion(oracle_lib, FakeDataset(seq, masks), options, range(n))
+    assert np.array_equal(chunked._vol_bnds[:, 0], whole._vol_bnds[:, 0]) and np.array_equal(chunked._vol_dim, whole._vol_dim)
+    for vol in (whole, chunked):
+        tsdf, color, weight = vol.get_volume(with_weight=True)
+        assert np.array_equal(tsdf, o_vol._tsdf) and np.array_equal(color, o_vol._color) and np.array_equal(weight, o_vol._weight)
+    vols = fusion.tsdf_fusion_fg_bg(FakeDataset(seq, masks), options, chunk_frames=5)
+    assert np.array_equal(vols["bg"].get_volume()[0], o_vol._tsdf) and float(vols["fg"].get_volume(with_weight=True)[2].max()) > 0
+    # more frames than one batched launch of the bounds / masking kernels takes: the wrappers split the set
+    old = fusion.MAX_BATCH_FRAMES
+    fusion.MAX_BATCH_FRAMES = 4
+    try:
+        frames = fusion.DeviceFrames.from_dataset(FakeDataset(seq, masks), list(range(n)), with_masks=True)
+        assert np.array_equal(fusion.scene_bounds(frames, seq["K"]), o_bnds)
+        import torch
+        a = frames.masked_depth(2, fusion.MASK_BACKGROUND)
+    finally:
+        fusion.MAX_BATCH_FRAMES = old
+    assert torch.equal(a, frames.masked_depth(2, fusion.MASK_BACKGROUND))
+
+
 def test_fg_bg_partition_property_full_size(gpu_ctx):
     """Size-independent property at the benchmark's size (640 x 480 frames, 512^3): with no dilation the background and
     foreground depth maps partition every frame's valid pixels, and a voxel's update depends on its own pixel only, so the

@@ -267,16 +267,18 @@ def test_x_slab_volumes_are_slices_of_the_whole_volume(gpu_ctx, oracle_lib, smal
         fusion.TSDFVolume(bounds, voxel, ctx=gpu_ctx, x_range=(10, X + 1))
 
 
-def test_exact_slab_fusion_single_rank_and_device_volume_copies(gpu_ctx, oracle_lib, small_sequence):
-    """hive_amd.distributed.ExactSlabFusion with one rank (no process group): frames 'all-gathered', integrated, slabs
-    'all-gathered' into a whole volume whose mesh can be extracted; set_volume_device / device_tensors round trip."""
+def test_exact_slab_fusion_single_rank_and_device_volume_copies(gpu_ctx, oracle_lib, fusable_sequence):
+    """hive_amd.distributed.ExactSlabFusion with one rank (no process group): frames 'all-gathered', integrated (the fused sweep:
+    10 frames 9 degrees apart -> sweeps of 4 + 4 + 2, asserted), slabs 'all-gathered' into a whole volume whose mesh can be
+    extracted; set_volume_device / device_tensors round trip."""
     import torch
     from hive_amd import distributed as hdist, synthetic
-    seq = small_sequence
+    seq = fusable_sequence
     fus = hdist.ExactSlabFusion(synthetic.room_bounds(), 0.08, ctx=gpu_ctx)
     ora = oracle_lib.TSDFVolume(synthetic.room_bounds(), 0.08)
     n = seq["depth"].shape[0]
     fus.integrate(torch.from_numpy(seq["color"]).cuda(), torch.from_numpy(seq["depth"]).cuda(), seq["K"], seq["poses"], [n])
+    assert fus.slab.last_batch_groups() == [4, 4, 2], "the fused sweep did not run on the slab"
     for i in range(n):
         ora.integrate(seq["color"][i], seq["depth"][i], seq["K"], seq["poses"][i])
     full = fus.gather()
@@ -289,26 +291,111 @@ def test_exact_slab_fusion_single_rank_and_device_volume_copies(gpu_ctx, oracle_
 @pytest.mark.parametrize("round_mode", [0, 1])
 def test_multi_frame_sweep_is_bit_identical(gpu_ctx, oracle_lib, round_mode):
     """hive_tsdf_integrate_batch on device frames fuses up to four consecutive frames per sweep (volume loaded and stored once,
-    frames applied to the registers in order): bit-identical to one sweep per frame and to the oracle -- 7 frames (groups of 4 + 3)
-    into 128^3, both rounding modes, then at the benchmark's size against the single-frame kernel."""
+    frames applied to the registers in order): bit-identical to the C oracle's serial loop (hive/fusion.py:113-124) -- 7 frames
+    8 degrees apart = sweeps of 4 + 3 (asserted) into 128^3, both rounding modes; the single-frame kernel on the same frames
+    with alternating observation weights beside it."""
     import torch
     from hive_amd import fusion, synthetic
-    seq = synthetic.make_sequence(num_frames=7, height=120, width=160, yaw_step_deg=17.0, seed=5)
+    seq = synthetic.make_sequence(num_frames=7, height=120, width=160, yaw_step_deg=8.0, seed=5)
     ora = oracle_lib.TSDFVolume(synthetic.room_bounds(), 0.04, round_mode=round_mode)
     for i in range(7):
         ora.integrate(seq["color"][i], seq["depth"][i], seq["K"], seq["poses"][i], obs_weight=1.0 + 0.5 * (i % 2))
     color_d, depth_d = torch.from_numpy(seq["color"]).cuda(), torch.from_numpy(seq["depth"]).cuda()
     fused = fusion.TSDFVolume(synthetic.room_bounds(), 0.04, ctx=gpu_ctx, round_mode=round_mode)
     one = fusion.TSDFVolume(synthetic.room_bounds(), 0.04, ctx=gpu_ctx, round_mode=round_mode)
-    # obs_weight is per call: two batches with different weights, frames interleaved as in the oracle loop above
     for i in range(7):
         one.integrate(color_d[i], depth_d[i], seq["K"], seq["poses"][i], obs_weight=1.0 + 0.5 * (i % 2))
     ora2 = oracle_lib.TSDFVolume(synthetic.room_bounds(), 0.04, round_mode=round_mode)
     for i in range(7):
         ora2.integrate(seq["color"][i], seq["depth"][i], seq["K"], seq["poses"][i])
     fused.integrate_batch(color_d, depth_d, seq["K"], seq["poses"])
+    assert fused.last_batch_groups() == [4, 3]
     _volumes_equal(one, ora)
     _volumes_equal(fused, ora2)
+
+
+@pytest.mark.parametrize("round_mode", [0, 1])
+def test_multi_frame_sweep_bench_configuration_vs_oracle(gpu_ctx, oracle_lib, round_mode):
+    """The kernel and the configuration bench.py times: 640 x 480 frames of the bench trajectory (2.4 degree steps) into 512^3,
+    eight device-resident frames through integrate_batch = two sweeps of FOUR (asserted), against the C oracle's eight serial
+    integrates, bit for bit, both rounding modes (the oracle runs its x planes on the host's cores: same bits as one thread)."""
+    import torch
+    from hive_amd import fusion, synthetic
+    seq = synthetic.make_sequence(num_frames=8, yaw_step_deg=2.4)
+    oracle_lib.set_threads(0)
+    ora = oracle_lib.TSDFVolume(synthetic.room_bounds(), 0.01, round_mode=round_mode)
+    for i in range(8):
+        ora.integrate(seq["color"][i], seq["depth"][i], seq["K"], seq["poses"][i])
+    vol = fusion.TSDFVolume(synthetic.room_bounds(), 0.01, ctx=gpu_ctx, round_mode=round_mode)
+    assert tuple(vol.vol_dim) == (512, 512, 512)
+    vol.integrate_batch(torch.from_numpy(seq["color"]).cuda(), torch.from_numpy(seq["depth"]).cuda(), seq["K"], seq["poses"])
+    assert vol.last_batch_groups() == [4, 4]
+    _volumes_equal(vol, ora)
+    assert float(ora._weight.max()) == 8.0
+
+
+def _poses_yaw(degrees, centre_offsets=None):
+    """Camera-to-world poses on the room's circle at the given yaw angles (degrees); optional extra translation per frame."""
+    from hive_amd import synthetic
+    poses = []
+    for k, deg in enumerate(degrees):
+        p = synthetic.circular_trajectory(2, yaw_step_deg=float(deg))[1]
+        if centre_offsets is not None:
+            p = p.copy()
+            p[:3, 3] += np.asarray(centre_offsets[k], np.float64)
+        poses.append(p)
+    return np.stack(poses)
+
+
+def _render(poses, height=120, width=160, seed=11, zero_frames=()):
+    from hive_amd import synthetic
+    rng = np.random.default_rng(seed)
+    K = synthetic.scaled_intrinsics(height, width)
+    color = np.empty((len(poses), height, width, 3), np.uint8)
+    depth = np.empty((len(poses), height, width), np.float32)
+    for i, pose in enumerate(poses):
+        d, pts = synthetic.raycast_room_depth(pose, K, height, width, 0.32, 4.80)
+        d = d.copy()
+        d[rng.random(d.shape) < 0.02] = 0.0
+        if i in zero_frames:
+            d[:] = 0.0
+        color[i], depth[i] = synthetic.room_colour(pts, rng), d
+    return color, depth, K
+
+
+@pytest.mark.parametrize("case", ["five", "distance", "angle", "zero_depth", "weight", "odd_z"])
+def test_multi_frame_grouping_edge_cases(gpu_ctx, oracle_lib, case):
+    """How hive_tsdf_integrate_batch forms its sweeps (tsdf.hip `fusable`), each case bit for bit against the C oracle's serial
+    loop and with the expected grouping asserted: five frames (4 + 1), a group broken by the camera moving more than a quarter
+    of the volume's longest side, a group broken by the 36 degree limit to its FIRST frame, an all-zero depth map inside a
+    group, an observation weight other than 1, and Z % 4 != 0 (no fused sweep: the scalar kernel, one frame per launch)."""
+    import torch
+    from hive_amd import fusion, synthetic
+    bounds, voxel, obs_w, zero = synthetic.room_bounds(), 0.04, 1.0, ()
+    if case == "five":
+        poses, groups = _poses_yaw([0, 3, 6, 9, 12]), [4, 1]
+    elif case == "distance":  # frame 2 is 1.5 m away from frame 0 (> 5.12 / 4): the group closes before it
+        poses, groups = _poses_yaw([0, 2, 4, 6, 8, 10], [(0, 0, 0), (0, 0, 0), (0, -1.5, 0), (0, -1.5, 0), (0, -1.5, 0), (0, -1.5, 0)]), [2, 4]
+    elif case == "angle":  # 0, 20, 40: 40 degrees from the group's first frame -> [2, ...]; 40, 60, 70, 75: all within 36 of 40
+        poses, groups = _poses_yaw([0, 20, 40, 60, 70, 75]), [2, 4]
+    elif case == "zero_depth":
+        poses, groups, zero = _poses_yaw([0, 3, 6, 9, 12, 15]), [4, 2], (1, 5)
+    elif case == "weight":
+        poses, groups, obs_w = _poses_yaw([0, 3, 6, 9]), [4], 0.37
+    else:  # Z = 5.0 / 0.04 -> 125: not a multiple of 4
+        poses, groups = _poses_yaw([0, 3, 6, 9]), [1, 1, 1, 1]
+        bounds = np.array([[0.0, 5.12], [0.0, 5.12], [0.0, 5.0]])
+    color, depth, K = _render(poses, zero_frames=zero)
+    ora = oracle_lib.TSDFVolume(bounds, voxel)
+    for i in range(len(poses)):
+        ora.integrate(color[i], depth[i], K, poses[i], obs_weight=obs_w)
+    vol = fusion.TSDFVolume(bounds, voxel, ctx=gpu_ctx)
+    if case == "odd_z":
+        assert vol.vol_dim[2] % 4 != 0
+    vol.integrate_batch(torch.from_numpy(color).cuda(), torch.from_numpy(depth).cuda(), K, poses, obs_weight=obs_w)
+    assert vol.last_batch_groups() == groups
+    _volumes_equal(vol, ora)
+    assert ora._weight.max() > 0
 
 
 def test_multi_frame_sweep_full_size(gpu_ctx):
@@ -327,12 +414,13 @@ def test_multi_frame_sweep_full_size(gpu_ctx):
     assert float(fused.device_tensors()[1].max()) == 6.0
 
 
-def test_multi_frame_sweep_on_x_slabs(gpu_ctx, oracle_lib, small_sequence):
-    """The fused sweep on x-slab volumes (what the bit-exact multi-GPU mode runs): device frames through integrate_batch into
-    three uneven slabs == the oracle's whole volume, bit for bit."""
+def test_multi_frame_sweep_on_x_slabs(gpu_ctx, oracle_lib, fusable_sequence):
+    """The fused sweep on x-slab volumes (what the bit-exact multi-GPU mode runs on every rank): ten device frames 9 degrees
+    apart through integrate_batch into three uneven slabs -- sweeps of 4 + 4 + 2 on EVERY slab (asserted) -- == the oracle's whole
+    volume, bit for bit."""
     import torch
     from hive_amd import fusion, synthetic
-    seq = small_sequence
+    seq = fusable_sequence
     bounds, voxel = synthetic.room_bounds(), 0.0641  # 80^3
     ora = oracle_lib.TSDFVolume(bounds, voxel)
     n = seq["depth"].shape[0]
@@ -345,6 +433,8 @@ def test_multi_frame_sweep_on_x_slabs(gpu_ctx, oracle_lib, small_sequence):
     for a, b in zip(cuts, cuts[1:]):
         slab = fusion.TSDFVolume(bounds, voxel, ctx=gpu_ctx, x_range=(a, b))
         slab.integrate_batch(color_d, depth_d, seq["K"], seq["poses"])
+        assert slab.last_batch_groups() == [4, 4, 2], "the fused sweep did not run on the slab"
         parts.append(slab.get_volume(with_weight=True))
     for k, ref in enumerate((ora._tsdf, ora._color, ora._weight)):
         assert np.array_equal(np.concatenate([p[k] for p in parts], axis=0), ref)
+    assert ora._weight.max() >= 8
