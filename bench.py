@@ -52,6 +52,20 @@ def parse_args():
     return ap.parse_args()
 
 
+def host_cores():
+    """Cores this process may really use: the scheduler affinity, cut down to the cgroup's CPU quota where one is set (a GPU box
+    hands a 1-GPU job a share of the host: 256 threads on a 16-core share ran the torch-CPU DPT at 87 s per frame)."""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    env = os.environ.get("HIVE_BENCH_CPU_THREADS")
+    return int(env) if env else min(cores, 64)
+
+
 def cpu_baseline(seq, voxel, K):
     """The CPU path timed on this box's host cores, on a bounded sample of the same workload: the fp32 torch-CPU DPT-Hybrid on
     two frames (after one warm-up) and the C oracle's integrate -- the restatement of the reference library's loop, its x planes
@@ -61,7 +75,7 @@ def cpu_baseline(seq, voxel, K):
     from hive_amd import synthetic
     from hive_amd.dpt.init import seeded_init
     from hive_amd.dpt.models import DPTDepthModel
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = host_cores()
     torch.set_num_threads(cores)
     model = seeded_init(DPTDepthModel(path=None, scale=0.000305, shift=0.1378, invert=True, engine="torch"), seed=1234).eval()
     x = torch.from_numpy(seq["color"][:1].astype(np.float32) / 255.0 * 2.0 - 1.0).permute(0, 3, 1, 2).contiguous()

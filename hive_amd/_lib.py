@@ -18,6 +18,7 @@ OK, ERR_INVALID, ERR_DEVICE, ERR_NOMEM, ERR_EMPTY, ERR_STATE = 0, -1, -2, -3, -4
 MEM_HOST, MEM_DEVICE = 0, 1
 ROUND_HALF_EVEN, ROUND_HALF_AWAY = 0, 1
 F32, F16, BF16 = 0, 1, 2
+ABI_VERSION = 2  # include/hive_mi355x.h HIVE_ABI_VERSION: 2 = the network entry points take the 16-bit dtype (HIVE_F16 / HIVE_BF16)
 
 c_void_p, c_int, c_int64, c_float, c_double = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_double
 P = ctypes.POINTER
@@ -75,13 +76,13 @@ SIGNATURES = {
     "hive_filter_faces": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_double, c_double, c_int, c_void_p, P(c_int64)]),
     "hive_texture_window": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_double, c_int, c_void_p, c_void_p]),
     "hive_dilate_mask": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
-    "hive_vit_create": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, P(c_void_p)]),
+    "hive_vit_create": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, P(c_void_p)]),
     "hive_vit_destroy": (c_int, [c_void_p]),
     "hive_vit_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
-    "hive_vit_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float]),
-    "hive_vit_linear": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int]),
-    "hive_vit_qkv": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int]),
-    "hive_vit_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int]),
+    "hive_vit_layernorm": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float]),
+    "hive_vit_linear": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int]),
+    "hive_vit_qkv": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int]),
+    "hive_vit_attention": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int]),
     "hive_dpt_preprocess": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_float, c_int, c_void_p]),
     "hive_dpt_head_tail": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p, c_int, c_void_p, c_float, c_int, c_int, c_float,
                                    c_float, c_void_p, c_float, c_float, c_void_p, c_void_p]),
@@ -156,10 +157,20 @@ def load():
             fn = getattr(lib, name)
             fn.restype = restype
             fn.argtypes = argtypes
-        if lib.hive_abi_version() != 1:
-            raise ImportError(f"{LIB_PATH}: ABI version {lib.hive_abi_version()} != 1")
+        if lib.hive_abi_version() != ABI_VERSION:
+            raise ImportError(f"{LIB_PATH}: ABI version {lib.hive_abi_version()} != {ABI_VERSION} (rebuild: make -C hive_amd/csrc)")
         _lib = lib
         return _lib
+
+
+def dtype_code(torch_dtype):
+    """hive_dtype of a torch 16-bit type; raises for anything the network kernels do not compute in."""
+    name = str(torch_dtype)
+    if name == "torch.bfloat16":
+        return BF16
+    if name == "torch.float16":
+        return F16
+    raise HiveError(ERR_INVALID, f"{name}: the network kernels compute in float16 or bfloat16 (no silent down-cast)")
 
 
 def ptr(a):

@@ -1,4 +1,4 @@
-// Implicit-GEMM 3 x 3 convolution (stride 1, padding 1) on channels-last bf16 for gfx950, with the bias / ReLU / skip adds
+// Implicit-GEMM convolution (1 x 1 / 3 x 3, stride 1 / 2) on channels-last bf16 or fp16 (template parameter T) for gfx950, with the bias / ReLU / skip adds
 // of DPT's decoder fused into the epilogue.  No vendor library.
 //
 // Replaces the 3 x 3 convolutions of the reference's (absent) third_party/dpt decoder inside `DPTDepthModel.forward`
@@ -34,22 +34,21 @@
 
 #include <algorithm>
 
-typedef __bf16 bf16;
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+using hive_mfma::f32x4;
+using hive_mfma::vec;  // vec<T, 8>: 8 elements of the 16-bit type T (__bf16 or _Float16), one 16-byte register quad
 
 namespace {
 
+template <typename T>
 struct ConvParams {
-    const bf16 *x;      // [NB][H][W][Cin]
-    const bf16 *w;      // [Cout][R S Cin], k = (ky, kx, ci)
-    const bf16 *bias;   // [Cout] or nullptr
-    const bf16 *res1;   // [M][Cout] or nullptr
-    const bf16 *res2;   // [M][Cout] or nullptr
-    bf16 *out;          // [M][Cout]
-    bf16 *out_relu;     // [M][Cout] or nullptr: relu(out)
-    const bf16 *zeros;  // >= 128 bytes of zeros (padding taps)
+    const T *x;      // [NB][H][W][Cin]
+    const T *w;      // [Cout][R S Cin], k = (ky, kx, ci)
+    const T *bias;   // [Cout] or nullptr
+    const T *res1;   // [M][Cout] or nullptr
+    const T *res2;   // [M][Cout] or nullptr
+    T *out;          // [M][Cout]
+    T *out_relu;     // [M][Cout] or nullptr: relu(out)
+    const T *zeros;  // >= 128 bytes of zeros (padding taps)
     int H, W, Cin, Cout, relu;  // H, W: INPUT size
     int Ho, Wo;         // output size
     int S, taps;        // kernel width (1 or 3), R * S
@@ -59,7 +58,7 @@ struct ConvParams {
     int stats_only;     // GN == 1: nothing is stored but gn_partial (first pass of hive_nhwc_conv_gn_apply)
     // GN == 2 (second pass): out = relu?(bf16(gn(bf16(conv))) + residual) with the (mean, rstd) of gn_stats[sample * gn_G + group]
     const float *gn_stats;
-    const bf16 *gn_gamma, *gn_beta;
+    const T *gn_gamma, *gn_beta;
     int gn_G, gn_cpg;   // groups, channels per group (>= 8: a lane's 8 channels share a group)
 };
 
@@ -81,19 +80,19 @@ __device__ __forceinline__ float gn_affine_exact(float x, float rstd, float gamm
     return x * a + b;
 }
 
-template <int MT, int GN>
-__device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x4 (&acc)[4][MT], int m_base, int n_base, unsigned char *stage, int lane,
+template <typename T, int MT, int GN>
+__device__ __forceinline__ void conv_epilogue(const ConvParams<T> &p, f32x4 (&acc)[4][MT], int m_base, int n_base, unsigned char *stage, int lane,
                                               int boundary, bool straddles, float (&gsum)[2][8], float (&gsq)[2][8]) {
     const int n = n_base + (lane & 7) * 8;
     float b[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (p.bias) {
-        const bf16x8 bv = *reinterpret_cast<const bf16x8 *>(p.bias + n);
+        const vec<T, 8> bv = *reinterpret_cast<const vec<T, 8> *>(p.bias + n);
 #pragma unroll
         for (int j = 0; j < 8; ++j) b[j] = (float)bv[j];
     }
     float ggam[8], gbet[8], gmean[2] = {0.f, 0.f}, grstd[2] = {0.f, 0.f};
     if (GN == 2) {
-        const bf16x8 gv = *reinterpret_cast<const bf16x8 *>(p.gn_gamma + n), bv = *reinterpret_cast<const bf16x8 *>(p.gn_beta + n);
+        const vec<T, 8> gv = *reinterpret_cast<const vec<T, 8> *>(p.gn_gamma + n), bv = *reinterpret_cast<const vec<T, 8> *>(p.gn_beta + n);
 #pragma unroll
         for (int j = 0; j < 8; ++j) ggam[j] = (float)gv[j], gbet[j] = (float)bv[j];
         const int hw = p.Ho * p.Wo, img0 = boundary / hw - 1, n_img = p.M / hw, g = n / p.gn_cpg;
@@ -109,12 +108,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x4 (&acc)[
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] = lo[j] + b[j], o[4 + j] = hi[j] + b[4 + j];
         if (GN != 2 && p.res1) {
-            const bf16x8 rs = *reinterpret_cast<const bf16x8 *>(p.res1 + o_off);
+            const vec<T, 8> rs = *reinterpret_cast<const vec<T, 8> *>(p.res1 + o_off);
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] += (float)rs[j];
         }
         if (GN != 2 && p.res2) {
-            const bf16x8 rs = *reinterpret_cast<const bf16x8 *>(p.res2 + o_off);
+            const vec<T, 8> rs = *reinterpret_cast<const vec<T, 8> *>(p.res2 + o_off);
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] += (float)rs[j];
         }
@@ -122,9 +121,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x4 (&acc)[
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = fmaxf(o[j], 0.0f);
         }
-        bf16x8 ov;
+        vec<T, 8> ov;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) ov[j] = (bf16)o[j];
+        for (int j = 0; j < 8; ++j) ov[j] = (T)o[j];
         if (GN == 2) {
             // the GroupNorm behind this convolution, applied to the ROUNDED output with gn_apply_kernel's operations in its order
             // (no contraction: bit-identical to the separate pass), then the block's shortcut and ReLU
@@ -133,20 +132,20 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x4 (&acc)[
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = gn_affine_exact((float)ov[j], rstd, ggam[j], gbet[j], mean);
             if (p.res1) {
-                const bf16x8 rs = *reinterpret_cast<const bf16x8 *>(p.res1 + o_off);
+                const vec<T, 8> rs = *reinterpret_cast<const vec<T, 8> *>(p.res1 + o_off);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = (float)(bf16)o[j] + (float)rs[j];
+                for (int j = 0; j < 8; ++j) o[j] = (float)(T)o[j] + (float)rs[j];
             }
             if (p.relu) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) o[j] = fmaxf(o[j], 0.0f);
             }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) ov[j] = (bf16)o[j];
-            *reinterpret_cast<bf16x8 *>(p.out + o_off) = ov;
+            for (int j = 0; j < 8; ++j) ov[j] = (T)o[j];
+            *reinterpret_cast<vec<T, 8> *>(p.out + o_off) = ov;
             return;
         }
-        if (GN != 1 || !p.stats_only) *reinterpret_cast<bf16x8 *>(p.out + o_off) = ov;
+        if (GN != 1 || !p.stats_only) *reinterpret_cast<vec<T, 8> *>(p.out + o_off) = ov;
         if (GN == 1) {
             if (!straddles) {  // (workgroup-uniform) the whole tile lies in one sample: one set of sums
 #pragma unroll
@@ -169,16 +168,16 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams &p, f32x4 (&acc)[
         }
         if (p.out_relu) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) ov[j] = (bf16)fmaxf(o[j], 0.0f);
-            *reinterpret_cast<bf16x8 *>(p.out_relu + o_off) = ov;
+            for (int j = 0; j < 8; ++j) ov[j] = (T)fmaxf(o[j], 0.0f);
+            *reinterpret_cast<vec<T, 8> *>(p.out_relu + o_off) = ov;
         }
     });
 }
 
 constexpr int BK = 64;
 
-template <int TM, int TN, int GN>
-__global__ __launch_bounds__(512, 1) void conv_kernel(ConvParams p) {
+template <typename T, int TM, int TN, int GN>
+__global__ __launch_bounds__(512, 1) void conv_kernel(ConvParams<T> p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // 2 stages x (A tile TM x 64, W tile TN x 64) + 8 x 4 KiB for the epilogue
     constexpr int A_GROUPS = TM / 8, A_PW = A_GROUPS / 8;  // 1 KiB groups of the A tile, and how many each wave stages
     constexpr int W_GROUPS = TN / 8, GROUPS = A_GROUPS + W_GROUPS, PER_WAVE = GROUPS / 8;
@@ -204,7 +203,7 @@ __global__ __launch_bounds__(512, 1) void conv_kernel(ConvParams p) {
     struct Tile {
         int m0, n0;
         int py[A_PW], px[A_PW];
-        const bf16 *pbase[A_PW];
+        const T *pbase[A_PW];
     };
     int a_chunk[A_PW];
 #pragma unroll
@@ -212,36 +211,36 @@ __global__ __launch_bounds__(512, 1) void conv_kernel(ConvParams p) {
         const int row = (wave + 8 * j) * 8 + (lane >> 3);
         a_chunk[j] = ((lane & 7) ^ ((row >> 1) & 7)) * 8;  // source-side swizzle: LDS slot (lane & 7) receives this chunk
     }
-    auto setup = [&](int t, Tile &T) {
-        T.m0 = (t / tiles_n) * TM;
-        T.n0 = (t % tiles_n) * TN;
+    auto setup = [&](int t, Tile &tile) {
+        tile.m0 = (t / tiles_n) * TM;
+        tile.n0 = (t % tiles_n) * TN;
 #pragma unroll
         for (int j = 0; j < A_PW; ++j) {
             const int row = (wave + 8 * j) * 8 + (lane >> 3);
-            const int m = min(T.m0 + row, p.M - 1);  // rows past the end are never stored
+            const int m = min(tile.m0 + row, p.M - 1);  // rows past the end are never stored
             const int img = m / (p.Ho * p.Wo), rem = m - img * (p.Ho * p.Wo);
             const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-            T.py[j] = oy * p.stride - p.pad_t;  // input pixel of tap (0, 0)
-            T.px[j] = ox * p.stride - p.pad_l;
-            T.pbase[j] = p.x + (((long long)img * p.H + T.py[j]) * p.W + T.px[j]) * p.Cin + a_chunk[j];  // may point before the image: used only when inside
+            tile.py[j] = oy * p.stride - p.pad_t;  // input pixel of tap (0, 0)
+            tile.px[j] = ox * p.stride - p.pad_l;
+            tile.pbase[j] = p.x + (((long long)img * p.H + tile.py[j]) * p.W + tile.px[j]) * p.Cin + a_chunk[j];  // may point before the image: used only when inside
         }
     };
     const int w_lane_row = lane >> 3;
 
     // one LDS-DMA wave-instruction of a stage: j < A_PW an A group (8 output pixels x 128 B of one tap), else a W group
-    auto issue_piece = [&](const Tile &T, int stage, int tap, int cc, int j) {
+    auto issue_piece = [&](const Tile &tile, int stage, int tap, int cc, int j) {
         unsigned char *st = lds + stage * STAGE_BYTES;
         if (j < A_PW) {
             const int dy = tap / p.S, dx = tap - dy * p.S;
             const long long shift = ((long long)dy * p.W + dx) * p.Cin + cc * BK;
-            const bool inside = (unsigned)(T.py[j] + dy) < (unsigned)p.H && (unsigned)(T.px[j] + dx) < (unsigned)p.W;
-            const bf16 *g = inside ? T.pbase[j] + shift : p.zeros + a_chunk[j];
+            const bool inside = (unsigned)(tile.py[j] + dy) < (unsigned)p.H && (unsigned)(tile.px[j] + dx) < (unsigned)p.W;
+            const T *g = inside ? tile.pbase[j] + shift : p.zeros + a_chunk[j];
             __builtin_amdgcn_global_load_lds((const void *)g, (__attribute__((address_space(3))) void *)(st + (wave + 8 * j) * 1024), 16, 0, 0);
         } else {
             const int grp = wave + 8 * (j - A_PW);  // W group: rows grp * 8 .. + 7 of the weight tile
             const int row = grp * 8 + w_lane_row;
             const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-            const bf16 *g = p.w + (size_t)(T.n0 + row) * K + tap * p.Cin + cc * BK + chunk * 8;
+            const T *g = p.w + (size_t)(tile.n0 + row) * K + tap * p.Cin + cc * BK + chunk * 8;
             __builtin_amdgcn_global_load_lds((const void *)g, (__attribute__((address_space(3))) void *)(st + (A_GROUPS + grp) * 1024), 16, 0, 0);
         }
     };
@@ -251,15 +250,15 @@ __global__ __launch_bounds__(512, 1) void conv_kernel(ConvParams p) {
     // by a pixel or a row, so consecutive K-steps re-read bytes the previous ones just brought into the XCD's L2 (a tile's window
     // for one channel block is ~74 KB; 32 concurrent tiles per XCD: 2.4 MB of its 4 MB); with taps outer the re-use distance is
     // a whole sweep over the channels (tools/ubench/ldsdma.hip: a 64 KiB stage takes 2550 cycles from L2, 5400 from beyond it).
-    Tile T;  // the tile whose stages are being ISSUED (one K-step ahead of the MFMAs: the next tile's during a tile's last step)
-    setup(run0 + tl, T);
+    Tile tile;  // the tile whose stages are being ISSUED (one K-step ahead of the MFMAs: the next tile's during a tile's last step)
+    setup(run0 + tl, tile);
 #pragma unroll
-    for (int j = 0; j < PER_WAVE; ++j) issue_piece(T, 0, 0, 0, j);
+    for (int j = 0; j < PER_WAVE; ++j) issue_piece(tile, 0, 0, 0, j);
     const int fr = lane & 15, fq = lane >> 4;
     int buf = 0;  // LDS stage of the current K-step (alternates along the whole stream)
     for (;;) {
         const bool has_next = tl + per_xcd < run_n;
-        const int em0 = T.m0, en0 = T.n0;  // the tile being multiplied (for its epilogue)
+        const int em0 = tile.m0, en0 = tile.n0;  // the tile being multiplied (for its epilogue)
         f32x4 acc[4][MT];  // acc[nt][mt] = W_frag . A_frag^T : rows = output channel, cols = pixel
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -277,7 +276,7 @@ __global__ __launch_bounds__(512, 1) void conv_kernel(ConvParams p) {
             int is_tap = nx_tap, is_cc = nx_cc;
             if (kt + 1 == KT) {
                 if (has_next) {
-                    setup(run0 + tl + per_xcd, T);  // this tile's rows are not needed any more: its last stage is in LDS
+                    setup(run0 + tl + per_xcd, tile);  // this tile's rows are not needed any more: its last stage is in LDS
                     is_tap = 0, is_cc = 0;
                 } else {
                     is_tap = last_tap, is_cc = CPT - 1;
@@ -285,7 +284,7 @@ __global__ __launch_bounds__(512, 1) void conv_kernel(ConvParams p) {
             }
             if (++nx_tap == p.taps) nx_tap = 0, ++nx_cc;
             const unsigned char *a_t = lds + buf * STAGE_BYTES, *w_t = a_t + A_GROUPS * 1024;
-            hive_mfma::kstep64<MT, false>(a_t, w_t, wr * RW, wc * 64, fr, fq, acc, PER_WAVE, [&](int j) { issue_piece(T, buf ^ 1, is_tap, is_cc, j); });
+            hive_mfma::kstep64<T, MT, false>(a_t, w_t, wr * RW, wc * 64, fr, fq, acc, PER_WAVE, [&](int j) { issue_piece(tile, buf ^ 1, is_tap, is_cc, j); });
             buf ^= 1;
         }
         unsigned char *stage = lds + 2 * STAGE_BYTES + wave * 4096;
@@ -294,7 +293,7 @@ __global__ __launch_bounds__(512, 1) void conv_kernel(ConvParams p) {
         for (int j = 0; j < 8; ++j) gsum[0][j] = gsum[1][j] = gsq[0][j] = gsq[1][j] = 0.f;
         const int hw = p.Ho * p.Wo, boundary = (em0 / hw + 1) * hw;  // first row of the tile's second image
         const bool straddles = boundary < em0 + TM && boundary < p.M;  // the tile reaches into a second sample
-        conv_epilogue<MT, GN>(p, acc, em0 + wr * RW, en0 + wc * 64, stage, lane, boundary, straddles, gsum, gsq);
+        conv_epilogue<T, MT, GN>(p, acc, em0 + wr * RW, en0 + wc * 64, stage, lane, boundary, straddles, gsum, gsq);
         if (GN == 1) {
             // the 8 lanes with the same channels (lane bits 3..5), then the WM waves of the tile in wave order
 #pragma unroll
@@ -339,33 +338,43 @@ __global__ __launch_bounds__(512, 1) void conv_kernel(ConvParams p) {
 
 constexpr int conv_lds(int tm, int tn) { return 2 * (tm / 8 + tn / 8) * 1024 + hive_mfma::STAGED_ROWS_LDS; }  // two stages of (A tile + W tile), 128-byte rows; the epilogue's 8 x 4 KiB
 
-bool g_conv_attr_set[64] = {};
-
+template <typename T>
 int ensure_conv_attrs(hive_ctx *ctx) {
-    if (ctx->device < 64 && g_conv_attr_set[ctx->device]) return HIVE_OK;
-    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)conv_kernel<256, 256, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds(256, 256)));
-    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)conv_kernel<256, 256, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds(256, 256)));
-    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)conv_kernel<256, 128, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds(256, 128)));
-    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)conv_kernel<256, 128, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds(256, 128)));
-    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)conv_kernel<256, 64, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds(256, 64)));
-    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)conv_kernel<256, 64, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds(256, 64)));
-    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)conv_kernel<128, 256, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds(128, 256)));
-    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)conv_kernel<128, 256, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds(128, 256)));
-    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)conv_kernel<128, 128, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds(128, 128)));
-    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)conv_kernel<128, 128, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds(128, 128)));
-    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)conv_kernel<256, 256, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds(256, 256)));
-    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)conv_kernel<128, 256, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds(128, 256)));
-    if (ctx->device < 64) g_conv_attr_set[ctx->device] = true;
+    static bool set[64] = {};
+    if (ctx->device < 64 && set[ctx->device]) return HIVE_OK;
+#define HIVE_CONV_ATTR(TM_, TN_, GN_) \
+    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)conv_kernel<T, TM_, TN_, GN_>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds(TM_, TN_)))
+    HIVE_CONV_ATTR(256, 256, 0);
+    HIVE_CONV_ATTR(256, 256, 1);
+    HIVE_CONV_ATTR(256, 128, 0);
+    HIVE_CONV_ATTR(256, 128, 1);
+    HIVE_CONV_ATTR(256, 64, 0);
+    HIVE_CONV_ATTR(256, 64, 1);
+    HIVE_CONV_ATTR(128, 256, 0);
+    HIVE_CONV_ATTR(128, 256, 1);
+    HIVE_CONV_ATTR(128, 128, 0);
+    HIVE_CONV_ATTR(128, 128, 1);
+    HIVE_CONV_ATTR(256, 256, 2);
+    HIVE_CONV_ATTR(128, 256, 2);
+#undef HIVE_CONV_ATTR
+    if (ctx->device < 64) set[ctx->device] = true;
     return HIVE_OK;
 }
 
-int launch_conv(hive_ctx *ctx, const char *what, const void *d_x, int dtype, int N, int H, int W, int C_in, int C_out, int R, int stride, int pad_t,
-                       int pad_l, int Ho, int Wo, const void *d_w, const void *d_bias, int relu, const void *d_residual, const void *d_residual2,
-                       void *d_out, void *d_out_relu, void *d_gn_partial = nullptr, long long gn_partial_floats = 0, int *gn_tile_rows = nullptr,
-                       const ConvParams *gn_mode = nullptr) {  // gn_mode: stats_only / gn_stats .. gn_cpg of the two-pass GroupNorm convolution
+// the two-pass GroupNorm convolution's mode (hive_nhwc_conv_gn_apply): statistics only / normalise in the epilogue
+struct GnMode {
+    int stats_only = 0;
+    const float *gn_stats = nullptr;
+    const void *gn_gamma = nullptr, *gn_beta = nullptr;
+    int gn_G = 0, gn_cpg = 0;
+};
+
+template <typename T>
+int launch_conv_t(hive_ctx *ctx, const char *what, const void *d_x, int N, int H, int W, int C_in, int C_out, int R, int stride, int pad_t,
+                  int pad_l, int Ho, int Wo, const void *d_w, const void *d_bias, int relu, const void *d_residual, const void *d_residual2,
+                  void *d_out, void *d_out_relu, void *d_gn_partial, long long gn_partial_floats, int *gn_tile_rows, const GnMode *gn_mode) {
     HIVE_REQUIRE(ctx, d_x && d_w && d_out, "%s: NULL argument", what);
     if (gn_tile_rows) *gn_tile_rows = 0;
-    HIVE_REQUIRE(ctx, dtype == HIVE_BF16, "%s: bf16 only", what);
     HIVE_REQUIRE(ctx, N > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && (long long)N * H * W < (1ll << 31) && (long long)N * Ho * Wo < (1ll << 31),
                  "%s: bad sizes %d x %d x %d -> %d x %d", what, N, H, W, Ho, Wo);
     HIVE_REQUIRE(ctx, (R == 1 || R == 3) && (stride == 1 || stride == 2) && pad_t >= 0 && pad_t < R && pad_l >= 0 && pad_l < R,
@@ -374,15 +383,15 @@ int launch_conv(hive_ctx *ctx, const char *what, const void *d_x, int dtype, int
                  Wo, H, W);
     HIVE_REQUIRE(ctx, C_in > 0 && C_in % 64 == 0 && C_out > 0 && C_out % 64 == 0, "%s: need C_in %% 64 == 0 and C_out %% 64 == 0, got %d -> %d", what, C_in, C_out);
     HIVE_REQUIRE(ctx, (R == 1 && stride == 1) || (d_out != d_x && d_out_relu != d_x), "%s: the output must not alias the input", what);
-    ConvParams p{};
-    p.x = (const bf16 *)d_x;
-    p.w = (const bf16 *)d_w;
-    p.bias = (const bf16 *)d_bias;
-    p.res1 = (const bf16 *)d_residual;
-    p.res2 = (const bf16 *)d_residual2;
-    p.out = (bf16 *)d_out;
-    p.out_relu = (bf16 *)d_out_relu;
-    p.zeros = (const bf16 *)ctx->d_zeros;
+    ConvParams<T> p{};
+    p.x = (const T *)d_x;
+    p.w = (const T *)d_w;
+    p.bias = (const T *)d_bias;
+    p.res1 = (const T *)d_residual;
+    p.res2 = (const T *)d_residual2;
+    p.out = (T *)d_out;
+    p.out_relu = (T *)d_out_relu;
+    p.zeros = (const T *)ctx->d_zeros;
     p.H = H;
     p.W = W;
     p.Cin = C_in;
@@ -396,7 +405,7 @@ int launch_conv(hive_ctx *ctx, const char *what, const void *d_x, int dtype, int
     p.pad_t = pad_t;
     p.pad_l = pad_l;
     p.M = N * Ho * Wo;
-    int rc = ensure_conv_attrs(ctx);
+    int rc = ensure_conv_attrs<T>(ctx);
     if (rc) return rc;
     const int tn = C_out % 256 == 0 ? 256 : (C_out % 128 == 0 ? 128 : 64);
     // 256 output pixels per tile, or 128 where that would leave CUs without a tile (30 x 40 and 15 x 20 maps: 113 / 29 tiles of 256)
@@ -404,8 +413,8 @@ int launch_conv(hive_ctx *ctx, const char *what, const void *d_x, int dtype, int
     if (gn_mode) {
         p.stats_only = gn_mode->stats_only;
         p.gn_stats = gn_mode->gn_stats;
-        p.gn_gamma = gn_mode->gn_gamma;
-        p.gn_beta = gn_mode->gn_beta;
+        p.gn_gamma = (const T *)gn_mode->gn_gamma;
+        p.gn_beta = (const T *)gn_mode->gn_beta;
         p.gn_G = gn_mode->gn_G;
         p.gn_cpg = gn_mode->gn_cpg;
     }
@@ -423,15 +432,15 @@ int launch_conv(hive_ctx *ctx, const char *what, const void *d_x, int dtype, int
 #define HIVE_CONV_LAUNCH(TM_, TN_)                                                                                   \
     do {                                                                                                             \
         if (p.gn_partial)                                                                                            \
-            hipLaunchKernelGGL((conv_kernel<TM_, TN_, 1>), grid, dim3(512), lds, ctx->stream, p);                    \
+            hipLaunchKernelGGL((conv_kernel<T, TM_, TN_, 1>), grid, dim3(512), lds, ctx->stream, p);                    \
         else                                                                                                         \
-            hipLaunchKernelGGL((conv_kernel<TM_, TN_, 0>), grid, dim3(512), lds, ctx->stream, p);                    \
+            hipLaunchKernelGGL((conv_kernel<T, TM_, TN_, 0>), grid, dim3(512), lds, ctx->stream, p);                    \
     } while (0)
     if (p.gn_stats) {  // second pass of hive_nhwc_conv_gn_apply: C_out % 256 == 0 (checked there)
         if (tm == 256)
-            hipLaunchKernelGGL((conv_kernel<256, 256, 2>), grid, dim3(512), lds, ctx->stream, p);
+            hipLaunchKernelGGL((conv_kernel<T, 256, 256, 2>), grid, dim3(512), lds, ctx->stream, p);
         else
-            hipLaunchKernelGGL((conv_kernel<128, 256, 2>), grid, dim3(512), lds, ctx->stream, p);
+            hipLaunchKernelGGL((conv_kernel<T, 128, 256, 2>), grid, dim3(512), lds, ctx->stream, p);
     } else if (tm == 256 && tn == 256)
         HIVE_CONV_LAUNCH(256, 256);
     else if (tm == 256 && tn == 128)
@@ -445,6 +454,21 @@ int launch_conv(hive_ctx *ctx, const char *what, const void *d_x, int dtype, int
 #undef HIVE_CONV_LAUNCH
     HIVE_CHECK_HIP(ctx, hipGetLastError());
     return HIVE_OK;
+}
+
+// dtype dispatch: HIVE_BF16 (north_star's contract) or HIVE_F16 (the reference's `model.half()`)
+int launch_conv(hive_ctx *ctx, const char *what, const void *d_x, int dtype, int N, int H, int W, int C_in, int C_out, int R, int stride, int pad_t,
+                int pad_l, int Ho, int Wo, const void *d_w, const void *d_bias, int relu, const void *d_residual, const void *d_residual2,
+                void *d_out, void *d_out_relu, void *d_gn_partial = nullptr, long long gn_partial_floats = 0, int *gn_tile_rows = nullptr,
+                const GnMode *gn_mode = nullptr) {
+    if (dtype == HIVE_BF16)
+        return launch_conv_t<__bf16>(ctx, what, d_x, N, H, W, C_in, C_out, R, stride, pad_t, pad_l, Ho, Wo, d_w, d_bias, relu, d_residual, d_residual2, d_out, d_out_relu,
+                                     d_gn_partial, gn_partial_floats, gn_tile_rows, gn_mode);
+    if (dtype == HIVE_F16)
+        return launch_conv_t<_Float16>(ctx, what, d_x, N, H, W, C_in, C_out, R, stride, pad_t, pad_l, Ho, Wo, d_w, d_bias, relu, d_residual, d_residual2, d_out,
+                                       d_out_relu, d_gn_partial, gn_partial_floats, gn_tile_rows, gn_mode);
+    if (gn_tile_rows) *gn_tile_rows = 0;
+    return hive_fail(ctx, HIVE_ERR_INVALID, "%s: dtype must be HIVE_F16 or HIVE_BF16", what);
 }
 
 }  // namespace
@@ -490,7 +514,7 @@ extern "C" int hive_nhwc_conv_gn_apply(hive_ctx *ctx, const void *d_x, int dtype
     HIVE_REQUIRE(ctx, scratch_floats >= partial_floats + 2ll * N * G, "nhwc_conv_gn_apply: scratch holds %lld floats, %lld needed", (long long)scratch_floats,
                  (long long)(partial_floats + 2ll * N * G));
     float *partial = (float *)d_scratch, *stats = partial + partial_floats;
-    ConvParams mode{};
+    GnMode mode;
     mode.stats_only = 1;
     int tile_rows = 0;
     int rc = launch_conv(ctx, "nhwc_conv_gn_apply", d_x, dtype, N, H, W, C_in, C_out, kernel, stride, pad_top, pad_left, H_out, W_out, d_w, nullptr, 0, nullptr,
@@ -501,8 +525,8 @@ extern "C" int hive_nhwc_conv_gn_apply(hive_ctx *ctx, const void *d_x, int dtype
     if (rc) return rc;
     mode.stats_only = 0;
     mode.gn_stats = stats;
-    mode.gn_gamma = (const bf16 *)d_gamma;
-    mode.gn_beta = (const bf16 *)d_beta;
+    mode.gn_gamma = d_gamma;
+    mode.gn_beta = d_beta;
     mode.gn_G = G;
     mode.gn_cpg = C_out / G;
     rc = launch_conv(ctx, "nhwc_conv_gn_apply", d_x, dtype, N, H, W, C_in, C_out, kernel, stride, pad_top, pad_left, H_out, W_out, d_w, nullptr, relu, d_residual,

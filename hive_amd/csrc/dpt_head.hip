@@ -25,12 +25,12 @@
 //     ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ...) each hold 16 different columns of the 2 x 16 pixel block: conflict-free
 //     (with the natural pitch 18 x 272 the two rows of a group overlapped: SQ_LDS_BANK_CONFLICT 26 % of the LDS cycles).
 #include "hive_internal.hpp"
+#include "mfma_pipe.hpp"
 
 #include <algorithm>
 
-typedef __bf16 bf16;
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+using hive_mfma::f32x16;
+using hive_mfma::vec;  // T = __bf16 or _Float16 (the reference's model.half()): v_mfma_f32_32x32x16_{bf16,f16}
 
 namespace {
 
@@ -44,9 +44,10 @@ constexpr int UP_BYTES = UP_H * UP_PITCH;      // 51200, also >= the partial-sum
 constexpr int LO_BYTES = LO_H * LO_W * PIX;    // 20944
 static_assert(UP_W * PIX <= UP_PITCH && UP_PITCH % 256 == 0 && UP_BYTES >= 49152, "upsampled patch layout");
 
+template <typename T>
 struct HeadParams {
-    const bf16 *x;      // [N][H][W][128]
-    const bf16 *w3;     // [9][32][128]  (tap = ky * 3 + kx, output channel, input channel)
+    const T *x;      // [N][H][W][128]
+    const T *w3;     // [9][32][128]  (tap = ky * 3 + kx, output channel, input channel)
     float b3[COUT];     // bias of the 3x3 convolution
     float w1[COUT];     // 1x1 convolution
     const float *b0;    // device, [128]: bias of the convolution that produced x, added on load (or null)
@@ -59,11 +60,13 @@ struct HeadParams {
     float *out_m;       // or null
 };
 
-__device__ __forceinline__ bf16x8 lds_read8(const unsigned char *base, int byte_off) {
-    return *reinterpret_cast<const bf16x8 *>(base + byte_off);
+template <typename T>
+__device__ __forceinline__ vec<T, 8> lds_read8(const unsigned char *base, int byte_off) {
+    return *reinterpret_cast<const vec<T, 8> *>(base + byte_off);
 }
 
-__global__ __launch_bounds__(256, 2) void head_conv_kernel(HeadParams p) {
+template <typename T>
+__global__ __launch_bounds__(256, 2) void head_conv_kernel(HeadParams<T> p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char *up = smem;             // upsampled patch, later the partial-sum exchange
     unsigned char *lo = smem + UP_BYTES;  // low-resolution patch
@@ -76,12 +79,12 @@ __global__ __launch_bounds__(256, 2) void head_conv_kernel(HeadParams p) {
     const float sw = OW > 1 ? (float)(p.W - 1) / (float)(OW - 1) : 0.f;
 
     // this wave's weight fragments: input channels [32 * wave, 32 * wave + 32), lane = (output channel nn, k half hh)
-    bf16x8 wf[9][2];
+    vec<T, 8> wf[9][2];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
-            wf[t][ks] = *reinterpret_cast<const bf16x8 *>(p.w3 + ((size_t)(t * COUT + nn) * CIN + 32 * wave + 16 * ks + 8 * hh));
+            wf[t][ks] = *reinterpret_cast<const vec<T, 8> *>(p.w3 + ((size_t)(t * COUT + nn) * CIN + 32 * wave + 16 * ks + 8 * hh));
     // epilogue constants (bias of the 3x3 convolution, 1x1 weights) live in LDS: 32 registers less in the MFMA loop
     float *tab = reinterpret_cast<float *>(smem + UP_BYTES + LO_BYTES);
     if (tid < COUT) {
@@ -98,17 +101,17 @@ __global__ __launch_bounds__(256, 2) void head_conv_kernel(HeadParams p) {
         // (a) low-resolution patch -> LDS (rows / columns past the image edge are clamped duplicates: exactly what
         // align_corners' i1 = min(i0 + 1, size - 1) reads).  Prefetching it a tile ahead through registers was
         // measured slower (20 more live VGPRs spill in the MFMA phase); the second workgroup of the CU covers the latency.
-        const bf16 *img = p.x + (size_t)n * p.H * p.W * CIN;
+        const T *img = p.x + (size_t)n * p.H * p.W * CIN;
         for (int item = tid; item < LO_H * LO_W * 16; item += 256) {
             const int v = item & 15, q = item >> 4;
             const int gy = min(lo_y0 + q / LO_W, p.H - 1), gx = min(lo_x0 + q % LO_W, p.W - 1);
             uint4 raw = *reinterpret_cast<const uint4 *>(img + ((size_t)gy * p.W + gx) * CIN + v * 8);
             if (p.b0) {  // x + bias rounded to bf16, as the separate bias add of the unfused network rounds it
-                bf16x8 xv = *reinterpret_cast<const bf16x8 *>(&raw);
+                vec<T, 8> xv = *reinterpret_cast<const vec<T, 8> *>(&raw);
                 const float4 ba = *reinterpret_cast<const float4 *>(p.b0 + v * 8), bb = *reinterpret_cast<const float4 *>(p.b0 + v * 8 + 4);
                 const float bias8[8] = {ba.x, ba.y, ba.z, ba.w, bb.x, bb.y, bb.z, bb.w};
 #pragma unroll
-                for (int j = 0; j < 8; ++j) xv[j] = (bf16)((float)xv[j] + bias8[j]);
+                for (int j = 0; j < 8; ++j) xv[j] = (T)((float)xv[j] + bias8[j]);
                 raw = *reinterpret_cast<const uint4 *>(&xv);
             }
             *reinterpret_cast<uint4 *>(lo + q * PIX + v * 16) = raw;
@@ -136,13 +139,13 @@ __global__ __launch_bounds__(256, 2) void head_conv_kernel(HeadParams p) {
             }
             float ta[8], tb[8];
             {
-                const bf16x8 a0 = lds_read8(lo, c0), a1 = lds_read8(lo, c1);
+                const vec<T, 8> a0 = lds_read8<T>(lo, c0), a1 = lds_read8<T>(lo, c1);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) ta[j] = w0 * (float)a0[j] + w1 * (float)a1[j];
             }
 #pragma unroll
             for (int r = 0; r < LO_H - 1; ++r) {  // low-resolution rows r, r + 1 (clamped duplicates past the image edge)
-                const bf16x8 a0 = lds_read8(lo, (r + 1) * LO_W * PIX + c0), a1 = lds_read8(lo, (r + 1) * LO_W * PIX + c1);
+                const vec<T, 8> a0 = lds_read8<T>(lo, (r + 1) * LO_W * PIX + c0), a1 = lds_read8<T>(lo, (r + 1) * LO_W * PIX + c1);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) tb[j] = w0 * (float)a0[j] + w1 * (float)a1[j];
                 while (uy < UP_H && R0 + uy < OH) {  // the output rows whose upper source row is r: at most three
@@ -152,9 +155,9 @@ __global__ __launch_bounds__(256, 2) void head_conv_kernel(HeadParams p) {
                     const float h1 = fy - (float)y0, h0 = 1.f - h1;
                     uint4 packed = zero;
                     if (col_ok) {
-                        bf16x8 o;
+                        vec<T, 8> o;
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) o[j] = (bf16)(h0 * ta[j] + h1 * tb[j]);
+                        for (int j = 0; j < 8; ++j) o[j] = (T)(h0 * ta[j] + h1 * tb[j]);
                         packed = *reinterpret_cast<const uint4 *>(&o);
                     }
                     *reinterpret_cast<uint4 *>(dst + uy * UP_PITCH) = packed;
@@ -183,13 +186,13 @@ __global__ __launch_bounds__(256, 2) void head_conv_kernel(HeadParams p) {
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
-                    const bf16x8 xf = lds_read8(up, pix_base + tap_off + 2 * m * UP_PITCH + ks * 32);
-                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[t][ks], xf, acc[m], 0, 0, 0);
+                    const vec<T, 8> xf = lds_read8<T>(up, pix_base + tap_off + 2 * m * UP_PITCH + ks * 32);
+                    acc[m] = hive_mfma::mfma32(wf[t][ks], xf, acc[m]);
                 }
         }
         __syncthreads();  // every wave is done reading the patch: its space becomes the exchange buffer
         // (d) wave w owns pixel tile w: the other three waves hand it their channel-partial sums
-        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        typedef hive_mfma::f32x4 f32x4;
         f32x4 *part = reinterpret_cast<f32x4 *>(up);
 #pragma unroll
         for (int m = 0; m < 4; ++m)
@@ -233,22 +236,12 @@ __global__ __launch_bounds__(256, 2) void head_conv_kernel(HeadParams p) {
     }
 }
 
-}  // namespace
-
-extern "C" int hive_dpt_head_fused(hive_ctx *ctx, const void *d_x, const float *d_b0, int dtype, int N, int H, int W, int C_in, int C_mid,
-                                   const void *d_w3, const float *h_b3, const float *h_w1, float b1, int non_negative, int invert,
-                                   float scale, float shift, float *d_depth, float depth_scale, float max_depth,
-                                   uint16_t *d_out_mm, float *d_out_m) {
-    HIVE_ENTER(ctx);
-    if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
-    HIVE_REQUIRE(ctx, d_x && d_w3 && h_b3 && h_w1, "dpt_head_fused: NULL argument");
-    HIVE_REQUIRE(ctx, dtype == HIVE_BF16, "dpt_head_fused: bf16 only (use hive_dpt_head_tail behind a library convolution for f16)");
-    HIVE_REQUIRE(ctx, C_in == CIN && C_mid == COUT, "dpt_head_fused: built for 128 -> 32 channels, got %d -> %d", C_in, C_mid);
-    HIVE_REQUIRE(ctx, N > 0 && H > 1 && W > 1 && (long long)N * H * W < (1ll << 28), "dpt_head_fused: bad shape N=%d H=%d W=%d", N, H, W);
-    HIVE_REQUIRE(ctx, d_depth || d_out_mm || d_out_m, "dpt_head_fused: no output requested");
-    HeadParams p;
-    p.x = (const bf16 *)d_x;
-    p.w3 = (const bf16 *)d_w3;
+template <typename T>
+int launch_head(hive_ctx *ctx, const void *d_x, const float *d_b0, int N, int H, int W, const void *d_w3, const float *h_b3, const float *h_w1, float b1,
+                int non_negative, int invert, float scale, float shift, float *d_depth, float depth_scale, float max_depth, uint16_t *d_out_mm, float *d_out_m) {
+    HeadParams<T> p;
+    p.x = (const T *)d_x;
+    p.w3 = (const T *)d_w3;
     p.b0 = d_b0;
     for (int i = 0; i < COUT; ++i) {
         p.b3[i] = h_b3[i];
@@ -270,12 +263,30 @@ extern "C" int hive_dpt_head_fused(hive_ctx *ctx, const void *d_x, const float *
     static bool attr_set[64] = {};
     const int lds = UP_BYTES + LO_BYTES + 2 * COUT * (int)sizeof(float);
     if (ctx->device >= 64 || !attr_set[ctx->device]) {
-        HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)head_conv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)head_conv_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         if (ctx->device < 64) attr_set[ctx->device] = true;
     }
     const long long tiles = (long long)N * ((2 * H + TH - 1) / TH) * ((2 * W + TW - 1) / TW);
     const dim3 grid((unsigned)std::min<long long>(tiles, (long long)ctx->num_cus * 2));
-    hipLaunchKernelGGL(head_conv_kernel, grid, dim3(256), lds, ctx->stream, p);
+    hipLaunchKernelGGL(head_conv_kernel<T>, grid, dim3(256), lds, ctx->stream, p);
     HIVE_CHECK_HIP(ctx, hipGetLastError());
     return HIVE_OK;
+}
+
+}  // namespace
+
+extern "C" int hive_dpt_head_fused(hive_ctx *ctx, const void *d_x, const float *d_b0, int dtype, int N, int H, int W, int C_in, int C_mid,
+                                   const void *d_w3, const float *h_b3, const float *h_w1, float b1, int non_negative, int invert,
+                                   float scale, float shift, float *d_depth, float depth_scale, float max_depth,
+                                   uint16_t *d_out_mm, float *d_out_m) {
+    HIVE_ENTER(ctx);
+    if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
+    HIVE_REQUIRE(ctx, d_x && d_w3 && h_b3 && h_w1, "dpt_head_fused: NULL argument");
+    HIVE_REQUIRE(ctx, dtype == HIVE_BF16 || dtype == HIVE_F16, "dpt_head_fused: dtype must be HIVE_F16 or HIVE_BF16");
+    HIVE_REQUIRE(ctx, C_in == CIN && C_mid == COUT, "dpt_head_fused: built for 128 -> 32 channels, got %d -> %d", C_in, C_mid);
+    HIVE_REQUIRE(ctx, N > 0 && H > 1 && W > 1 && (long long)N * H * W < (1ll << 28), "dpt_head_fused: bad shape N=%d H=%d W=%d", N, H, W);
+    HIVE_REQUIRE(ctx, d_depth || d_out_mm || d_out_m, "dpt_head_fused: no output requested");
+    if (dtype == HIVE_BF16)
+        return launch_head<__bf16>(ctx, d_x, d_b0, N, H, W, d_w3, h_b3, h_w1, b1, non_negative, invert, scale, shift, d_depth, depth_scale, max_depth, d_out_mm, d_out_m);
+    return launch_head<_Float16>(ctx, d_x, d_b0, N, H, W, d_w3, h_b3, h_w1, b1, non_negative, invert, scale, shift, d_depth, depth_scale, max_depth, d_out_mm, d_out_m);
 }

@@ -15,40 +15,50 @@
 #include <map>
 #include <string>
 
-typedef __bf16 bf16;
+typedef unsigned short half_t;  // an element of either 16-bit type (HIVE_BF16 / HIVE_F16): the host side only sizes and offsets buffers
 
 namespace {
 
-// tokens[b][0] = cls + pos[0];  tokens[b][1 + i] = patch[b][i] + pos[1 + i]   (bf16, D % 8 == 0; the adds in float, one rounding)
-__global__ __launch_bounds__(256) void assemble_tokens_kernel(const bf16 *__restrict__ patch, const bf16 *__restrict__ cls, const bf16 *__restrict__ pos,
-                                                              bf16 *__restrict__ tokens, int B, int n_patch, int D) {
+// tokens[b][0] = cls + pos[0];  tokens[b][1 + i] = patch[b][i] + pos[1 + i]   (T = __bf16 or _Float16, D % 8 == 0; the adds in float, one rounding)
+template <typename T>
+__global__ __launch_bounds__(256) void assemble_tokens_kernel(const T *__restrict__ patch, const T *__restrict__ cls, const T *__restrict__ pos,
+                                                              T *__restrict__ tokens, int B, int n_patch, int D) {
     const int dv = D / 8;
     const long long total = (long long)B * (n_patch + 1) * dv;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int c = (int)(i % dv) * 8;
         const long long row = i / dv;
         const int t = (int)(row % (n_patch + 1)), b = (int)(row / (n_patch + 1));
-        const bf16 *src = t == 0 ? cls + c : patch + ((size_t)b * n_patch + (t - 1)) * D + c;
+        const T *src = t == 0 ? cls + c : patch + ((size_t)b * n_patch + (t - 1)) * D + c;
         const uint4 ra = *reinterpret_cast<const uint4 *>(src), rp = *reinterpret_cast<const uint4 *>(pos + (size_t)t * D + c);
-        const bf16 *a = reinterpret_cast<const bf16 *>(&ra), *p = reinterpret_cast<const bf16 *>(&rp);
-        bf16 o[8];
+        const T *a = reinterpret_cast<const T *>(&ra), *p = reinterpret_cast<const T *>(&rp);
+        T o[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (bf16)((float)a[j] + (float)p[j]);
+        for (int j = 0; j < 8; ++j) o[j] = (T)((float)a[j] + (float)p[j]);
         *reinterpret_cast<uint4 *>(tokens + (size_t)row * D + c) = *reinterpret_cast<const uint4 *>(o);
     }
 }
 
-// "project" readout input: out[b][i] = concat(tokens[b][1 + i], tokens[b][0])  -> [B * n_patch][2 D]
-__global__ __launch_bounds__(256) void readout_concat_kernel(const bf16 *__restrict__ tokens, bf16 *__restrict__ out, int B, int n_patch, int D) {
+// "project" readout input: out[b][i] = concat(tokens[b][1 + i], tokens[b][0])  -> [B * n_patch][2 D]   (16-byte copies: either 16-bit type)
+__global__ __launch_bounds__(256) void readout_concat_kernel(const half_t *__restrict__ tokens, half_t *__restrict__ out, int B, int n_patch, int D) {
     const int dv = D / 8;
     const long long total = (long long)B * n_patch * 2 * dv;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int c = (int)(i % (2 * dv));
         const long long row = i / (2 * dv);
         const int b = (int)(row / n_patch), t = (int)(row % n_patch);
-        const bf16 *src = c < dv ? tokens + ((size_t)b * (n_patch + 1) + 1 + t) * D + c * 8 : tokens + (size_t)b * (n_patch + 1) * D + (c - dv) * 8;
+        const half_t *src = c < dv ? tokens + ((size_t)b * (n_patch + 1) + 1 + t) * D + c * 8 : tokens + (size_t)b * (n_patch + 1) * D + (c - dv) * 8;
         *reinterpret_cast<uint4 *>(out + (size_t)row * 2 * D + c * 8) = *reinterpret_cast<const uint4 *>(src);
     }
+}
+
+void launch_assemble_tokens(hive_ctx *ctx, int dtype, int blocks, const void *patch, const void *cls, const void *pos, void *tokens, int B, int n_patch, int D) {
+    if (dtype == HIVE_BF16)
+        hipLaunchKernelGGL(assemble_tokens_kernel<__bf16>, dim3(blocks), dim3(256), 0, ctx->stream, (const __bf16 *)patch, (const __bf16 *)cls, (const __bf16 *)pos,
+                           (__bf16 *)tokens, B, n_patch, D);
+    else
+        hipLaunchKernelGGL(assemble_tokens_kernel<_Float16>, dim3(blocks), dim3(256), 0, ctx->stream, (const _Float16 *)patch, (const _Float16 *)cls,
+                           (const _Float16 *)pos, (_Float16 *)tokens, B, n_patch, D);
 }
 
 }  // namespace
@@ -66,9 +76,9 @@ struct hive_dpt {
         auto it = w.find(name);
         return it == w.end() ? nullptr : it->second;
     }
-    bf16 *alloc(size_t elems) {  // bump allocation in the activation arena (sized by a dry run before the first launch)
-        const size_t bytes = (elems * sizeof(bf16) + 255) & ~(size_t)255;
-        bf16 *p = arena ? (bf16 *)((char *)arena + arena_used) : nullptr;
+    half_t *alloc(size_t elems) {  // bump allocation in the activation arena (sized by a dry run before the first launch)
+        const size_t bytes = (elems * sizeof(half_t) + 255) & ~(size_t)255;
+        half_t *p = arena ? (half_t *)((char *)arena + arena_used) : nullptr;
         arena_used += bytes;
         return p;
     }
@@ -77,7 +87,7 @@ struct hive_dpt {
 namespace {
 
 struct Map {  // a channels-last activation [N][H][W][C]
-    bf16 *p;
+    half_t *p;
     int H, W, C;
     float *gn = nullptr;  // GroupNorm statistics of the tensor, per tile of gn_tm rows, left by the convolution that wrote it
     int gn_tm = 0;        // (hive_nhwc_conv_gn); 0: none, the GroupNorm makes its own pass
@@ -93,6 +103,7 @@ struct Map {  // a channels-last activation [N][H][W][C]
 int run_forward(hive_dpt *d, bool dry, const uint8_t *d_rgb, int B, int H, int W, const void *d_pos, float *d_depth, float max_depth,
                 uint16_t *d_mm, float *d_m) {
     hive_ctx *ctx = d->ctx;
+    const int dt = d->cfg.dtype;
     const std::string bb = "pretrained.model.patch_embed.backbone.";
     auto need = [&](const std::string &n, const void **out) -> int {
         *out = d->get(n);
@@ -100,8 +111,8 @@ int run_forward(hive_dpt *d, bool dry, const uint8_t *d_rgb, int B, int H, int W
         return HIVE_OK;
     };
     auto same_out = [](int i, int s) { return (i + s - 1) / s; };
-    auto conv = [&](const Map &x, const std::string &wname, const char *bias_name, int cout, int k, int stride, bool same_pad, int relu, const bf16 *res1,
-                    const bf16 *res2, bool want_relu_copy, Map *out, Map *out_relu, bool gn_stats = false) -> int {
+    auto conv = [&](const Map &x, const std::string &wname, const char *bias_name, int cout, int k, int stride, bool same_pad, int relu, const half_t *res1,
+                    const half_t *res2, bool want_relu_copy, Map *out, Map *out_relu, bool gn_stats = false) -> int {
         int pt, pl, oh, ow;
         if (same_pad) {  // timm StdConv2dSame: TensorFlow "SAME", the odd pixel at the bottom / right
             oh = same_out(x.H, stride);
@@ -122,13 +133,13 @@ int run_forward(hive_dpt *d, bool dry, const uint8_t *d_rgb, int B, int H, int W
         DPT_TRY(need(wname, &wp));
         if (bias_name) DPT_TRY(need(bias_name, &bp));
         if (gn_stats)  // the ResNetV2 convolutions: the GroupNorm behind each gets its statistics from this epilogue
-            return hive_nhwc_conv_gn(ctx, x.p, HIVE_BF16, B, x.H, x.W, x.C, cout, k, stride, pt, pl, oh, ow, wp, bp, relu, res1, res2, out->p,
+            return hive_nhwc_conv_gn(ctx, x.p, dt, B, x.H, x.W, x.C, cout, k, stride, pt, pl, oh, ow, wp, bp, relu, res1, res2, out->p,
                                      out_relu ? out_relu->p : nullptr, out->gn, gn_floats, &out->gn_tm);
-        return hive_nhwc_conv(ctx, x.p, HIVE_BF16, B, x.H, x.W, x.C, cout, k, stride, pt, pl, oh, ow, wp, bp, relu, res1, res2, out->p,
+        return hive_nhwc_conv(ctx, x.p, dt, B, x.H, x.W, x.C, cout, k, stride, pt, pl, oh, ow, wp, bp, relu, res1, res2, out->p,
                               out_relu ? out_relu->p : nullptr);
     };
     // conv + GroupNorm (+ shortcut + ReLU) of a bottleneck's expanding 1 x 1 convolutions as the two-pass operation; falls back to the pair
-    auto conv_norm = [&](const Map &x, const std::string &wname, const std::string &norm_prefix, int cout, int stride, const bf16 *residual, int relu,
+    auto conv_norm = [&](const Map &x, const std::string &wname, const std::string &norm_prefix, int cout, int stride, const half_t *residual, int relu,
                          Map *out) -> int {
         const int oh = same_out(x.H, stride), ow = same_out(x.W, stride);
         const int64_t scratch_floats = hive_nhwc_conv_gn_partial_floats((int64_t)B * oh * ow, cout) + 2ll * B * 32;
@@ -142,38 +153,38 @@ int run_forward(hive_dpt *d, bool dry, const uint8_t *d_rgb, int B, int H, int W
         DPT_TRY(need(norm_prefix + ".weight", &g));
         DPT_TRY(need(norm_prefix + ".bias", &b));
         int fused = 0;
-        DPT_TRY(hive_nhwc_conv_gn_apply(ctx, x.p, HIVE_BF16, B, x.H, x.W, x.C, cout, 1, stride, 0, 0, oh, ow, wp, 32, g, b, d->cfg.gn_eps, residual, relu, out->p,
+        DPT_TRY(hive_nhwc_conv_gn_apply(ctx, x.p, dt, B, x.H, x.W, x.C, cout, 1, stride, 0, 0, oh, ow, wp, 32, g, b, d->cfg.gn_eps, residual, relu, out->p,
                                         scratch, scratch_floats, &fused));
         if (fused) return HIVE_OK;
         if (eligible) return hive_fail(ctx, HIVE_ERR_INVALID, "hive_dpt: conv + GroupNorm of '%s' was not fused", wname.c_str());
-        DPT_TRY(hive_nhwc_conv_gn(ctx, x.p, HIVE_BF16, B, x.H, x.W, x.C, cout, 1, stride, 0, 0, oh, ow, wp, nullptr, 0, nullptr, nullptr, t.p, nullptr, scratch,
+        DPT_TRY(hive_nhwc_conv_gn(ctx, x.p, dt, B, x.H, x.W, x.C, cout, 1, stride, 0, 0, oh, ow, wp, nullptr, 0, nullptr, nullptr, t.p, nullptr, scratch,
                                   scratch_floats, &t.gn_tm));
-        return hive_nhwc_group_norm_stats(ctx, t.p, HIVE_BF16, B, oh * ow, cout, 32, g, b, d->cfg.gn_eps, residual, relu, out->p, scratch, t.gn_tm);
+        return hive_nhwc_group_norm_stats(ctx, t.p, dt, B, oh * ow, cout, 32, g, b, d->cfg.gn_eps, residual, relu, out->p, scratch, t.gn_tm);
     };
-    auto group_norm = [&](const Map &x, const std::string &prefix, const bf16 *residual, int relu, Map *out) -> int {
+    auto group_norm = [&](const Map &x, const std::string &prefix, const half_t *residual, int relu, Map *out) -> int {
         *out = Map{d->alloc((size_t)B * x.H * x.W * x.C), x.H, x.W, x.C};
         if (dry) return HIVE_OK;
         const void *g, *b;
         DPT_TRY(need(prefix + ".weight", &g));
         DPT_TRY(need(prefix + ".bias", &b));
-        return hive_nhwc_group_norm_stats(ctx, x.p, HIVE_BF16, B, x.H * x.W, x.C, 32, g, b, d->cfg.gn_eps, residual, relu, out->p, x.gn, x.gn_tm);
+        return hive_nhwc_group_norm_stats(ctx, x.p, dt, B, x.H * x.W, x.C, 32, g, b, d->cfg.gn_eps, residual, relu, out->p, x.gn, x.gn_tm);
     };
 
     Map layer_1, layer_2, layer_3, layer_4;
     auto hybrid_backbone = [&]() -> int {
         // ---- pre-processing + ResNetV2 stem -----------------------------------------------------------------------------------
-        bf16 *xin = d->alloc((size_t)B * H * W * 3);
+        half_t *xin = d->alloc((size_t)B * H * W * 3);
         Map s0{d->alloc((size_t)B * same_out(H, 2) * same_out(W, 2) * 64), same_out(H, 2), same_out(W, 2), 64};
         if (!dry) {
-            DPT_TRY(hive_dpt_preprocess(ctx, d_rgb, (int64_t)B * H * W * 3, 0.5f, 0.5f, HIVE_BF16, xin));
+            DPT_TRY(hive_dpt_preprocess(ctx, d_rgb, (int64_t)B * H * W * 3, 0.5f, 0.5f, dt, xin));
             const void *sw;
             DPT_TRY(need(bb + "stem.conv.weight", &sw));
-            DPT_TRY(hive_resnet_stem_conv(ctx, xin, HIVE_BF16, B, H, W, sw, s0.p));
+            DPT_TRY(hive_resnet_stem_conv(ctx, xin, dt, B, H, W, sw, s0.p));
         }
         Map s1, feat;
         DPT_TRY(group_norm(s0, bb + "stem.norm", nullptr, 1, &s1));
         feat = Map{d->alloc((size_t)B * same_out(s1.H, 2) * same_out(s1.W, 2) * 64), same_out(s1.H, 2), same_out(s1.W, 2), 64};
-        if (!dry) DPT_TRY(hive_nhwc_maxpool3x3s2(ctx, s1.p, HIVE_BF16, B, s1.H, s1.W, 64, feat.p));
+        if (!dry) DPT_TRY(hive_nhwc_maxpool3x3s2(ctx, s1.p, dt, B, s1.H, s1.W, 64, feat.p));
 
         // ---- ResNetV2 stages: non pre-activation bottlenecks, GroupNorm behind every convolution ------------------------------
         const int depths[3] = {3, 4, 9}, chans[3] = {256, 512, 1024};
@@ -200,20 +211,19 @@ int run_forward(hive_dpt *d, bool dry, const uint8_t *d_rgb, int B, int H, int W
         Map pe;
         DPT_TRY(conv(feat, "pretrained.model.patch_embed.proj.weight", "pretrained.model.patch_embed.proj.bias", D, 1, 1, false, 0, nullptr, nullptr, false, &pe,
                      nullptr));
-        bf16 *tokens = d->alloc((size_t)B * N * D), *tap3 = d->alloc((size_t)B * N * D), *tap4 = d->alloc((size_t)B * N * D);
-        bf16 *cat = d->alloc((size_t)B * n_patch * 2 * D);
+        half_t *tokens = d->alloc((size_t)B * N * D), *tap3 = d->alloc((size_t)B * N * D), *tap4 = d->alloc((size_t)B * N * D);
+        half_t *cat = d->alloc((size_t)B * n_patch * 2 * D);
         Map map3{d->alloc((size_t)B * n_patch * D), gh, gw, D}, map4{d->alloc((size_t)B * n_patch * D), gh, gw, D};
         if (!dry) {
             const void *cls;
             DPT_TRY(need("pretrained.model.cls_token", &cls));
             const int blocks = (int)std::min<long long>(((long long)B * N * D / 8 + 255) / 256, (long long)ctx->num_cus * 16);
-            hipLaunchKernelGGL(assemble_tokens_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const bf16 *)pe.p, (const bf16 *)cls, (const bf16 *)d_pos, tokens, B,
-                               n_patch, D);
+            launch_assemble_tokens(ctx, dt, blocks, pe.p, cls, d_pos, tokens, B, n_patch, D);
             HIVE_CHECK_HIP(ctx, hipGetLastError());
             const int taps[2] = {8, 11};
             void *tap_out[2] = {tap3, tap4};
             DPT_TRY(hive_vit_forward(d->vit, tokens, B, N, taps, 2, tap_out));
-            const bf16 *tap[2] = {tap3, tap4};
+            const half_t *tap[2] = {tap3, tap4};
             Map *maps[2] = {&map3, &map4};
             for (int r = 0; r < 2; ++r) {
                 hipLaunchKernelGGL(readout_concat_kernel, dim3(blocks), dim3(256), 0, ctx->stream, tap[r], cat, B, n_patch, D);
@@ -222,7 +232,7 @@ int run_forward(hive_dpt *d, bool dry, const uint8_t *d_rgb, int B, int H, int W
                 const void *rw, *rb;
                 DPT_TRY(need(pre + "weight", &rw));
                 DPT_TRY(need(pre + "bias", &rb));  // float32
-                DPT_TRY(hive_vit_linear(ctx, cat, rw, (const float *)rb, nullptr, maps[r]->p, B * n_patch, D, 2 * D, 1 /* GELU */));
+                DPT_TRY(hive_vit_linear(ctx, cat, dt, rw, (const float *)rb, nullptr, maps[r]->p, B * n_patch, D, 2 * D, 1 /* GELU */));
             }
         }
         Map t4;
@@ -236,37 +246,36 @@ int run_forward(hive_dpt *d, bool dry, const uint8_t *d_rgb, int B, int H, int W
     // readouts -> reassemble: 1x1 (+ ConvTranspose 4x4/4 | ConvTranspose 2x2/2 | nothing | 3x3/2) to 256 / 512 / 1024 / 1024 channels
     auto large_backbone = [&]() -> int {
         const int D = 1024, gh = H / 16, gw = W / 16, n_patch = gh * gw, N = n_patch + 1;
-        bf16 *xin = d->alloc((size_t)B * H * W * 3), *cols = d->alloc((size_t)B * n_patch * 768), *pe = d->alloc((size_t)B * n_patch * D);
-        bf16 *tokens = d->alloc((size_t)B * N * D), *cat = d->alloc((size_t)B * n_patch * 2 * D);
-        bf16 *tapb[4];
+        half_t *xin = d->alloc((size_t)B * H * W * 3), *cols = d->alloc((size_t)B * n_patch * 768), *pe = d->alloc((size_t)B * n_patch * D);
+        half_t *tokens = d->alloc((size_t)B * N * D), *cat = d->alloc((size_t)B * n_patch * 2 * D);
+        half_t *tapb[4];
         Map maps[4];
         for (int r = 0; r < 4; ++r) {
             tapb[r] = d->alloc((size_t)B * N * D);
             maps[r] = Map{d->alloc((size_t)B * n_patch * D), gh, gw, D};
         }
         if (!dry) {
-            DPT_TRY(hive_dpt_preprocess(ctx, d_rgb, (int64_t)B * H * W * 3, 0.5f, 0.5f, HIVE_BF16, xin));
-            DPT_TRY(hive_patch_rows(ctx, xin, HIVE_BF16, B, H, W, 3, 16, cols));
+            DPT_TRY(hive_dpt_preprocess(ctx, d_rgb, (int64_t)B * H * W * 3, 0.5f, 0.5f, dt, xin));
+            DPT_TRY(hive_patch_rows(ctx, xin, dt, B, H, W, 3, 16, cols));
             const void *pw, *pb, *cls;
             DPT_TRY(need("pretrained.model.patch_embed.proj.weight", &pw));    // [D][16][16][3] = [D][768]
             DPT_TRY(need("pretrained.model.patch_embed.proj.bias.f32", &pb));
             DPT_TRY(need("pretrained.model.cls_token", &cls));
-            DPT_TRY(hive_vit_linear(ctx, cols, pw, (const float *)pb, nullptr, pe, B * n_patch, D, 768, 0));
+            DPT_TRY(hive_vit_linear(ctx, cols, dt, pw, (const float *)pb, nullptr, pe, B * n_patch, D, 768, 0));
             const int blocks = (int)std::min<long long>(((long long)B * N * D / 8 + 255) / 256, (long long)ctx->num_cus * 16);
-            hipLaunchKernelGGL(assemble_tokens_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const bf16 *)pe, (const bf16 *)cls, (const bf16 *)d_pos, tokens, B,
-                               n_patch, D);
+            launch_assemble_tokens(ctx, dt, blocks, pe, cls, d_pos, tokens, B, n_patch, D);
             HIVE_CHECK_HIP(ctx, hipGetLastError());
             const int taps[4] = {5, 11, 17, 23};
             void *tap_out[4] = {tapb[0], tapb[1], tapb[2], tapb[3]};
             DPT_TRY(hive_vit_forward(d->vit, tokens, B, N, taps, 4, tap_out));
             for (int r = 0; r < 4; ++r) {
-                hipLaunchKernelGGL(readout_concat_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const bf16 *)tapb[r], cat, B, n_patch, D);
+                hipLaunchKernelGGL(readout_concat_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const half_t *)tapb[r], cat, B, n_patch, D);
                 HIVE_CHECK_HIP(ctx, hipGetLastError());
                 const std::string pre = "pretrained.act_postprocess" + std::to_string(r + 1) + ".0.project.0.";
                 const void *rw, *rb;
                 DPT_TRY(need(pre + "weight", &rw));
                 DPT_TRY(need(pre + "bias", &rb));  // float32
-                DPT_TRY(hive_vit_linear(ctx, cat, rw, (const float *)rb, nullptr, maps[r].p, B * n_patch, D, 2 * D, 1 /* GELU */));
+                DPT_TRY(hive_vit_linear(ctx, cat, dt, rw, (const float *)rb, nullptr, maps[r].p, B * n_patch, D, 2 * D, 1 /* GELU */));
             }
         }
         // ConvTranspose2d(C, C, s, s) = 1 x 1 convolution to s s C channels ((dy, dx, co) rows of the re-laid-out weight) + scatter + bias
@@ -277,8 +286,8 @@ int run_forward(hive_dpt *d, bool dry, const uint8_t *d_rgb, int B, int H, int W
             const void *wr, *bias;
             DPT_TRY(need(prefix + ".weight.rows", &wr));
             DPT_TRY(need(prefix + ".bias", &bias));
-            DPT_TRY(hive_nhwc_conv(ctx, x.p, HIVE_BF16, B, x.H, x.W, x.C, s_ * s_ * x.C, 1, 1, 0, 0, x.H, x.W, wr, nullptr, 0, nullptr, nullptr, tmp.p, nullptr));
-            return hive_nhwc_pixel_shuffle_bias(ctx, tmp.p, bias, HIVE_BF16, B, x.H, x.W, x.C, s_, out->p);
+            DPT_TRY(hive_nhwc_conv(ctx, x.p, dt, B, x.H, x.W, x.C, s_ * s_ * x.C, 1, 1, 0, 0, x.H, x.W, wr, nullptr, 0, nullptr, nullptr, tmp.p, nullptr));
+            return hive_nhwc_pixel_shuffle_bias(ctx, tmp.p, bias, dt, B, x.H, x.W, x.C, s_, out->p);
         };
         const std::string pp = "pretrained.act_postprocess";
         Map t;
@@ -311,7 +320,7 @@ int run_forward(hive_dpt *d, bool dry, const uint8_t *d_rgb, int B, int H, int W
         if (dry) return HIVE_OK;
         const void *ob;
         DPT_TRY(need(pre + "out_conv.bias", &ob));
-        return hive_nhwc_upsample2x(ctx, low.p, ob, HIVE_BF16, B, low.H, low.W, 256, out->p);
+        return hive_nhwc_upsample2x(ctx, low.p, ob, dt, B, low.H, low.W, 256, out->p);
     };
     const Map *layers[4] = {&layer_1, &layer_2, &layer_3, &layer_4};
     Map path{}, prev{};
@@ -329,7 +338,7 @@ int run_forward(hive_dpt *d, bool dry, const uint8_t *d_rgb, int B, int H, int W
     const void *w3;
     DPT_TRY(need("scratch.output_conv.2.weight", &w3));  // [ky][kx][32][128]
     HIVE_REQUIRE(ctx, 2 * lo.H == H && 2 * lo.W == W, "hive_dpt: frame size %d x %d must be a multiple of 32", H, W);
-    return hive_dpt_head_fused(ctx, lo.p, d->d_head_b0, HIVE_BF16, B, lo.H, lo.W, 128, 32, w3, d->cfg.head_b3, d->cfg.head_w1, d->cfg.head_b1,
+    return hive_dpt_head_fused(ctx, lo.p, d->d_head_b0, dt, B, lo.H, lo.W, 128, 32, w3, d->cfg.head_b3, d->cfg.head_w1, d->cfg.head_b1,
                                d->cfg.non_negative, d->cfg.invert, d->cfg.scale, d->cfg.shift, d_depth, 1.0f / 1000.0f, max_depth, d_mm, d_m);
 }
 
@@ -342,6 +351,8 @@ int hive_dpt_create(hive_ctx *ctx, const hive_dpt_config *config, const hive_dpt
     if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
     HIVE_REQUIRE(ctx, config && tensors && n_tensors > 0 && out, "hive_dpt_create: NULL argument");
     HIVE_REQUIRE(ctx, config->backbone == 0 || config->backbone == 1, "hive_dpt_create: backbone %d (0 = vitb_rn50_384, 1 = vitl16_384)", config->backbone);
+    HIVE_REQUIRE(ctx, config->dtype == HIVE_BF16 || config->dtype == HIVE_F16, "hive_dpt_create: dtype %d (HIVE_F16 = %d or HIVE_BF16 = %d)", config->dtype, (int)HIVE_F16,
+                 (int)HIVE_BF16);
     const int vit_depth = config->backbone == 0 ? 12 : 24, vit_dim = config->backbone == 0 ? 768 : 1024, vit_heads = vit_dim / 64;
     *out = nullptr;
     hive_dpt *d = new hive_dpt();
@@ -365,7 +376,7 @@ int hive_dpt_create(hive_ctx *ctx, const hive_dpt_config *config, const hive_dpt
             }
         }
     }
-    int rc = hive_vit_create(ctx, vit_depth, vit_dim, vit_heads, 4 * vit_dim, config->ln_eps, blocks.data(), &d->vit);
+    int rc = hive_vit_create(ctx, config->dtype, vit_depth, vit_dim, vit_heads, 4 * vit_dim, config->ln_eps, blocks.data(), &d->vit);
     const void *b0 = d->get("scratch.output_conv.0.bias.f32");
     if (!rc && !b0) rc = hive_fail(ctx, HIVE_ERR_INVALID, "hive_dpt_create: tensor 'scratch.output_conv.0.bias.f32' missing from the table");
     if (rc) {

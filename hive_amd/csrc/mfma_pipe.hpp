@@ -1,5 +1,7 @@
-// One 64-deep K-step of the bf16 MFMA tile kernels (csrc/vit.hip GEMMs, csrc/conv.hip), shared so that the schedule that was
-// measured once is the schedule everywhere.  gfx950 only.
+// One 64-deep K-step of the 16-bit MFMA tile kernels (csrc/vit.hip GEMMs, csrc/conv.hip), shared so that the schedule that was
+// measured once is the schedule everywhere.  gfx950 only.  The element type T is __bf16 (north_star's contract) or _Float16 (what the
+// reference runs: `model.half()`, /root/reference/hive/dataset_adaptors.py:1394-1401): v_mfma_f32_16x16x32_{bf16,f16} have the same
+// shape, operand layout and rate, so one schedule serves both; only the instruction and the epilogue's conversion differ.
 //
 // A wave owns MT x 4 accumulators of 16 x 16 (MT fragments along the A rows, 4 along the W rows); operands sit in LDS as
 // 128-byte rows with the source-side chunk swizzle (swz).  The step is 2 MT "slots" (sub-step of 32 k, A fragment) of 4
@@ -17,8 +19,16 @@
 
 namespace hive_mfma {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+template <typename T, int N>
+using vec = T __attribute__((ext_vector_type(N)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// acc += A . B^T on one 16 x 16 (k = 32) or 32 x 32 (k = 16) tile; 8 elements of T per lane and operand
+__device__ __forceinline__ f32x4 mfma16(vec<__bf16, 8> a, vec<__bf16, 8> b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4 mfma16(vec<_Float16, 8> a, vec<_Float16, 8> b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x16 mfma32(vec<__bf16, 8> a, vec<__bf16, 8> b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x16 mfma32(vec<_Float16, 8> a, vec<_Float16, 8> b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 
 // byte offset of 16-byte chunk `c` (0..7) of row `r` in a tile with 128-byte rows: the chunk is XORed with (r >> 1) & 7 so that
 // any 16 consecutive rows at one chunk index land on 16 distinct 16-byte slots
@@ -26,15 +36,16 @@ __device__ __forceinline__ int swz(int r, int c) { return r * 128 + ((c ^ ((r >>
 
 // SWAP = false: acc[nt][mt] += W_frag[nt] . A_frag[mt]^T (rows = W rows: a lane owns 4 consecutive W rows of one A row)
 // SWAP = true : acc[mt][nt] += A_frag[mt] . W_frag[nt]^T (MT == 4 only: the transposed v^T store of the QKV GEMM)
-template <int MT, bool SWAP, typename Acc, typename Issue>
+template <typename T, int MT, bool SWAP, typename Acc, typename Issue>
 __device__ __forceinline__ void kstep64(const unsigned char *a_t, const unsigned char *w_t, int a_row0, int w_row0, int fr, int fq, Acc &acc,
                                         int n_pieces, Issue &&issue) {
     constexpr int SLOTS = 2 * MT, D = 3;
     constexpr int WPS = MT >= 4 ? 1 : 4 / MT;  // W fragments of sub-step 1 prefetched per slot
     static_assert(MT == 2 || MT == 4 || MT == 8, "A fragments per wave");
-    auto rd_a = [&](int sl) { return *reinterpret_cast<const bf16x8 *>(a_t + swz(a_row0 + (sl % MT) * 16 + fr, (sl / MT) * 4 + fq)); };
-    auto rd_w = [&](int sub, int t) { return *reinterpret_cast<const bf16x8 *>(w_t + swz(w_row0 + t * 16 + fr, sub * 4 + fq)); };
-    bf16x8 ring[4], wfr[2][4];
+    typedef vec<T, 8> frag;
+    auto rd_a = [&](int sl) { return *reinterpret_cast<const frag *>(a_t + swz(a_row0 + (sl % MT) * 16 + fr, (sl / MT) * 4 + fq)); };
+    auto rd_w = [&](int sub, int t) { return *reinterpret_cast<const frag *>(w_t + swz(w_row0 + t * 16 + fr, sub * 4 + fq)); };
+    frag ring[4], wfr[2][4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) wfr[0][t] = rd_w(0, t);
 #pragma unroll
@@ -50,9 +61,9 @@ __device__ __forceinline__ void kstep64(const unsigned char *a_t, const unsigned
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             if (SWAP)
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ring[sl & 3], wfr[sub][nt], acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = mfma16(ring[sl & 3], wfr[sub][nt], acc[mt][nt]);
             else
-                acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[sub][nt], ring[sl & 3], acc[nt][mt], 0, 0, 0);
+                acc[nt][mt] = mfma16(wfr[sub][nt], ring[sl & 3], acc[nt][mt]);
         }
         if (sl < n_pieces) issue(sl);
     }
@@ -65,26 +76,27 @@ __device__ __forceinline__ void kstep64(const unsigned char *a_t, const unsigned
 // fragments are in registers), and the next step, after the barrier, first issues its fragment reads (`begin`), then runs the
 // held-back MFMAs under that latency (`flush`), then its own slots (`body`).  Per tile: begin/body for the first step, barrier +
 // begin/flush/body for the others, one flush before the epilogue.
-template <int MT, bool SWAP>
+template <typename T, int MT, bool SWAP>
 struct KPipe {
+    typedef vec<T, 8> frag;
     static constexpr int SLOTS = 2 * MT, DEFER = 2, D = 3;
     static constexpr int WPS = MT >= 4 ? 1 : 4 / MT;
     static_assert(MT == 2 || MT == 4 || MT == 8, "A fragments per wave");
-    bf16x8 ring[4], wfr[2][4];  // slot sl uses ring[sl & 3]; the deferred slots SLOTS - 2, SLOTS - 1 sit in ring[2], ring[3]
+    frag ring[4], wfr[2][4];  // slot sl uses ring[sl & 3]; the deferred slots SLOTS - 2, SLOTS - 1 sit in ring[2], ring[3]
     const unsigned char *a_t, *w_t;
     int a_row0, w_row0, fr, fq;
 
-    __device__ __forceinline__ bf16x8 rd_a(int sl) const { return *reinterpret_cast<const bf16x8 *>(a_t + swz(a_row0 + (sl % MT) * 16 + fr, (sl / MT) * 4 + fq)); }
-    __device__ __forceinline__ bf16x8 rd_w(int sub, int t) const { return *reinterpret_cast<const bf16x8 *>(w_t + swz(w_row0 + t * 16 + fr, sub * 4 + fq)); }
+    __device__ __forceinline__ frag rd_a(int sl) const { return *reinterpret_cast<const frag *>(a_t + swz(a_row0 + (sl % MT) * 16 + fr, (sl / MT) * 4 + fq)); }
+    __device__ __forceinline__ frag rd_w(int sub, int t) const { return *reinterpret_cast<const frag *>(w_t + swz(w_row0 + t * 16 + fr, sub * 4 + fq)); }
     template <typename Acc>
     __device__ __forceinline__ void mfma_slot(int sl, Acc &acc) {
         const int sub = sl / MT, mt = sl % MT;
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             if (SWAP)
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ring[sl & 3], wfr[sub][nt], acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = mfma16(ring[sl & 3], wfr[sub][nt], acc[mt][nt]);
             else
-                acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wfr[sub][nt], ring[sl & 3], acc[nt][mt], 0, 0, 0);
+                acc[nt][mt] = mfma16(wfr[sub][nt], ring[sl & 3], acc[nt][mt]);
         }
     }
     // right behind the barrier: point at the new stage and issue its first reads (W of sub-step 0, A of slots 0 and 1)

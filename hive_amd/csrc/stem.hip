@@ -13,10 +13,10 @@
 
 #include <algorithm>
 
-typedef __bf16 bf16;
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+#include "mfma_pipe.hpp"
+
+using hive_mfma::f32x4;
+using hive_mfma::vec;  // T = __bf16 or _Float16 (the reference's model.half())
 
 namespace {
 
@@ -25,16 +25,18 @@ constexpr int ST_PH = 2 * ST_TH + 5, ST_PW = 2 * ST_TW + 5;  // input patch 21 x
 constexpr int ST_ROW = 240;                               // patch row pitch in bf16 (69 x 3 = 207, + slack for the 32-wide k-steps; 480 B)
 constexpr int ST_K = 7 * 32;                              // padded K
 
+template <typename T>
 struct StemParams {
-    const bf16 *x;   // [N][H][W][3]
-    const bf16 *w;   // [64][7][32]: (ky, (kx, c) padded from 21 to 32 with zeros)
-    bf16 *out;       // [N][Ho][Wo][64]
+    const T *x;   // [N][H][W][3]
+    const T *w;   // [64][7][32]: (ky, (kx, c) padded from 21 to 32 with zeros)
+    T *out;       // [N][Ho][Wo][64]
     int H, W, Ho, Wo, pad_t, pad_l;
 };
 
-__global__ __launch_bounds__(256) void stem_conv_kernel(StemParams p) {
-    __shared__ __attribute__((aligned(16))) bf16 patch[ST_PH * ST_ROW + 64];
-    __shared__ __attribute__((aligned(16))) bf16 wl[64 * ST_K];
+template <typename T>
+__global__ __launch_bounds__(256) void stem_conv_kernel(StemParams<T> p) {
+    __shared__ __attribute__((aligned(16))) T patch[ST_PH * ST_ROW + 64];
+    __shared__ __attribute__((aligned(16))) T wl[64 * ST_K];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles_x = (p.Wo + ST_TW - 1) / ST_TW, tiles_y = (p.Ho + ST_TH - 1) / ST_TH;
     const int img = blockIdx.x / (tiles_x * tiles_y), t = blockIdx.x % (tiles_x * tiles_y);
@@ -44,16 +46,16 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(StemParams p) {
     for (int i = tid; i < 64 * ST_K / 8; i += 256) reinterpret_cast<uint4 *>(wl)[i] = reinterpret_cast<const uint4 *>(p.w)[i];
     // patch: rows iy0 .. iy0 + 20, columns ix0 .. ix0 + 68, 3 channels; zero outside the frame.  One bf16 per thread and step
     // (a patch row starts 2 * pad_l pixels left of a 384-byte boundary: element granularity keeps it simple; 9 KB per tile)
-    const bf16 *xin = p.x + (size_t)img * p.H * p.W * 3;
+    const T *xin = p.x + (size_t)img * p.H * p.W * 3;
     for (int i = tid; i < ST_PH * ST_ROW; i += 256) {
         const int r = i / ST_ROW, e = i - r * ST_ROW;  // element e = (col, c)
         const int col = e / 3, c = e - col * 3;
         const int iy = iy0 + r, ix = ix0 + col;
-        bf16 v = (bf16)0.0f;
+        T v = (T)0.0f;
         if (e < ST_PW * 3 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) v = xin[((size_t)iy * p.W + ix) * 3 + c];
         patch[i] = v;
     }
-    if (tid < 64) patch[ST_PH * ST_ROW + tid] = (bf16)0.0f;
+    if (tid < 64) patch[ST_PH * ST_ROW + tid] = (T)0.0f;
     __syncthreads();
     const int fr = lane & 15, fq = lane >> 4;
     // wave w: output rows 2 w, 2 w + 1 of the tile; m fragment mt: row 2 w + (mt >> 1), columns 16 (mt & 1) .. + 15
@@ -64,42 +66,43 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(StemParams p) {
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ky = 0; ky < 7; ++ky) {
-        bf16x8 wf[4], af[4];
+        vec<T, 8> wf[4], af[4];
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) wf[nt] = *reinterpret_cast<const bf16x8 *>(wl + (nt * 16 + fr) * ST_K + ky * 32 + fq * 8);
+        for (int nt = 0; nt < 4; ++nt) wf[nt] = *reinterpret_cast<const vec<T, 8> *>(wl + (nt * 16 + fr) * ST_K + ky * 32 + fq * 8);
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
             const int oy = 2 * wave + (mt >> 1), ox = 16 * (mt & 1) + fr;
-            const bf16 *src = patch + (2 * oy + ky) * ST_ROW + 6 * ox + fq * 8;  // 4-byte aligned: 12 ox + 16 fq bytes
+            const T *src = patch + (2 * oy + ky) * ST_ROW + 6 * ox + fq * 8;  // 4-byte aligned: 12 ox + 16 fq bytes
             uint32_t raw[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) raw[q] = reinterpret_cast<const uint32_t *>(src)[q];
-            af[mt] = *reinterpret_cast<const bf16x8 *>(raw);
+            af[mt] = *reinterpret_cast<const vec<T, 8> *>(raw);
         }
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], af[mt], acc[nt][mt], 0, 0, 0);
+            for (int nt = 0; nt < 4; ++nt) acc[nt][mt] = hive_mfma::mfma16(wf[nt], af[mt], acc[nt][mt]);
     }
     // a lane owns 4 consecutive channels (16 nt + 4 fq ..) of pixel (2 w + (mt >> 1), 16 (mt & 1) + fr)
-    bf16 *out = p.out + (size_t)img * p.Ho * p.Wo * 64;
+    T *out = p.out + (size_t)img * p.Ho * p.Wo * 64;
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
         const int oy = oy0 + 2 * wave + (mt >> 1), ox = ox0 + 16 * (mt & 1) + fr;
         if (oy < p.Ho && ox < p.Wo) {
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
-                bf16x4 ov;
+                vec<T, 4> ov;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) ov[j] = (bf16)acc[nt][mt][j];
-                *reinterpret_cast<bf16x4 *>(out + ((size_t)oy * p.Wo + ox) * 64 + nt * 16 + fq * 4) = ov;
+                for (int j = 0; j < 4; ++j) ov[j] = (T)acc[nt][mt][j];
+                *reinterpret_cast<vec<T, 4> *>(out + ((size_t)oy * p.Wo + ox) * 64 + nt * 16 + fq * 4) = ov;
             }
         }
     }
 }
 
 // 3 x 3 stride-2 max pool with explicit top / left padding (padded positions never win: -inf), channels-last, 8 channels per lane
-__global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const bf16 *__restrict__ x, bf16 *__restrict__ out, int N, int H, int W, int C, int Ho,
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const T *__restrict__ x, T *__restrict__ out, int N, int H, int W, int C, int Ho,
                                                            int Wo, int pad_t, int pad_l) {
     const int c8 = C / 8;
     const long long total = (long long)N * Ho * Wo * c8;
@@ -116,16 +119,34 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const bf16 *__restric
             for (int kx = 0; kx < 3; ++kx) {
                 const int iy = 2 * oy + ky - pad_t, ix = 2 * ox + kx - pad_l;
                 if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
-                    const bf16x8 v = *reinterpret_cast<const bf16x8 *>(x + (((size_t)n * H + iy) * W + ix) * C + cc * 8);
+                    const vec<T, 8> v = *reinterpret_cast<const vec<T, 8> *>(x + (((size_t)n * H + iy) * W + ix) * C + cc * 8);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) m[j] = fmaxf(m[j], (float)v[j]);
                 }
             }
-        bf16x8 o;
+        vec<T, 8> o;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (bf16)m[j];
-        *reinterpret_cast<bf16x8 *>(out + (size_t)pix * C + cc * 8) = o;
+        for (int j = 0; j < 8; ++j) o[j] = (T)m[j];
+        *reinterpret_cast<vec<T, 8> *>(out + (size_t)pix * C + cc * 8) = o;
     }
+}
+
+template <typename T>
+int launch_stem(hive_ctx *ctx, const void *d_x, int N, int H, int W, const void *d_w, void *d_out) {
+    StemParams<T> p{};
+    p.x = (const T *)d_x;
+    p.w = (const T *)d_w;
+    p.out = (T *)d_out;
+    p.H = H;
+    p.W = W;
+    p.Ho = (H + 1) / 2;
+    p.Wo = (W + 1) / 2;
+    p.pad_t = std::max((p.Ho - 1) * 2 + 7 - H, 0) / 2;  // TensorFlow "SAME": the odd pixel goes to the bottom / right
+    p.pad_l = std::max((p.Wo - 1) * 2 + 7 - W, 0) / 2;
+    const long long tiles = (long long)N * ((p.Ho + ST_TH - 1) / ST_TH) * ((p.Wo + ST_TW - 1) / ST_TW);
+    hipLaunchKernelGGL(stem_conv_kernel<T>, dim3((unsigned)tiles), dim3(256), 0, ctx->stream, p);
+    HIVE_CHECK_HIP(ctx, hipGetLastError());
+    return HIVE_OK;
 }
 
 }  // namespace
@@ -136,35 +157,25 @@ int hive_resnet_stem_conv(hive_ctx *ctx, const void *d_x, int dtype, int N, int 
     HIVE_ENTER(ctx);
     if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
     HIVE_REQUIRE(ctx, d_x && d_w && d_out, "resnet_stem_conv: NULL argument");
-    HIVE_REQUIRE(ctx, dtype == HIVE_BF16, "resnet_stem_conv: bf16 only");
+    HIVE_REQUIRE(ctx, dtype == HIVE_BF16 || dtype == HIVE_F16, "resnet_stem_conv: dtype must be HIVE_F16 or HIVE_BF16");
     HIVE_REQUIRE(ctx, N > 0 && H >= 7 && W >= 7 && (long long)N * H * W < (1ll << 31), "resnet_stem_conv: bad sizes %d x %d x %d", N, H, W);
-    StemParams p{};
-    p.x = (const bf16 *)d_x;
-    p.w = (const bf16 *)d_w;
-    p.out = (bf16 *)d_out;
-    p.H = H;
-    p.W = W;
-    p.Ho = (H + 1) / 2;
-    p.Wo = (W + 1) / 2;
-    p.pad_t = std::max((p.Ho - 1) * 2 + 7 - H, 0) / 2;  // TensorFlow "SAME": the odd pixel goes to the bottom / right
-    p.pad_l = std::max((p.Wo - 1) * 2 + 7 - W, 0) / 2;
-    const long long tiles = (long long)N * ((p.Ho + ST_TH - 1) / ST_TH) * ((p.Wo + ST_TW - 1) / ST_TW);
-    hipLaunchKernelGGL(stem_conv_kernel, dim3((unsigned)tiles), dim3(256), 0, ctx->stream, p);
-    HIVE_CHECK_HIP(ctx, hipGetLastError());
-    return HIVE_OK;
+    return dtype == HIVE_BF16 ? launch_stem<__bf16>(ctx, d_x, N, H, W, d_w, d_out) : launch_stem<_Float16>(ctx, d_x, N, H, W, d_w, d_out);
 }
 
 int hive_nhwc_maxpool3x3s2(hive_ctx *ctx, const void *d_x, int dtype, int N, int H, int W, int C, void *d_out) {
     HIVE_ENTER(ctx);
     if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
     HIVE_REQUIRE(ctx, d_x && d_out && d_x != d_out, "nhwc_maxpool3x3s2: bad pointers");
-    HIVE_REQUIRE(ctx, dtype == HIVE_BF16, "nhwc_maxpool3x3s2: bf16 only");
+    HIVE_REQUIRE(ctx, dtype == HIVE_BF16 || dtype == HIVE_F16, "nhwc_maxpool3x3s2: dtype must be HIVE_F16 or HIVE_BF16");
     HIVE_REQUIRE(ctx, N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "nhwc_maxpool3x3s2: bad sizes %d x %d x %d x %d", N, H, W, C);
     const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
     const int pad_t = std::max((Ho - 1) * 2 + 3 - H, 0) / 2, pad_l = std::max((Wo - 1) * 2 + 3 - W, 0) / 2;
     const long long total = (long long)N * Ho * Wo * (C / 8);
     const int blocks = (int)std::min<long long>((total + 255) / 256, (long long)ctx->num_cus * 32);
-    hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const bf16 *)d_x, (bf16 *)d_out, N, H, W, C, Ho, Wo, pad_t, pad_l);
+    if (dtype == HIVE_BF16)
+        hipLaunchKernelGGL(maxpool3x3s2_kernel<__bf16>, dim3(blocks), dim3(256), 0, ctx->stream, (const __bf16 *)d_x, (__bf16 *)d_out, N, H, W, C, Ho, Wo, pad_t, pad_l);
+    else
+        hipLaunchKernelGGL(maxpool3x3s2_kernel<_Float16>, dim3(blocks), dim3(256), 0, ctx->stream, (const _Float16 *)d_x, (_Float16 *)d_out, N, H, W, C, Ho, Wo, pad_t, pad_l);
     HIVE_CHECK_HIP(ctx, hipGetLastError());
     return HIVE_OK;
 }

@@ -14,8 +14,8 @@
 // every (x,y) row analytically against the view frustum (the camera-space position is affine in z; one LANE
 // per row) and emits one item per 64-voxel segment of the surviving z interval; integrate is a grid-stride
 // sweep over that list: a wave takes 4 segments per trip (16 lanes x 4 consecutive z voxels = 16 bytes per
-// lane and volume), packed-f32 arithmetic.  The clip is padded and every voxel of a segment still runs the
-// exact tests above, so results do not depend on it.
+// lane and volume, for rows of ANY length: the accesses need dword alignment only), packed-f32 arithmetic.  The clip is
+// padded and every voxel of a segment still runs the exact tests above, so results do not depend on it.
 #include "hive_internal.hpp"
 
 #include <algorithm>
@@ -98,6 +98,7 @@ __global__ __launch_bounds__(256) void pack_frame_kernel(const float *__restrict
 #define HIVE_GRID_MULT 16
 #endif
 constexpr int SEG_LANES = HIVE_SEG_LANES;
+constexpr int VPT = 4;  // consecutive z voxels per lane: one 16-byte access per lane and volume plane
 constexpr int COUNT_SLOTS = 64, COUNT_STRIDE = 16;  // update counters of the COUNT kernels: 64 x u64, 128 bytes apart (hive_ctx::d_scalars + 128)
 struct WorkItem {
     unsigned xy;  // x | y << 16
@@ -146,7 +147,6 @@ __device__ __forceinline__ RowClip clip_row(const FrameParams &p, float ax, floa
     return r;
 }
 
-template <int VPT>
 __global__ __launch_bounds__(1024) void build_worklist_kernel(FrameParams p, WorkItem *__restrict__ items, unsigned *n_items) {
     __shared__ unsigned wave_sum[16];
     __shared__ unsigned block_base;
@@ -302,7 +302,13 @@ __device__ __forceinline__ void update_voxels(V &t, V &w, V &c, V dist, const un
     const V vow = v_splat(ow, w);
     const V w_new = w_old + vow;
     const V wr = refined_rcp(w_new);
-    const V t_new = div_exact(t * w_old + vow * dist, w_new, wr);
+    // free space in front of the surface that was free space before (tsdf 1, dist 1): (1 w_old + ow 1) / w_new = w_new / w_new = 1
+    // exactly -- most sweeps of a carved scene.  The division is skipped when that holds for every updated voxel of the WAVE.
+    bool still_one = true;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) still_one = still_one && (!ok[i] || (v_get(t, i) == 1.0f && v_get(dist, i) == 1.0f && v_get(w_new, i) > 0.0f));
+    V t_new = t;
+    if (!__all(still_one)) t_new = div_exact(t * w_old + vow * dist, w_new, wr);
     V or_, og, ob, nr, ng, nb;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -318,40 +324,86 @@ __device__ __forceinline__ void update_voxels(V &t, V &w, V &c, V dist, const un
     const V r = v_min(v_round<RM>(div_exact(or_ * w_old + vow * nr, w_new, wr)), lim);
     const V g = v_min(v_round<RM>(div_exact(og * w_old + vow * ng, w_new, wr)), lim);
     const V b = v_min(v_round<RM>(div_exact(ob * w_old + vow * nb, w_new, wr)), lim);
+    // b 65536 + g 256 + r: integers below 2^24, exact in float32 (the oracle's own expression); two packed fma instead of three
+    // conversions, two shift-ors and a conversion back per voxel
+    const V c_new = v_fma(b, v_splat(65536.0f, w), v_fma(g, v_splat(256.0f, w), r));
 #pragma unroll
     for (int i = 0; i < NV; ++i)
         if (ok[i]) {
             v_set(t, i, v_get(t_new, i));
             v_set(w, i, v_get(w_new, i));
-            v_set(c, i, (float)(((unsigned)v_get(b, i) << 16) | ((unsigned)v_get(g, i) << 8) | (unsigned)v_get(r, i)));
+            v_set(c, i, v_get(c_new, i));
         }
+}
+
+// The depth tests of the volume role for a lane's 4 voxels (2 packed pairs) and the truncated distance.  `diff >= trunc` (free space
+// in front of the surface) gives min(1, diff / trunc) = 1 without the division; it is skipped when that holds for every voxel of the
+// WAVE that passes the tests -- most trips of a sweep: the truncation band is 5 voxels of a row.
+template <typename V>
+__device__ __forceinline__ bool depth_tests(const FrameParams &p, float trunc_rcp, const float (&depth_v)[4], const V (&cam_z)[2], bool live, int nrow,
+                                            V (&dist)[2], bool (&ok)[4]) {
+    V diff[2];
+    bool any = false, band = false;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        V depth;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) v_set(depth, i, depth_v[2 * g + i]);
+        diff[g] = depth - cam_z[g];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int j = 2 * g + i;
+            ok[j] = live && j < nrow && (v_get(depth, i) != 0.0f) && !(v_get(diff[g], i) < -p.trunc);
+            any = any || ok[j];
+            band = band || (ok[j] && !(v_get(diff[g], i) >= p.trunc));
+        }
+    }
+    if (__any(band)) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) dist[g] = v_min(v_splat(1.0f, diff[g]), div_exact(diff[g], v_splat(p.trunc, diff[g]), v_splat(trunc_rcp, diff[g])));
+    } else {
+        dist[0] = dist[1] = v_splat(1.0f, diff[0]);
+    }
+    return any;
 }
 
 // Volume accesses: one 16-byte access per lane and volume.  Default cache policy -- the non-temporal forms
 // measured 6 % faster on a frame that updates every voxel and 3 % slower on the room scene (A/B in one
 // process group, tools/ab_integrate.py), so they are not used.
+// A row starts at ((x Y) + y) Z floats: 16-byte aligned only when Z % 4 == 0.  global_load / global_store_dwordx4 need dword alignment
+// only (gfx950 runs in unaligned-access mode), so the volume side of the access is typed with 4-byte alignment and rows of ANY length take
+// the vector path; `n` < 4 is the last quad of a row with Z % 4 != 0: its tail lies in the NEXT row and is neither read nor written.
 typedef float f4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void vol_load4(float *dst, const float *src) {
-    *reinterpret_cast<f4 *>(dst) = *reinterpret_cast<const f4 *>(src);
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+__device__ __forceinline__ void vol_load4(float *dst, const float *src, int n) {
+    if (n >= 4) {
+        *reinterpret_cast<f4 *>(dst) = *reinterpret_cast<const f4u *>(src);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dst[j] = j < n ? src[j] : 0.0f;
+    }
 }
-__device__ __forceinline__ void vol_store4(float *dst, const float *src) {
-    *reinterpret_cast<f4 *>(dst) = *reinterpret_cast<const f4 *>(src);
+__device__ __forceinline__ void vol_store4(float *dst, const float *src, int n) {
+    if (n >= 4) {
+        *reinterpret_cast<f4u *>(dst) = *reinterpret_cast<const f4 *>(src);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (j < n) dst[j] = src[j];
+    }
 }
-__device__ __forceinline__ float vol_load1(const float *src) { return *src; }
-__device__ __forceinline__ void vol_store1(float *dst, float v) { *dst = v; }
 
-// Shape of one lane's share of a work item: VPT consecutive z voxels of one segment, as NG groups of NV (= 2 packed,
-// or 1 for the scalar kernel).
-template <int VPT>
+// Shape of one lane's share of a work item: VPT = 4 consecutive z voxels of one segment, as NG = 2 packed pairs.
 struct ItemShape {
-    static constexpr int NV = VPT >= 2 ? 2 : 1;
+    static constexpr int NV = 2;
     static constexpr int NG = VPT / NV;
-    typedef typename std::conditional<NV == 2, f2, float>::type V;
+    typedef f2 V;
 };
 
 // Grid-stride sweep over the work list: a wave takes 64 / SEG_LANES consecutive segments per trip (16 lanes
-// x VPT voxels each; VPT = 4 needs Z % 4 == 0), 16-byte accesses per lane and volume.  Lanes past the end of
-// the list or of their row's clipped interval are dead (no volume access).
+// x 4 voxels each), 16-byte accesses per lane and volume.  Lanes past the end of the list or of their row's
+// clipped interval are dead (no volume access); the voxels of a row's last quad that lie past the row (Z % 4 != 0)
+// are excluded from the tests and from the access.
 //
 // What bounds it (512^3, room scene; experiments in DESIGN.md section 5): the CU's vector-memory pipeline, per
 // INSTRUCTION.  A trip issues 4 texel gathers (8 B / lane) + 3 volume loads + 3 volume stores (16 B / lane).  A
@@ -360,7 +412,7 @@ struct ItemShape {
 // 4- and 8-byte texels), so what a gather instruction costs is decided by which voxels share it.
 //   * volume role: lane j of a segment owns voxels 4j .. 4j+3 (one 16-byte access per volume).  Gathering in this
 //     role puts voxels 4 apart (~12 pixels, 96 bytes) on neighbouring lanes: 64 lines per instruction.
-//   * gather role (VPT = 4): for the texel fetch the lanes of a segment take CONSECUTIVE voxels -- gather k covers
+//   * gather role: for the texel fetch the lanes of a segment take CONSECUTIVE voxels -- gather k covers
 //     voxels 16k .. 16k+15 of each of the wave's 4 segments -- so neighbouring lanes hit neighbouring pixels (a z run
 //     projects to a pixel run; ~3 lanes per line when it runs along the image rows).  The fetched {depth, rgb} pairs
 //     go through a 2 KB per-wave LDS exchange (ds_write_b64 / 2 x ds_read_b128, no workgroup barrier: LDS operations
@@ -369,15 +421,15 @@ struct ItemShape {
 //     depth test rejects -- the same outcome as the contract's separate test.
 // ACCUM = false: running-average update of (tsdf, weight, colour) -- the reference semantics.
 // ACCUM = true : add into the 5 accumulator planes [num, w, r, g, b] (frame-sharded fusion).
-template <int VPT, int RM, bool COUNT, bool ACCUM>
+template <int RM, bool COUNT, bool ACCUM>
 __global__ __launch_bounds__(256) void integrate_kernel(FrameParams p, const WorkItem *__restrict__ items,
                                                         const unsigned *__restrict__ n_items_ptr, float *__restrict__ v0,
                                                         float *__restrict__ v1, float *__restrict__ v2, long long plane) {
     constexpr int PER_WAVE = 64 / SEG_LANES;
-    typedef ItemShape<VPT> Sh;
-    typedef typename Sh::V V;
-    constexpr int SEG_VOX = SEG_LANES * 4;                           // voxels of a segment (VPT = 4)
-    __shared__ uint2 xchg[VPT == 4 ? 4 * PER_WAVE * SEG_VOX : 1];  // per wave: PER_WAVE segments x SEG_VOX voxels x {depth bits, rgb}
+    typedef ItemShape Sh;
+    typedef Sh::V V;
+    constexpr int SEG_VOX = SEG_LANES * 4;             // voxels of a segment
+    __shared__ uint2 xchg[4 * PER_WAVE * SEG_VOX];  // per wave: PER_WAVE segments x SEG_VOX voxels x {depth bits, rgb}
     const int lane = threadIdx.x & 63;
     const int seg = lane / SEG_LANES, sl = lane % SEG_LANES;
     const unsigned n_items = *n_items_ptr;
@@ -394,34 +446,10 @@ __global__ __launch_bounds__(256) void integrate_kernel(FrameParams p, const Wor
         const int zseg = (int)(item.zz & 0xffffu);
         const int zb = zseg + sl * VPT;  // volume role: this lane's first voxel
         const bool live = zb < (int)(item.zz >> 16);
+        const int nrow = p.Z - zb;  // voxels of this quad inside the row (>= 4 except in the last quad of a row with Z % 4 != 0)
         const long long idx = ((long long)x * p.Y + y) * p.Z + zb;
         float t[VPT], w[VPT], c[VPT];  // ACCUM: planes 0..2
         float c3[VPT], c4[VPT];        // ACCUM: planes 3..4
-        auto load_volume = [&]() {
-            if (VPT == 4) {
-                vol_load4(t, v0 + idx);
-                if (!ACCUM) {
-                    vol_load4(w, v1 + idx);
-                    vol_load4(c, v2 + idx);
-                } else {
-                    vol_load4(w, v0 + plane + idx);
-                    vol_load4(c, v0 + 2 * plane + idx);
-                    vol_load4(c3, v0 + 3 * plane + idx);
-                    vol_load4(c4, v0 + 4 * plane + idx);
-                }
-            } else {
-                t[0] = vol_load1(v0 + idx);
-                if (!ACCUM) {
-                    w[0] = vol_load1(v1 + idx);
-                    c[0] = vol_load1(v2 + idx);
-                } else {
-                    w[0] = vol_load1(v0 + plane + idx);
-                    c[0] = vol_load1(v0 + 2 * plane + idx);
-                    c3[0] = vol_load1(v0 + 3 * plane + idx);
-                    c4[0] = vol_load1(v0 + 4 * plane + idx);
-                }
-            }
-        };
         // row constants, in the contract's operation order
         const float tx = (p.ox + (float)(x + p.x_off) * p.vs) - p.T[0];
         const float ty = (p.oy + (float)y * p.vs) - p.T[1];
@@ -431,7 +459,7 @@ __global__ __launch_bounds__(256) void integrate_kernel(FrameParams p, const Wor
         V cam_z[Sh::NG];
         float depth_v[VPT];
         unsigned rgb[VPT];
-        if (VPT == 4) {
+        {
             // gather role: voxels zseg + SEG_LANES k + sl, k = 0 .. 3 (packed pairs k = {0, 1}, {2, 3})
             uint2 tex[4];
 #pragma unroll
@@ -441,9 +469,9 @@ __global__ __launch_bounds__(256) void integrate_kernel(FrameParams p, const Wor
                 voxel_pixels<RM, V, Sh::NV, SEG_LANES>(p, ax, ay, az, zseg + sl + 2 * SEG_LANES * g, cz, pix);
 #pragma unroll
                 for (int i = 0; i < Sh::NV; ++i) {
-                    uint2 t = p.frame[max(pix[i], 0)];
-                    if (pix[i] < 0) t.x = 0u;  // outside the image / behind the camera: rejected by the depth test
-                    tex[g * Sh::NV + i] = t;
+                    uint2 tx2 = p.frame[max(pix[i], 0)];
+                    if (pix[i] < 0) tx2.x = 0u;  // outside the image / behind the camera: rejected by the depth test
+                    tex[g * Sh::NV + i] = tx2;
                 }
             }
             uint2 *mine = xchg + ((threadIdx.x >> 6) * PER_WAVE + seg) * SEG_VOX;
@@ -456,47 +484,30 @@ __global__ __launch_bounds__(256) void integrate_kernel(FrameParams p, const Wor
             const uint4 lo = *reinterpret_cast<const uint4 *>(mine + 4 * sl);
             const uint4 hi = *reinterpret_cast<const uint4 *>(mine + 4 * sl + 2);
             depth_v[0] = __uint_as_float(lo.x), rgb[0] = lo.y;
-            depth_v[VPT > 1 ? 1 : 0] = __uint_as_float(lo.z), rgb[VPT > 1 ? 1 : 0] = lo.w;
-            depth_v[VPT > 2 ? 2 : 0] = __uint_as_float(hi.x), rgb[VPT > 2 ? 2 : 0] = hi.y;
-            depth_v[VPT > 3 ? 3 : 0] = __uint_as_float(hi.z), rgb[VPT > 3 ? 3 : 0] = hi.w;
+            depth_v[1] = __uint_as_float(lo.z), rgb[1] = lo.w;
+            depth_v[2] = __uint_as_float(hi.x), rgb[2] = hi.y;
+            depth_v[3] = __uint_as_float(hi.z), rgb[3] = hi.w;
             __builtin_amdgcn_wave_barrier();  // the next trip's writes stay behind these reads
 #pragma unroll
             for (int g = 0; g < Sh::NG; ++g) cam_z[g] = voxel_cam_z<V, Sh::NV>(p, az, zb + g * Sh::NV);
-        } else {
-#pragma unroll
-            for (int g = 0; g < Sh::NG; ++g) {
-                int pix[Sh::NV];
-                voxel_pixels<RM, V, Sh::NV>(p, ax, ay, az, zb + g * Sh::NV, cam_z[g], pix);
-#pragma unroll
-                for (int i = 0; i < Sh::NV; ++i) {
-                    const uint2 t = p.frame[max(pix[i], 0)];
-                    depth_v[g * Sh::NV + i] = pix[i] < 0 ? 0.0f : __uint_as_float(t.x);
-                    rgb[g * Sh::NV + i] = t.y;
-                }
-            }
         }
         // inclusion tests
         V dist[Sh::NG];
         bool ok[VPT];
-        bool any = false;
-#pragma unroll
-        for (int g = 0; g < Sh::NG; ++g) {
-            V depth;
-#pragma unroll
-            for (int i = 0; i < Sh::NV; ++i) v_set(depth, i, depth_v[g * Sh::NV + i]);
-            const V diff = depth - cam_z[g];
-            dist[g] = v_min(v_splat(1.0f, diff), div_exact(diff, v_splat(p.trunc, diff), v_splat(trunc_rcp, diff)));
-#pragma unroll
-            for (int i = 0; i < Sh::NV; ++i) {
-                const int j = g * Sh::NV + i;
-                ok[j] = live && (v_get(depth, i) != 0.0f) && !(v_get(diff, i) < -p.trunc);
-                any = any || ok[j];
-            }
-        }
+        const bool any = depth_tests<V>(p, trunc_rcp, depth_v, cam_z, live, nrow, dist, ok);
         // (measured and rejected: issuing these loads for all live lanes BEFORE the geometry, beside the texel gathers, to take one
         // round trip out of the wave's dependency chain -- 95 vs 92 us: the bytes loaded for lanes that then fail the test cost more)
-        if (any) load_volume();
         if (any) {
+            vol_load4(t, v0 + idx, nrow);
+            if (!ACCUM) {
+                vol_load4(w, v1 + idx, nrow);
+                vol_load4(c, v2 + idx, nrow);
+            } else {
+                vol_load4(w, v0 + plane + idx, nrow);
+                vol_load4(c, v0 + 2 * plane + idx, nrow);
+                vol_load4(c3, v0 + 3 * plane + idx, nrow);
+                vol_load4(c4, v0 + 4 * plane + idx, nrow);
+            }
             if (!ACCUM) {
 #pragma unroll
                 for (int g = 0; g < Sh::NG; ++g) {
@@ -535,28 +546,15 @@ __global__ __launch_bounds__(256) void integrate_kernel(FrameParams p, const Wor
                         if (COUNT) ++n_upd;
                     }
             }
-            if (VPT == 4) {
-                vol_store4(v0 + idx, t);
-                if (!ACCUM) {
-                    vol_store4(v1 + idx, w);
-                    vol_store4(v2 + idx, c);
-                } else {
-                    vol_store4(v0 + plane + idx, w);
-                    vol_store4(v0 + 2 * plane + idx, c);
-                    vol_store4(v0 + 3 * plane + idx, c3);
-                    vol_store4(v0 + 4 * plane + idx, c4);
-                }
+            vol_store4(v0 + idx, t, nrow);
+            if (!ACCUM) {
+                vol_store4(v1 + idx, w, nrow);
+                vol_store4(v2 + idx, c, nrow);
             } else {
-                vol_store1(v0 + idx, t[0]);
-                if (!ACCUM) {
-                    vol_store1(v1 + idx, w[0]);
-                    vol_store1(v2 + idx, c[0]);
-                } else {
-                    vol_store1(v0 + plane + idx, w[0]);
-                    vol_store1(v0 + 2 * plane + idx, c[0]);
-                    vol_store1(v0 + 3 * plane + idx, c3[0]);
-                    vol_store1(v0 + 4 * plane + idx, c4[0]);
-                }
+                vol_store4(v0 + plane + idx, w, nrow);
+                vol_store4(v0 + 2 * plane + idx, c, nrow);
+                vol_store4(v0 + 3 * plane + idx, c3, nrow);
+                vol_store4(v0 + 4 * plane + idx, c4, nrow);
             }
         }
     }
@@ -593,7 +591,6 @@ struct MultiParams {
     int nf;
 };
 
-template <int VPT>
 __global__ __launch_bounds__(1024) void build_worklist_multi_kernel(MultiParams mp, WorkItem *__restrict__ items, unsigned *n_items) {
     __shared__ unsigned wave_sum[16];
     __shared__ unsigned block_base;
@@ -658,9 +655,9 @@ __global__ __launch_bounds__(1024) void build_worklist_multi_kernel(MultiParams 
 template <int RM>
 __global__ __launch_bounds__(256) void integrate_multi_kernel(MultiParams mp, const WorkItem *__restrict__ items, const unsigned *__restrict__ n_items_ptr,
                                                               float *__restrict__ v0, float *__restrict__ v1, float *__restrict__ v2) {
-    constexpr int VPT = 4, PER_WAVE = 64 / SEG_LANES, SEG_VOX = SEG_LANES * 4;
-    typedef ItemShape<VPT> Sh;
-    typedef typename Sh::V V;
+    constexpr int PER_WAVE = 64 / SEG_LANES, SEG_VOX = SEG_LANES * 4;
+    typedef ItemShape Sh;
+    typedef Sh::V V;
     __shared__ uint2 xchg[4 * PER_WAVE * SEG_VOX];
     const int lane = threadIdx.x & 63;
     const int seg = lane / SEG_LANES, sl = lane % SEG_LANES;
@@ -678,6 +675,7 @@ __global__ __launch_bounds__(256) void integrate_multi_kernel(MultiParams mp, co
         const int zseg = (int)(item.zz & 0xffffu);
         const int zb = zseg + sl * VPT;
         const bool live = zb < (int)(item.zz >> 16);
+        const int nrow = p0.Z - zb;  // voxels of this quad inside the row (< 4 only in the last quad of a row with Z % 4 != 0)
         const long long idx = ((long long)x * p0.Y + y) * p0.Z + zb;
         float t[VPT], w[VPT], c[VPT];
         bool loaded = false;
@@ -718,26 +716,12 @@ __global__ __launch_bounds__(256) void integrate_multi_kernel(MultiParams mp, co
 #pragma unroll
             for (int g = 0; g < Sh::NG; ++g) cam_z[g] = voxel_cam_z<V, Sh::NV>(p, az, zb + g * Sh::NV);
             bool ok[VPT];
-            bool any = false;
-#pragma unroll
-            for (int g = 0; g < Sh::NG; ++g) {
-                V depth;
-#pragma unroll
-                for (int i = 0; i < Sh::NV; ++i) v_set(depth, i, depth_v[g * Sh::NV + i]);
-                const V diff = depth - cam_z[g];
-                dist[g] = v_min(v_splat(1.0f, diff), div_exact(diff, v_splat(p.trunc, diff), v_splat(trunc_rcp, diff)));
-#pragma unroll
-                for (int i = 0; i < Sh::NV; ++i) {
-                    const int j = g * Sh::NV + i;
-                    ok[j] = live && (v_get(depth, i) != 0.0f) && !(v_get(diff, i) < -p.trunc);
-                    any = any || ok[j];
-                }
-            }
+            const bool any = depth_tests<V>(p, trunc_rcp, depth_v, cam_z, live, nrow, dist, ok);
             if (any) {
                 if (!loaded) {  // the lane's first frame with an update: its voxels come in now and stay in registers
-                    vol_load4(t, v0 + idx);
-                    vol_load4(w, v1 + idx);
-                    vol_load4(c, v2 + idx);
+                    vol_load4(t, v0 + idx, nrow);
+                    vol_load4(w, v1 + idx, nrow);
+                    vol_load4(c, v2 + idx, nrow);
                     loaded = true;
                 }
 #pragma unroll
@@ -766,9 +750,9 @@ __global__ __launch_bounds__(256) void integrate_multi_kernel(MultiParams mp, co
             }
         }
         if (loaded) {
-            vol_store4(v0 + idx, t);
-            vol_store4(v1 + idx, w);
-            vol_store4(v2 + idx, c);
+            vol_store4(v0 + idx, t, nrow);
+            vol_store4(v1 + idx, w, nrow);
+            vol_store4(v2 + idx, c, nrow);
         }
     }
 }
@@ -934,8 +918,13 @@ static int launch_integrate_multi(hive_tsdf *v, int nf, const uint8_t *color, co
     unsigned *idle_block = ctx->d_scalars + (ctx->tsdf_scalars ? 0 : 48);  // the single-frame path's next block: cleared anyway
     MultiParams mp;
     mp.nf = nf;
-    hipLaunchKernelGGL(pack_frame_kernel<true>, dim3((unsigned)((npx / 4 + 255) / 256), (unsigned)nf), dim3(256), 0, ctx->stream, depth, color, (int)npx,
-                       (uint2 *)ctx->d_frame, sc, idle_block);  // all nf frames in one launch
+    // all nf frames in one launch; the 4-pixels-per-lane form needs every frame's depth 16-byte and colour 4-byte aligned
+    if (npx % 4 == 0 && (uintptr_t)depth % 16 == 0 && (uintptr_t)color % 4 == 0)
+        hipLaunchKernelGGL(pack_frame_kernel<true>, dim3((unsigned)((npx / 4 + 255) / 256), (unsigned)nf), dim3(256), 0, ctx->stream, depth, color, (int)npx,
+                           (uint2 *)ctx->d_frame, sc, idle_block);
+    else
+        hipLaunchKernelGGL(pack_frame_kernel<false>, dim3((unsigned)((npx + 255) / 256), (unsigned)nf), dim3(256), 0, ctx->stream, depth, color, (int)npx,
+                           (uint2 *)ctx->d_frame, sc, idle_block);
     for (int f = 0; f < nf; ++f) {
         uint2 *packed = (uint2 *)ctx->d_frame + (size_t)f * npx;
         fill_frame_params(v, H, W, K, poses + 16 * (size_t)f, obs_weight, mp.f[f]);
@@ -952,7 +941,7 @@ static int launch_integrate_multi(hive_tsdf *v, int nf, const uint8_t *color, co
     if ((rc = hive_reserve_device(ctx, &ctx->d_scratch, &ctx->scratch_bytes, max_items * sizeof(WorkItem)))) return rc;
     WorkItem *items = (WorkItem *)ctx->d_scratch;
     unsigned *n_items = sc + MAXF;
-    hipLaunchKernelGGL(build_worklist_multi_kernel<4>, dim3((unsigned)((rows + 1023) / 1024)), dim3(1024), 0, ctx->stream, mp, items, n_items);
+    hipLaunchKernelGGL(build_worklist_multi_kernel, dim3((unsigned)((rows + 1023) / 1024)), dim3(1024), 0, ctx->stream, mp, items, n_items);
     const long long max_trips = (long long)((max_items + 64 / SEG_LANES - 1) / (64 / SEG_LANES));
     const dim3 grid((unsigned)std::min<long long>((long long)ctx->num_cus * 8 * HIVE_GRID_MULT, (max_trips + 3) / 4)), block(256);
     if ((rc = hive_time_begin(ctx))) return rc;
@@ -976,38 +965,29 @@ static int launch_integrate(hive_tsdf *v, float *accum, int H, int W, const floa
     if (count) HIVE_CHECK_HIP(ctx, hipMemsetAsync(p.n_updated, 0, COUNT_SLOTS * COUNT_STRIDE * sizeof(unsigned long long), ctx->stream));
     const long long rows = (long long)p.X * p.Y;
     float *a0 = ACCUM ? accum : v->d_tsdf;
-    const bool vec = (p.Z % 4 == 0) && (((uintptr_t)a0 | (uintptr_t)v->d_weight | (uintptr_t)v->d_color) % 16 == 0);
     // work list: at most ceil(Z / segment) items per row
-    const long long seg = SEG_LANES * (vec ? 4 : 1);
+    const long long seg = SEG_LANES * VPT;
     const size_t max_items = (size_t)rows * (size_t)((p.Z + seg - 1) / seg);
     int rc = hive_reserve_device(ctx, &ctx->d_scratch, &ctx->scratch_bytes, max_items * sizeof(WorkItem));
     if (rc) return rc;
     WorkItem *items = (WorkItem *)ctx->d_scratch;
     unsigned *n_items = tsdf_scalars(ctx) + 4;
     const dim3 wl_grid((unsigned)((rows + 1023) / 1024));
-    if (vec)
-        hipLaunchKernelGGL(build_worklist_kernel<4>, wl_grid, dim3(1024), 0, ctx->stream, p, items, n_items);
-    else
-        hipLaunchKernelGGL(build_worklist_kernel<1>, wl_grid, dim3(1024), 0, ctx->stream, p, items, n_items);
+    hipLaunchKernelGGL(build_worklist_kernel, wl_grid, dim3(1024), 0, ctx->stream, p, items, n_items);
     // grid-stride sweep: HIVE_GRID_MULT (16) x the resident workgroup count (8 workgroups of 4 waves per CU), so that the
     // dispatcher evens out trips of unequal cost (room scene, 512^3: x2 97, x4 90-94, x8 91, x16 87, x32 95 us; at x16 the
     // 32768 workgroups hold ~0.5 trips each: most waves run exactly one); a wave takes 64 / SEG_LANES items per trip
     const long long max_trips = (long long)((max_items + 64 / SEG_LANES - 1) / (64 / SEG_LANES));
     const dim3 grid((unsigned)std::min<long long>((long long)ctx->num_cus * 8 * HIVE_GRID_MULT, (max_trips + 3) / 4)), block(256);
     if ((rc = hive_time_begin(ctx))) return rc;
-#define HIVE_LAUNCH(VPT, RM, CNT)                                                                                      \
-    hipLaunchKernelGGL((integrate_kernel<VPT, RM, CNT, ACCUM>), grid, block, 0, ctx->stream, p, items, n_items, a0, \
+#define HIVE_LAUNCH(RM, CNT)                                                                                      \
+    hipLaunchKernelGGL((integrate_kernel<RM, CNT, ACCUM>), grid, block, 0, ctx->stream, p, items, n_items, a0, \
                        v->d_weight, v->d_color, (long long)v->n)
-    const int sel = (vec ? 4 : 0) | (v->round_mode ? 2 : 0) | (count ? 1 : 0);
-    switch (sel) {
-        case 0: HIVE_LAUNCH(1, 0, false); break;
-        case 1: HIVE_LAUNCH(1, 0, true); break;
-        case 2: HIVE_LAUNCH(1, 1, false); break;
-        case 3: HIVE_LAUNCH(1, 1, true); break;
-        case 4: HIVE_LAUNCH(4, 0, false); break;
-        case 5: HIVE_LAUNCH(4, 0, true); break;
-        case 6: HIVE_LAUNCH(4, 1, false); break;
-        case 7: HIVE_LAUNCH(4, 1, true); break;
+    switch ((v->round_mode ? 2 : 0) | (count ? 1 : 0)) {
+        case 0: HIVE_LAUNCH(0, false); break;
+        case 1: HIVE_LAUNCH(0, true); break;
+        case 2: HIVE_LAUNCH(1, false); break;
+        case 3: HIVE_LAUNCH(1, true); break;
     }
 #undef HIVE_LAUNCH
     HIVE_CHECK_HIP(ctx, hipGetLastError());
@@ -1193,8 +1173,7 @@ int hive_tsdf_integrate_batch(hive_tsdf *vol, int n, const uint8_t *color, const
     // device-resident frames on the vector path: groups of up to MAXF consecutive frames per sweep (bit-identical to one sweep each)
     static const char *frames_env = getenv("HIVE_TSDF_FRAMES_PER_LAUNCH");  // "1": the single-frame kernel (tuning / A-B)
     const int group = frames_env ? std::max(1, std::min(MAXF, atoi(frames_env))) : MAXF;
-    const bool multi = mem == HIVE_MEM_DEVICE && group > 1 && vol->dim[2] % 4 == 0 && npx % 4 == 0 && ((uintptr_t)depth % 16 == 0) && ((uintptr_t)color % 4 == 0) &&
-                       (npx * 3) % 4 == 0 && (((uintptr_t)vol->d_tsdf | (uintptr_t)vol->d_weight | (uintptr_t)vol->d_color) % 16 == 0);
+    const bool multi = mem == HIVE_MEM_DEVICE && group > 1;  // any volume shape, any image size (rows of any length take the 16-byte path)
     // Fusing pays when the frames look at (almost) the same voxels -- consecutive frames of a video; frames far apart share little and
     // every voxel of the union still runs every frame's tests.  Measured on the room scene (640 x 480 into 512^3, us per frame: alone |
     // pairs | fours): 2.4 degrees apart 90 | 70 | 62; 12 degrees 90 | - | 75; 15 degrees 85 | 77 | 82; 20 degrees 85 | 81 | 93; 30 degrees

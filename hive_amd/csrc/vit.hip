@@ -30,11 +30,10 @@
 #include <cstdlib>
 #include <cmath>
 
-typedef __bf16 bf16;
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+using hive_mfma::f32x4;
+using hive_mfma::f32x16;
+using hive_mfma::vec;  // vec<T, 8>: 8 elements of the 16-bit element type T = __bf16 (north_star's contract) or _Float16 (what the
+                       // reference runs, /root/reference/hive/dataset_adaptors.py:1394-1401, 1415-1417): same MFMA shapes and rates
 
 enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RESIDUAL = 2, EPI_QKV = 3 };
 
@@ -50,20 +49,20 @@ using hive_mfma::swz;  // byte offset of 16-byte chunk c of row r in a 128-byte-
 
 // ------------------------------------------------------------------------------------------------
 // LayerNorm over the last dimension D (multiple of 256), one wave per row, f32 statistics
-template <int CH>  // D = 256 * CH
-__global__ __launch_bounds__(256) void layernorm_kernel(const bf16 *__restrict__ x, const float *__restrict__ gamma,
-                                                        const float *__restrict__ beta, bf16 *__restrict__ out, int M, float eps) {
+template <typename T, int CH>  // D = 256 * CH
+__global__ __launch_bounds__(256) void layernorm_kernel(const T *__restrict__ x, const float *__restrict__ gamma,
+                                                        const float *__restrict__ beta, T *__restrict__ out, int M, float eps) {
     constexpr int D = 256 * CH;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= M) return;
-    const bf16 *xr = x + (size_t)row * D;
+    const T *xr = x + (size_t)row * D;
     float v[4 * CH];
     constexpr int n_chunks = CH;
     float sum = 0.f;
 #pragma unroll
     for (int i = 0; i < n_chunks; ++i) {
-        const bf16x4 t = *reinterpret_cast<const bf16x4 *>(xr + i * 256 + lane * 4);
+        const vec<T, 4> t = *reinterpret_cast<const vec<T, 4> *>(xr + i * 256 + lane * 4);
         for (int j = 0; j < 4; ++j) {
             v[4 * i + j] = (float)t[j];
             sum += v[4 * i + j];
@@ -79,29 +78,30 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16 *__restrict__
     }
     for (int off = 32; off > 0; off >>= 1) var += __shfl_xor(var, off);
     const float rstd = rsqrtf(var / (float)D + eps);
-    bf16 *orow = out + (size_t)row * D;
+    T *orow = out + (size_t)row * D;
 #pragma unroll
     for (int i = 0; i < n_chunks; ++i) {
         const int c = i * 256 + lane * 4;
         const float4 g = *reinterpret_cast<const float4 *>(gamma + c);
         const float4 b = *reinterpret_cast<const float4 *>(beta + c);
-        bf16x4 o;
-        o[0] = (bf16)((v[4 * i + 0] - mean) * rstd * g.x + b.x);
-        o[1] = (bf16)((v[4 * i + 1] - mean) * rstd * g.y + b.y);
-        o[2] = (bf16)((v[4 * i + 2] - mean) * rstd * g.z + b.z);
-        o[3] = (bf16)((v[4 * i + 3] - mean) * rstd * g.w + b.w);
-        *reinterpret_cast<bf16x4 *>(orow + c) = o;
+        vec<T, 4> o;
+        o[0] = (T)((v[4 * i + 0] - mean) * rstd * g.x + b.x);
+        o[1] = (T)((v[4 * i + 1] - mean) * rstd * g.y + b.y);
+        o[2] = (T)((v[4 * i + 2] - mean) * rstd * g.z + b.z);
+        o[3] = (T)((v[4 * i + 3] - mean) * rstd * g.w + b.w);
+        *reinterpret_cast<vec<T, 4> *>(orow + c) = o;
     }
 }
 
 // ------------------------------------------------------------------------------------------------
+template <typename T>
 struct GemmParams {
-    const bf16 *A;       // [M][K]
-    const bf16 *W;       // [N][K]
+    const T *A;       // [M][K]
+    const T *W;       // [N][K]
     const float *bias;   // [N]
-    const bf16 *residual;  // [M][ldc] (EPI_BIAS_RESIDUAL)
-    bf16 *C;             // [M][ldc]
-    bf16 *vT;            // EPI_QKV: [B][H][64][Np]
+    const T *residual;  // [M][ldc] (EPI_BIAS_RESIDUAL)
+    T *C;             // [M][ldc]
+    T *vT;            // EPI_QKV: [B][H][64][Np]
     int M, N, K, ldc;
     int Np, H;           // EPI_QKV: tokens per image (padded), heads
     int n_split;         // EPI_QKV: columns >= n_split are V columns
@@ -135,29 +135,30 @@ __device__ __forceinline__ f32x2 gelu_exact2(f32x2 x) {
 // Global -> LDS staging with LDS-DMA (global_load_lds_dwordx4): one wave instruction deposits 64 x 16 B =
 // 8 rows of 128 B, lane-linear.  The bank swizzle therefore lives on the SOURCE side: LDS slot (row, s)
 // receives global chunk s ^ ((row >> 1) & 7), and the fragment reads apply the same XOR (swz()).
-__device__ __forceinline__ void stage_group(const bf16 *__restrict__ src, int ld, int row0, int row_max, int k0,
+template <typename T>
+__device__ __forceinline__ void stage_group(const T *__restrict__ src, int ld, int row0, int row_max, int k0,
                                             unsigned char *tile, int grp, int lane) {
     const int row = grp * 8 + (lane >> 3);
     const int chunk = (lane & 7) ^ ((row >> 1) & 7);
     const int grow = min(row0 + row, row_max);  // clamp: rows past the end are never stored
-    const bf16 *g = src + (size_t)grow * ld + k0 + chunk * 8;
+    const T *g = src + (size_t)grow * ld + k0 + chunk * 8;
     __builtin_amdgcn_global_load_lds((const void *)g, (__attribute__((address_space(3))) void *)(tile + grp * 1024), 16, 0, 0);
 }
 
 // Epilogue of the A.W^T GEMM tiles (EPI_BIAS / _GELU / _RESIDUAL): bias, GELU or residual in f32, one rounding to bf16; through the
 // wave's 4 KiB of LDS (mfma_pipe.hpp staged_rows) so that the residual loads and the stores are 16 bytes per lane on whole lines.
-template <int EPI, int MT>
-__device__ __forceinline__ void gemm_store_rows(const GemmParams &p, const f32x4 (&acc)[4][MT], int m_base, int n_base, unsigned char *stage, int lane) {
+template <typename T, int EPI, int MT>
+__device__ __forceinline__ void gemm_store_rows(const GemmParams<T> &p, const f32x4 (&acc)[4][MT], int m_base, int n_base, unsigned char *stage, int lane) {
     const int n = n_base + (lane & 7) * 8, rr = lane >> 3;
     const float4 b0 = *reinterpret_cast<const float4 *>(p.bias + n), b1 = *reinterpret_cast<const float4 *>(p.bias + n + 4);
     // residual rows: loaded one fragment row ahead (two register sets), not in front of each store.  The residual may BE the output
     // (x += proj(...)): every element is read by the lane that later writes it, rows of fragment row mt + 1 are read before rows of
     // mt are written -- no hazard, but the compiler cannot know, so the order is set by hand.
-    bf16x8 rs[2][2];
+    vec<T, 8> rs[2][2];
     auto pre = [&](int mt, int j) {
         if (EPI == EPI_BIAS_RESIDUAL) {
             const int m = min(m_base + mt * 16 + 8 * j + rr, p.M - 1);
-            rs[mt & 1][j] = *reinterpret_cast<const bf16x8 *>(p.residual + (size_t)m * p.ldc + n);
+            rs[mt & 1][j] = *reinterpret_cast<const vec<T, 8> *>(p.residual + (size_t)m * p.ldc + n);
         }
     };
     hive_mfma::staged_rows<MT>(stage, acc, lane, pre, [&](int r, int, const f32x4 &lo, const f32x4 &hi, int mt, int j) {
@@ -180,10 +181,10 @@ __device__ __forceinline__ void gemm_store_rows(const GemmParams &p, const f32x4
 #pragma unroll
             for (int k = 0; k < 8; ++k) o[k] += (float)rs[mt & 1][j][k];
         }
-        bf16x8 ov;
+        vec<T, 8> ov;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) ov[k] = (bf16)o[k];
-        *reinterpret_cast<bf16x8 *>(p.C + (size_t)m * p.ldc + n) = ov;
+        for (int k = 0; k < 8; ++k) ov[k] = (T)o[k];
+        *reinterpret_cast<vec<T, 8> *>(p.C + (size_t)m * p.ldc + n) = ov;
     });
 }
 
@@ -198,8 +199,8 @@ __device__ __forceinline__ void gemm_store_rows(const GemmParams &p, const f32x4
 //            wave (half the LDS bytes per flop, one wave per SIMD: 570-680 TFLOP/s, register-staged variant spills),
 //            LDS-DMA pieces interleaved between the MFMAs (no change).
 // EPI_QKV here means "v^T tile": orientation A.W^T and the transposed store; q|k columns use EPI_BIAS.
-template <int EPI, int TM, int NST>
-__global__ __launch_bounds__(TM * 2, 1) void gemm_kernel(GemmParams p) {
+template <typename T, int EPI, int TM, int NST>
+__global__ __launch_bounds__(TM * 2, 1) void gemm_kernel(GemmParams<T> p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // NST stages x (A tile TM x 64, W tile 128 x 64) + 4 KiB per wave for the epilogue
     constexpr int NWAVES = TM / 32;
     constexpr int A_GROUPS = TM / 8, GROUPS = A_GROUPS + 16, PER_WAVE = GROUPS / NWAVES;
@@ -253,13 +254,13 @@ __global__ __launch_bounds__(TM * 2, 1) void gemm_kernel(GemmParams p) {
         const int sm0 = last ? nm0 : m0, sn0 = last ? nn0 : n0, sk = last ? (has_next ? 0 : KT - 1) : kt + 1;
         const unsigned char *a_t = lds + buf * STAGE_BYTES, *w_t = a_t + A_GROUPS * 1024;
         // VT: acc[mt][nt] = A_frag . W_frag^T (rows = m, cols = n); else acc[nt][mt] = W_frag . A_frag^T (rows = n, cols = m)
-        hive_mfma::kstep64<4, VT>(a_t, w_t, wr * 64, wc * 64, fr, fq, acc, PER_WAVE, [&](int j) { issue_piece(sm0, sn0, sk, buf ^ 1, j); });
+        hive_mfma::kstep64<T, 4, VT>(a_t, w_t, wr * 64, wc * 64, fr, fq, acc, PER_WAVE, [&](int j) { issue_piece(sm0, sn0, sk, buf ^ 1, j); });
         buf ^= 1;
     }
 
     // epilogue
     if constexpr (!VT) {
-        gemm_store_rows<EPI, 4>(p, acc, m0 + wr * 64, n0 + wc * 64, lds + NST * STAGE_BYTES + wave * 4096, lane);
+        gemm_store_rows<T, EPI, 4>(p, acc, m0 + wr * 64, n0 + wc * 64, lds + NST * STAGE_BYTES + wave * 4096, lane);
     } else {
         // v^T[b][h][c][token]: the wave's 64 tokens x 64 channels are one head of one image (Np % 64 == 0): 64 rows of 128 contiguous
         // bytes.  A lane owns 4 consecutive tokens of one channel, so a direct store is 16 rows x 32 bytes per instruction; instead
@@ -277,10 +278,10 @@ __global__ __launch_bounds__(TM * 2, 1) void gemm_kernel(GemmParams p) {
                 const float b = p.bias[n0 + wc * 64 + nt * 16 + fr];
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) {
-                    bf16x4 ov;
+                    vec<T, 4> ov;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) ov[j] = (bf16)(acc[mt][nt][j] + b);
-                    *reinterpret_cast<bf16x4 *>(ot + row * 128 + (((mt * 2 + (fqs >> 1)) ^ (row & 7)) << 4) + (fqs & 1) * 8) = ov;
+                    for (int j = 0; j < 4; ++j) ov[j] = (T)(acc[mt][nt][j] + b);
+                    *reinterpret_cast<vec<T, 4> *>(ot + row * 128 + (((mt * 2 + (fqs >> 1)) ^ (row & 7)) << 4) + (fqs & 1) * 8) = ov;
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -291,8 +292,8 @@ __global__ __launch_bounds__(TM * 2, 1) void gemm_kernel(GemmParams p) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int row = 8 * i + (lane >> 3), c = lane & 7;
-                    const bf16x8 o8 = *reinterpret_cast<const bf16x8 *>(ot + row * 128 + ((c ^ (row & 7)) << 4));
-                    *reinterpret_cast<bf16x8 *>(p.vT + (((size_t)img * p.H + head) * 64 + half * 32 + row) * p.Np + tok0 + 8 * c) = o8;
+                    const vec<T, 8> o8 = *reinterpret_cast<const vec<T, 8> *>(ot + row * 128 + ((c ^ (row & 7)) << 4));
+                    *reinterpret_cast<vec<T, 8> *>(p.vT + (((size_t)img * p.H + head) * 64 + half * 32 + row) * p.Np + tok0 + 8 * c) = o8;
                 }
             }
             __builtin_amdgcn_wave_barrier();  // the second half's writes stay behind these reads
@@ -337,8 +338,8 @@ extern "C" int hive_debug_read_stamps(void *host, size_t bytes) {
 #define HIVE_STAMP_ADD(i, v) do { } while (0)
 #endif
 
-template <int EPI>
-__global__ __launch_bounds__(512, 1) void gemm256_kernel(GemmParams p) {
+template <typename T, int EPI>
+__global__ __launch_bounds__(512, 1) void gemm256_kernel(GemmParams<T> p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // 2 stages x (A tile 256 x 64, W tile 256 x 64) + 8 x 4 KiB for the epilogue
     constexpr int A_GROUPS = T256 / 8, GROUPS = 2 * A_GROUPS, PER_WAVE = GROUPS / 8;
     static_assert(EPI != EPI_QKV, "the transposed v^T store stays with the 128-row kernel (N = 768)");
@@ -381,7 +382,7 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(GemmParams p) {
 #ifdef HIVE_GEMM_STAMPS
     unsigned long long waited = 0, waited_vm = 0;
 #endif
-    hive_mfma::KPipe<8, false> pipe;
+    hive_mfma::KPipe<T, 8, false> pipe;
     pipe.a_row0 = wr * 128, pipe.w_row0 = wc * 64, pipe.fr = fr, pipe.fq = fq;
     for (int kt = 0; kt < KT; ++kt) {
 #ifdef HIVE_GEMM_STAMPS
@@ -408,7 +409,7 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(GemmParams p) {
     HIVE_STAMP_ADD(6, waited);
     HIVE_STAMP_ADD(7, waited_vm);
 
-    gemm_store_rows<EPI, 8>(p, acc, m0 + wr * 128, n0 + wc * 64, lds + 2 * T256_STAGE + wave * 4096, lane);
+    gemm_store_rows<T, EPI, 8>(p, acc, m0 + wr * 128, n0 + wc * 64, lds + 2 * T256_STAGE + wave * 4096, lane);
     HIVE_STAMP(4);
 #ifdef HIVE_GEMM_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -418,8 +419,8 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(GemmParams p) {
 
 // The same tile as PERSISTENT workgroups (one per CU, XCD-aware runs of tiles as in csrc/conv.hip): the K-steps of a workgroup's tiles
 // form one stream, the first stage of the next tile is issued during the last K-step of the current one and lands under its epilogue.
-template <int EPI>
-__global__ __launch_bounds__(512, 1) void gemm256p_kernel(GemmParams p) {
+template <typename T, int EPI>
+__global__ __launch_bounds__(512, 1) void gemm256p_kernel(GemmParams<T> p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr int A_GROUPS = T256 / 8, GROUPS = 2 * A_GROUPS, PER_WAVE = GROUPS / 8;
     constexpr bool VT = (EPI == EPI_QKV);  // the v columns of the QKV projection: orientation A.W^T (a lane owns 4 consecutive TOKENS of one channel)
@@ -454,7 +455,7 @@ __global__ __launch_bounds__(512, 1) void gemm256p_kernel(GemmParams p) {
     setup(run0 + tl);
 #pragma unroll
     for (int j = 0; j < PER_WAVE; ++j) issue_piece(0, 0, j);
-    hive_mfma::KPipe<8, VT> pipe;
+    hive_mfma::KPipe<T, 8, VT> pipe;
     pipe.a_row0 = wr * 128, pipe.w_row0 = wc * 64, pipe.fr = lane & 15, pipe.fq = lane >> 4;
     int buf = 0;
     for (;;) {
@@ -485,7 +486,7 @@ __global__ __launch_bounds__(512, 1) void gemm256p_kernel(GemmParams p) {
         }
         pipe.flush(acc);
         if constexpr (!VT) {
-            gemm_store_rows<EPI, 8>(p, acc, em0 + wr * 128, en0 + wc * 64, lds + 2 * T256_STAGE + wave * 4096, lane);
+            gemm_store_rows<T, EPI, 8>(p, acc, em0 + wr * 128, en0 + wc * 64, lds + 2 * T256_STAGE + wave * 4096, lane);
         } else {
             // v^T[b][h][c][token]: the wave's 128 tokens x 64 channels are two 64-token blocks of one head (Np % 64 == 0), each 64 rows of
             // 128 contiguous bytes; turned around in the wave's 4 KiB of LDS, 64 tokens x 32 channels at a time (see gemm_kernel's v^T path)
@@ -502,10 +503,10 @@ __global__ __launch_bounds__(512, 1) void gemm256p_kernel(GemmParams p) {
                         const float bv = p.bias[en0 + wc * 64 + nt * 16 + fr];
 #pragma unroll
                         for (int mtl = 0; mtl < 4; ++mtl) {
-                            bf16x4 ov;
+                            vec<T, 4> ov;
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) ov[j] = (bf16)(acc[blk * 4 + mtl][nt][j] + bv);
-                            *reinterpret_cast<bf16x4 *>(ot + row * 128 + (((mtl * 2 + (fqs >> 1)) ^ (row & 7)) << 4) + (fqs & 1) * 8) = ov;
+                            for (int j = 0; j < 4; ++j) ov[j] = (T)(acc[blk * 4 + mtl][nt][j] + bv);
+                            *reinterpret_cast<vec<T, 4> *>(ot + row * 128 + (((mtl * 2 + (fqs >> 1)) ^ (row & 7)) << 4) + (fqs & 1) * 8) = ov;
                         }
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -516,8 +517,8 @@ __global__ __launch_bounds__(512, 1) void gemm256p_kernel(GemmParams p) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
                             const int row = 8 * i + (lane >> 3), c = lane & 7;
-                            const bf16x8 o8 = *reinterpret_cast<const bf16x8 *>(ot + row * 128 + ((c ^ (row & 7)) << 4));
-                            *reinterpret_cast<bf16x8 *>(p.vT + (((size_t)img * p.H + head) * 64 + half * 32 + row) * p.Np + tok0 + 8 * c) = o8;
+                            const vec<T, 8> o8 = *reinterpret_cast<const vec<T, 8> *>(ot + row * 128 + ((c ^ (row & 7)) << 4));
+                            *reinterpret_cast<vec<T, 8> *>(p.vT + (((size_t)img * p.H + head) * 64 + half * 32 + row) * p.Np + tok0 + 8 * c) = o8;
                         }
                     }
                     __builtin_amdgcn_wave_barrier();
@@ -531,10 +532,11 @@ __global__ __launch_bounds__(512, 1) void gemm256p_kernel(GemmParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+template <typename T>
 struct AttnParams {
-    const bf16 *qk;  // [B*Np][2D]; q pre-multiplied by head_dim^-0.5 * log2(e) (hive_vit_qkv)
-    const bf16 *vT;  // [B][H][64][Np]
-    bf16 *out;       // [B*Np][D]
+    const T *qk;  // [B*Np][2D]; q pre-multiplied by head_dim^-0.5 * log2(e) (hive_vit_qkv)
+    const T *vT;  // [B][H][64][Np]
+    T *out;       // [B*Np][D]
     int B, H, N, Np, D;
 };
 
@@ -547,7 +549,8 @@ __device__ __forceinline__ float max3_raw(float a, float b, float c) {
     return r;
 }
 
-__global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
+template <typename T>
+__global__ __launch_bounds__(256) void attention_kernel(AttnParams<T> p) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * ATT_KV * 128];  // 2 stages x (K tile, V^T tile)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q_blocks = (p.Np + 127) / 128;
@@ -561,14 +564,14 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
     const int ld = 2 * p.D;
 
     // Q as the B operand of S^T = K Q^T: lane holds Q[q][16 ks + 8 hh + j]
-    bf16x8 qf[4];
+    vec<T, 8> qf[4];
     for (int ks = 0; ks < 4; ++ks)
-        qf[ks] = *reinterpret_cast<const bf16x8 *>(p.qk + (row0 + q_tok) * ld + head * 64 + ks * 16 + hh * 8);
+        qf[ks] = *reinterpret_cast<const vec<T, 8> *>(p.qk + (row0 + q_tok) * ld + head * 64 + ks * 16 + hh * 8);
 
     // staging of one K tile [64 keys][64 ch] and one V^T tile [64 ch][64 keys] by LDS-DMA: 8 + 8 groups of 8 rows x 128 B,
     // 4 per wave, with the GEMM's source-side chunk swizzle (slot = chunk ^ ((row >> 1) & 7))
-    const bf16 *k_base = p.qk + row0 * ld + p.D + head * 64;
-    const bf16 *v_base = p.vT + ((size_t)img * p.H + head) * 64 * p.Np;
+    const T *k_base = p.qk + row0 * ld + p.D + head * 64;
+    const T *v_base = p.vT + ((size_t)img * p.H + head) * 64 * p.Np;
     auto issue_tile = [&](int t, int stage) {
         unsigned char *k_t = lds + stage * 2 * ATT_KV * 128, *v_t = k_t + ATT_KV * 128;
 #pragma unroll
@@ -606,8 +609,8 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(k_t + swz(kb * 32 + lq, ks * 2 + hh));
-                sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], ks == 0 ? neg_m : sacc[kb], 0, 0, 0);
+                const vec<T, 8> kf = *reinterpret_cast<const vec<T, 8> *>(k_t + swz(kb * 32 + lq, ks * 2 + hh));
+                sacc[kb] = hive_mfma::mfma32(kf, qf[ks], ks == 0 ? neg_m : sacc[kb]);
             }
         // key row of register i: 32 kb + (i & 3) + 8 (i >> 2) + 4 hh.  Keys >= N exist only in the last tile.
         if (t == n_tiles - 1) {
@@ -651,14 +654,14 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
             }
         }
         float l_tile = 0.f;
-        bf16x8 pf[2][2];
+        vec<T, 8> pf[2][2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const float e = __builtin_amdgcn_exp2f(sacc[kb][i]);
                 l_tile += e;
-                pf[kb][i >> 3][i & 7] = (bf16)e;
+                pf[kb][i >> 3][i & 7] = (T)e;
             }
         l_run += l_tile;
         // O^T[ch][q] += V^T[ch][key] P^T[key][q]; k index j of half hh <-> key 32 kb + 16 s + 8 (j >> 2) + 4 hh + (j & 3) (see vt_slot)
@@ -670,8 +673,8 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
                 for (int db = 0; db < 2; ++db) {
                     // the lane's 8 keys {16 s + 4 hh + 0..3, + 8..11} of key block kb sit in slots 16 s + 8 hh .. + 7 of the stored
                     // (quad-swapped) order: chunk 4 kb + 2 s + hh of the row, one 16-byte read through the tile's swizzle
-                    const bf16x8 vf = *reinterpret_cast<const bf16x8 *>(v_t + swz(db * 32 + lq, 4 * kb + 2 * s + hh));
-                    oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kb][s], oacc[db], 0, 0, 0);
+                    const vec<T, 8> vf = *reinterpret_cast<const vec<T, 8> *>(v_t + swz(db * 32 + lq, 4 * kb + 2 * s + hh));
+                    oacc[db] = hive_mfma::mfma32(vf, pf[kb][s], oacc[db]);
                 }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my pieces of tile t+1 have landed
         __syncthreads();
@@ -687,9 +690,9 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
     for (int db = 0; db < 2; ++db)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            bf16x4 ov;
-            for (int j = 0; j < 4; ++j) ov[j] = (bf16)(oacc[db][4 * g + j] * inv);
-            *reinterpret_cast<bf16x4 *>(ot + lq * 128 + (((4 * db + g) ^ (lq & 7)) << 4) + 8 * hh) = ov;  // channels 32 db + 8 g + 4 hh ..+3
+            vec<T, 4> ov;
+            for (int j = 0; j < 4; ++j) ov[j] = (T)(oacc[db][4 * g + j] * inv);
+            *reinterpret_cast<vec<T, 4> *>(ot + lq * 128 + (((4 * db + g) ^ (lq & 7)) << 4) + 8 * hh) = ov;  // channels 32 db + 8 g + 4 hh ..+3
         }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -697,15 +700,16 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int r = 8 * j + (lane >> 3), c = lane & 7;
-        const bf16x8 row = *reinterpret_cast<const bf16x8 *>(ot + r * 128 + ((c ^ (r & 7)) << 4));
+        const vec<T, 8> row = *reinterpret_cast<const vec<T, 8> *>(ot + r * 128 + ((c ^ (r & 7)) << 4));
         const int q = qb * 128 + wave * 32 + r;
-        if (q < p.Np) *reinterpret_cast<bf16x8 *>(p.out + (row0 + q) * p.D + head * 64 + 8 * c) = row;
+        if (q < p.Np) *reinterpret_cast<vec<T, 8> *>(p.out + (row0 + q) * p.D + head * 64 + 8 * c) = row;
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // token (un)padding: [B][N][D] <-> [B][Np][D], pad rows zero
-__global__ __launch_bounds__(256) void pad_tokens_kernel(const bf16 *__restrict__ src, bf16 *__restrict__ dst, int B, int N, int Np,
+typedef unsigned short half_bits;  // either 16-bit type: copied, never interpreted
+__global__ __launch_bounds__(256) void pad_tokens_kernel(const half_bits *__restrict__ src, half_bits *__restrict__ dst, int B, int N, int Np,
                                                          int D, int to_padded) {
     const size_t chunks_per_row = D / 8;
     const size_t total = (size_t)B * Np * chunks_per_row;
@@ -793,6 +797,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t *__restri
 // ------------------------------------------------------------------------------------------------
 struct hive_vit {
     hive_ctx *ctx = nullptr;
+    int dtype = HIVE_BF16;
     int depth = 0, dim = 0, heads = 0, mlp = 0;
     float eps = 1e-6f;
     std::vector<hive_vit_block_weights> blocks;
@@ -801,13 +806,16 @@ struct hive_vit {
     size_t ws_bytes = 0;
 };
 
-static int launch_layernorm(hive_ctx *ctx, const bf16 *x, const float *g, const float *b, bf16 *out, int M, int D, float eps) {
+template <typename T>
+static int launch_layernorm(hive_ctx *ctx, const void *x, const float *g, const float *b, void *out, int M, int D, float eps) {
     const dim3 grid((M + 3) / 4), block(256);
+    const T *xi = (const T *)x;
+    T *xo = (T *)out;
     switch (D / 256) {
-        case 1: hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, ctx->stream, x, g, b, out, M, eps); break;
-        case 2: hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, ctx->stream, x, g, b, out, M, eps); break;
-        case 3: hipLaunchKernelGGL(layernorm_kernel<3>, grid, block, 0, ctx->stream, x, g, b, out, M, eps); break;
-        case 4: hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, ctx->stream, x, g, b, out, M, eps); break;
+        case 1: hipLaunchKernelGGL((layernorm_kernel<T, 1>), grid, block, 0, ctx->stream, xi, g, b, xo, M, eps); break;
+        case 2: hipLaunchKernelGGL((layernorm_kernel<T, 2>), grid, block, 0, ctx->stream, xi, g, b, xo, M, eps); break;
+        case 3: hipLaunchKernelGGL((layernorm_kernel<T, 3>), grid, block, 0, ctx->stream, xi, g, b, xo, M, eps); break;
+        case 4: hipLaunchKernelGGL((layernorm_kernel<T, 4>), grid, block, 0, ctx->stream, xi, g, b, xo, M, eps); break;
         default: return hive_fail(ctx, HIVE_ERR_INVALID, "layernorm: unsupported D %d", D);
     }
     HIVE_CHECK_HIP(ctx, hipGetLastError());
@@ -816,36 +824,39 @@ static int launch_layernorm(hive_ctx *ctx, const bf16 *x, const float *g, const 
 
 constexpr int GEMM_TM = 128, GEMM_NST = 2;
 constexpr size_t GEMM_LDS = (size_t)GEMM_NST * (GEMM_TM / 8 + 16) * 1024 + (GEMM_TM / 32) * 4096;  // the stages + 4 KiB per wave for the epilogue: 80 KiB, two workgroups per CU
+constexpr int GEMM256_LDS = 2 * T256_STAGE + hive_mfma::STAGED_ROWS_LDS;
 
-static int launch_gemm256(hive_ctx *ctx, int epi, const GemmParams &p) {
+template <typename T>
+static int launch_gemm256(hive_ctx *ctx, int epi, const GemmParams<T> &p) {
     const dim3 grid((unsigned)(((p.M + T256 - 1) / T256) * (p.N / T256))), block(512);
-    const size_t lds_bytes = 2 * T256_STAGE + hive_mfma::STAGED_ROWS_LDS;
+    const size_t lds_bytes = GEMM256_LDS;
     // persistent workgroups by default (+2-4 % where a workgroup gets more than one tile: the next tile's first fill is hidden);
     // HIVE_GEMM_PERSIST=0 selects the one-tile-per-workgroup kernel, the one the phase clocks of `make stamps` instrument
     static const char *persist = getenv("HIVE_GEMM_PERSIST");
     if (!(persist && persist[0] == '0')) {
         const dim3 pgrid((unsigned)std::min<long long>(((long long)grid.x + 7) / 8 * 8, (long long)ctx->num_cus / 8 * 8));
         switch (epi) {
-            case EPI_BIAS: hipLaunchKernelGGL((gemm256p_kernel<EPI_BIAS>), pgrid, block, lds_bytes, ctx->stream, p); break;
-            case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm256p_kernel<EPI_BIAS_GELU>), pgrid, block, lds_bytes, ctx->stream, p); break;
-            case EPI_BIAS_RESIDUAL: hipLaunchKernelGGL((gemm256p_kernel<EPI_BIAS_RESIDUAL>), pgrid, block, lds_bytes, ctx->stream, p); break;
-            case EPI_QKV: hipLaunchKernelGGL((gemm256p_kernel<EPI_QKV>), pgrid, block, lds_bytes, ctx->stream, p); break;
+            case EPI_BIAS: hipLaunchKernelGGL((gemm256p_kernel<T, EPI_BIAS>), pgrid, block, lds_bytes, ctx->stream, p); break;
+            case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm256p_kernel<T, EPI_BIAS_GELU>), pgrid, block, lds_bytes, ctx->stream, p); break;
+            case EPI_BIAS_RESIDUAL: hipLaunchKernelGGL((gemm256p_kernel<T, EPI_BIAS_RESIDUAL>), pgrid, block, lds_bytes, ctx->stream, p); break;
+            case EPI_QKV: hipLaunchKernelGGL((gemm256p_kernel<T, EPI_QKV>), pgrid, block, lds_bytes, ctx->stream, p); break;
             default: return hive_fail(ctx, HIVE_ERR_INVALID, "gemm: unknown epilogue %d", epi);
         }
         HIVE_CHECK_HIP(ctx, hipGetLastError());
         return HIVE_OK;
     }
     switch (epi) {
-        case EPI_BIAS: hipLaunchKernelGGL((gemm256_kernel<EPI_BIAS>), grid, block, lds_bytes, ctx->stream, p); break;
-        case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm256_kernel<EPI_BIAS_GELU>), grid, block, lds_bytes, ctx->stream, p); break;
-        case EPI_BIAS_RESIDUAL: hipLaunchKernelGGL((gemm256_kernel<EPI_BIAS_RESIDUAL>), grid, block, lds_bytes, ctx->stream, p); break;
+        case EPI_BIAS: hipLaunchKernelGGL((gemm256_kernel<T, EPI_BIAS>), grid, block, lds_bytes, ctx->stream, p); break;
+        case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm256_kernel<T, EPI_BIAS_GELU>), grid, block, lds_bytes, ctx->stream, p); break;
+        case EPI_BIAS_RESIDUAL: hipLaunchKernelGGL((gemm256_kernel<T, EPI_BIAS_RESIDUAL>), grid, block, lds_bytes, ctx->stream, p); break;
         default: return hive_fail(ctx, HIVE_ERR_INVALID, "gemm: unknown epilogue %d", epi);
     }
     HIVE_CHECK_HIP(ctx, hipGetLastError());
     return HIVE_OK;
 }
 
-static int launch_gemm(hive_ctx *ctx, int epi, const GemmParams &p) {
+template <typename T>
+static int launch_gemm(hive_ctx *ctx, int epi, const GemmParams<T> &p) {
     // 256 x 256 tiles (half the operand bytes per flop: 690-970 TFLOP/s against 510-680 for the 128-row tiles on the ViT shapes)
     // wherever they fill the chip: one workgroup per CU, so what matters is how full the last round of tiles is -- at M = 29184,
     // N = 768 there are 342 tiles for 256 CUs (67 %), at M = 19456 228 (89 %: 970 TFLOP/s), at M = 9728 114 (44 %); below 60 % the persistent
@@ -856,139 +867,151 @@ static int launch_gemm(hive_ctx *ctx, int epi, const GemmParams &p) {
     const bool fills = tiles256 * 5 >= rounds * ctx->num_cus * 3;  // >= 60 % of the CU slots of its rounds (67 %: 635 / 763 vs 612 / 705 TFLOP/s for proj / fc2 at M = 29184; 44 %: 655 vs 858)
     static const char *persist_env = getenv("HIVE_GEMM_PERSIST");
     const bool one_tile_kernel = persist_env && persist_env[0] == '0';  // that kernel has no v^T epilogue
-    if ((epi != EPI_QKV || !one_tile_kernel) && p.N % T256 == 0 && ((force && force[0] == '2') || (!force && fills))) return launch_gemm256(ctx, epi, p);
+    if ((epi != EPI_QKV || !one_tile_kernel) && p.N % T256 == 0 && ((force && force[0] == '2') || (!force && fills))) return launch_gemm256<T>(ctx, epi, p);
     // persistent workgroups: two per CU (64 KiB of LDS each), a multiple of 8 so that every XCD gets the same number
     const long long tiles = (long long)((p.M + GEMM_TM - 1) / GEMM_TM) * (p.N / BN);
     const dim3 grid((unsigned)std::min<long long>((tiles + 7) / 8 * 8, (long long)(2 * ctx->num_cus) / 8 * 8)), block(GEMM_TM * 2);
     switch (epi) {
-        case EPI_BIAS: hipLaunchKernelGGL((gemm_kernel<EPI_BIAS, GEMM_TM, GEMM_NST>), grid, block, GEMM_LDS, ctx->stream, p); break;
-        case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm_kernel<EPI_BIAS_GELU, GEMM_TM, GEMM_NST>), grid, block, GEMM_LDS, ctx->stream, p); break;
-        case EPI_BIAS_RESIDUAL: hipLaunchKernelGGL((gemm_kernel<EPI_BIAS_RESIDUAL, GEMM_TM, GEMM_NST>), grid, block, GEMM_LDS, ctx->stream, p); break;
-        case EPI_QKV: hipLaunchKernelGGL((gemm_kernel<EPI_QKV, GEMM_TM, GEMM_NST>), grid, block, GEMM_LDS, ctx->stream, p); break;
+        case EPI_BIAS: hipLaunchKernelGGL((gemm_kernel<T, EPI_BIAS, GEMM_TM, GEMM_NST>), grid, block, GEMM_LDS, ctx->stream, p); break;
+        case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm_kernel<T, EPI_BIAS_GELU, GEMM_TM, GEMM_NST>), grid, block, GEMM_LDS, ctx->stream, p); break;
+        case EPI_BIAS_RESIDUAL: hipLaunchKernelGGL((gemm_kernel<T, EPI_BIAS_RESIDUAL, GEMM_TM, GEMM_NST>), grid, block, GEMM_LDS, ctx->stream, p); break;
+        case EPI_QKV: hipLaunchKernelGGL((gemm_kernel<T, EPI_QKV, GEMM_TM, GEMM_NST>), grid, block, GEMM_LDS, ctx->stream, p); break;
         default: return hive_fail(ctx, HIVE_ERR_INVALID, "gemm: unknown epilogue %d", epi);
     }
     HIVE_CHECK_HIP(ctx, hipGetLastError());
     return HIVE_OK;
 }
 
-static int launch_attention(hive_ctx *ctx, const AttnParams &p) {
-    const int q_blocks = (p.Np + 127) / 128;
-    hipLaunchKernelGGL(attention_kernel, dim3((unsigned)(p.B * p.H * q_blocks)), dim3(256), 0, ctx->stream, p);
-    HIVE_CHECK_HIP(ctx, hipGetLastError());
-    return HIVE_OK;
-}
-
-static bool g_gemm_attr_set[64] = {false};
-
-template <int EPI>
-static hipError_t set_gemm_lds() {
-    return hipFuncSetAttribute((const void *)gemm_kernel<EPI, GEMM_TM, GEMM_NST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS);
-}
-
+template <typename T>
 static int ensure_gemm_attrs(hive_ctx *ctx) {
-    if (ctx->device < 64 && g_gemm_attr_set[ctx->device]) return HIVE_OK;
-    HIVE_CHECK_HIP(ctx, (set_gemm_lds<EPI_BIAS>()));
-    HIVE_CHECK_HIP(ctx, (set_gemm_lds<EPI_BIAS_GELU>()));
-    HIVE_CHECK_HIP(ctx, (set_gemm_lds<EPI_BIAS_RESIDUAL>()));
-    HIVE_CHECK_HIP(ctx, (set_gemm_lds<EPI_QKV>()));
-    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)gemm256_kernel<EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * T256_STAGE + hive_mfma::STAGED_ROWS_LDS));
-    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)gemm256p_kernel<EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * T256_STAGE + hive_mfma::STAGED_ROWS_LDS));
-    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)gemm256_kernel<EPI_BIAS_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * T256_STAGE + hive_mfma::STAGED_ROWS_LDS));
-    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)gemm256p_kernel<EPI_BIAS_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * T256_STAGE + hive_mfma::STAGED_ROWS_LDS));
-    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)gemm256_kernel<EPI_BIAS_RESIDUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * T256_STAGE + hive_mfma::STAGED_ROWS_LDS));
-    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)gemm256p_kernel<EPI_BIAS_RESIDUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * T256_STAGE + hive_mfma::STAGED_ROWS_LDS));
-    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)gemm256p_kernel<EPI_QKV>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * T256_STAGE + hive_mfma::STAGED_ROWS_LDS));
-    if (ctx->device < 64) g_gemm_attr_set[ctx->device] = true;
+    static bool set[64] = {false};
+    if (ctx->device < 64 && set[ctx->device]) return HIVE_OK;
+#define HIVE_GEMM_ATTR(EPI_)                                                                                                                                  \
+    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)gemm_kernel<T, EPI_, GEMM_TM, GEMM_NST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS)); \
+    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)gemm256p_kernel<T, EPI_>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM256_LDS))
+    HIVE_GEMM_ATTR(EPI_BIAS);
+    HIVE_GEMM_ATTR(EPI_BIAS_GELU);
+    HIVE_GEMM_ATTR(EPI_BIAS_RESIDUAL);
+    HIVE_GEMM_ATTR(EPI_QKV);
+#undef HIVE_GEMM_ATTR
+    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)gemm256_kernel<T, EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM256_LDS));
+    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)gemm256_kernel<T, EPI_BIAS_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM256_LDS));
+    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)gemm256_kernel<T, EPI_BIAS_RESIDUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM256_LDS));
+    if (ctx->device < 64) set[ctx->device] = true;
     return HIVE_OK;
 }
 
 static inline int pad64(int n) { return (n + 63) / 64 * 64; }
 
-extern "C" {
-
-int hive_vit_layernorm(hive_ctx *ctx, const void *x, const float *gamma, const float *beta, void *out, int M, int D, float eps) {
-    HIVE_ENTER(ctx);
-    if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
-    HIVE_REQUIRE(ctx, x && gamma && beta && out, "layernorm: NULL argument");
-    HIVE_REQUIRE(ctx, M > 0 && D > 0 && D % 256 == 0 && D <= 1024, "layernorm: D must be a multiple of 256 and <= 1024, got %d", D);
-    return launch_layernorm(ctx, (const bf16 *)x, gamma, beta, (bf16 *)out, M, D, eps);
-}
-
-int hive_vit_linear(hive_ctx *ctx, const void *A, const void *W, const float *bias, const void *residual, void *C, int M, int N,
-                    int K, int epilogue) {
-    HIVE_ENTER(ctx);
-    if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
-    HIVE_REQUIRE(ctx, A && W && bias && C, "linear: NULL argument");
-    HIVE_REQUIRE(ctx, M > 0 && N > 0 && K > 0 && N % BN == 0 && K % BK == 0, "linear: need N %% 128 == 0 and K %% 64 == 0 (M=%d N=%d K=%d)", M, N, K);
-    HIVE_REQUIRE(ctx, epilogue == EPI_BIAS || epilogue == EPI_BIAS_GELU || (epilogue == EPI_BIAS_RESIDUAL && residual),
-                 "linear: bad epilogue %d", epilogue);
-    int rc = ensure_gemm_attrs(ctx);
+template <typename T>
+static int linear_t(hive_ctx *ctx, const void *A, const void *W, const float *bias, const void *residual, void *C, int M, int N, int K, int epilogue) {
+    int rc = ensure_gemm_attrs<T>(ctx);
     if (rc) return rc;
-    GemmParams p{};
-    p.A = (const bf16 *)A;
-    p.W = (const bf16 *)W;
+    GemmParams<T> p{};
+    p.A = (const T *)A;
+    p.W = (const T *)W;
     p.bias = bias;
-    p.residual = (const bf16 *)residual;
-    p.C = (bf16 *)C;
+    p.residual = (const T *)residual;
+    p.C = (T *)C;
     p.M = M;
     p.N = N;
     p.K = K;
     p.ldc = N;
-    return launch_gemm(ctx, epilogue, p);
+    return launch_gemm<T>(ctx, epilogue, p);
 }
 
-int hive_vit_qkv(hive_ctx *ctx, const void *x, const void *W, const float *bias, void *qk, void *vT, int B, int Np, int D, int H) {
-    HIVE_ENTER(ctx);
-    if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
-    HIVE_REQUIRE(ctx, x && W && bias && qk && vT, "qkv: NULL argument");
-    HIVE_REQUIRE(ctx, B > 0 && Np > 0 && Np % 64 == 0 && D == H * 64 && D % 128 == 0, "qkv: need Np %% 64 == 0, D == 64 H, D %% 128 == 0");
-    int rc = ensure_gemm_attrs(ctx);
+template <typename T>
+static int qkv_t(hive_ctx *ctx, const void *x, const void *W, const float *bias, void *qk, void *vT, int B, int Np, int D, int H) {
+    int rc = ensure_gemm_attrs<T>(ctx);
     if (rc) return rc;
     // q | k columns: plain bias epilogue into qk [M][2D]
-    GemmParams p{};
-    p.A = (const bf16 *)x;
-    p.W = (const bf16 *)W;
+    GemmParams<T> p{};
+    p.A = (const T *)x;
+    p.W = (const T *)W;
     p.bias = bias;
-    p.C = (bf16 *)qk;
+    p.C = (T *)qk;
     p.M = B * Np;
     p.N = 2 * D;
     p.K = D;
     p.ldc = 2 * D;
     p.q_cols = D;  // q leaves the GEMM in the softmax's base-2 exponent units: (x Wq + b) * head_dim^-0.5 * log2(e), rounded once
     p.q_scale = 0.125f * 1.44269504088896340736f;
-    if ((rc = launch_gemm(ctx, EPI_BIAS, p))) return rc;
+    if ((rc = launch_gemm<T>(ctx, EPI_BIAS, p))) return rc;
     // v columns: transposed store into vT [B][H][64][Np]
-    GemmParams pv{};
-    pv.A = (const bf16 *)x;
-    pv.W = (const bf16 *)W + (size_t)2 * D * D;
+    GemmParams<T> pv{};
+    pv.A = (const T *)x;
+    pv.W = (const T *)W + (size_t)2 * D * D;
     pv.bias = bias + 2 * D;
-    pv.vT = (bf16 *)vT;
+    pv.vT = (T *)vT;
     pv.M = B * Np;
     pv.N = D;
     pv.K = D;
     pv.ldc = D;
     pv.Np = Np;
     pv.H = H;
-    return launch_gemm(ctx, EPI_QKV, pv);
+    return launch_gemm<T>(ctx, EPI_QKV, pv);
 }
 
-int hive_vit_attention(hive_ctx *ctx, const void *qk, const void *vT, void *out, int B, int N, int Np, int D, int H) {
-    HIVE_ENTER(ctx);
-    if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
-    HIVE_REQUIRE(ctx, qk && vT && out, "attention: NULL argument");
-    HIVE_REQUIRE(ctx, B > 0 && N > 0 && N <= Np && Np % 64 == 0 && D == H * 64, "attention: need N <= Np, Np %% 64 == 0, head dim 64");
-    // the kernel masks pad keys in the LAST 64-key tile only: Np must be N rounded up to a multiple of 64
-    HIVE_REQUIRE(ctx, Np - N < 64, "attention: Np (%d) must be N (%d) rounded up to a multiple of 64", Np, N);
-    AttnParams p{};
-    p.qk = (const bf16 *)qk;
-    p.vT = (const bf16 *)vT;
-    p.out = (bf16 *)out;
+template <typename T>
+static int attention_t(hive_ctx *ctx, const void *qk, const void *vT, void *out, int B, int N, int Np, int D, int H) {
+    AttnParams<T> p{};
+    p.qk = (const T *)qk;
+    p.vT = (const T *)vT;
+    p.out = (T *)out;
     p.B = B;
     p.H = H;
     p.N = N;
     p.Np = Np;
     p.D = D;
-    return launch_attention(ctx, p);
+    const int q_blocks = (p.Np + 127) / 128;
+    hipLaunchKernelGGL(attention_kernel<T>, dim3((unsigned)(p.B * p.H * q_blocks)), dim3(256), 0, ctx->stream, p);
+    HIVE_CHECK_HIP(ctx, hipGetLastError());
+    return HIVE_OK;
+}
+
+#define HIVE_REQUIRE_16BIT(ctx, dtype, what) HIVE_REQUIRE(ctx, (dtype) == HIVE_BF16 || (dtype) == HIVE_F16, what ": dtype must be HIVE_F16 or HIVE_BF16, got %d", (int)(dtype))
+
+extern "C" {
+
+int hive_vit_layernorm(hive_ctx *ctx, const void *x, int dtype, const float *gamma, const float *beta, void *out, int M, int D, float eps) {
+    HIVE_ENTER(ctx);
+    if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
+    HIVE_REQUIRE(ctx, x && gamma && beta && out, "layernorm: NULL argument");
+    HIVE_REQUIRE_16BIT(ctx, dtype, "layernorm");
+    HIVE_REQUIRE(ctx, M > 0 && D > 0 && D % 256 == 0 && D <= 1024, "layernorm: D must be a multiple of 256 and <= 1024, got %d", D);
+    return dtype == HIVE_BF16 ? launch_layernorm<__bf16>(ctx, x, gamma, beta, out, M, D, eps) : launch_layernorm<_Float16>(ctx, x, gamma, beta, out, M, D, eps);
+}
+
+int hive_vit_linear(hive_ctx *ctx, const void *A, int dtype, const void *W, const float *bias, const void *residual, void *C, int M, int N,
+                    int K, int epilogue) {
+    HIVE_ENTER(ctx);
+    if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
+    HIVE_REQUIRE(ctx, A && W && bias && C, "linear: NULL argument");
+    HIVE_REQUIRE_16BIT(ctx, dtype, "linear");
+    HIVE_REQUIRE(ctx, M > 0 && N > 0 && K > 0 && N % BN == 0 && K % BK == 0, "linear: need N %% 128 == 0 and K %% 64 == 0 (M=%d N=%d K=%d)", M, N, K);
+    HIVE_REQUIRE(ctx, epilogue == EPI_BIAS || epilogue == EPI_BIAS_GELU || (epilogue == EPI_BIAS_RESIDUAL && residual),
+                 "linear: bad epilogue %d", epilogue);
+    return dtype == HIVE_BF16 ? linear_t<__bf16>(ctx, A, W, bias, residual, C, M, N, K, epilogue) : linear_t<_Float16>(ctx, A, W, bias, residual, C, M, N, K, epilogue);
+}
+
+int hive_vit_qkv(hive_ctx *ctx, const void *x, int dtype, const void *W, const float *bias, void *qk, void *vT, int B, int Np, int D, int H) {
+    HIVE_ENTER(ctx);
+    if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
+    HIVE_REQUIRE(ctx, x && W && bias && qk && vT, "qkv: NULL argument");
+    HIVE_REQUIRE_16BIT(ctx, dtype, "qkv");
+    HIVE_REQUIRE(ctx, B > 0 && Np > 0 && Np % 64 == 0 && D == H * 64 && D % 128 == 0, "qkv: need Np %% 64 == 0, D == 64 H, D %% 128 == 0");
+    return dtype == HIVE_BF16 ? qkv_t<__bf16>(ctx, x, W, bias, qk, vT, B, Np, D, H) : qkv_t<_Float16>(ctx, x, W, bias, qk, vT, B, Np, D, H);
+}
+
+int hive_vit_attention(hive_ctx *ctx, const void *qk, int dtype, const void *vT, void *out, int B, int N, int Np, int D, int H) {
+    HIVE_ENTER(ctx);
+    if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
+    HIVE_REQUIRE(ctx, qk && vT && out, "attention: NULL argument");
+    HIVE_REQUIRE_16BIT(ctx, dtype, "attention");
+    HIVE_REQUIRE(ctx, B > 0 && N > 0 && N <= Np && Np % 64 == 0 && D == H * 64, "attention: need N <= Np, Np %% 64 == 0, head dim 64");
+    // the kernel masks pad keys in the LAST 64-key tile only: Np must be N rounded up to a multiple of 64
+    HIVE_REQUIRE(ctx, Np - N < 64, "attention: Np (%d) must be N (%d) rounded up to a multiple of 64", Np, N);
+    return dtype == HIVE_BF16 ? attention_t<__bf16>(ctx, qk, vT, out, B, N, Np, D, H) : attention_t<_Float16>(ctx, qk, vT, out, B, N, Np, D, H);
 }
 
 int hive_dpt_preprocess(hive_ctx *ctx, const uint8_t *d_rgb, int64_t n_values, float mean, float std, int dtype, void *d_out) {
@@ -1000,7 +1023,7 @@ int hive_dpt_preprocess(hive_ctx *ctx, const uint8_t *d_rgb, int64_t n_values, f
     PreprocessLut lut;
     for (int i = 0; i < 256; ++i) lut.v[i] = (float)(((double)i / 255.0 - (double)mean) / (double)std);
     if (dtype == HIVE_BF16)
-        hipLaunchKernelGGL(preprocess_kernel<bf16>, grid, dim3(256), 0, ctx->stream, d_rgb, (long long)n_values, lut, (bf16 *)d_out);
+        hipLaunchKernelGGL(preprocess_kernel<__bf16>, grid, dim3(256), 0, ctx->stream, d_rgb, (long long)n_values, lut, (__bf16 *)d_out);
     else if (dtype == HIVE_F16)
         hipLaunchKernelGGL(preprocess_kernel<_Float16>, grid, dim3(256), 0, ctx->stream, d_rgb, (long long)n_values, lut, (_Float16 *)d_out);
     else
@@ -1032,7 +1055,7 @@ int hive_dpt_head_tail(hive_ctx *ctx, const void *d_feat, int dtype, int64_t n_p
     p.max_depth = max_depth;
     const dim3 grid((unsigned)((n_px + 255) / 256));
     if (dtype == HIVE_BF16)
-        hipLaunchKernelGGL(head_tail_kernel<bf16>, grid, dim3(256), 0, ctx->stream, (const bf16 *)d_feat, p, d_depth, d_out_mm, d_out_m);
+        hipLaunchKernelGGL(head_tail_kernel<__bf16>, grid, dim3(256), 0, ctx->stream, (const __bf16 *)d_feat, p, d_depth, d_out_mm, d_out_m);
     else if (dtype == HIVE_F16)
         hipLaunchKernelGGL(head_tail_kernel<_Float16>, grid, dim3(256), 0, ctx->stream, (const _Float16 *)d_feat, p, d_depth, d_out_mm, d_out_m);
     else
@@ -1041,11 +1064,12 @@ int hive_dpt_head_tail(hive_ctx *ctx, const void *d_feat, int dtype, int64_t n_p
     return HIVE_OK;
 }
 
-int hive_vit_create(hive_ctx *ctx, int depth, int dim, int heads, int mlp_dim, float ln_eps, const hive_vit_block_weights *blocks,
+int hive_vit_create(hive_ctx *ctx, int dtype, int depth, int dim, int heads, int mlp_dim, float ln_eps, const hive_vit_block_weights *blocks,
                     hive_vit **out) {
     HIVE_ENTER(ctx);
     if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
     HIVE_REQUIRE(ctx, out && blocks && depth > 0, "vit_create: NULL argument");
+    HIVE_REQUIRE_16BIT(ctx, dtype, "vit_create");
     HIVE_REQUIRE(ctx, dim == heads * 64 && dim % 256 == 0 && dim <= 1024 && mlp_dim % 128 == 0,
                  "vit_create: need head dim 64, dim %% 256 == 0, dim <= 1024, mlp %% 128 == 0 (dim=%d heads=%d mlp=%d)", dim, heads, mlp_dim);
     for (int i = 0; i < depth; ++i) {
@@ -1055,6 +1079,7 @@ int hive_vit_create(hive_ctx *ctx, int depth, int dim, int heads, int mlp_dim, f
     }
     hive_vit *v = new hive_vit();
     v->ctx = ctx;
+    v->dtype = dtype;
     v->depth = depth;
     v->dim = dim;
     v->heads = heads;
@@ -1080,32 +1105,31 @@ int hive_vit_forward(hive_vit *v, const void *x, int B, int N, const int *tap_bl
     hive_ctx *ctx = v->ctx;
     HIVE_REQUIRE(ctx, x && B > 0 && N > 0, "vit_forward: bad arguments");
     HIVE_REQUIRE(ctx, n_taps >= 0 && (n_taps == 0 || (tap_blocks && tap_out)), "vit_forward: bad taps");
-    int rc = ensure_gemm_attrs(ctx);
-    if (rc) return rc;
-    const int D = v->dim, H = v->heads, Np = pad64(N), M = B * Np;
-    const size_t tok = (size_t)M * D * sizeof(bf16);
+    int rc;
+    const int D = v->dim, H = v->heads, Np = pad64(N), M = B * Np, dt = v->dtype;
+    const size_t tok = (size_t)M * D * sizeof(half_bits);
     // workspace: x (residual stream), ln, qk (2D), vT (D), attn, hidden (mlp)
     const size_t off_x = 0, off_ln = off_x + tok, off_qk = off_ln + tok, off_vt = off_qk + 2 * tok, off_attn = off_vt + tok,
-                 off_hid = off_attn + tok, total = off_hid + (size_t)M * v->mlp * sizeof(bf16);
+                 off_hid = off_attn + tok, total = off_hid + (size_t)M * v->mlp * sizeof(half_bits);
     if ((rc = hive_reserve_device(ctx, &v->ws, &v->ws_bytes, total))) return rc;
     char *ws = (char *)v->ws;
-    bf16 *xs = (bf16 *)(ws + off_x), *ln = (bf16 *)(ws + off_ln), *qk = (bf16 *)(ws + off_qk), *vt = (bf16 *)(ws + off_vt),
-         *attn = (bf16 *)(ws + off_attn), *hid = (bf16 *)(ws + off_hid);
+    half_bits *xs = (half_bits *)(ws + off_x), *ln = (half_bits *)(ws + off_ln), *qk = (half_bits *)(ws + off_qk), *vt = (half_bits *)(ws + off_vt),
+              *attn = (half_bits *)(ws + off_attn), *hid = (half_bits *)(ws + off_hid);
     const int cp_blocks = std::min<int>((int)(((size_t)M * D / 8 + 255) / 256), ctx->num_cus * 8);
-    hipLaunchKernelGGL(pad_tokens_kernel, dim3(cp_blocks), dim3(256), 0, ctx->stream, (const bf16 *)x, xs, B, N, Np, D, 1);
+    hipLaunchKernelGGL(pad_tokens_kernel, dim3(cp_blocks), dim3(256), 0, ctx->stream, (const half_bits *)x, xs, B, N, Np, D, 1);
     HIVE_CHECK_HIP(ctx, hipGetLastError());
     for (int i = 0; i < v->depth; ++i) {
         const hive_vit_block_weights &w = v->blocks[i];
-        if ((rc = launch_layernorm(ctx, xs, (const float *)w.ln1_g, (const float *)w.ln1_b, ln, M, D, v->eps))) return rc;
-        if ((rc = hive_vit_qkv(ctx, ln, w.qkv_w, (const float *)w.qkv_b, qk, vt, B, Np, D, H))) return rc;
-        if ((rc = hive_vit_attention(ctx, qk, vt, attn, B, N, Np, D, H))) return rc;
-        if ((rc = hive_vit_linear(ctx, attn, w.proj_w, (const float *)w.proj_b, xs, xs, M, D, D, EPI_BIAS_RESIDUAL))) return rc;
-        if ((rc = launch_layernorm(ctx, xs, (const float *)w.ln2_g, (const float *)w.ln2_b, ln, M, D, v->eps))) return rc;
-        if ((rc = hive_vit_linear(ctx, ln, w.fc1_w, (const float *)w.fc1_b, nullptr, hid, M, v->mlp, D, EPI_BIAS_GELU))) return rc;
-        if ((rc = hive_vit_linear(ctx, hid, w.fc2_w, (const float *)w.fc2_b, xs, xs, M, D, v->mlp, EPI_BIAS_RESIDUAL))) return rc;
+        if ((rc = hive_vit_layernorm(ctx, xs, dt, (const float *)w.ln1_g, (const float *)w.ln1_b, ln, M, D, v->eps))) return rc;
+        if ((rc = hive_vit_qkv(ctx, ln, dt, w.qkv_w, (const float *)w.qkv_b, qk, vt, B, Np, D, H))) return rc;
+        if ((rc = hive_vit_attention(ctx, qk, dt, vt, attn, B, N, Np, D, H))) return rc;
+        if ((rc = hive_vit_linear(ctx, attn, dt, w.proj_w, (const float *)w.proj_b, xs, xs, M, D, D, EPI_BIAS_RESIDUAL))) return rc;
+        if ((rc = hive_vit_layernorm(ctx, xs, dt, (const float *)w.ln2_g, (const float *)w.ln2_b, ln, M, D, v->eps))) return rc;
+        if ((rc = hive_vit_linear(ctx, ln, dt, w.fc1_w, (const float *)w.fc1_b, nullptr, hid, M, v->mlp, D, EPI_BIAS_GELU))) return rc;
+        if ((rc = hive_vit_linear(ctx, hid, dt, w.fc2_w, (const float *)w.fc2_b, xs, xs, M, D, v->mlp, EPI_BIAS_RESIDUAL))) return rc;
         for (int t = 0; t < n_taps; ++t)
             if (tap_blocks[t] == i) {
-                hipLaunchKernelGGL(pad_tokens_kernel, dim3(cp_blocks), dim3(256), 0, ctx->stream, (const bf16 *)xs, (bf16 *)tap_out[t], B,
+                hipLaunchKernelGGL(pad_tokens_kernel, dim3(cp_blocks), dim3(256), 0, ctx->stream, (const half_bits *)xs, (half_bits *)tap_out[t], B,
                                    N, Np, D, 0);
                 HIVE_CHECK_HIP(ctx, hipGetLastError());
             }

@@ -50,8 +50,7 @@ def preprocess_on_device(frames_u8, dtype=torch.bfloat16, ctx=None):
     b, h, w, _ = frames_u8.shape
     ctx = ctx or _lib.default_context(frames_u8.device.index or 0)
     out = torch.empty((b, 3, h, w), dtype=dtype, device=frames_u8.device, memory_format=torch.channels_last)
-    ctx.check(ctx.lib.hive_dpt_preprocess(ctx.handle, frames_u8.data_ptr(), frames_u8.numel(), 0.5, 0.5,
-                                          _lib.BF16 if dtype == torch.bfloat16 else _lib.F16, out.data_ptr()))
+    ctx.check(ctx.lib.hive_dpt_preprocess(ctx.handle, frames_u8.data_ptr(), frames_u8.numel(), 0.5, 0.5, _lib.dtype_code(dtype), out.data_ptr()))
     return out
 
 
@@ -60,12 +59,17 @@ def _write_png16(path, depth_mm_u16):
     Image.fromarray(np.ascontiguousarray(depth_mm_u16, dtype=np.uint16)).save(path)  # uint16 -> 16-bit PNG
 
 
-def estimate_depth_dpt(rgb_dataset, output_path: str, weights_filename='dpt_hybrid_nyu.pt', optimize=True, batch_size=8):
+def estimate_depth_dpt(rgb_dataset, output_path: str, weights_filename='dpt_hybrid_nyu.pt', optimize=True, batch_size=8, dtype=None):
     """Estimate a depth map for every frame of ``rgb_dataset`` and write it as ``%06d.png`` (16-bit,
     millimetres) into ``output_path`` -- the side effect on disk is the contract
     (dataset_adaptors.py:1346-1435).  Frames are batched on the GPU (the reference runs them one by
     one); frames whose size is not the network's 640 x 480 go through the reference's resize rule and a
     nearest-neighbour resize of the prediction back to the frame size (:1421-1426).
+
+    ``optimize=True`` is the reference's ``model.to(memory_format=channels_last); model.half()`` (:1394-1401): the network in
+    float16 on the HIP engine (``dtype=torch.bfloat16`` selects the bfloat16 kernels instead: wider range, 3 bits less
+    precision).  ``optimize=False`` is the reference's float32 network: PyTorch operators (``engine="torch"``), stated here, not
+    a silent substitute -- the HIP engine computes in 16-bit types only.
     """
     weights_dir = os.environ.get('WEIGHTS_PATH', 'weights')
     model_path = os.path.join(weights_dir, weights_filename)
@@ -75,8 +79,14 @@ def estimate_depth_dpt(rgb_dataset, output_path: str, weights_filename='dpt_hybr
         raise FileNotFoundError(f"DPT weights not found: {model_path} (set WEIGHTS_PATH)")
     if not torch.cuda.is_available():
         raise _lib.HiveError(_lib.ERR_DEVICE, "estimate_depth_dpt needs an MI355X; hive_amd has no CPU fallback")
-    dtype = torch.bfloat16 if optimize else None
-    model = build_model(model_path, dtype=dtype)
+    if optimize:
+        dtype = dtype or torch.float16
+        if dtype not in (torch.float16, torch.bfloat16):
+            raise ValueError(f"optimize=True runs the HIP engine in float16 or bfloat16, not {dtype}")
+        model = build_model(model_path, dtype=dtype, engine="hip")
+    else:
+        dtype = None
+        model = build_model(model_path, dtype=None, engine="torch")
     os.makedirs(output_path, exist_ok=True)
     transform = make_transform()
     n = len(rgb_dataset)
@@ -110,7 +120,7 @@ class DepthFusionStream:
 
     def __init__(self, model, volume, cam_intr, max_depth=10.0, accumulate=False, native=True):
         self.model = model
-        self.native = native  # run the network as one hive_dpt_forward call where it applies (bf16, frame size % 32 == 0)
+        self.native = native  # run the network as one hive_dpt_forward call where it applies (frame size % 32 == 0)
         self.volume = volume
         self.K = np.ascontiguousarray(cam_intr, dtype=np.float32)
         self.max_depth = float(max_depth)
@@ -123,7 +133,7 @@ class DepthFusionStream:
     @torch.no_grad()
     def depth(self, frames_u8):
         """[B, H, W, 3] uint8 (GPU) -> (depth_m f32 [B, H, W] after the hand-off, depth_mm int16-viewed-as-uint16)."""
-        if (self.native and self.dtype == torch.bfloat16 and frames_u8.shape[1] % 32 == 0 and frames_u8.shape[2] % 32 == 0
+        if (self.native and self.dtype in (torch.bfloat16, torch.float16) and frames_u8.shape[1] % 32 == 0 and frames_u8.shape[2] % 32 == 0
                 and getattr(self.model, "engine", None) == "hip"):
             _, mm, m = self.model.forward_frames(frames_u8, max_depth=self.max_depth)  # ONE C-ABI call: hive_dpt_forward
             return m, mm

@@ -7,17 +7,18 @@ those of the published checkpoints (``pretrained.model.*``, ``pretrained.act_pos
 ``scratch.*``), so ``dpt_hybrid_nyu-2ce69ec7.pt`` loads with ``load_state_dict`` unchanged; without a
 checkpoint (``path=None``) the network is randomly initialised -- parity unpinned.
 
-What runs where:
-  * ViT encoder blocks (LayerNorm, QKV / proj / MLP GEMMs, attention): hand-written HIP kernels for
-    gfx950 (bf16 MFMA, LDS-tiled QK^T) behind the C ABI -- ``hive_amd/csrc/vit.hip``.  ``engine="hip"``.
-  * convolutions (ResNetV2 stem, reassemble, RefineNet fusion, first head convolution): MIOpen through
-    PyTorch-ROCm, as SURVEY.md §7 step 7 plans for the first rounds.
-  * GroupNorm(+residual+ReLU), bias / ReLU / skip adds, x2 bilinear upsampling and the rest of the depth head
-    (upsample + conv 128->32 + ReLU + conv 32->1 + inversion + mm hand-off): HIP kernels on channels-last bf16
-    -- ``hive_amd/csrc/dpt_ops.hip``, ``hive_amd/csrc/dpt_head.hip``.
-  * ``engine="torch"`` runs the ViT blocks with plain PyTorch ops too: it is the fp32 reference that
-    the numerics tests compare the HIP engine against, not a fallback -- ``engine="hip"`` raises if
-    the extension is missing.
+What runs where with ``engine="hip"`` (the default) -- every layer on a hand-written gfx950 kernel behind the C ABI, in the
+model's 16-bit type: bfloat16, or float16 exactly as the reference runs it (``model.half()`` + fp16 samples,
+dataset_adaptors.py:1394-1401, 1415-1417):
+  * ViT encoder blocks (LayerNorm, QKV / proj / MLP GEMMs, attention) and the readout projections: MFMA GEMMs with fused
+    epilogues and an LDS-tiled flash attention -- ``hive_amd/csrc/vit.hip``.
+  * every convolution (ResNetV2 stem and stages, reassemble, RefineNet fusion, head): implicit-GEMM MFMA kernels on channels-last
+    activations with bias / ReLU / skip adds / GroupNorm statistics in the epilogue -- ``csrc/conv.hip``, ``csrc/stem.hip``.
+  * GroupNorm(+residual+ReLU), x2 bilinear upsampling, max pool, and the fused depth head (upsample + conv 128->32 + ReLU +
+    conv 32->1 + inversion + mm hand-off) -- ``csrc/dpt_ops.hip``, ``csrc/dpt_head.hip``.
+A layer (or a tensor: float32, CPU, not channels-last) the kernels do not cover RAISES ``HiveError``: the HIP engine never drops
+to a PyTorch operator.  ``engine="torch"`` is the same module tree on plain PyTorch ops: the float32 reference the numerics tests
+compare against, and the float32 network of ``estimate_depth_dpt(optimize=False)``.
 """
 import math
 
@@ -70,10 +71,11 @@ class StdConv2dSame(nn.Conv2d):
         return super()._apply(fn, *args, **kwargs)
 
     def forward(self, x):
-        if self.engine == "hip" and dpt_ops.conv_eligible(x, self):
+        if self.engine == "hip":
+            if dpt_ops.stem_conv_eligible(x, self):
+                return dpt_ops.stem_conv(x, self, self.standardized_weight())
+            dpt_ops.require_conv(x, self, "weight-standardised convolution")
             return dpt_ops.conv2d(x, self, weight=self.standardized_weight(), same_pad=True, gn_stats=True)  # a GroupNorm follows every StdConv2dSame
-        if self.engine == "hip" and dpt_ops.stem_conv_eligible(x, self):
-            return dpt_ops.stem_conv(x, self, self.standardized_weight())
         ih, iw = x.shape[-2:]
         kh, kw = self.kernel_size
         ph, pw = _same_pad(ih, kh, self.stride[0]), _same_pad(iw, kw, self.stride[1])
@@ -105,10 +107,10 @@ class MaxPool2dSame(nn.Module):
         self.k, self.s = kernel_size, stride
 
     def forward(self, x):
-        if self.engine == "hip" and (self.k, self.s) == (3, 2):
-            y = dpt_ops.maxpool3x3s2_same(x, engine="hip")
-            if y is not None:
-                return y
+        if self.engine == "hip":
+            if (self.k, self.s) != (3, 2):
+                dpt_ops.not_covered("max pool", f"kernel {self.k}, stride {self.s}: 3 / 2 only")
+            return dpt_ops.maxpool3x3s2_same(x, engine="hip")
         ih, iw = x.shape[-2:]
         ph, pw = _same_pad(ih, self.k, self.s), _same_pad(iw, self.k, self.s)
         x = F.pad(x, (pw // 2, pw - pw // 2, ph // 2, ph - ph // 2), value=float("-inf"))
@@ -287,10 +289,11 @@ class ProjectReadout(nn.Module):
         readout = x[:, 0].unsqueeze(1).expand_as(x[:, self.start_index:])
         cat = torch.cat((x[:, self.start_index:], readout), -1)
         lin = self.project[0]
-        if (self.engine == "hip" and cat.is_cuda and cat.dtype == torch.bfloat16 and lin.weight.dtype == torch.bfloat16
-                and lin.out_features % 128 == 0 and lin.in_features % 64 == 0):
+        if self.engine == "hip":
             # Linear + GELU in the hand-written GEMM (bias and erf-GELU in its epilogue, one rounding): csrc/vit.hip
             from hive_amd import _lib
+            if not (cat.is_cuda and cat.dtype in dpt_ops.HALF_TYPES and lin.weight.dtype == cat.dtype and lin.out_features % 128 == 0 and lin.in_features % 64 == 0):
+                dpt_ops.not_covered("readout projection", f"{cat.dtype} on {cat.device}, {lin.in_features} -> {lin.out_features}")
             key = (lin.bias.data_ptr(), lin.bias._version)
             if getattr(self, "_bias32", (None,))[0] != key:
                 self._bias32 = (key, lin.bias.detach().float().contiguous())
@@ -298,8 +301,8 @@ class ProjectReadout(nn.Module):
             cat = cat.contiguous()
             out = torch.empty((b, n, lin.out_features), dtype=cat.dtype, device=cat.device)
             ctx = _lib.default_context(cat.device.index or 0)
-            ctx.check(ctx.lib.hive_vit_linear(ctx.handle, cat.data_ptr(), lin.weight.data_ptr(), self._bias32[1].data_ptr(), None, out.data_ptr(),
-                                              b * n, lin.out_features, k, 1))
+            ctx.check(ctx.lib.hive_vit_linear(ctx.handle, cat.data_ptr(), dpt_ops._code(cat.dtype), lin.weight.data_ptr(), self._bias32[1].data_ptr(), None,
+                                              out.data_ptr(), b * n, lin.out_features, k, 1))
             return out
         return self.project(cat)
 
@@ -346,14 +349,12 @@ class FeatureFusionBlock(nn.Module):
         if self.engine == "hip":
             # The reference interpolates, then applies the 1x1 out_conv.  A 1x1 convolution (per-pixel, with
             # bias) and bilinear interpolation (per-channel, weights summing to 1) commute exactly in real
-            # arithmetic, so the projection runs on a quarter of the pixels; the results differ only by bf16
+            # arithmetic, so the projection runs on a quarter of the pixels; the results differ only by 16-bit
             # rounding order (covered by the tolerance of tests/test_vit_gpu.py against the torch engine).
             # (and its bias is added by the upsampling kernel while loading)
             oc = self.out_conv
-            if dpt_ops.conv_eligible(output, oc):
-                low = dpt_ops.conv2d(output, oc, with_bias=False)
-            else:
-                low = F.conv2d(output, oc.weight, None, oc.stride, oc.padding)
+            dpt_ops.require_conv(output, oc, "out_conv of a fusion block")
+            low = dpt_ops.conv2d(output, oc, with_bias=False)
             return dpt_ops.upsample2x(low, engine=self.engine, bias=oc.bias)
         output = dpt_ops.upsample2x(output, engine=self.engine)  # bilinear, align_corners=True
         return self.out_conv(output)
@@ -369,6 +370,8 @@ class Interpolate(nn.Module):
     def forward(self, x):
         if self.scale_factor == 2 and self.mode == "bilinear" and self.align_corners:
             return dpt_ops.upsample2x(x, engine=self.engine)
+        if self.engine == "hip":
+            dpt_ops.not_covered("Interpolate", f"scale {self.scale_factor}, {self.mode}, align_corners={self.align_corners}: x2 bilinear align_corners only")
         return F.interpolate(x, scale_factor=self.scale_factor, mode=self.mode, align_corners=self.align_corners)
 
 
@@ -444,19 +447,13 @@ class DPT(nn.Module):
             return tuple(taps[h] for h in hooks)
         if self.engine != "hip":
             raise ValueError(f"unknown engine {self.engine!r}")
-        if tokens.dtype == torch.float32:
+        if tokens.dtype not in dpt_ops.HALF_TYPES or not tokens.is_cuda:
             # optimize=False in the reference = the network in float32 (dataset_adaptors.py:1396-1399 only halves it when
-            # optimising).  The HIP engine computes in bf16; running a float32 model through it would be a silent
-            # precision downgrade, so float32 blocks run as float32 PyTorch ops, like the reference's.
-            x, taps = tokens, {}
-            for i, blk in enumerate(vit.blocks):
-                x = blk(x)
-                if i in hooks:
-                    taps[i] = x
-            return tuple(taps[h] for h in hooks)
-        # The engine packs private f32 copies of the biases / LayerNorm parameters (and bf16 copies of matrices that are not
-        # bf16 already): rebuild it when any parameter was replaced or written (load_state_dict, .to(), optimiser step).
-        stamp = tuple((p.data_ptr(), p._version) for p in vit.blocks.parameters())
+            # optimising).  The HIP engine computes in the model's 16-bit type; a float32 model is not silently down-cast
+            dpt_ops.not_covered("the ViT encoder", f"{tokens.dtype} tokens on {tokens.device}: the model must be .half() / .bfloat16() on the GPU")
+        # The engine packs private f32 copies of the biases / LayerNorm parameters (the matrices are used in place): rebuild it when
+        # any parameter was replaced or written (load_state_dict, .to(), optimiser step).
+        stamp = tuple((p.data_ptr(), p._version, p.dtype) for p in vit.blocks.parameters())
         if self._vit_engine is None or self._vit_stamp != stamp:
             from hive_amd.dpt.vit_engine import VitEngine  # raises if libhive_mi355x.so is missing
             if self._vit_engine is not None:
@@ -467,10 +464,16 @@ class DPT(nn.Module):
 
     def _conv(self, layer, x):
         """An nn.Conv2d of the reassemble / embedding stages: the hand-written kernel where it applies (1 x 1, 3 x 3 stride 2)."""
-        if self.engine == "hip" and isinstance(layer, nn.Conv2d) and not isinstance(layer, nn.ConvTranspose2d) and dpt_ops.conv_eligible(x, layer):
-            return dpt_ops.conv2d(x, layer)
-        if self.engine == "hip" and dpt_ops.conv_transpose_eligible(x, layer):  # DPT-Large: ConvTranspose2d(k = s) as conv 1 x 1 + scatter
-            return dpt_ops.conv_transpose(x, layer)
+        if self.engine == "hip":
+            if isinstance(layer, nn.ConvTranspose2d):  # DPT-Large: ConvTranspose2d(k = s) as conv 1 x 1 + scatter
+                if not dpt_ops.conv_transpose_eligible(x, layer):
+                    dpt_ops.not_covered("transposed convolution", f"kernel {tuple(layer.kernel_size)}, stride {tuple(layer.stride)}, {x.dtype}: kernel == stride only")
+                return dpt_ops.conv_transpose(x, layer)
+            if isinstance(layer, nn.Conv2d):
+                dpt_ops.require_conv(x, layer, "reassemble convolution")
+                return dpt_ops.conv2d(x, layer)
+            if not isinstance(layer, nn.Identity):
+                dpt_ops.not_covered(type(layer).__name__, "no kernel for this layer type")
         return layer(x)
 
     def forward_backbone(self, x, stages=None):
@@ -500,7 +503,9 @@ class DPT(nn.Module):
             feat = vit.patch_embed.backbone.stages[2](layer_2)
         else:
             feat = x
-        if self.engine == "hip" and not p.hybrid and dpt_ops.patch_embed_eligible(feat, vit.patch_embed.proj):
+        if self.engine == "hip" and not p.hybrid:
+            if not dpt_ops.patch_embed_eligible(feat, vit.patch_embed.proj):
+                dpt_ops.not_covered("patch embedding", f"{feat.dtype} input of {tuple(feat.shape)}: 16-bit channels-last frames, sides multiples of the patch")
             tokens = dpt_ops.patch_embed(feat, vit.patch_embed.proj)  # ViT-L/16: the 16 x 16 / 16 convolution as rows + GEMM
         else:
             tokens = self._conv(vit.patch_embed.proj, feat).flatten(2).transpose(1, 2)
@@ -526,7 +531,9 @@ class DPT(nn.Module):
         s = self.scratch
 
         def rn(conv, x):  # scratch.layerN_rn (3 x 3, no bias) -> (y, relu(y)): the residual unit behind it starts with a ReLU
-            if self.engine == "hip" and dpt_ops.conv3x3_eligible(x, conv):
+            if self.engine == "hip":
+                if not dpt_ops.conv3x3_eligible(x, conv):
+                    dpt_ops.not_covered("scratch.layer_rn", f"{x.dtype} {tuple(x.shape)} -> {conv.out_channels}")
                 return dpt_ops.conv3x3(x, conv, also_relu=True)
             return conv(x), None
 
@@ -572,7 +579,6 @@ class DPTDepthModel(DPT):
         )
         super().__init__(head, features=features, engine=engine, backbone=backbone)
         self.scale, self.shift, self.invert = scale, shift, invert
-        self.fused_head = True  # HIP engine, bf16: output_conv[1:] + the depth tail as one kernel (csrc/dpt_head.hip)
         if path is not None:
             self.load(path)
 
@@ -590,7 +596,7 @@ class DPTDepthModel(DPT):
 
     def native(self):
         """The network as one C-ABI object (``hive_dpt_create``, csrc/dpt_net.hip): rebuilt when a parameter was replaced or
-        written.  bf16 hybrid models on the GPU only."""
+        written.  16-bit (bfloat16 / float16) models on the GPU only."""
         from hive_amd.dpt.native import NativeDPT, parameter_stamp
         cur = getattr(self, "_native", None)
         if cur is None or cur.stamp != parameter_stamp(self):
@@ -614,64 +620,48 @@ class DPTDepthModel(DPT):
         128-channel map behind ``output_conv[0]``).
 
         The reference returns the network's working precision (fp16 on a GPU); the last 1x1 convolution and
-        the inversion ``1 / (scale * x + shift)`` run in float32 here because bf16 cannot resolve metric depth
-        (8 significant bits: 3 cm steps at 7 m).  ``handoff=(max_depth,)`` additionally applies the
+        the inversion ``1 / (scale * x + shift)`` run in float32 here because 16 bits cannot resolve metric depth
+        (bfloat16's 8 significant bits: 3 cm steps at 7 m; float16's 11: 4 mm).  ``handoff=(max_depth,)`` additionally applies the
         reference's depth hand-off on the device -- uint16 millimetres (dataset_adaptors.py:1432-1433), read
         back as float32 metres with ``> max_depth -> 0`` (io.py:1032-1039) -- and returns (depth, depth_mm, depth_m).
         """
         head = self.scratch.output_conv
         conv = head[4]
         non_negative = isinstance(head[5], nn.ReLU)
-        if self.engine == "hip" and x.is_cuda and x.dtype in (torch.float16, torch.bfloat16):
+        if self.engine == "hip":
             from hive_amd import _lib
+            if not (x.is_cuda and x.dtype in dpt_ops.HALF_TYPES):
+                dpt_ops.not_covered("DPTDepthModel.forward", f"{x.dtype} input on {x.device}: a .half() / .bfloat16() model on the GPU takes 16-bit channels-last input")
             ctx = _lib.default_context(x.device.index or 0)
             pre = head[2]
             first = head[0]
+            if not (isinstance(head[1], Interpolate) and head[1].scale_factor == 2 and head[1].mode == "bilinear" and head[1].align_corners
+                    and isinstance(head[3], nn.ReLU) and tuple(pre.weight.shape) == (32, 128, 3, 3) and pre.stride == (1, 1) and pre.padding == (1, 1)):
+                dpt_ops.not_covered("the depth head", "the fused head kernel is built for Interpolate(x2) -> Conv3x3(128 -> 32) -> ReLU -> Conv1x1(32 -> 1)")
             key = (conv.weight.data_ptr(), conv.weight._version, conv.bias._version, pre.bias._version, pre.weight._version,
-                   first.bias.data_ptr(), first.bias._version)
+                   first.bias.data_ptr(), first.bias._version, pre.weight.dtype)
             if getattr(self, "_tail_host", (None,))[0] != key:  # one D2H per set of weights, not per forward
                 self._tail_host = (key, conv.weight.detach().float().reshape(-1).cpu().numpy(), float(conv.bias.detach().float().item()),
                                    pre.bias.detach().float().cpu().numpy(),
                                    pre.weight.detach().permute(2, 3, 0, 1).contiguous(),  # [ky][kx][out][in] for the fused head
                                    first.bias.detach().float().contiguous())
             weight, bias, pre_bias, w3, b0 = self._tail_host[1:6]
-            fused = (self.fused_head and x.dtype == torch.bfloat16 and isinstance(head[1], Interpolate) and head[1].scale_factor == 2
-                     and head[1].mode == "bilinear" and head[1].align_corners and isinstance(head[3], nn.ReLU)
-                     and tuple(pre.weight.shape) == (32, 128, 3, 3) and pre.stride == (1, 1) and pre.padding == (1, 1))
-            if fused:
-                # Interpolate + conv 128 -> 32 + ReLU + conv 32 -> 1 + inversion + hand-off: one HIP kernel (csrc/dpt_head.hip)
-                # (output_conv[0] runs without its bias: the kernel adds it while loading, one pass over 315 MB less)
-                path_1 = self.forward_decoder(x, stages)
-                if dpt_ops.conv3x3_eligible(path_1, first):
-                    lo = dpt_ops.conv3x3(path_1, first, with_bias=False)  # its bias is added by the fused head while loading
-                else:
-                    lo = F.conv2d(path_1, first.weight, None, first.stride, first.padding).contiguous(memory_format=torch.channels_last)
-                if stages is not None:
-                    stages["head_in"] = lo + first.bias.view(1, -1, 1, 1)
-                b, c, h, w = lo.shape
-                depth = torch.empty((b, 2 * h, 2 * w), dtype=torch.float32, device=lo.device)
-                mm = torch.empty((b, 2 * h, 2 * w), dtype=torch.int16, device=lo.device) if handoff else None
-                m = torch.empty((b, 2 * h, 2 * w), dtype=torch.float32, device=lo.device) if handoff else None
-                ctx.check(ctx.lib.hive_dpt_head_fused(
-                    ctx.handle, lo.data_ptr(), b0.data_ptr(), _lib.BF16, b, h, w, c, 32, w3.data_ptr(), pre_bias.ctypes.data, weight.ctypes.data, bias,
-                    int(non_negative), int(bool(self.invert)), float(self.scale), float(self.shift), depth.data_ptr(), 1.0 / 1000.0,
-                    float(handoff[0]) if handoff else 0.0, _lib.ptr(mm), _lib.ptr(m)))
-                return (depth, mm, m) if handoff else depth
-            # conv 128 -> 32 without its bias (MIOpen); bias + ReLU + conv 32 -> 1 + inversion + hand-off in one HIP kernel
-            head_in = head[0](self.forward_decoder(x, stages))
+            # Interpolate + conv 128 -> 32 + ReLU + conv 32 -> 1 + inversion + hand-off: one HIP kernel (csrc/dpt_head.hip)
+            # (output_conv[0] runs without its bias: the kernel adds it while loading, one pass over 315 MB less)
+            path_1 = self.forward_decoder(x, stages)
+            if not dpt_ops.conv3x3_eligible(path_1, first):
+                dpt_ops.not_covered("scratch.output_conv[0]", f"{path_1.dtype} {tuple(path_1.shape)} -> {first.out_channels}")
+            lo = dpt_ops.conv3x3(path_1, first, with_bias=False)  # its bias is added by the fused head while loading
             if stages is not None:
-                stages["head_in"] = head_in
-            feat = F.conv2d(head[1](head_in), pre.weight, None, pre.stride, pre.padding)
-            feat = feat.contiguous(memory_format=torch.channels_last)
-            b, c, h, w = feat.shape
-            depth = torch.empty((b, h, w), dtype=torch.float32, device=feat.device)
-            mm = torch.empty((b, h, w), dtype=torch.int16, device=feat.device) if handoff else None
-            m = torch.empty((b, h, w), dtype=torch.float32, device=feat.device) if handoff else None
-            ctx.check(ctx.lib.hive_dpt_head_tail(
-                ctx.handle, feat.data_ptr(), _lib.BF16 if feat.dtype == torch.bfloat16 else _lib.F16, b * h * w, c,
-                pre_bias.ctypes.data, 1, weight.ctypes.data, bias, int(non_negative), int(bool(self.invert)),
-                float(self.scale), float(self.shift), depth.data_ptr(), 1.0 / 1000.0, float(handoff[0]) if handoff else 0.0,
-                _lib.ptr(mm), _lib.ptr(m)))
+                stages["head_in"] = lo + first.bias.view(1, -1, 1, 1)
+            b, c, h, w = lo.shape
+            depth = torch.empty((b, 2 * h, 2 * w), dtype=torch.float32, device=lo.device)
+            mm = torch.empty((b, 2 * h, 2 * w), dtype=torch.int16, device=lo.device) if handoff else None
+            m = torch.empty((b, 2 * h, 2 * w), dtype=torch.float32, device=lo.device) if handoff else None
+            ctx.check(ctx.lib.hive_dpt_head_fused(
+                ctx.handle, lo.data_ptr(), b0.data_ptr(), dpt_ops._code(lo.dtype), b, h, w, c, 32, w3.data_ptr(), pre_bias.ctypes.data, weight.ctypes.data, bias,
+                int(non_negative), int(bool(self.invert)), float(self.scale), float(self.shift), depth.data_ptr(), 1.0 / 1000.0,
+                float(handoff[0]) if handoff else 0.0, _lib.ptr(mm), _lib.ptr(m)))
             return (depth, mm, m) if handoff else depth
         head_in = head[0](self.forward_decoder(x, stages))
         if stages is not None:

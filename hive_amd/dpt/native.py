@@ -1,6 +1,7 @@
 """Host side of the C-ABI network object (``hive_dpt_create / forward / destroy``, csrc/dpt_net.hip): builds the tensor table
-from a ``DPTDepthModel`` (DPT-Hybrid or DPT-Large) -- standardised ResNet weights, channels-last convolution weights, bf16 matrices,
-f32 biases / LayerNorm parameters, as ``include/hive_mi355x.h`` documents -- and runs whole batches of uint8 frames through it:
+from a ``DPTDepthModel`` (DPT-Hybrid or DPT-Large) -- standardised ResNet weights, channels-last convolution weights, matrices in the
+model's 16-bit type (bfloat16, or float16 as the reference's ``model.half()``), f32 biases / LayerNorm parameters, as
+``include/hive_mi355x.h`` documents -- and runs whole batches of uint8 frames through it:
 frames in HBM -> depth maps in HBM without a PyTorch operator in between.  No fallback: construction raises if the library or
 the device is missing."""
 import ctypes
@@ -18,11 +19,11 @@ class _Tensor(ctypes.Structure):
 class _Config(ctypes.Structure):
     _fields_ = [("backbone", ctypes.c_int), ("scale", ctypes.c_float), ("shift", ctypes.c_float), ("invert", ctypes.c_int),
                 ("non_negative", ctypes.c_int), ("gn_eps", ctypes.c_float), ("ln_eps", ctypes.c_float),
-                ("head_b3", ctypes.c_float * 32), ("head_w1", ctypes.c_float * 32), ("head_b1", ctypes.c_float)]
+                ("head_b3", ctypes.c_float * 32), ("head_w1", ctypes.c_float * 32), ("head_b1", ctypes.c_float), ("dtype", ctypes.c_int)]
 
 
 def parameter_stamp(model):
-    return tuple((p.data_ptr(), p._version) for p in model.parameters())
+    return tuple((p.data_ptr(), p._version, p.dtype) for p in model.parameters())
 
 
 class NativeDPT:
@@ -34,6 +35,10 @@ class NativeDPT:
             raise _lib.HiveError(_lib.ERR_DEVICE, "the native DPT network needs the model on an MI355X (model.cuda()); no CPU fallback")
         self.ctx = ctx or _lib.default_context(dev.index or 0)
         self.model = model
+        self.dtype = next(model.parameters()).dtype
+        self.code = _lib.dtype_code(self.dtype)  # float32 (optimize=False) raises: the network object computes in the model's 16-bit type
+        if any(p.dtype != self.dtype for p in model.parameters()):
+            raise _lib.HiveError(_lib.ERR_INVALID, "the model's parameters are of mixed types: convert it as a whole (.half() / .bfloat16())")
         self.stamp = parameter_stamp(model)
         self._keep, names, ptrs = [], [], []
 
@@ -43,7 +48,7 @@ class NativeDPT:
             names.append(name.encode())
             ptrs.append(t.data_ptr())
 
-        bf, f32 = torch.bfloat16, torch.float32
+        bf, f32 = self.dtype, torch.float32  # bf: the model's 16-bit type
         conv_w = lambda w: w.detach().to(device=dev, dtype=bf).permute(0, 2, 3, 1)  # [C_out][ky][kx][C_in]
         mods = dict(model.named_modules())
         for name, p in model.named_parameters():
@@ -79,6 +84,7 @@ class NativeDPT:
             add("pretrained.model.patch_embed.proj.bias.f32", model.pretrained.model.patch_embed.proj.bias.to(device=dev, dtype=f32))
         cfg = _Config(0 if model.pretrained.hybrid else 1, float(model.scale), float(model.shift), int(bool(model.invert)), int(isinstance(head[5], nn.ReLU)), 1e-5,
                       float(model.pretrained.model.blocks[0].norm1.eps))
+        cfg.dtype = self.code
         b3, w1 = head[2].bias.detach().float().cpu(), head[4].weight.detach().float().reshape(-1).cpu()
         for i in range(32):
             cfg.head_b3[i], cfg.head_w1[i] = float(b3[i]), float(w1[i])
@@ -96,7 +102,7 @@ class NativeDPT:
         if key not in self._pos:
             with torch.no_grad():
                 pos = self.model.pretrained.model.resize_pos_embed(gh, gw)  # dpt `_resize_pos_embed` (bilinear, float32 inside)
-            self._pos[key] = pos.detach().to(torch.bfloat16).reshape(gh * gw + 1, -1).contiguous()
+            self._pos[key] = pos.detach().to(self.dtype).reshape(gh * gw + 1, -1).contiguous()
         return self._pos[key]
 
     @torch.no_grad()

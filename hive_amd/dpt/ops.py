@@ -1,16 +1,39 @@
-"""Fused channels-last glue ops of DPT-Hybrid's convolutional parts (``csrc/dpt_ops.hip``): GroupNorm
-[+ residual] [+ ReLU] and bilinear x2 upsampling.  ``engine="hip"`` uses the HIP kernels for 16-bit
-channels-last CUDA tensors; ``engine="torch"`` is the plain PyTorch formulation the numerics tests
-compare against (and what fp32 / CPU reference runs use)."""
+"""The layers of DPT's convolutional parts on the hand-written kernels (``csrc/conv.hip``, ``stem.hip``, ``dpt_ops.hip``,
+``vit.hip``): implicit-GEMM convolutions with fused epilogues, GroupNorm [+ residual] [+ ReLU], bilinear x2 upsampling.
+
+``engine="hip"`` means EVERY layer runs a HIP kernel, on 16-bit (bfloat16, or float16 as the reference's ``model.half()``,
+/root/reference/hive/dataset_adaptors.py:1394-1401) channels-last CUDA tensors; a layer the kernels do not cover raises
+``HiveError`` -- there is no per-layer drop to a PyTorch operator.  ``engine="torch"`` is the plain PyTorch formulation: the
+float32 / CPU reference the numerics tests compare against (and ``estimate_depth_dpt(optimize=False)``'s float32 network)."""
 import torch
 import torch.nn.functional as F
 
 from hive_amd import _lib
 
+HALF_TYPES = (torch.float16, torch.bfloat16)
+
+
+def not_covered(what, why):
+    """engine="hip" and a layer outside what the kernels cover: fail loudly."""
+    raise _lib.HiveError(_lib.ERR_INVALID, f"engine='hip': {what} is not covered by the HIP kernels ({why}); the HIP engine never drops to a "
+                                           f"PyTorch operator -- build the model with engine='torch' for the PyTorch formulation")
+
+
+def _why_not_map(x, channels_multiple=8):
+    """None if ``x`` is a 16-bit channels-last CUDA activation the kernels take, else the reason."""
+    if not x.is_cuda:
+        return "the tensor is not on the GPU"
+    if x.dtype not in HALF_TYPES:
+        return f"dtype {x.dtype}: the kernels compute in float16 / bfloat16"
+    if x.dim() != 4 or not x.is_contiguous(memory_format=torch.channels_last):
+        return "the activation must be a 4-d tensor in channels_last memory format"
+    if x.shape[1] % channels_multiple:
+        return f"{x.shape[1]} channels: a multiple of {channels_multiple} is needed"
+    return None
+
 
 def _hip_eligible(x):
-    return (x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and x.dim() == 4 and x.shape[1] % 8 == 0
-            and x.is_contiguous(memory_format=torch.channels_last))
+    return _why_not_map(x) is None
 
 
 def _code(dtype):
@@ -21,7 +44,11 @@ def group_norm_act(x, num_groups, weight, bias, eps, relu=True, residual=None, e
     """relu?(group_norm(x) (+ residual)).  x: [N, C, H, W].  ``stats``: the (partial sums, tile rows) the convolution that wrote
     ``x`` left (``conv2d(..., gn_stats=True)``): the statistics pass over ``x`` is skipped."""
     c = x.shape[1]
-    if engine == "hip" and _hip_eligible(x) and (c & (c - 1)) == 0 and c <= 2048 and weight.dtype == x.dtype:
+    if engine == "hip":
+        why = _why_not_map(x) or (None if (c & (c - 1)) == 0 and c <= 2048 else f"{c} channels: a power of two <= 2048 is needed") or \
+            (None if weight.dtype == x.dtype else f"affine parameters are {weight.dtype}, the tensor {x.dtype}")
+        if why:
+            not_covered("group_norm", why)
         if residual is not None:
             assert residual.shape == x.shape and residual.dtype == x.dtype
             residual = residual.contiguous(memory_format=torch.channels_last)
@@ -62,13 +89,30 @@ def _conv3x3_weight(conv):
     return hit[1]
 
 
+def _why_not_conv(x, conv, kernels=(1, 3), cout_multiple=64):
+    why = _why_not_map(x, 64)
+    if why:
+        return why
+    k = conv.kernel_size
+    if not (k[0] == k[1] and k[0] in kernels):
+        return f"kernel {tuple(k)}"
+    if not (conv.stride[0] == conv.stride[1] and conv.stride[0] in (1, 2)):
+        return f"stride {tuple(conv.stride)}"
+    if tuple(conv.dilation) != (1, 1) or conv.groups != 1:
+        return "dilation / groups"
+    if conv.in_channels % 64 or conv.out_channels % cout_multiple or x.shape[1] != conv.in_channels:
+        return f"{conv.in_channels} -> {conv.out_channels} channels: multiples of 64 -> {cout_multiple} are needed"
+    if conv.weight.dtype != x.dtype:
+        return f"weights are {conv.weight.dtype}, the tensor {x.dtype}"
+    if not (conv.padding[0] == conv.padding[1] and conv.padding[0] < k[0]):
+        return f"padding {tuple(conv.padding)}"
+    return None
+
+
 def conv3x3_eligible(x, conv):
-    """The hand-written implicit-GEMM kernel (csrc/conv.hip) covers 3 x 3, stride 1, padding 1 on bf16 channels-last with
+    """The implicit-GEMM kernel (csrc/conv.hip) with the decoder's fused tail covers 3 x 3, stride 1, padding 1 on 16-bit channels-last with
     C_in % 64 == 0 and C_out % 128 == 0 -- every 3 x 3 convolution of DPT's decoder."""
-    return (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)
-            and tuple(conv.kernel_size) == (3, 3) and tuple(conv.stride) == (1, 1) and tuple(conv.padding) == (1, 1)
-            and tuple(conv.dilation) == (1, 1) and conv.groups == 1 and conv.in_channels % 64 == 0 and conv.out_channels % 128 == 0
-            and conv.weight.dtype == torch.bfloat16 and x.shape[1] == conv.in_channels)
+    return (_why_not_conv(x, conv, kernels=(3,), cout_multiple=128) is None and tuple(conv.stride) == (1, 1) and tuple(conv.padding) == (1, 1))
 
 
 def conv3x3(x, conv, relu=False, residual=None, residual2=None, also_relu=False, with_bias=True):
@@ -80,7 +124,7 @@ def conv3x3(x, conv, relu=False, residual=None, residual2=None, also_relu=False,
         assert r is None or (r.shape == out.shape and r.dtype == out.dtype and r.is_contiguous(memory_format=torch.channels_last))
     bias = conv.bias if (with_bias and conv.bias is not None) else None
     ctx = _lib.default_context(x.device.index or 0)
-    ctx.check(ctx.lib.hive_nhwc_conv3x3(ctx.handle, x.data_ptr(), _lib.BF16, n, h, w, conv.in_channels, conv.out_channels,
+    ctx.check(ctx.lib.hive_nhwc_conv3x3(ctx.handle, x.data_ptr(), _code(x.dtype), n, h, w, conv.in_channels, conv.out_channels,
                                         _conv3x3_weight(conv).data_ptr(), _lib.ptr(bias), int(bool(relu)), _lib.ptr(residual),
                                         _lib.ptr(residual2), out.data_ptr(), _lib.ptr(out_relu)))
     return (out, out_relu) if also_relu else out
@@ -100,13 +144,15 @@ def conv_geometry(conv, ih, iw, same_pad=False):
 
 
 def conv_eligible(x, conv):
-    """csrc/conv.hip covers square kernels 1 / 3, stride 1 / 2, bf16 channels-last, C_in % 64 == 0, C_out % 64 == 0, no groups /
+    """csrc/conv.hip covers square kernels 1 / 3, stride 1 / 2, 16-bit channels-last, C_in % 64 == 0, C_out % 64 == 0, no groups /
     dilation -- every convolution of DPT-Hybrid except the 7 x 7 stem (its own kernel)."""
-    k = conv.kernel_size
-    return (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)
-            and k[0] == k[1] and k[0] in (1, 3) and conv.stride[0] == conv.stride[1] and conv.stride[0] in (1, 2)
-            and tuple(conv.dilation) == (1, 1) and conv.groups == 1 and conv.in_channels % 64 == 0 and conv.out_channels % 64 == 0
-            and conv.weight.dtype == torch.bfloat16 and x.shape[1] == conv.in_channels and conv.padding[0] == conv.padding[1] and conv.padding[0] < k[0])
+    return _why_not_conv(x, conv) is None
+
+
+def require_conv(x, conv, what="convolution"):
+    why = _why_not_conv(x, conv)
+    if why:
+        not_covered(what, why)
 
 
 def conv2d(x, conv, weight=None, same_pad=False, relu=False, residual=None, residual2=None, also_relu=False, with_bias=True, gn_stats=False):
@@ -129,12 +175,12 @@ def conv2d(x, conv, weight=None, same_pad=False, relu=False, residual=None, resi
         import ctypes
         partial = torch.empty(int(ctx.lib.hive_nhwc_conv_gn_partial_floats(n * oh * ow, conv.out_channels)), dtype=torch.float32, device=x.device)
         tile_rows = ctypes.c_int(0)
-        ctx.check(ctx.lib.hive_nhwc_conv_gn(ctx.handle, x.data_ptr(), _lib.BF16, n, ih, iw, conv.in_channels, conv.out_channels, k, st, pt, pl, oh, ow,
+        ctx.check(ctx.lib.hive_nhwc_conv_gn(ctx.handle, x.data_ptr(), _code(x.dtype), n, ih, iw, conv.in_channels, conv.out_channels, k, st, pt, pl, oh, ow,
                                             w.data_ptr(), _lib.ptr(bias), int(bool(relu)), _lib.ptr(residual), _lib.ptr(residual2), out.data_ptr(),
                                             _lib.ptr(out_relu), partial.data_ptr(), partial.numel(), ctypes.byref(tile_rows)))
         out.hive_gn_stats = (partial, tile_rows.value)
     else:
-        ctx.check(ctx.lib.hive_nhwc_conv(ctx.handle, x.data_ptr(), _lib.BF16, n, ih, iw, conv.in_channels, conv.out_channels, k, st, pt, pl, oh, ow,
+        ctx.check(ctx.lib.hive_nhwc_conv(ctx.handle, x.data_ptr(), _code(x.dtype), n, ih, iw, conv.in_channels, conv.out_channels, k, st, pt, pl, oh, ow,
                                          w.data_ptr(), _lib.ptr(bias), int(bool(relu)), _lib.ptr(residual), _lib.ptr(residual2), out.data_ptr(),
                                          _lib.ptr(out_relu)))
     return (out, out_relu) if also_relu else out
@@ -159,7 +205,7 @@ def conv_gn_act(x, conv, norm, weight=None, same_pad=False, relu=True, residual=
     ctx = _lib.default_context(x.device.index or 0)
     scratch = torch.empty(int(ctx.lib.hive_nhwc_conv_gn_partial_floats(n * oh * ow, cout)) + 2 * n * g, dtype=torch.float32, device=x.device)
     fused = ctypes.c_int(0)
-    ctx.check(ctx.lib.hive_nhwc_conv_gn_apply(ctx.handle, x.data_ptr(), _lib.BF16, n, ih, iw, conv.in_channels, cout, k, st, pt, pl, oh, ow, w.data_ptr(), g,
+    ctx.check(ctx.lib.hive_nhwc_conv_gn_apply(ctx.handle, x.data_ptr(), _code(x.dtype), n, ih, iw, conv.in_channels, cout, k, st, pt, pl, oh, ow, w.data_ptr(), g,
                                               norm.weight.data_ptr(), norm.bias.data_ptr(), float(norm.eps), _lib.ptr(residual), int(bool(relu)),
                                               out.data_ptr(), scratch.data_ptr(), scratch.numel(), ctypes.byref(fused)))
     return out if fused.value else None
@@ -178,8 +224,8 @@ def _cached(layer, what, params, build):
 
 def patch_embed_eligible(x, conv):
     k = conv.kernel_size
-    return (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last) and type(conv) is torch.nn.Conv2d
-            and k[0] == k[1] and tuple(conv.stride) == tuple(k) and tuple(conv.padding) == (0, 0) and conv.groups == 1 and conv.weight.dtype == torch.bfloat16
+    return (x.is_cuda and x.dtype in HALF_TYPES and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last) and type(conv) is torch.nn.Conv2d
+            and k[0] == k[1] and tuple(conv.stride) == tuple(k) and tuple(conv.padding) == (0, 0) and conv.groups == 1 and conv.weight.dtype == x.dtype
             and x.shape[2] % k[0] == 0 and x.shape[3] % k[0] == 0 and (k[0] * k[0] * conv.in_channels) % 64 == 0 and conv.out_channels % 128 == 0)
 
 
@@ -194,16 +240,16 @@ def patch_embed(x, conv):
     cols = torch.empty((m, p * p * c), dtype=x.dtype, device=x.device)
     out = torch.empty((n, (h // p) * (w // p), d), dtype=x.dtype, device=x.device)
     ctx = _lib.default_context(x.device.index or 0)
-    ctx.check(ctx.lib.hive_patch_rows(ctx.handle, x.data_ptr(), _lib.BF16, n, h, w, c, p, cols.data_ptr()))
-    ctx.check(ctx.lib.hive_vit_linear(ctx.handle, cols.data_ptr(), wmat.data_ptr(), bias.data_ptr(), None, out.data_ptr(), m, d, p * p * c, 0))
+    ctx.check(ctx.lib.hive_patch_rows(ctx.handle, x.data_ptr(), _code(x.dtype), n, h, w, c, p, cols.data_ptr()))
+    ctx.check(ctx.lib.hive_vit_linear(ctx.handle, cols.data_ptr(), _code(x.dtype), wmat.data_ptr(), bias.data_ptr(), None, out.data_ptr(), m, d, p * p * c, 0))
     return out
 
 
 def conv_transpose_eligible(x, layer):
     k = layer.kernel_size
-    return (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)
+    return (x.is_cuda and x.dtype in HALF_TYPES and x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)
             and isinstance(layer, torch.nn.ConvTranspose2d) and k[0] == k[1] and tuple(layer.stride) == tuple(k) and tuple(layer.padding) == (0, 0)
-            and tuple(layer.output_padding) == (0, 0) and layer.groups == 1 and tuple(layer.dilation) == (1, 1) and layer.weight.dtype == torch.bfloat16
+            and tuple(layer.output_padding) == (0, 0) and layer.groups == 1 and tuple(layer.dilation) == (1, 1) and layer.weight.dtype == x.dtype
             and layer.in_channels % 64 == 0 and layer.out_channels % 64 == 0 and k[0] <= 8)
 
 
@@ -216,74 +262,63 @@ def conv_transpose(x, layer):
     tmp = torch.empty((n * h * w, s_ * s_ * cout), dtype=x.dtype, device=x.device)
     out = torch.empty((n, cout, h * s_, w * s_), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
     ctx = _lib.default_context(x.device.index or 0)
-    ctx.check(ctx.lib.hive_nhwc_conv(ctx.handle, x.data_ptr(), _lib.BF16, n, h, w, cin, s_ * s_ * cout, 1, 1, 0, 0, h, w, wmat.data_ptr(), None, 0, None, None,
+    ctx.check(ctx.lib.hive_nhwc_conv(ctx.handle, x.data_ptr(), _code(x.dtype), n, h, w, cin, s_ * s_ * cout, 1, 1, 0, 0, h, w, wmat.data_ptr(), None, 0, None, None,
                                      tmp.data_ptr(), None))
-    ctx.check(ctx.lib.hive_nhwc_pixel_shuffle_bias(ctx.handle, tmp.data_ptr(), _lib.ptr(layer.bias), _lib.BF16, n, h, w, cout, s_, out.data_ptr()))
+    ctx.check(ctx.lib.hive_nhwc_pixel_shuffle_bias(ctx.handle, tmp.data_ptr(), _lib.ptr(layer.bias), _code(x.dtype), n, h, w, cout, s_, out.data_ptr()))
     return out
 
 
 def stem_conv_eligible(x, conv):
-    return (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and x.shape[1] == 3 and x.is_contiguous(memory_format=torch.channels_last)
+    return (x.is_cuda and x.dtype in HALF_TYPES and x.dim() == 4 and x.shape[1] == 3 and x.is_contiguous(memory_format=torch.channels_last)
             and tuple(conv.kernel_size) == (7, 7) and tuple(conv.stride) == (2, 2) and conv.in_channels == 3 and conv.out_channels == 64
             and conv.bias is None and x.shape[2] >= 7 and x.shape[3] >= 7)
 
 
 def stem_conv(x, conv, weight):
     """The 7 x 7 / 2 "SAME" stem convolution (csrc/stem.hip).  ``weight``: the standardised [64, 3, 7, 7] weights."""
-    stamp = (weight.data_ptr(), weight._version)
+    stamp = (weight.data_ptr(), weight._version, weight.dtype)
     cache = _module_cache(conv)
     hit = cache.get("stem")
     if hit is None or hit[0] != stamp:
-        w = torch.zeros((64, 7, 32), dtype=torch.bfloat16, device=weight.device)
+        w = torch.zeros((64, 7, 32), dtype=x.dtype, device=weight.device)
         w[:, :, :21] = weight.detach().permute(0, 2, 3, 1).reshape(64, 7, 21)  # (ky, (kx, c)), a kernel row padded to 32
         hit = cache["stem"] = (stamp, w.contiguous())
     n, _, h, w_ = x.shape
     out = torch.empty((n, 64, (h + 1) // 2, (w_ + 1) // 2), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
     ctx = _lib.default_context(x.device.index or 0)
-    ctx.check(ctx.lib.hive_resnet_stem_conv(ctx.handle, x.data_ptr(), _lib.BF16, n, h, w_, hit[1].data_ptr(), out.data_ptr()))
+    ctx.check(ctx.lib.hive_resnet_stem_conv(ctx.handle, x.data_ptr(), _code(x.dtype), n, h, w_, hit[1].data_ptr(), out.data_ptr()))
     return out
 
 
 def maxpool3x3s2_same(x, engine="torch"):
-    """MaxPool2dSame(3, 2) of the ResNetV2 stem."""
-    if engine == "hip" and _hip_eligible(x) and x.dtype == torch.bfloat16:
+    """MaxPool2dSame(3, 2) of the ResNetV2 stem (``engine="hip"``; raises where the kernel does not apply)."""
+    if engine == "hip":
+        why = _why_not_map(x)
+        if why:
+            not_covered("max_pool 3 x 3 / 2", why)
         n, c, h, w = x.shape
         out = torch.empty((n, c, (h + 1) // 2, (w + 1) // 2), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
         ctx = _lib.default_context(x.device.index or 0)
-        ctx.check(ctx.lib.hive_nhwc_maxpool3x3s2(ctx.handle, x.data_ptr(), _lib.BF16, n, h, w, c, out.data_ptr()))
+        ctx.check(ctx.lib.hive_nhwc_maxpool3x3s2(ctx.handle, x.data_ptr(), _code(x.dtype), n, h, w, c, out.data_ptr()))
         return out
     return None
 
 
 def conv_bias_act(x, conv, relu=False, residual=None, residual2=None, engine="torch", also_relu=False):
     """relu?(conv(x) (+ residual) (+ residual2)) for an ``nn.Conv2d`` with bias.  HIP engine: the decoder's 3 x 3
-    convolutions run in the hand-written implicit-GEMM kernel with bias, skip connections and ReLU in its epilogue; other
-    shapes run the convolution without its bias (MIOpen) and one fused kernel adds bias, skip connection and ReLU.
+    convolutions run in the hand-written implicit-GEMM kernel with bias, skip connections and ReLU in its epilogue.
     ``also_relu=True`` returns ``(y, relu(y))``: the second tensor is what the next residual unit feeds to its first convolution."""
-    if engine == "hip" and conv3x3_eligible(x, conv) and (conv.bias is None or conv.bias.dtype == x.dtype):
+    if engine == "hip":
+        why = _why_not_conv(x, conv, kernels=(3,), cout_multiple=128) or (None if conv3x3_eligible(x, conv) else "3 x 3 / stride 1 / padding 1 only") or \
+            (None if conv.bias is None or conv.bias.dtype == x.dtype else f"bias is {conv.bias.dtype}, the tensor {x.dtype}")
+        if why:
+            not_covered("convolution of a residual unit", why)
         if residual is not None:
             residual = residual.contiguous(memory_format=torch.channels_last)
         if residual2 is not None:
             residual2 = residual2.contiguous(memory_format=torch.channels_last)
         return conv3x3(x, conv, relu=relu, residual=residual, residual2=residual2, also_relu=also_relu)
-    if engine == "hip" and conv.bias is not None and _hip_eligible(x) and conv.out_channels % 8 == 0 and conv.bias.dtype == x.dtype:
-        y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
-        if _hip_eligible(y):
-            if residual is not None:
-                assert residual.shape == y.shape and residual.dtype == y.dtype
-                residual = residual.contiguous(memory_format=torch.channels_last)
-            if residual2 is not None:
-                assert residual2.shape == y.shape and residual2.dtype == y.dtype
-                residual2 = residual2.contiguous(memory_format=torch.channels_last)
-            n, c, h, w = y.shape
-            y_relu = torch.empty_like(y) if also_relu else None
-            ctx = _lib.default_context(y.device.index or 0)
-            ctx.check(ctx.lib.hive_nhwc_bias_act(ctx.handle, y.data_ptr(), _code(y.dtype), n * h * w, c, conv.bias.data_ptr(), int(bool(relu)),
-                                                 _lib.ptr(residual), _lib.ptr(residual2), y.data_ptr(), _lib.ptr(y_relu)))  # y in place
-            return (y, y_relu) if also_relu else y
-        y = y + conv.bias.view(1, -1, 1, 1)
-    else:
-        y = conv(x)
+    y = conv(x)
     if residual is not None:
         y = y + residual
     if residual2 is not None:
@@ -296,7 +331,10 @@ def upsample2x(x, engine="torch", bias=None):
     """interpolate(x (+ bias per channel), scale_factor=2, mode="bilinear", align_corners=True).  ``bias`` folds the bias
     pass of the convolution that produced ``x`` into the load (x + b is rounded to the tensor dtype first, as a separate
     add would round it)."""
-    if engine == "hip" and _hip_eligible(x) and (bias is None or bias.dtype == x.dtype):
+    if engine == "hip":
+        why = _why_not_map(x) or (None if bias is None or bias.dtype == x.dtype else f"bias is {bias.dtype}, the tensor {x.dtype}")
+        if why:
+            not_covered("bilinear x2 upsampling", why)
         n, c, h, w = x.shape
         out = torch.empty((n, c, 2 * h, 2 * w), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
         ctx = _lib.default_context(x.device.index or 0)

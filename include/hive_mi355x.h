@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define HIVE_ABI_VERSION 1
+#define HIVE_ABI_VERSION 2
 
 typedef enum hive_status {
     HIVE_OK = 0,
@@ -256,40 +256,42 @@ int hive_depth_quantize(hive_ctx *ctx, const void *d_depth, int dtype, int H, in
 
 /* ---- DPT ViT encoder blocks: replaces the transformer blocks of dpt.models.DPTDepthModel.forward
  *      (timm vit_base_resnet50_384) -- hive/dataset_adaptors.py:1366-1374,1419 --------------------- */
-/* All pointers are device memory.  Activations / weights are bf16 ([out][in] row-major weights, as
- * nn.Linear stores them); biases and LayerNorm affine parameters are float32. */
+/* All pointers are device memory.  Activations / weights are the 16-bit type `dtype` names -- HIVE_BF16, or HIVE_F16: what the
+ * reference runs (`model.half()` and fp16 samples, hive/dataset_adaptors.py:1394-1401, 1415-1417); same kernels, same rates
+ * (v_mfma_f32_16x16x32_{bf16,f16}) -- with [out][in] row-major weights, as nn.Linear stores them; biases and LayerNorm affine
+ * parameters are float32.  Below "16-bit" stands for that type. */
 typedef struct hive_vit hive_vit;
 typedef struct hive_vit_block_weights {
     const void *ln1_g, *ln1_b;   /* f32 [D]            norm1            */
-    const void *qkv_w, *qkv_b;   /* bf16 [3D][D], f32 [3D]   attn.qkv   */
-    const void *proj_w, *proj_b; /* bf16 [D][D],  f32 [D]    attn.proj  */
+    const void *qkv_w, *qkv_b;   /* 16-bit [3D][D], f32 [3D] attn.qkv   */
+    const void *proj_w, *proj_b; /* 16-bit [D][D], f32 [D]   attn.proj  */
     const void *ln2_g, *ln2_b;   /* f32 [D]            norm2            */
-    const void *fc1_w, *fc1_b;   /* bf16 [F][D],  f32 [F]    mlp.fc1    */
-    const void *fc2_w, *fc2_b;   /* bf16 [D][F],  f32 [D]    mlp.fc2    */
+    const void *fc1_w, *fc1_b;   /* 16-bit [F][D], f32 [F]   mlp.fc1    */
+    const void *fc2_w, *fc2_b;   /* 16-bit [D][F], f32 [D]   mlp.fc2    */
 } hive_vit_block_weights;
 /* head dim must be 64 (D = 64 * heads), D a multiple of 256 and <= 1024, F a multiple of 128. */
-int hive_vit_create(hive_ctx *ctx, int depth, int dim, int heads, int mlp_dim, float ln_eps,
+int hive_vit_create(hive_ctx *ctx, int dtype, int depth, int dim, int heads, int mlp_dim, float ln_eps,
                     const hive_vit_block_weights *blocks, hive_vit **out);
 int hive_vit_destroy(hive_vit *vit);
-/* x bf16 [B][N][D] -> runs all blocks; after block tap_blocks[t] its output is copied to tap_out[t]
- * (bf16 [B][N][D]).  x = x + proj(attn(LN1 x)); x = x + fc2(gelu(fc1(LN2 x))). */
+/* x 16-bit [B][N][D] -> runs all blocks; after block tap_blocks[t] its output is copied to tap_out[t]
+ * (16-bit [B][N][D]).  x = x + proj(attn(LN1 x)); x = x + fc2(gelu(fc1(LN2 x))). */
 int hive_vit_forward(hive_vit *vit, const void *x, int B, int N, const int *tap_blocks, int n_taps,
                      void *const *tap_out);
 /* the individual kernels (used by hive_vit_forward; exposed for the numerics tests) */
-int hive_vit_layernorm(hive_ctx *ctx, const void *x, const float *gamma, const float *beta, void *out,
+int hive_vit_layernorm(hive_ctx *ctx, const void *x, int dtype, const float *gamma, const float *beta, void *out,
                        int M, int D, float eps);
 /* C = epilogue(A[M][K] W[N][K]^T + bias): epilogue 0 = none, 1 = GELU (erf), 2 = + residual[M][N] */
-int hive_vit_linear(hive_ctx *ctx, const void *A, const void *W, const float *bias, const void *residual,
+int hive_vit_linear(hive_ctx *ctx, const void *A, int dtype, const void *W, const float *bias, const void *residual,
                     void *C, int M, int N, int K, int epilogue);
 /* qkv projection of x [B*Np][D] (Np a multiple of 64): q|k -> qk [B*Np][2D], v -> vT [B][H][64][Np].  Both are operands
- * private to hive_vit_attention: q is stored multiplied by head_dim^-0.5 * log2(e) (in f32, before the one rounding to bf16), so
+ * private to hive_vit_attention: q is stored multiplied by head_dim^-0.5 * log2(e) (in f32, before the one rounding to 16 bits), so
  * the attention's score products are base-2 exponents; vT is laid out for its fragment reads: along its last axis the token quads 4..7 and 8..11 of every group of 16 are swapped
  * (token t is stored at t with bits 2 and 3 exchanged), which makes the attention's V fragments single 16-byte LDS reads. */
-int hive_vit_qkv(hive_ctx *ctx, const void *x, const void *W, const float *bias, void *qk, void *vT,
+int hive_vit_qkv(hive_ctx *ctx, const void *x, int dtype, const void *W, const float *bias, void *qk, void *vT,
                  int B, int Np, int D, int H);
 /* softmax(q k^T / 8) v over the first N keys of each image -> out [B*Np][D]; Np = N rounded up to a multiple of 64; qk, vT as
  * hive_vit_qkv writes them (q pre-scaled: the kernel evaluates exp2(q' k^T - max)) */
-int hive_vit_attention(hive_ctx *ctx, const void *qk, const void *vT, void *out, int B, int N, int Np,
+int hive_vit_attention(hive_ctx *ctx, const void *qk, int dtype, const void *vT, void *out, int B, int N, int Np,
                        int D, int H);
 
 /* ---- DPT pre/post-processing around the network (device pointers) -------------------------------- */
@@ -308,11 +310,11 @@ int hive_dpt_head_tail(hive_ctx *ctx, const void *d_feat, int dtype, int64_t n_p
                        const float *h_pre_bias, int pre_relu, const float *h_weight, float bias,
                        int non_negative, int invert, float scale, float shift, float *d_depth,
                        float depth_scale, float max_depth, uint16_t *d_out_mm, float *d_out_m);
-/* The second half of the depth head as one kernel (bf16): Interpolate(x2, bilinear, align_corners=True) ->
+/* The second half of the depth head as one kernel (f16 / bf16): Interpolate(x2, bilinear, align_corners=True) ->
  * Conv3x3(C_in=128 -> C_mid=32) + bias -> ReLU -> Conv1x1(32 -> 1) + bias -> [ReLU] -> [1 / max(scale x + shift, 1e-8)]
  * -> optional uint16-mm hand-off, i.e. scratch.output_conv[1:] of DPTDepthModel plus the tail above
  * (hive/dataset_adaptors.py:1419, 1432-1433).  d_x: channels-last [N][H][W][C_in] (output of output_conv[0]);
- * d_b0 (optional, device, f32 [C_in]): bias of output_conv[0], added to d_x on load (x + b rounded to bf16 first, as the
+ * d_b0 (optional, device, f32 [C_in]): bias of output_conv[0], added to d_x on load (x + b rounded to the tensor dtype first, as the
  * separate bias add rounds it), so that convolution can run without its bias pass;
  * d_w3: the 3x3 weights on the device as [ky][kx][C_mid][C_in]; h_b3 [C_mid], h_w1 [C_mid] on the host.
  * Outputs are [N][2H][2W]; any of them may be NULL (not all). */
@@ -339,7 +341,7 @@ int hive_nhwc_bias_act(hive_ctx *ctx, const void *d_x, int dtype, int64_t n_px, 
  * dtype) is added to the input on load, rounded to the tensor dtype first: the bias pass of the producing convolution. */
 int hive_nhwc_upsample2x(hive_ctx *ctx, const void *d_in, const void *d_bias, int dtype, int N, int H, int W, int C, void *d_out);
 
-/* 3 x 3 convolution, stride 1, padding 1, channels-last bf16, as an implicit GEMM on the matrix cores with the decoder's
+/* 3 x 3 convolution, stride 1, padding 1, channels-last f16 / bf16, as an implicit GEMM on the matrix cores with the decoder's
  * element-wise tail fused:  out = relu?( conv(x, w) (+ bias) (+ residual) (+ residual2) ), and optionally out_relu = relu(out).
  * The 3 x 3 convolutions of isl-org/DPT's decoder reached from DPTDepthModel.forward (hive/dataset_adaptors.py:1419):
  * scratch.layer{1..4}_rn, ResidualConvUnit_custom.conv1 / conv2, scratch.output_conv[0].
@@ -409,7 +411,7 @@ int hive_nhwc_maxpool3x3s2(hive_ctx *ctx, const void *d_x, int dtype, int N, int
  * 1407-1419, 1432-1433; hive/io.py:1032-1039): uint8 RGB frames in HBM -> depth maps in HBM.
  *
  * The weights come as a table of (name, device pointer).  Names are the parameter names of the published isl-org/DPT checkpoint
- * (`dpt_hybrid_nyu-2ce69ec7.pt`); every tensor is bf16 unless noted:
+ * (`dpt_hybrid_nyu-2ce69ec7.pt`); every tensor is of the config's 16-bit `dtype` unless noted:
  *   pretrained.model.patch_embed.backbone.stem.conv.weight        [64][7][32]: STANDARDISED weights, (ky, (kx, c) padded 21 -> 32)
  *   ...backbone.stem.norm.{weight,bias}, ...stages.S.blocks.B.{norm1,norm2,norm3,downsample.norm}.{weight,bias}     [C]
  *   ...stages.S.blocks.B.{conv1,conv2,conv3,downsample.conv}.weight   [C_out][k][k][C_in]: STANDARDISED (timm StdConv2dSame, eps 1e-8)
@@ -442,9 +444,10 @@ typedef struct hive_dpt_config {
     int invert, non_negative;
     float gn_eps, ln_eps;         /* 1e-5 (GroupNorm), 1e-6 (timm ViT LayerNorm) */
     float head_b3[32], head_w1[32], head_b1;
+    int dtype;                    /* HIVE_BF16 or HIVE_F16: the type of every 16-bit tensor of the table, of d_pos_embed and of the activations */
 } hive_dpt_config;
 int hive_dpt_create(hive_ctx *ctx, const hive_dpt_config *config, const hive_dpt_tensor *tensors, int n_tensors, hive_dpt **out);
-/* d_rgb u8 [B][H][W][3] (H, W multiples of 32), d_pos_embed bf16 [(H/16)(W/16) + 1][768 | 1024] = the position embedding resized to this
+/* d_rgb u8 [B][H][W][3] (H, W multiples of 32), d_pos_embed (the config's dtype) [(H/16)(W/16) + 1][768 | 1024] = the position embedding resized to this
  * token grid (dpt `_resize_pos_embed`: evaluated once per frame size by the host binding).  Outputs [B][H][W], any may be NULL (not
  * all): d_depth f32 metres; d_out_mm = uint16(depth * 1000); d_out_m = mm / 1000 with > max_depth -> 0. */
 int hive_dpt_forward(hive_dpt *dpt, const uint8_t *d_rgb, int B, int H, int W, const void *d_pos_embed, float *d_depth, float max_depth,

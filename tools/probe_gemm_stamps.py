@@ -5,12 +5,13 @@ prologue fill | K loop (of which waiting for the next stage) | drain | epilogue 
 import ctypes, os, sys, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hive_amd import _lib
+DT = int(__import__("os").environ.get("HIVE_PROBE_DTYPE", "2"))  # hive_dtype of the operands: 2 = bf16 (default), 1 = f16
 ctx = _lib.default_context(0); lib = ctx.lib
 raw = ctypes.CDLL(_lib.LIB_PATH)
 for (M, N, K, epi) in [(29184, 3072, 768, 1), (29184, 1536, 768, 0), (19456, 768, 3072, 2), (4096, 4096, 4096, 0)]:
     A = torch.randn(M, K, device="cuda").bfloat16(); W = (torch.randn(N, K, device="cuda") / K ** 0.5).bfloat16(); b = torch.randn(N, device="cuda") * 0.1
     R = torch.randn(M, N, device="cuda").bfloat16(); C = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
-    run = lambda: ctx.check(lib.hive_vit_linear(ctx.handle, A.data_ptr(), W.data_ptr(), b.data_ptr(), R.data_ptr() if epi == 2 else None, C.data_ptr(), M, N, K, epi))
+    run = lambda: ctx.check(lib.hive_vit_linear(ctx.handle, A.data_ptr(), DT, W.data_ptr(), b.data_ptr(), R.data_ptr() if epi == 2 else None, C.data_ptr(), M, N, K, epi))
     for _ in range(3): run()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

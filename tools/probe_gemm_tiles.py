@@ -4,6 +4,7 @@ in the environment of the process), against torch (hipBLASLt).  Also checks the 
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hive_amd import _lib
+DT = int(__import__("os").environ.get("HIVE_PROBE_DTYPE", "2"))  # hive_dtype of the operands: 2 = bf16 (default), 1 = f16
 ctx = _lib.default_context(0); lib = ctx.lib
 def timed(fn, reps=20):
     for _ in range(3): fn()
@@ -18,7 +19,7 @@ for (M, N, K, epi) in [(29184, 1536, 768, 0), (29184, 768, 768, 2), (29184, 3072
     A = torch.randn(M, K, device="cuda").bfloat16(); W = (torch.randn(N, K, device="cuda") / K ** 0.5).bfloat16(); b = torch.randn(N, device="cuda") * 0.1
     R = torch.randn(M, N, device="cuda").bfloat16()
     C = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
-    run = lambda: ctx.check(lib.hive_vit_linear(ctx.handle, A.data_ptr(), W.data_ptr(), b.data_ptr(), R.data_ptr() if epi == 2 else None, C.data_ptr(), M, N, K, epi))
+    run = lambda: ctx.check(lib.hive_vit_linear(ctx.handle, A.data_ptr(), DT, W.data_ptr(), b.data_ptr(), R.data_ptr() if epi == 2 else None, C.data_ptr(), M, N, K, epi))
     dt = timed(run)
     ref = A.float() @ W.float().t() + b
     if epi == 1: ref = torch.nn.functional.gelu(ref)

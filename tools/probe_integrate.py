@@ -18,9 +18,10 @@ ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--height", type=int, default=480)
 ap.add_argument("--width", type=int, default=640, help="--height 1080 --width 1920 --voxel 0.005: BASELINE config 4 (1024^3)")
 ap.add_argument("--no-mesh", action="store_true")
+ap.add_argument("--yaw-step", type=float, default=None, help="degrees between frames (default: 360 / frames; 2.4 = the bench trajectory's consecutive frames)")
 args = ap.parse_args()
 
-seq = synthetic.make_sequence(num_frames=args.frames, height=args.height, width=args.width, yaw_step_deg=360.0 / args.frames)
+seq = synthetic.make_sequence(num_frames=args.frames, height=args.height, width=args.width, yaw_step_deg=args.yaw_step if args.yaw_step is not None else 360.0 / args.frames)
 ctx = _lib.default_context(0)
 vol = fusion.TSDFVolume(synthetic.room_bounds(), args.voxel, ctx=ctx)
 color = torch.from_numpy(seq["color"]).cuda()

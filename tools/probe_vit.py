@@ -8,6 +8,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hive_amd import _lib  # noqa: E402
+DT = int(__import__("os").environ.get("HIVE_PROBE_DTYPE", "2"))  # hive_dtype of the operands: 2 = bf16 (default), 1 = f16
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--batches", default="1,8")
@@ -35,7 +36,7 @@ def timed(fn):
 for B in [int(b) for b in args.batches.split(",")]:
     N, Np = 1201, 1216
     M = B * Np
-    bf = dict(device="cuda", dtype=torch.bfloat16)
+    bf = dict(device="cuda", dtype=torch.bfloat16 if DT == 2 else torch.float16)
     x = torch.randn(M, D, **bf)
     res = torch.randn(M, D, **bf)
     hid = torch.randn(M, F, **bf)
@@ -48,17 +49,17 @@ for B in [int(b) for b in args.batches.split(",")]:
     out = torch.empty(M, D, **bf)
     outf = torch.empty(M, F, **bf)
     rows = [
-        ("layernorm", lambda: lib.hive_vit_layernorm(ctx.handle, x.data_ptr(), g.data_ptr(), b_d.data_ptr(), out.data_ptr(), M, D, 1e-6), 0),
-        ("qkv gemm", lambda: lib.hive_vit_qkv(ctx.handle, x.data_ptr(), w_qkv.data_ptr(), b_qkv.data_ptr(), qk.data_ptr(), vT.data_ptr(), B, Np, D, H),
+        ("layernorm", lambda: lib.hive_vit_layernorm(ctx.handle, x.data_ptr(), DT, g.data_ptr(), b_d.data_ptr(), out.data_ptr(), M, D, 1e-6), 0),
+        ("qkv gemm", lambda: lib.hive_vit_qkv(ctx.handle, x.data_ptr(), DT, w_qkv.data_ptr(), b_qkv.data_ptr(), qk.data_ptr(), vT.data_ptr(), B, Np, D, H),
          2 * M * D * 3 * D),
-        ("attention", lambda: lib.hive_vit_attention(ctx.handle, qk.data_ptr(), vT.data_ptr(), out.data_ptr(), B, N, Np, D, H), 4 * B * H * N * N * 64),
-        ("proj gemm+res", lambda: lib.hive_vit_linear(ctx.handle, x.data_ptr(), w_proj.data_ptr(), b_d.data_ptr(), res.data_ptr(), out.data_ptr(), M, D, D, 2),
+        ("attention", lambda: lib.hive_vit_attention(ctx.handle, qk.data_ptr(), DT, vT.data_ptr(), out.data_ptr(), B, N, Np, D, H), 4 * B * H * N * N * 64),
+        ("proj gemm+res", lambda: lib.hive_vit_linear(ctx.handle, x.data_ptr(), DT, w_proj.data_ptr(), b_d.data_ptr(), res.data_ptr(), out.data_ptr(), M, D, D, 2),
          2 * M * D * D),
-        ("fc1 gemm+gelu", lambda: lib.hive_vit_linear(ctx.handle, x.data_ptr(), w_fc1.data_ptr(), b_f.data_ptr(), None, outf.data_ptr(), M, F, D, 1),
+        ("fc1 gemm+gelu", lambda: lib.hive_vit_linear(ctx.handle, x.data_ptr(), DT, w_fc1.data_ptr(), b_f.data_ptr(), None, outf.data_ptr(), M, F, D, 1),
          2 * M * D * F),
-        ("fc1 gemm", lambda: lib.hive_vit_linear(ctx.handle, x.data_ptr(), w_fc1.data_ptr(), b_f.data_ptr(), None, outf.data_ptr(), M, F, D, 0),
+        ("fc1 gemm", lambda: lib.hive_vit_linear(ctx.handle, x.data_ptr(), DT, w_fc1.data_ptr(), b_f.data_ptr(), None, outf.data_ptr(), M, F, D, 0),
          2 * M * D * F),
-        ("fc2 gemm+res", lambda: lib.hive_vit_linear(ctx.handle, hid.data_ptr(), w_fc2.data_ptr(), b_d.data_ptr(), res.data_ptr(), out.data_ptr(), M, D, F, 2),
+        ("fc2 gemm+res", lambda: lib.hive_vit_linear(ctx.handle, hid.data_ptr(), DT, w_fc2.data_ptr(), b_d.data_ptr(), res.data_ptr(), out.data_ptr(), M, D, F, 2),
          2 * M * D * F),
     ]
     if args.torch:

@@ -1,0 +1,37 @@
+#!/bin/bash
+# Round-3 profile set (GPU box: gpurun -- bash tools/profile_r03.sh [parts]); parts = any of: trace pmc valu small mfma (default: all but mfma)
+#   trace: rocprofv3 --kernel-trace --stats of the default bench command                        -> gpurun_out/prof_r03/trace
+#   pmc  : FETCH_SIZE / WRITE_SIZE of the integrate kernels, separate passes, bench scene (DPT depth) and room scene (analytic depth,
+#          consecutive frames: tools/probe_integrate.py --yaw-step 2.4)                          -> gpurun_out/prof_r03/pmc_{fetch,write}_{bench,room}
+#   valu : SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES / SQ_WAVE_CYCLES / SQ_WAVES / GRBM_GUI_ACTIVE of the same          -> .../pmc_valu_*
+#   small: kernel trace of tools/probe_small_kernels.py (marching cubes 512^3, unproject, project_bbox, grid_mesh, ...)           -> .../small
+# tools/profile_r03_summary.py condenses them into profiles/r03_*.
+PARTS=${*:-trace pmc valu small}
+OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_r03
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+BENCH="python3 $GRAFT_REPO_ROOT/bench.py --timed-only --steps 3 --warmup 1"
+ROOM="python3 $GRAFT_REPO_ROOT/tools/probe_integrate.py --reps 1 --frames 32 --yaw-step 2.4 --no-mesh"
+has() { [[ " $PARTS " == *" $1 "* ]]; }
+if has trace; then
+  rm -rf $OUT/trace
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline > $OUT/trace.log 2>&1 || echo "trace failed"
+  find $OUT/trace -name "*kernel_trace.csv" -delete
+fi
+pmc() {  # name, counters...
+  n=$1; shift
+  for scene in bench room; do
+    rm -rf $OUT/pmc_${n}_$scene
+    if [ $scene = bench ]; then CMD=$BENCH; else CMD=$ROOM; fi
+    timeout -k 10 200 rocprofv3 --pmc "$@" --output-format csv -d $OUT/pmc_${n}_$scene -- $CMD > $OUT/pmc_${n}_$scene.log 2>&1 || echo "$n $scene failed"
+  done
+}
+if has pmc; then pmc fetch FETCH_SIZE; pmc write WRITE_SIZE; fi
+if has valu; then pmc valu SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE; fi
+if has small; then
+  rm -rf $OUT/small
+  timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/small -- python3 $GRAFT_REPO_ROOT/tools/probe_small_kernels.py > $OUT/small.json 2> $OUT/small.err || echo "small failed"
+  find $OUT/small -name "*kernel_trace.csv" -delete
+fi
+for f in $(find $OUT -name "*counter_collection.csv"); do (head -1 $f; grep -E "integrate_kernel|integrate_multi_kernel" $f) > $f.tmp && mv $f.tmp $f; done
+du -sh $OUT; echo profile done
