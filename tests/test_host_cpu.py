@@ -117,7 +117,8 @@ def test_capi_library_exports_every_declared_symbol():
     assert not missing, f"declared in the header but not exported: {missing}"
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
     lib.hive_abi_version.restype = ctypes.c_int
-    assert lib.hive_abi_version() == 1
+    version = int(re.search(r"#define HIVE_ABI_VERSION (\d+)", header).group(1))
+    assert lib.hive_abi_version() == version == _lib.ABI_VERSION
 
 
 def test_no_cpu_fallback_without_device():
