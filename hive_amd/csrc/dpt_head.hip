@@ -10,9 +10,9 @@
 // writes 6 bytes per pixel; it is bound by MFMA issue / LDS operand bandwidth:
 //
 //   * workgroup = 8 x 16 output pixels, 4 waves, persistent over the tile list;
-//   * the low-resolution patch (7 x 11 pixels) is staged in LDS with coalesced 16-byte loads, the 10 x 18
-//     upsampled patch (halo for the 3x3 taps, zero outside the image) is built from it once, rounded to bf16
-//     exactly as the stand-alone upsampling kernel rounds its output;
+//   * the low-resolution patch (7 x 11 pixels) is staged in LDS by LDS-DMA, one tile AHEAD (it lands under the previous tile's MFMA
+//     and epilogue phases); the 10 x 18 upsampled patch (halo for the 3x3 taps, zero outside the image) is built from it once, rounded
+//     to the 16-bit type exactly as the stand-alone upsampling kernel rounds its output;
 //   * D^T[oc][px] = sum_tap W_tap[oc][ic] X_tap[ic][px] on v_mfma_f32_32x32x16_bf16: output channels are the rows
 //     (A operand), pixels the columns (B operand), so a lane ends up with 16 of the 32 channels of ONE pixel and
 //     the 1x1 convolution is a register sum plus one cross-half shuffle;
@@ -32,16 +32,25 @@
 using hive_mfma::f32x16;
 using hive_mfma::vec;  // T = __bf16 or _Float16 (the reference's model.half()): v_mfma_f32_32x32x16_{bf16,f16}
 
+// tuning builds only (make -C hive_amd/csrc ablate): bit mask of phases left out of head_conv_kernel, to read what each costs from
+// tools/probe_head.py (1 = low-resolution patch load, 2 = upsampled patch, 4 = MFMA loop, 8 = partial-sum exchange).  0 in the library.
+#ifndef HIVE_HEAD_ABLATE
+#define HIVE_HEAD_ABLATE 0
+#endif
+
 namespace {
 
 constexpr int TH = 8, TW = 16;                 // output tile
 constexpr int UP_H = TH + 2, UP_W = TW + 2;    // upsampled patch with the 3x3 halo
 constexpr int LO_H = 7, LO_W = 11;             // low-resolution patch that feeds it (scale < 0.5)
 constexpr int CIN = 128, COUT = 32;
-constexpr int PIX = 272;                       // bytes per pixel in LDS
+constexpr int PIX = 272;                       // bytes per pixel of the upsampled patch in LDS
 constexpr int UP_PITCH = 5120;                 // bytes per row of the upsampled patch: >= UP_W * PIX (4896) and a multiple of 256
 constexpr int UP_BYTES = UP_H * UP_PITCH;      // 51200, also >= the partial-sum exchange (4*3*16*64*4 = 49152)
-constexpr int LO_BYTES = LO_H * LO_W * PIX;    // 20944
+constexpr int LO_PIX = 256;                    // bytes per pixel of the low-resolution patch: lane-linear, as the LDS-DMA deposits it
+constexpr int LO_ITEMS = LO_H * LO_W * 16;     // its 16-byte pieces: 1232
+constexpr int LO_DMA = (LO_ITEMS + 63) / 64;   // LDS-DMA wave-instructions per patch: 20 (the last one 16 lanes of payload)
+constexpr int LO_BYTES = LO_DMA * 1024;        // 20480
 static_assert(UP_W * PIX <= UP_PITCH && UP_PITCH % 256 == 0 && UP_BYTES >= 49152, "upsampled patch layout");
 
 template <typename T>
@@ -92,46 +101,65 @@ __global__ __launch_bounds__(256, 2) void head_conv_kernel(HeadParams<T> p) {
         tab[COUT + tid] = p.w1[tid];
     }
 
+    // (a) low-resolution patch -> LDS by LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 B = 4 pixels per wave-instruction, lane-linear:
+    // pixel q = item >> 4 at q * 256 bytes).  Rows / columns past the image edge are clamped duplicates: exactly what align_corners'
+    // i1 = min(i0 + 1, size - 1) reads.  The patch of the NEXT tile is issued right behind the barrier that ends phase (b) -- from there
+    // on nobody reads `lo` -- and lands under the MFMA, exchange and epilogue phases: the ~1 ms (of 5.1 at 96 frames) the kernel used to
+    // wait for these loads at the top of every tile is gone, at no cost in registers (a register prefetch spilled) or LDS.
+    auto issue_lo = [&](int tile) {
+        const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, n = tile / (tiles_x * tiles_y);
+        const int lo_y0 = (int)(sh * (float)max(ty * TH - 1, 0)), lo_x0 = (int)(sw * (float)max(tx * TW - 1, 0));
+        const T *img = p.x + (size_t)n * p.H * p.W * CIN;
+#pragma unroll
+        for (int j = 0; j < LO_DMA / 4; ++j) {
+            const int piece = __builtin_amdgcn_readfirstlane(wave) + 4 * j;         // wave-uniform: the LDS base of the piece goes to M0
+            const int item = min(piece * 64 + lane, LO_ITEMS - 1);                  // lanes past the patch: its last piece again (inside LO_BYTES)
+            const int v = item & 15, q = item >> 4;
+            const int gy = min(lo_y0 + q / LO_W, p.H - 1), gx = min(lo_x0 + q % LO_W, p.W - 1);
+            __builtin_amdgcn_global_load_lds((const void *)(img + ((size_t)gy * p.W + gx) * CIN + v * 8), (__attribute__((address_space(3))) void *)(lo + piece * 1024), 16, 0,
+                                             0);
+        }
+    };
+    static_assert(LO_DMA % 4 == 0, "pieces per wave");
+    if (!(HIVE_HEAD_ABLATE & 1) && (int)blockIdx.x < n_tiles) issue_lo(blockIdx.x);
+
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int tx = tile % tiles_x;
         const int ty = (tile / tiles_x) % tiles_y;
         const int n = tile / (tiles_x * tiles_y);
         const int R0 = ty * TH - 1, C0 = tx * TW - 1;  // output coordinates of the patch origin
         const int lo_y0 = (int)(sh * (float)max(R0, 0)), lo_x0 = (int)(sw * (float)max(C0, 0));
-        // (a) low-resolution patch -> LDS (rows / columns past the image edge are clamped duplicates: exactly what
-        // align_corners' i1 = min(i0 + 1, size - 1) reads).  Prefetching it a tile ahead through registers was
-        // measured slower (20 more live VGPRs spill in the MFMA phase); the second workgroup of the CU covers the latency.
-        const T *img = p.x + (size_t)n * p.H * p.W * CIN;
-        for (int item = tid; item < LO_H * LO_W * 16; item += 256) {
-            const int v = item & 15, q = item >> 4;
-            const int gy = min(lo_y0 + q / LO_W, p.H - 1), gx = min(lo_x0 + q % LO_W, p.W - 1);
-            uint4 raw = *reinterpret_cast<const uint4 *>(img + ((size_t)gy * p.W + gx) * CIN + v * 8);
-            if (p.b0) {  // x + bias rounded to bf16, as the separate bias add of the unfused network rounds it
-                vec<T, 8> xv = *reinterpret_cast<const vec<T, 8> *>(&raw);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the patch have landed
+        __syncthreads();                                   // ... and everyone's
+        if (p.b0) {  // x + bias rounded to T, as a separate bias add rounds it (the network passes NULL: output_conv[0] adds its bias itself)
+            for (int item = tid; item < LO_ITEMS; item += 256) {
+                vec<T, 8> xv = lds_read8<T>(lo, item * 16);
+                const int v = item & 15;
                 const float4 ba = *reinterpret_cast<const float4 *>(p.b0 + v * 8), bb = *reinterpret_cast<const float4 *>(p.b0 + v * 8 + 4);
                 const float bias8[8] = {ba.x, ba.y, ba.z, ba.w, bb.x, bb.y, bb.z, bb.w};
 #pragma unroll
                 for (int j = 0; j < 8; ++j) xv[j] = (T)((float)xv[j] + bias8[j]);
-                raw = *reinterpret_cast<const uint4 *>(&xv);
+                *reinterpret_cast<vec<T, 8> *>(lo + item * 16) = xv;
             }
-            *reinterpret_cast<uint4 *>(lo + q * PIX + v * 16) = raw;
+            __syncthreads();
         }
-        __syncthreads();
         // (b) upsampled patch: PyTorch's align_corners=True formula in float, evaluated as upsample2x_kernel does,
-        //   y = h0 * (w0 * v00 + w1 * v01) + h1 * (w0 * v10 + w1 * v11),
-        // but a thread owns one (patch column, 8-channel vector) and walks down the rows, so the horizontal terms
-        // t(r) = w0 * v(r, x0) + w1 * v(r, x1) of a low-resolution row r are computed once and kept in registers for
-        // the two or three output rows that use them (same values, 43 % fewer flops and LDS reads than per pixel)
-        const int rt = (tid + 64 * (tile & 3)) & 255;  // the 32 left-over pairs rotate over the waves
-        for (int pr = rt; pr < UP_W * 16; pr += 256) {
-            const int v = pr & 15, ux = pr >> 4, ox = C0 + ux;
+        //   y = h0 * (w0 * v00 + w1 * v01) + h1 * (w0 * v10 + w1 * v11).
+        // Pass 1, columns 0 .. 15 (all 256 threads): a thread owns one (patch column, 8-channel vector) and walks down the rows, so the
+        // horizontal terms t(r) = w0 * v(r, x0) + w1 * v(r, x1) of a low-resolution row r are computed once and kept in registers for the
+        // two or three output rows that use them (same values, 43 % fewer flops and LDS reads than per pixel).
+        // Pass 2, the two halo columns 16, 17: 32 (column, vector) items -- walked like pass 1 they kept half a wave busy for as long as all
+        // of pass 1 (this phase was HALF of the kernel's time: ablation builds, tools/probe_head.py); as 320 independent (item, row) units they
+        // take 1 - 2 short steps per thread.
+        const uint4 zero = make_uint4(0u, 0u, 0u, 0u);  // zero padding of the convolution
+        if (!(HIVE_HEAD_ABLATE & 2)) {
+            const int v = tid & 15, ux = tid >> 4, ox = C0 + ux;
             const bool col_ok = ox >= 0 && ox < OW;
             const float fx = sw * (float)ox;
             const int x0 = (int)fx, x1 = min(x0 + 1, p.W - 1);
             const float w1 = fx - (float)x0, w0 = 1.f - w1;
-            const int c0 = col_ok ? (x0 - lo_x0) * PIX + v * 16 : 0, c1 = col_ok ? (x1 - lo_x0) * PIX + v * 16 : 0;
+            const int c0 = col_ok ? (x0 - lo_x0) * LO_PIX + v * 16 : 0, c1 = col_ok ? (x1 - lo_x0) * LO_PIX + v * 16 : 0;
             unsigned char *dst = up + ux * PIX + v * 16;  // + uy * UP_PITCH
-            const uint4 zero = make_uint4(0u, 0u, 0u, 0u);  // zero padding of the convolution
             int uy = 0;                                      // patch row to emit next (uniform over the workgroup)
             while (uy < UP_H && R0 + uy < 0) {               // rows above the image
                 *reinterpret_cast<uint4 *>(dst + uy * UP_PITCH) = zero;
@@ -145,7 +173,7 @@ __global__ __launch_bounds__(256, 2) void head_conv_kernel(HeadParams<T> p) {
             }
 #pragma unroll
             for (int r = 0; r < LO_H - 1; ++r) {  // low-resolution rows r, r + 1 (clamped duplicates past the image edge)
-                const vec<T, 8> a0 = lds_read8<T>(lo, (r + 1) * LO_W * PIX + c0), a1 = lds_read8<T>(lo, (r + 1) * LO_W * PIX + c1);
+                const vec<T, 8> a0 = lds_read8<T>(lo, (r + 1) * LO_W * LO_PIX + c0), a1 = lds_read8<T>(lo, (r + 1) * LO_W * LO_PIX + c1);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) tb[j] = w0 * (float)a0[j] + w1 * (float)a1[j];
                 while (uy < UP_H && R0 + uy < OH) {  // the output rows whose upper source row is r: at most three
@@ -170,8 +198,27 @@ __global__ __launch_bounds__(256, 2) void head_conv_kernel(HeadParams<T> p) {
                 *reinterpret_cast<uint4 *>(dst + uy * UP_PITCH) = zero;
                 ++uy;
             }
+            for (int u = tid; u < 2 * 16 * UP_H; u += 256) {  // pass 2: unit = (halo column, vector, patch row)
+                const int v2 = u & 15, ux2 = 16 + ((u >> 4) & 1), uy2 = u >> 5, ox2 = C0 + ux2, oy2 = R0 + uy2;
+                uint4 packed = zero;
+                if (ox2 < OW && oy2 >= 0 && oy2 < OH) {  // (ox2 >= 15 > 0)
+                    const float fx2 = sw * (float)ox2, fy2 = sh * (float)oy2;
+                    const int xa = (int)fx2, xb = min(xa + 1, p.W - 1), ya = (int)fy2;
+                    const float q1 = fx2 - (float)xa, q0 = 1.f - q1, g1 = fy2 - (float)ya, g0 = 1.f - g1;
+                    const int ra = (ya - lo_y0) * LO_W * LO_PIX, ca = (xa - lo_x0) * LO_PIX + v2 * 16, cb = (xb - lo_x0) * LO_PIX + v2 * 16;
+                    const vec<T, 8> a00 = lds_read8<T>(lo, ra + ca), a01 = lds_read8<T>(lo, ra + cb);
+                    const vec<T, 8> a10 = lds_read8<T>(lo, ra + LO_W * LO_PIX + ca), a11 = lds_read8<T>(lo, ra + LO_W * LO_PIX + cb);
+                    vec<T, 8> o;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = (T)(g0 * (q0 * (float)a00[j] + q1 * (float)a01[j]) + g1 * (q0 * (float)a10[j] + q1 * (float)a11[j]));
+                    packed = *reinterpret_cast<const uint4 *>(&o);
+                }
+                *reinterpret_cast<uint4 *>(up + uy2 * UP_PITCH + ux2 * PIX + v2 * 16) = packed;
+            }
         }
         __syncthreads();
+        // nobody reads `lo` any more: the next tile's patch streams in under phases (c), (d) and the epilogue
+        if (!(HIVE_HEAD_ABLATE & 1) && tile + (int)gridDim.x < n_tiles) issue_lo(tile + gridDim.x);
         // (c) 9 taps x 2 k-steps x 4 pixel tiles of 32 (tile m = output rows 2m, 2m+1 of the 8 x 16 patch)
         f32x16 acc[4];
 #pragma unroll
@@ -180,7 +227,7 @@ __global__ __launch_bounds__(256, 2) void head_conv_kernel(HeadParams<T> p) {
             for (int v = 0; v < 16; ++v) acc[m][v] = 0.f;
         const int pix_base = (nn >> 4) * UP_PITCH + (nn & 15) * PIX + (32 * wave + 8 * hh) * 2;
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
+        for (int t = 0; t < ((HIVE_HEAD_ABLATE & 4) ? 0 : 9); ++t) {
             const int tap_off = (t / 3) * UP_PITCH + (t % 3) * PIX;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
@@ -195,7 +242,7 @@ __global__ __launch_bounds__(256, 2) void head_conv_kernel(HeadParams<T> p) {
         typedef hive_mfma::f32x4 f32x4;
         f32x4 *part = reinterpret_cast<f32x4 *>(up);
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
+        for (int m = 0; m < ((HIVE_HEAD_ABLATE & 8) ? 0 : 4); ++m)
             if (wave != m) {
                 const int slot = wave < m ? wave : wave - 1;
 #pragma unroll
@@ -209,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void head_conv_kernel(HeadParams<T> p) {
         for (int g = 0; g < 4; ++g) {  // registers 4g .. 4g+3 = output channels 8g + 4hh .. + 3 of pixel nn
             f32x4 sum = f32x4{mine[4 * g], mine[4 * g + 1], mine[4 * g + 2], mine[4 * g + 3]};
 #pragma unroll
-            for (int slot = 0; slot < 3; ++slot) sum += part[((wave * 3 + slot) * 4 + g) * 64 + lane];
+            for (int slot = 0; slot < ((HIVE_HEAD_ABLATE & 8) ? 0 : 3); ++slot) sum += part[((wave * 3 + slot) * 4 + g) * 64 + lane];
             const f32x4 b3q = *reinterpret_cast<const f32x4 *>(tab + 8 * g + 4 * hh);
             const f32x4 w1q = *reinterpret_cast<const f32x4 *>(tab + COUT + 8 * g + 4 * hh);
 #pragma unroll

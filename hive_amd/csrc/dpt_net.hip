@@ -70,7 +70,6 @@ struct hive_dpt {
     hive_vit *vit = nullptr;
     void *arena = nullptr;
     size_t arena_bytes = 0, arena_used = 0;
-    float *d_head_b0 = nullptr;  // f32 copy of output_conv[0].bias for the fused head
 
     const void *get(const std::string &name) const {
         auto it = w.find(name);
@@ -331,14 +330,14 @@ int run_forward(hive_dpt *d, bool dry, const uint8_t *d_rgb, int B, int H, int W
         prev = path;
     }
 
-    // ---- depth head: conv 256 -> 128 (bias folded into the fused kernel), x2 upsample + conv 128 -> 32 + ReLU + 1x1 + ReLU + inversion
+    // ---- depth head: conv 256 -> 128 (+ bias, in its epilogue), x2 upsample + conv 128 -> 32 + ReLU + 1x1 + ReLU + inversion
     Map lo;
-    DPT_TRY(conv(path, "scratch.output_conv.0.weight", nullptr, 128, 3, 1, false, 0, nullptr, nullptr, false, &lo, nullptr));
+    DPT_TRY(conv(path, "scratch.output_conv.0.weight", "scratch.output_conv.0.bias", 128, 3, 1, false, 0, nullptr, nullptr, false, &lo, nullptr));
     if (dry) return HIVE_OK;
     const void *w3;
     DPT_TRY(need("scratch.output_conv.2.weight", &w3));  // [ky][kx][32][128]
     HIVE_REQUIRE(ctx, 2 * lo.H == H && 2 * lo.W == W, "hive_dpt: frame size %d x %d must be a multiple of 32", H, W);
-    return hive_dpt_head_fused(ctx, lo.p, d->d_head_b0, dt, B, lo.H, lo.W, 128, 32, w3, d->cfg.head_b3, d->cfg.head_w1, d->cfg.head_b1,
+    return hive_dpt_head_fused(ctx, lo.p, nullptr, dt, B, lo.H, lo.W, 128, 32, w3, d->cfg.head_b3, d->cfg.head_w1, d->cfg.head_b1,
                                d->cfg.non_negative, d->cfg.invert, d->cfg.scale, d->cfg.shift, d_depth, 1.0f / 1000.0f, max_depth, d_mm, d_m);
 }
 
@@ -377,13 +376,10 @@ int hive_dpt_create(hive_ctx *ctx, const hive_dpt_config *config, const hive_dpt
         }
     }
     int rc = hive_vit_create(ctx, config->dtype, vit_depth, vit_dim, vit_heads, 4 * vit_dim, config->ln_eps, blocks.data(), &d->vit);
-    const void *b0 = d->get("scratch.output_conv.0.bias.f32");
-    if (!rc && !b0) rc = hive_fail(ctx, HIVE_ERR_INVALID, "hive_dpt_create: tensor 'scratch.output_conv.0.bias.f32' missing from the table");
     if (rc) {
         hive_dpt_destroy(d);
         return rc;
     }
-    d->d_head_b0 = (float *)b0;
     *out = d;
     return HIVE_OK;
 }

@@ -42,6 +42,7 @@ struct hive_ctx {
     void *d_in = nullptr;  // device copy of host inputs
     size_t in_bytes = 0;
     int tsdf_scalars = 0;           // which of the two TSDF scalar blocks the frame in flight uses (tsdf.hip prepare_frame)
+    int tsdf_multi_scalars = 0;     // the same for the multi-frame sweep's blocks (d_scalars + 64 / + 80)
     unsigned *d_scalars = nullptr;  // [0]=max depth bits, [2..3]=u64 counter, ...
     void *d_zeros = nullptr;        // 256 bytes of zeros: the source of padding taps in the implicit-GEMM convolutions
 

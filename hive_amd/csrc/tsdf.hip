@@ -913,9 +913,12 @@ static int launch_integrate_multi(hive_tsdf *v, int nf, const uint8_t *color, co
     const size_t npx = (size_t)H * W;
     int rc = hive_reserve_device(ctx, &ctx->d_frame, &ctx->frame_bytes, (size_t)nf * npx * sizeof(uint2));
     if (rc) return rc;
-    unsigned *sc = ctx->d_scalars + 64;  // [64 + f] = max depth of frame f, [64 + MAXF] = work-list length
-    HIVE_CHECK_HIP(ctx, hipMemsetAsync(sc, 0, (MAXF + 1) * sizeof(unsigned), ctx->stream));
-    unsigned *idle_block = ctx->d_scalars + (ctx->tsdf_scalars ? 0 : 48);  // the single-frame path's next block: cleared anyway
+    // scalar block of this sweep: [f] = max depth of frame f, [MAXF] = work-list length.  Two blocks alternate (both zero after
+    // hive_ctx_create); this sweep's pack kernel clears the other one, which the previous sweep used (stream order) -- no memset launch
+    static_assert(MAXF + 1 <= 8, "pack_frame_kernel clears 8 words of the next block");
+    ctx->tsdf_multi_scalars ^= 1;
+    unsigned *sc = ctx->d_scalars + (ctx->tsdf_multi_scalars ? 80 : 64);
+    unsigned *idle_block = ctx->d_scalars + (ctx->tsdf_multi_scalars ? 64 : 80);
     MultiParams mp;
     mp.nf = nf;
     // all nf frames in one launch; the 4-pixels-per-lane form needs every frame's depth 16-byte and colour 4-byte aligned

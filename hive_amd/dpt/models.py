@@ -638,28 +638,26 @@ class DPTDepthModel(DPT):
             if not (isinstance(head[1], Interpolate) and head[1].scale_factor == 2 and head[1].mode == "bilinear" and head[1].align_corners
                     and isinstance(head[3], nn.ReLU) and tuple(pre.weight.shape) == (32, 128, 3, 3) and pre.stride == (1, 1) and pre.padding == (1, 1)):
                 dpt_ops.not_covered("the depth head", "the fused head kernel is built for Interpolate(x2) -> Conv3x3(128 -> 32) -> ReLU -> Conv1x1(32 -> 1)")
-            key = (conv.weight.data_ptr(), conv.weight._version, conv.bias._version, pre.bias._version, pre.weight._version,
-                   first.bias.data_ptr(), first.bias._version, pre.weight.dtype)
+            key = (conv.weight.data_ptr(), conv.weight._version, conv.bias._version, pre.bias._version, pre.weight._version, pre.weight.dtype)
             if getattr(self, "_tail_host", (None,))[0] != key:  # one D2H per set of weights, not per forward
                 self._tail_host = (key, conv.weight.detach().float().reshape(-1).cpu().numpy(), float(conv.bias.detach().float().item()),
                                    pre.bias.detach().float().cpu().numpy(),
-                                   pre.weight.detach().permute(2, 3, 0, 1).contiguous(),  # [ky][kx][out][in] for the fused head
-                                   first.bias.detach().float().contiguous())
-            weight, bias, pre_bias, w3, b0 = self._tail_host[1:6]
-            # Interpolate + conv 128 -> 32 + ReLU + conv 32 -> 1 + inversion + hand-off: one HIP kernel (csrc/dpt_head.hip)
-            # (output_conv[0] runs without its bias: the kernel adds it while loading, one pass over 315 MB less)
+                                   pre.weight.detach().permute(2, 3, 0, 1).contiguous())  # [ky][kx][out][in] for the fused head
+            weight, bias, pre_bias, w3 = self._tail_host[1:5]
+            # output_conv[0] with its bias in the epilogue; then Interpolate + conv 128 -> 32 + ReLU + conv 32 -> 1 + inversion + hand-off:
+            # one HIP kernel (csrc/dpt_head.hip)
             path_1 = self.forward_decoder(x, stages)
             if not dpt_ops.conv3x3_eligible(path_1, first):
                 dpt_ops.not_covered("scratch.output_conv[0]", f"{path_1.dtype} {tuple(path_1.shape)} -> {first.out_channels}")
-            lo = dpt_ops.conv3x3(path_1, first, with_bias=False)  # its bias is added by the fused head while loading
+            lo = dpt_ops.conv3x3(path_1, first)
             if stages is not None:
-                stages["head_in"] = lo + first.bias.view(1, -1, 1, 1)
+                stages["head_in"] = lo
             b, c, h, w = lo.shape
             depth = torch.empty((b, 2 * h, 2 * w), dtype=torch.float32, device=lo.device)
             mm = torch.empty((b, 2 * h, 2 * w), dtype=torch.int16, device=lo.device) if handoff else None
             m = torch.empty((b, 2 * h, 2 * w), dtype=torch.float32, device=lo.device) if handoff else None
             ctx.check(ctx.lib.hive_dpt_head_fused(
-                ctx.handle, lo.data_ptr(), b0.data_ptr(), dpt_ops._code(lo.dtype), b, h, w, c, 32, w3.data_ptr(), pre_bias.ctypes.data, weight.ctypes.data, bias,
+                ctx.handle, lo.data_ptr(), None, dpt_ops._code(lo.dtype), b, h, w, c, 32, w3.data_ptr(), pre_bias.ctypes.data, weight.ctypes.data, bias,
                 int(non_negative), int(bool(self.invert)), float(self.scale), float(self.shift), depth.data_ptr(), 1.0 / 1000.0,
                 float(handoff[0]) if handoff else 0.0, _lib.ptr(mm), _lib.ptr(m)))
             return (depth, mm, m) if handoff else depth

@@ -79,7 +79,6 @@ class NativeDPT:
             elif name != "pretrained.model.pos_embed":  # conv biases, GroupNorm affine: the tensor dtype
                 add(name, p.to(device=dev, dtype=bf))
         head = model.scratch.output_conv
-        add("scratch.output_conv.0.bias.f32", head[0].bias.to(device=dev, dtype=f32))
         if not model.pretrained.hybrid:  # the 16 x 16 / 16 patch embedding runs as a GEMM: float32 bias
             add("pretrained.model.patch_embed.proj.bias.f32", model.pretrained.model.patch_embed.proj.bias.to(device=dev, dtype=f32))
         cfg = _Config(0 if model.pretrained.hybrid else 1, float(model.scale), float(model.shift), int(bool(model.invert)), int(isinstance(head[5], nn.ReLU)), 1e-5,

@@ -422,7 +422,7 @@ int hive_nhwc_maxpool3x3s2(hive_ctx *ctx, const void *d_x, int dtype, int N, int
  *   pretrained.act_postprocess3.3.*, act_postprocess4.3.* ([768][1][1][768] + bias), act_postprocess4.4.* ([768][3][3][768] + bias)
  *   scratch.layer{1..4}_rn.weight [256][3][3][C_in];  scratch.refinenet{1..4}.resConfUnit{1,2}.conv{1,2}.{weight [256][3][3][256], bias};
  *   scratch.refinenet{1..4}.out_conv.{weight [256][1][1][256], bias}
- *   scratch.output_conv.0.weight [128][3][3][256]; scratch.output_conv.0.bias.f32 (f32 [128]); scratch.output_conv.2.weight as
+ *   scratch.output_conv.0.{weight [128][3][3][256], bias [128]}; scratch.output_conv.2.weight as
  *   [ky][kx][32][128]; the last two layers' host values go in the config (head_b3 = output_conv.2.bias, head_w1 / head_b1 = output_conv.4).
  * All convolution weights are [C_out][ky][kx][C_in] (= the PyTorch tensor in channels-last memory format).  The pointers must
  * stay valid for the life of the handle.

@@ -14,7 +14,7 @@ H, W = 240, 320
 ctx = _lib.default_context(0)
 x = (torch.randn(B, H, W, 128, device="cuda") * 0.5).bfloat16()
 w3 = (torch.randn(3, 3, 32, 128, device="cuda") * 0.05).bfloat16()
-b0 = torch.randn(128, device="cuda") * 0.1
+b0 = torch.randn(128, device="cuda") * 0.1 if os.environ.get("HIVE_PROBE_HEAD_B0") else None  # the network passes NULL (output_conv[0] adds its bias itself)
 b3 = np.random.randn(32).astype(np.float32) * 0.1
 w1 = np.random.randn(32).astype(np.float32) * 0.3
 depth = torch.empty((B, 2 * H, 2 * W), dtype=torch.float32, device="cuda")
@@ -23,7 +23,7 @@ m = torch.empty((B, 2 * H, 2 * W), dtype=torch.float32, device="cuda")
 
 
 def run():
-    ctx.check(ctx.lib.hive_dpt_head_fused(ctx.handle, x.data_ptr(), b0.data_ptr(), _lib.BF16, B, H, W, 128, 32, w3.data_ptr(), b3.ctypes.data, w1.ctypes.data,
+    ctx.check(ctx.lib.hive_dpt_head_fused(ctx.handle, x.data_ptr(), _lib.ptr(b0), _lib.BF16, B, H, W, 128, 32, w3.data_ptr(), b3.ctypes.data, w1.ctypes.data,
                                           0.05, 1, 1, 0.01, 0.1, depth.data_ptr(), 1e-3, 10.0, mm.data_ptr(), m.data_ptr()))
 
 
