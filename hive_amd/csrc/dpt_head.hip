@@ -20,6 +20,13 @@
 //     x 2 k-steps) in registers for the whole kernel and reads only pixel operands from LDS -- 1 KiB per MFMA,
 //     which is the LDS bandwidth of a CU at full MFMA rate, so weights must not come from LDS as well;
 //     the 4 partial sums per pixel tile are exchanged through LDS once per tile;
+//   * tried in round 3 and taken out again: producer / consumer waves (one workgroup of eight waves per CU: four build the next tile's
+//     patch into a second buffer while four multiply the current one, K split two ways, 160,000 bytes of LDS) -- correct, but 4.1 ms
+//     against 3.7: the patch construction is bound by what ONE wave issues (conversions, un-contracted multiplies and adds), so four
+//     producer waves (one per SIMD) need 3.5 ms for what eight waves of two co-resident workgroups do in 1.5; reading the 14 vectors of a
+//     column pair up front instead of row by row changes nothing either (not LDS latency).  What did help: compiling this file without
+//     SLP vectorisation (-fno-slp-vectorize, csrc/Makefile): the packed f32 forms the vectoriser makes of the interpolation arithmetic
+//     issue slowly beside the other workgroup's MFMAs (3.69 -> 3.53 ms; same values, IEEE per element);
 //   * LDS layout of the upsampled patch: 272 bytes per pixel (256 + 16) and a row pitch that is a multiple of 256 bytes,
 //     so the 16-byte bank slot of a pixel depends on its column only; the lane groups in which ds_read_b128 is serviced
 //     ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ...) each hold 16 different columns of the 2 x 16 pixel block: conflict-free
@@ -165,17 +172,17 @@ __global__ __launch_bounds__(256, 2) void head_conv_kernel(HeadParams<T> p) {
                 *reinterpret_cast<uint4 *>(dst + uy * UP_PITCH) = zero;
                 ++uy;
             }
-            float ta[8], tb[8];
-            {
-                const vec<T, 8> a0 = lds_read8<T>(lo, c0), a1 = lds_read8<T>(lo, c1);
+            // all 14 reads of the column pair first (56 registers, free in this phase): one LDS round trip for the walk instead of seven
+            vec<T, 8> col0[LO_H], col1[LO_H];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) ta[j] = w0 * (float)a0[j] + w1 * (float)a1[j];
-            }
+            for (int r = 0; r < LO_H; ++r) col0[r] = lds_read8<T>(lo, r * LO_W * LO_PIX + c0), col1[r] = lds_read8<T>(lo, r * LO_W * LO_PIX + c1);
+            float ta[8], tb[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ta[j] = w0 * (float)col0[0][j] + w1 * (float)col1[0][j];
 #pragma unroll
             for (int r = 0; r < LO_H - 1; ++r) {  // low-resolution rows r, r + 1 (clamped duplicates past the image edge)
-                const vec<T, 8> a0 = lds_read8<T>(lo, (r + 1) * LO_W * LO_PIX + c0), a1 = lds_read8<T>(lo, (r + 1) * LO_W * LO_PIX + c1);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) tb[j] = w0 * (float)a0[j] + w1 * (float)a1[j];
+                for (int j = 0; j < 8; ++j) tb[j] = w0 * (float)col0[r + 1][j] + w1 * (float)col1[r + 1][j];
                 while (uy < UP_H && R0 + uy < OH) {  // the output rows whose upper source row is r: at most three
                     const float fy = sh * (float)(R0 + uy);
                     const int y0 = (int)fy;
