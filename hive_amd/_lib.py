@@ -28,6 +28,7 @@ SIGNATURES = {
     "hive_abi_version": (c_int, []),
     "hive_ctx_create": (c_int, [c_int, c_void_p, P(c_void_p)]),
     "hive_ctx_destroy": (c_int, [c_void_p]),
+    "hive_ctx_get_stream": (c_int, [c_void_p, P(c_void_p)]),
     "hive_ctx_synchronize": (c_int, [c_void_p]),
     "hive_last_error": (ctypes.c_char_p, [c_void_p]),
     "hive_ctx_set_stream": (c_int, [c_void_p, c_void_p]),
@@ -202,6 +203,7 @@ class Context:
         handle = c_void_p()
         self._follow_torch = stream == "torch"
         self._stream = None
+        self._side_stream = None  # the torch.cuda.Stream this context was made for (DepthFusionStream.side_stream_context)
         if stream == "torch":
             import torch
             if not torch.cuda.is_available():
@@ -210,6 +212,8 @@ class Context:
             stream_ptr = c_void_p(self._stream)
         elif stream == "own":
             stream_ptr = c_void_p(-1)  # HIVE_STREAM_OWN
+        elif stream == "own_low":
+            stream_ptr = c_void_p(-2)  # HIVE_STREAM_OWN_LOW: a private stream of the lowest dispatch priority
         else:
             stream_ptr = c_void_p(int(stream or 0))
         check(lib.hive_ctx_create(self.device, stream_ptr, ctypes.byref(handle)))
@@ -230,6 +234,12 @@ class Context:
                 self.check(self.lib.hive_ctx_set_stream(self.handle, c_void_p(cur)))
                 self._stream = cur
         return self
+
+    def stream_handle(self):
+        """The hipStream_t (int) this context issues on."""
+        h = c_void_p()
+        self.check(self.lib.hive_ctx_get_stream(self.handle, ctypes.byref(h)))
+        return int(h.value or 0)
 
     def synchronize(self):
         self.check(self.lib.hive_ctx_synchronize(self.handle))

@@ -111,6 +111,11 @@ int hive_ctx_create(int device_id, void *stream, hive_ctx **out) {
         if (stream == HIVE_STREAM_OWN) {
             e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
             ctx->owns_stream = true;
+        } else if (stream == HIVE_STREAM_OWN_LOW) {  // lowest dispatch priority: work that should only fill what other streams leave idle
+            int least = 0, greatest = 0;
+            e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+            if (e == hipSuccess) e = hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, least);
+            ctx->owns_stream = true;
         } else {
             ctx->stream = (hipStream_t)stream;  // NULL = the default stream
         }
@@ -153,7 +158,7 @@ int hive_ctx_destroy(hive_ctx *ctx) {
 int hive_ctx_set_stream(hive_ctx *ctx, void *stream) {
     HIVE_ENTER(ctx);
     if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
-    HIVE_REQUIRE(ctx, stream != HIVE_STREAM_OWN, "hive_ctx_set_stream: pass a hipStream_t (NULL = the default stream)");
+    HIVE_REQUIRE(ctx, stream != HIVE_STREAM_OWN && stream != HIVE_STREAM_OWN_LOW, "hive_ctx_set_stream: pass a hipStream_t (NULL = the default stream)");
     hipStream_t next = (hipStream_t)stream;
     if (next == ctx->stream) return HIVE_OK;
     // work already queued on the old stream may still use the context's scratch buffers: order the new stream behind it
@@ -169,6 +174,12 @@ int hive_ctx_set_stream(hive_ctx *ctx, void *stream) {
         ctx->owns_stream = false;
     }
     ctx->stream = next;
+    return HIVE_OK;
+}
+
+int hive_ctx_get_stream(hive_ctx *ctx, void **stream) {
+    if (!ctx || !stream) return hive_fail(ctx, HIVE_ERR_INVALID, "hive_ctx_get_stream: NULL argument");
+    *stream = (void *)ctx->stream;
     return HIVE_OK;
 }
 

@@ -118,7 +118,12 @@ class DepthFusionStream:
     frame-sharded multi-GPU fusion (``hive_amd.distributed``).
     """
 
-    def __init__(self, model, volume, cam_intr, max_depth=10.0, accumulate=False, native=True):
+    def __init__(self, model, volume, cam_intr, max_depth=10.0, accumulate=False, native=True, overlap=False):
+        """``overlap=True``: the TSDF sweeps of batch i run on a second HIP stream while the network already works on batch
+        i + 1.  The network's MFMA kernels leave the vector ALUs idle and whole CUs idle in the tails of their tile rounds; the sweep
+        is vector-ALU work with 8 KB of LDS.  ``volume`` must then live on a context of that stream
+        (``side_stream_context()`` makes one); ``step`` returns an event that fires when its sweeps are done (for whoever recycles the
+        frame buffers) and ``join()`` orders the caller's stream behind the sweeps (before reading or merging the volume)."""
         self.model = model
         self.native = native  # run the network as one hive_dpt_forward call where it applies (frame size % 32 == 0)
         self.volume = volume
@@ -126,9 +131,27 @@ class DepthFusionStream:
         self.max_depth = float(max_depth)
         self.dtype = next(model.parameters()).dtype
         self.accum = None
+        self.side = None
+        if overlap:
+            vctx = volume._ctx
+            if vctx._follow_torch or not vctx._side_stream:
+                raise ValueError("overlap=True needs a volume created on DepthFusionStream.side_stream_context(device)")
+            self.side = vctx._side_stream
         if accumulate:
             self.accum = torch.empty(5 * volume.num_voxels, dtype=torch.float32, device="cuda")
             volume.accum_reset(self.accum)
+
+    @staticmethod
+    def side_stream_context(device=0):
+        """A context (and its torch stream) for the volume of an overlapping stream: ``TSDFVolume(..., ctx=this)``."""
+        ctx = _lib.Context(device, stream="own_low")  # lowest dispatch priority: the sweeps fill what the network leaves idle
+        ctx._side_stream = torch.cuda.ExternalStream(ctx.stream_handle(), device=device)
+        return ctx
+
+    def join(self):
+        """Order the caller's current stream behind every sweep queued so far (no-op without overlap)."""
+        if self.side is not None:
+            torch.cuda.current_stream().wait_stream(self.side)
 
     @torch.no_grad()
     def depth(self, frames_u8):
@@ -143,11 +166,26 @@ class DepthFusionStream:
 
     @torch.no_grad()
     def step(self, frames_u8, poses_c2w, obs_weight=1.0):
-        """One batch through the whole path; returns the depth maps that were integrated."""
+        """One batch through the whole path; returns the depth maps that were integrated (with ``overlap``: that are being
+        integrated on the side stream -- ``self.last_done`` fires when they are)."""
         depth_m, _ = self.depth(frames_u8)
+        if self.side is not None:
+            main = torch.cuda.current_stream()
+            self.side.wait_stream(main)  # the depth maps (and the uploaded frames) are complete
+            with torch.cuda.stream(self.side):
+                self._integrate(frames_u8, depth_m, poses_c2w, obs_weight)
+                self.last_done = torch.cuda.Event()
+                self.last_done.record(self.side)
+            for t in (frames_u8, depth_m):  # the caching allocator must not hand these to the main stream while the sweeps read them
+                t.record_stream(self.side)
+            return depth_m
+        self._integrate(frames_u8, depth_m, poses_c2w, obs_weight)
+        self.last_done = None
+        return depth_m
+
+    def _integrate(self, frames_u8, depth_m, poses_c2w, obs_weight):
         if self.accum is None:
             self.volume.integrate_batch(frames_u8, depth_m, self.K, poses_c2w, obs_weight=obs_weight)
         else:
             for i in range(frames_u8.shape[0]):
                 self.volume.accum_integrate(self.accum, frames_u8[i], depth_m[i], self.K, poses_c2w[i], obs_weight=obs_weight)
-        return depth_m

@@ -166,6 +166,17 @@ def fuse_sharded(volume, stream_or_accum=None):
     ``[tsdf * w, w, r * w, g * w, b * w]`` straight into the piece-major buffer.  Otherwise: the accumulators of a
     ``DepthFusionStream(accumulate=True)`` or a raw accumulator tensor filled with ``accum_integrate`` (sums of the raw
     observations, 40 B / voxel / frame)."""
+    side = getattr(volume._ctx, "_side_stream", None)  # a volume of an overlapping DepthFusionStream lives on its own stream:
+    if side is not None:                                # the collectives and the buffers go there too, in order with its kernels
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            _fuse_sharded(volume, stream_or_accum)
+        torch.cuda.current_stream().wait_stream(side)
+        return volume
+    return _fuse_sharded(volume, stream_or_accum)
+
+
+def _fuse_sharded(volume, stream_or_accum):
     n = volume.num_voxels
     part = VoxelPartition(n)
     accum = getattr(stream_or_accum, "accum", stream_or_accum)

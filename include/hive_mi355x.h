@@ -63,8 +63,13 @@ int hive_abi_version(void);
  * expression returns for PyTorch's default stream -- and HIVE_STREAM_OWN makes the context create a
  * non-blocking stream of its own. */
 #define HIVE_STREAM_OWN ((void *)(intptr_t)-1)
+/* ... and HIVE_STREAM_OWN_LOW one of the LOWEST dispatch priority (hipStreamCreateWithPriority): for work that should fill what the
+ * other streams leave idle -- the TSDF sweeps of a batch under the next batch's network (hive_amd.depth.DepthFusionStream(overlap=True)). */
+#define HIVE_STREAM_OWN_LOW ((void *)(intptr_t)-2)
 int hive_ctx_create(int device_id, void *stream, hive_ctx **out);
 int hive_ctx_destroy(hive_ctx *ctx);
+/* The hipStream_t the context issues on (e.g. to wrap a context-owned stream in torch.cuda.ExternalStream). */
+int hive_ctx_get_stream(hive_ctx *ctx, void **stream);
 int hive_ctx_synchronize(hive_ctx *ctx);
 const char *hive_last_error(hive_ctx *ctx);
 /* Re-binds the context to another hipStream_t (NULL = the default stream).  The new stream is ordered behind

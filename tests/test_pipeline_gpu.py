@@ -125,6 +125,36 @@ def test_depth_fusion_stream_equals_manual_steps(gpu_ctx, oracle_lib):
     assert np.array_equal(tsdf, ora._tsdf) and np.array_equal(color, ora._color) and np.array_equal(weight, ora._weight)
 
 
+def test_overlapped_stream_equals_single_stream(gpu_ctx):
+    """DepthFusionStream(overlap=True): the TSDF sweeps of batch i run on a second (lowest-priority) HIP stream under the network of
+    batch i + 1.  Same frames, same order -> the volume is bit-identical to the single-stream run; frame and depth buffers are freed by
+    the caller right after `step` (the caching allocator must not recycle them under the sweeps), six batches back to back."""
+    import torch
+    from hive_amd import depth as depth_mod, fusion, synthetic
+    seq = synthetic.make_sequence(num_frames=24, height=96, width=128, yaw_step_deg=3.0)
+    model = depth_mod.build_model(None, dtype=torch.float16, init_seed=5)
+    vols = []
+    for overlap in (False, True):
+        ctx = depth_mod.DepthFusionStream.side_stream_context(0) if overlap else gpu_ctx
+        vol = fusion.TSDFVolume(synthetic.room_bounds(), 0.04, ctx=ctx)
+        stream = depth_mod.DepthFusionStream(model, vol, seq["K"], overlap=overlap)
+        for b in range(6):
+            frames = torch.from_numpy(seq["color"][4 * b:4 * b + 4]).cuda()
+            depth = stream.step(frames, seq["poses"][4 * b:4 * b + 4])
+            assert (stream.last_done is not None) == overlap
+            del frames, depth  # freed while (overlap) the sweeps may still be reading them
+            torch.empty(1 << 20, device="cuda").fill_(1.0)  # main-stream allocations in between
+        stream.join()
+        assert vol.last_batch_groups() == [4]
+        vols.append(vol.device_tensors())
+    torch.cuda.synchronize()
+    assert float(vols[0][1].max()) >= 8.0, "consecutive frames must overlap in the volume"
+    for a, b in zip(*vols):
+        assert torch.equal(a, b)
+    with pytest.raises(ValueError):
+        depth_mod.DepthFusionStream(model, fusion.TSDFVolume(synthetic.room_bounds(), 0.16, ctx=gpu_ctx), seq["K"], overlap=True)
+
+
 def test_accumulate_stream_then_fuse_single_rank(gpu_ctx, oracle_lib):
     import torch
     from hive_amd import depth as depth_mod, distributed as hdist, fusion, synthetic
