@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-3 profile set (GPU box: gpurun -- bash tools/profile_r03.sh [parts]); parts = any of: trace pmc valu small mfma (default: all but mfma)
-#   trace: rocprofv3 --kernel-trace --stats of the default bench command                        -> gpurun_out/prof_r03/trace
+#   trace: rocprofv3 --kernel-trace --stats of the default bench command, and of the same with --no-overlap  -> gpurun_out/prof_r03/trace{,_no_overlap}
 #   pmc  : FETCH_SIZE / WRITE_SIZE of the integrate kernels, separate passes, bench scene (DPT depth) and room scene (analytic depth,
 #          consecutive frames: tools/probe_integrate.py --yaw-step 2.4)                          -> gpurun_out/prof_r03/pmc_{fetch,write}_{bench,room}
 #   valu : SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES / SQ_WAVE_CYCLES / SQ_WAVES / GRBM_GUI_ACTIVE of the same          -> .../pmc_valu_*
@@ -10,13 +10,17 @@ PARTS=${*:-trace pmc valu small}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_r03
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $GRAFT_REPO_ROOT/bench.py --timed-only --steps 3 --warmup 1"
+BENCH="python3 $GRAFT_REPO_ROOT/bench.py --timed-only --no-overlap --steps 3 --warmup 1"  # counters of the sweep ALONE (the timed job overlaps it with the network)
 ROOM="python3 $GRAFT_REPO_ROOT/tools/probe_integrate.py --reps 1 --frames 32 --yaw-step 2.4 --no-mesh"
 has() { [[ " $PARTS " == *" $1 "* ]]; }
 if has trace; then
   rm -rf $OUT/trace
   timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline > $OUT/trace.log 2>&1 || echo "trace failed"
   find $OUT/trace -name "*kernel_trace.csv" -delete
+  # the same command with the sweeps on the network's stream: every kernel's duration is its own (what roofline.avg_launch_us is compared with)
+  rm -rf $OUT/trace_no_overlap
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_no_overlap -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-overlap > $OUT/trace_no_overlap.log 2>&1 || echo "trace (no overlap) failed"
+  find $OUT/trace_no_overlap -name "*kernel_trace.csv" -delete
 fi
 pmc() {  # name, counters...
   n=$1; shift

@@ -49,9 +49,18 @@ def counters(sub):
 
 
 stats = newest("trace", "*kernel_stats.csv")
-dur_us = {}
 if stats:
     shutil.copy(stats, os.path.join(dst, "r03_kernel_stats.csv"))
+for log, name in (("trace.log", "r03_bench_line.json"), ("trace_no_overlap.log", "r03_bench_line_no_overlap.json")):
+    lp = os.path.join(src, log)
+    if os.path.exists(lp):
+        lines = [l for l in open(lp) if l.startswith('{"metric"')]
+        if lines:
+            open(os.path.join(dst, name), "w").write(lines[-1])
+stats = newest("trace_no_overlap", "*kernel_stats.csv")  # every kernel alone: the durations roofline.avg_launch_us is compared with
+dur_us = {}
+if stats:
+    shutil.copy(stats, os.path.join(dst, "r03_kernel_stats_no_overlap.csv"))
     for r in csv.DictReader(open(stats)):
         kind = timed_kernel(r["Name"])
         if kind:
@@ -72,7 +81,10 @@ for scene in ("bench", "room"):
     if kind in valu:
         v = {c: m for c, (m, _) in valu[kind].items()}
         v["launches"] = valu[kind]["SQ_INSTS_VALU"][1]
-        v["clock_ghz"] = 2.4
+        v["clock_ghz"] = 2.4  # nominal; replaced below by the measured shader clock where the trace gives the launch duration
+        if kind in dur_us and v.get("GRBM_GUI_ACTIVE"):
+            v["clock_ghz_nominal"] = 2.4
+            v["clock_ghz"] = round(min(2.4, v["GRBM_GUI_ACTIVE"] / 8.0 / (dur_us[kind] * 1e3)), 3)  # GRBM_GUI_ACTIVE sums the 8 XCDs
         if "SQ_ACTIVE_INST_VALU" in v and "GRBM_GUI_ACTIVE" in v and v["GRBM_GUI_ACTIVE"] > 0:
             # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs
             v["simd_busy_valu"] = v["SQ_ACTIVE_INST_VALU"] * 4.0 / (v["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
