@@ -302,13 +302,7 @@ __device__ __forceinline__ void update_voxels(V &t, V &w, V &c, V dist, const un
     const V vow = v_splat(ow, w);
     const V w_new = w_old + vow;
     const V wr = refined_rcp(w_new);
-    // free space in front of the surface that was free space before (tsdf 1, dist 1): (1 w_old + ow 1) / w_new = w_new / w_new = 1
-    // exactly -- most sweeps of a carved scene.  The division is skipped when that holds for every updated voxel of the WAVE.
-    bool still_one = true;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) still_one = still_one && (!ok[i] || (v_get(t, i) == 1.0f && v_get(dist, i) == 1.0f && v_get(w_new, i) > 0.0f));
-    V t_new = t;
-    if (!__all(still_one)) t_new = div_exact(t * w_old + vow * dist, w_new, wr);
+    const V t_new = div_exact(t * w_old + vow * dist, w_new, wr);
     V or_, og, ob, nr, ng, nb;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -336,33 +330,27 @@ __device__ __forceinline__ void update_voxels(V &t, V &w, V &c, V dist, const un
         }
 }
 
-// The depth tests of the volume role for a lane's 4 voxels (2 packed pairs) and the truncated distance.  `diff >= trunc` (free space
-// in front of the surface) gives min(1, diff / trunc) = 1 without the division; it is skipped when that holds for every voxel of the
-// WAVE that passes the tests -- most trips of a sweep: the truncation band is 5 voxels of a row.
+// The depth tests of the volume role for a lane's 4 voxels (2 packed pairs) and the truncated distance.
+// (Round 3, measured and taken out: skipping the distance division where `diff >= trunc` holds for every voxel of the WAVE -- min(1, .) = 1
+// exactly -- and the tsdf division where tsdf and dist are both 1.  A wave spans four 64-voxel segments of different rows; 13 % of the
+// waves lie entirely outside the 5-voxel truncation band, so the tests cost more instructions than the skips save: SQ_INSTS_VALU +4 %.)
 template <typename V>
 __device__ __forceinline__ bool depth_tests(const FrameParams &p, float trunc_rcp, const float (&depth_v)[4], const V (&cam_z)[2], bool live, int nrow,
                                             V (&dist)[2], bool (&ok)[4]) {
-    V diff[2];
-    bool any = false, band = false;
+    bool any = false;
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
         V depth;
 #pragma unroll
         for (int i = 0; i < 2; ++i) v_set(depth, i, depth_v[2 * g + i]);
-        diff[g] = depth - cam_z[g];
+        const V diff = depth - cam_z[g];
+        dist[g] = v_min(v_splat(1.0f, diff), div_exact(diff, v_splat(p.trunc, diff), v_splat(trunc_rcp, diff)));
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int j = 2 * g + i;
-            ok[j] = live && j < nrow && (v_get(depth, i) != 0.0f) && !(v_get(diff[g], i) < -p.trunc);
+            ok[j] = live && j < nrow && (v_get(depth, i) != 0.0f) && !(v_get(diff, i) < -p.trunc);
             any = any || ok[j];
-            band = band || (ok[j] && !(v_get(diff[g], i) >= p.trunc));
         }
-    }
-    if (__any(band)) {
-#pragma unroll
-        for (int g = 0; g < 2; ++g) dist[g] = v_min(v_splat(1.0f, diff[g]), div_exact(diff[g], v_splat(p.trunc, diff[g]), v_splat(trunc_rcp, diff[g])));
-    } else {
-        dist[0] = dist[1] = v_splat(1.0f, diff[0]);
     }
     return any;
 }

@@ -41,6 +41,33 @@ def test_restatement_matches_independent_implementation(fixture):
     assert float(inv.max()) > 1000 and float((inv == 0).float().mean()) < 0.05, "the seeded head must give a usable range"
 
 
+def test_restatement_matches_independent_implementation_at_the_benchmark_size():
+    """The same at 480 x 640 (30 x 40 token grid, 1,201 tokens -- the frame size of every BASELINE config but one): the float32
+    formulation the GPU tests use as their yardstick at that size is itself pinned to the independent implementation.  The fixture
+    keeps sub-sampled views (every 4th pixel, every 16th token); the input is regenerated from its seed and checked by checksum."""
+    import hashlib
+    from dpt_weights import seeded_input
+    from hive_amd.dpt.models import DPTDepthModel
+    gold = np.load(os.path.join(GOLDEN, "dpt_hybrid_hf_480x640.npz"))
+    b, h, w = (int(v) for v in gold["shape"])
+    assert (h, w) == (480, 640)
+    x = seeded_input(b, h, w, seed=int(gold["x_seed"])).half().float()
+    assert hashlib.sha256(x.numpy().astype(np.float16).tobytes()).hexdigest() == str(gold["x_sha256"]), "seeded input drifted: rerun tests/golden/make_dpt_golden.py"
+    model = DPTDepthModel(path=None, scale=1.0, shift=0.0, invert=False, engine="torch", backbone=str(gold["backbone"])).eval()
+    seeded_init(model, seed=int(gold["seed"]))
+    assert state_checksum(model) == str(gold["state_sha256"])
+    stages = {}
+    with torch.no_grad():
+        inv = model(x, stages=stages)
+    assert stages["tokens"].shape == (1, 1201, 768)
+    assert _rel(inv[:, ::4, ::4], gold["inv_depth_s4"]) < 1e-4
+    assert _rel(stages["tap_3"].mean(dim=2), gold["tap_3_mean"]) < 1e-4
+    assert _rel(stages["tap_4"][:, ::16], gold["tap_4_s16"].astype(np.float32)) < 1e-3
+    assert _rel(stages["path_4"], gold["path_4"].astype(np.float32)) < 1e-3
+    assert _rel(stages["path_1"].mean(dim=1)[:, ::2, ::2], gold["path_1_mean_s2"]) < 1e-4
+    assert _rel(stages["head_in"].mean(dim=1)[:, ::2, ::2], gold["head_in_mean_s2"]) < 1e-4
+
+
 def test_resize_rule_of_the_reference_call_site():
     """Resize(640, 480, keep_aspect_ratio, multiple of 32, "minimal") as constructed at
     /root/reference/hive/dataset_adaptors.py:1376-1385: network sizes for the frame sizes of the BASELINE configs."""

@@ -190,6 +190,29 @@ def test_hip_engine_against_independent_implementation(gpu_ctx, fixture):
     assert _rel(inv, gold["inv_depth"]) < 3e-2
 
 
+def test_hip_engine_against_independent_implementation_at_the_benchmark_size(gpu_ctx, half):
+    """480 x 640 (1,201 tokens), both element types, against the golden activations of the INDEPENDENT implementation
+    (tests/golden/dpt_hybrid_hf_480x640.npz: HuggingFace's DPT with the same seeded weights; sub-sampled views) -- not against this
+    build's own float32 formulation.  Bounds: the per-stage ones of `test_per_stage_480x640_batch4` (float16: divided by eight)."""
+    import hashlib
+    gold = np.load(os.path.join(GOLDEN, "dpt_hybrid_hf_480x640.npz"))
+    b, h, w = (int(v) for v in gold["shape"])
+    x = seeded_input(b, h, w, seed=int(gold["x_seed"])).half().float()
+    assert hashlib.sha256(x.numpy().astype(np.float16).tobytes()).hexdigest() == str(gold["x_sha256"])
+    ref, hip = _pair(backbone=str(gold["backbone"]), seed=int(gold["seed"]), scale=1.0, shift=0.0, invert=False, dtype=half)
+    assert state_checksum(ref) == str(gold["state_sha256"])
+    tight = HALF_TIGHT[half]
+    stages = {}
+    with torch.no_grad():
+        inv = hip(_net_input(x, half), stages=stages)
+    rep = {"tap_3_mean": _rel(stages["tap_3"].float().mean(dim=2), gold["tap_3_mean"]), "tap_4": _rel(stages["tap_4"][:, ::16], gold["tap_4_s16"].astype(np.float32)),
+           "path_4": _rel(stages["path_4"], gold["path_4"].astype(np.float32)), "path_1_mean": _rel(stages["path_1"].float().mean(dim=1)[:, ::2, ::2], gold["path_1_mean_s2"]),
+           "head_in_mean": _rel(stages["head_in"].float().mean(dim=1)[:, ::2, ::2], gold["head_in_mean_s2"]), "inv_depth": _rel(inv[:, ::4, ::4], gold["inv_depth_s4"])}
+    print(f"HIP {half} vs the independent implementation at 480 x 640:", {k: round(v, 6) for k, v in rep.items()})
+    assert rep["tap_4"] <= tight * 2.5e-2 and rep["path_4"] <= tight * 2.5e-2 and rep["inv_depth"] <= tight * 3e-2, rep
+    assert max(rep["tap_3_mean"], rep["path_1_mean"], rep["head_in_mean"]) <= tight * 2.5e-2, rep
+
+
 def test_dpt_large_1080p_network_size(gpu_ctx):
     """BASELINE config 4's network: DPT-Large on a 1920 x 1080 frame = 480 x 864 network input by the reference's resize
     rule (30 x 54 + 1 = 1,621 tokens, d = 1024, 16 heads, 24 blocks through the same HIP engine)."""
