@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <map>
 #include <string>
+#include <vector>
 
 typedef unsigned short half_t;  // an element of either 16-bit type (HIVE_BF16 / HIVE_F16): the host side only sizes and offsets buffers
 
@@ -75,11 +76,63 @@ struct hive_dpt {
         auto it = w.find(name);
         return it == w.end() ? nullptr : it->second;
     }
-    half_t *alloc(size_t elems) {  // bump allocation in the activation arena (sized by a dry run before the first launch)
+    // Activation arena with LIVENESS: run_forward releases a map behind its last consumer (everything runs in stream order, so a buffer
+    // may be handed out again as soon as the kernel that last reads it has been LAUNCHED); alloc takes the first free block that fits,
+    // else grows the high-water mark.  A dry run of the same alloc / release sequence sizes the arena (offsets are deterministic).
+    // At 96 frames of 480 x 640 the network's maps total 38 GB; live at any one time: ~10 GB.
+    struct Block {
+        size_t off, bytes;
+    };
+    std::vector<Block> free_blocks;          // sorted by offset, coalesced
+    std::map<const void *, Block> live;      // what alloc handed out and release has not taken back
+    char *base() const { return arena ? (char *)arena : (char *)(uintptr_t)4096; }  // dry run: fake addresses, never dereferenced
+    void reset_arena() {
+        free_blocks.clear();
+        live.clear();
+        arena_used = 0;
+    }
+    half_t *alloc(size_t elems) {
         const size_t bytes = (elems * sizeof(half_t) + 255) & ~(size_t)255;
-        half_t *p = arena ? (half_t *)((char *)arena + arena_used) : nullptr;
-        arena_used += bytes;
+        size_t off = arena_used;
+        bool found = false;
+        for (size_t i = 0; i < free_blocks.size(); ++i)
+            if (free_blocks[i].bytes >= bytes) {
+                off = free_blocks[i].off;
+                if (free_blocks[i].bytes == bytes)
+                    free_blocks.erase(free_blocks.begin() + i);
+                else
+                    free_blocks[i] = Block{off + bytes, free_blocks[i].bytes - bytes};
+                found = true;
+                break;
+            }
+        if (!found) {
+            if (!free_blocks.empty() && free_blocks.back().off + free_blocks.back().bytes == arena_used) {  // grow the free tail
+                off = free_blocks.back().off;
+                free_blocks.pop_back();
+            }
+            arena_used = off + bytes;
+        }
+        half_t *p = (half_t *)(base() + off);
+        live[p] = Block{off, bytes};
         return p;
+    }
+    void release(const void *p) {
+        if (!p) return;
+        auto it = live.find(p);
+        if (it == live.end()) return;  // not ours (a hook released twice, an external pointer): ignore
+        Block b = it->second;
+        live.erase(it);
+        size_t i = 0;
+        while (i < free_blocks.size() && free_blocks[i].off < b.off) ++i;
+        free_blocks.insert(free_blocks.begin() + i, b);
+        if (i + 1 < free_blocks.size() && free_blocks[i].off + free_blocks[i].bytes == free_blocks[i + 1].off) {
+            free_blocks[i].bytes += free_blocks[i + 1].bytes;
+            free_blocks.erase(free_blocks.begin() + i + 1);
+        }
+        if (i > 0 && free_blocks[i - 1].off + free_blocks[i - 1].bytes == free_blocks[i].off) {
+            free_blocks[i - 1].bytes += free_blocks[i].bytes;
+            free_blocks.erase(free_blocks.begin() + i);
+        }
     }
 };
 
@@ -110,6 +163,12 @@ int run_forward(hive_dpt *d, bool dry, const uint8_t *d_rgb, int B, int H, int W
         return HIVE_OK;
     };
     auto same_out = [](int i, int s) { return (i + s - 1) / s; };
+    auto drop = [&](Map &m) {  // the map (and the GroupNorm partial sums riding on it) has no consumer left to launch
+        d->release(m.p);
+        d->release(m.gn);
+        m.p = nullptr;
+        m.gn = nullptr;
+    };
     auto conv = [&](const Map &x, const std::string &wname, const char *bias_name, int cout, int k, int stride, bool same_pad, int relu, const half_t *res1,
                     const half_t *res2, bool want_relu_copy, Map *out, Map *out_relu, bool gn_stats = false) -> int {
         int pt, pl, oh, ow;
@@ -146,7 +205,12 @@ int run_forward(hive_dpt *d, bool dry, const uint8_t *d_rgb, int B, int H, int W
         *out = Map{d->alloc((size_t)B * oh * ow * cout), oh, ow, cout};
         const bool eligible = cout % 256 == 0 && (cout / 32) % 8 == 0 && (long long)oh * ow >= 256;  // hive_nhwc_conv_gn_apply's conditions
         Map t{eligible ? nullptr : d->alloc((size_t)B * oh * ow * cout), oh, ow, cout};               // the pair's intermediate: small maps only
-        if (dry) return HIVE_OK;
+        auto done = [&](int rc) {  // scratch and the pair's intermediate are dead once the launches are queued
+            d->release(scratch);
+            d->release(t.p);
+            return rc;
+        };
+        if (dry) return done(HIVE_OK);
         const void *wp, *g, *b;
         DPT_TRY(need(wname, &wp));
         DPT_TRY(need(norm_prefix + ".weight", &g));
@@ -154,11 +218,11 @@ int run_forward(hive_dpt *d, bool dry, const uint8_t *d_rgb, int B, int H, int W
         int fused = 0;
         DPT_TRY(hive_nhwc_conv_gn_apply(ctx, x.p, dt, B, x.H, x.W, x.C, cout, 1, stride, 0, 0, oh, ow, wp, 32, g, b, d->cfg.gn_eps, residual, relu, out->p,
                                         scratch, scratch_floats, &fused));
-        if (fused) return HIVE_OK;
+        if (fused) return done(HIVE_OK);
         if (eligible) return hive_fail(ctx, HIVE_ERR_INVALID, "hive_dpt: conv + GroupNorm of '%s' was not fused", wname.c_str());
         DPT_TRY(hive_nhwc_conv_gn(ctx, x.p, dt, B, x.H, x.W, x.C, cout, 1, stride, 0, 0, oh, ow, wp, nullptr, 0, nullptr, nullptr, t.p, nullptr, scratch,
                                   scratch_floats, &t.gn_tm));
-        return hive_nhwc_group_norm_stats(ctx, t.p, dt, B, oh * ow, cout, 32, g, b, d->cfg.gn_eps, residual, relu, out->p, scratch, t.gn_tm);
+        return done(hive_nhwc_group_norm_stats(ctx, t.p, dt, B, oh * ow, cout, 32, g, b, d->cfg.gn_eps, residual, relu, out->p, scratch, t.gn_tm));
     };
     auto group_norm = [&](const Map &x, const std::string &prefix, const half_t *residual, int relu, Map *out) -> int {
         *out = Map{d->alloc((size_t)B * x.H * x.W * x.C), x.H, x.W, x.C};
@@ -180,25 +244,34 @@ int run_forward(hive_dpt *d, bool dry, const uint8_t *d_rgb, int B, int H, int W
             DPT_TRY(need(bb + "stem.conv.weight", &sw));
             DPT_TRY(hive_resnet_stem_conv(ctx, xin, dt, B, H, W, sw, s0.p));
         }
+        d->release(xin);
         Map s1, feat;
         DPT_TRY(group_norm(s0, bb + "stem.norm", nullptr, 1, &s1));
+        drop(s0);
         feat = Map{d->alloc((size_t)B * same_out(s1.H, 2) * same_out(s1.W, 2) * 64), same_out(s1.H, 2), same_out(s1.W, 2), 64};
         if (!dry) DPT_TRY(hive_nhwc_maxpool3x3s2(ctx, s1.p, dt, B, s1.H, s1.W, 64, feat.p));
+        drop(s1);
 
         // ---- ResNetV2 stages: non pre-activation bottlenecks, GroupNorm behind every convolution ------------------------------
         const int depths[3] = {3, 4, 9}, chans[3] = {256, 512, 1024};
-        Map hook[2];
+        Map hook[2] = {Map{nullptr, 0, 0, 0}, Map{nullptr, 0, 0, 0}};
         for (int s = 0; s < 3; ++s) {
             for (int blk = 0; blk < depths[s]; ++blk) {
                 const std::string pre = bb + "stages." + std::to_string(s) + ".blocks." + std::to_string(blk) + ".";
                 const int cout = chans[s], mid = cout / 4, stride = (blk == 0 && s > 0) ? 2 : 1;
-                Map shortcut = feat, t, u;
-                if (blk == 0) DPT_TRY(conv_norm(feat, pre + "downsample.conv.weight", pre + "downsample.norm", cout, stride, nullptr, 0, &shortcut));
-                DPT_TRY(conv(feat, pre + "conv1.weight", nullptr, mid, 1, 1, true, 0, nullptr, nullptr, false, &t, nullptr, true));
+                Map in = feat, shortcut = feat, t, u, t2, u2;
+                if (blk == 0) DPT_TRY(conv_norm(in, pre + "downsample.conv.weight", pre + "downsample.norm", cout, stride, nullptr, 0, &shortcut));
+                DPT_TRY(conv(in, pre + "conv1.weight", nullptr, mid, 1, 1, true, 0, nullptr, nullptr, false, &t, nullptr, true));
                 DPT_TRY(group_norm(t, pre + "norm1", nullptr, 1, &u));
-                DPT_TRY(conv(u, pre + "conv2.weight", nullptr, mid, 3, stride, true, 0, nullptr, nullptr, false, &t, nullptr, true));
-                DPT_TRY(group_norm(t, pre + "norm2", nullptr, 1, &u));
-                DPT_TRY(conv_norm(u, pre + "conv3.weight", pre + "norm3", cout, 1, shortcut.p, 1, &feat));  // relu(norm3(conv3(.)) + shortcut)
+                drop(t);
+                DPT_TRY(conv(u, pre + "conv2.weight", nullptr, mid, 3, stride, true, 0, nullptr, nullptr, false, &t2, nullptr, true));
+                drop(u);
+                DPT_TRY(group_norm(t2, pre + "norm2", nullptr, 1, &u2));
+                drop(t2);
+                DPT_TRY(conv_norm(u2, pre + "conv3.weight", pre + "norm3", cout, 1, shortcut.p, 1, &feat));  // relu(norm3(conv3(.)) + shortcut)
+                drop(u2);
+                if (blk == 0) drop(shortcut);  // (otherwise the shortcut IS the block's input)
+                if (in.p != hook[0].p && in.p != hook[1].p) drop(in);  // the stage outputs stay: layer_1, layer_2
             }
             if (s < 2) hook[s] = feat;
         }
@@ -234,10 +307,19 @@ int run_forward(hive_dpt *d, bool dry, const uint8_t *d_rgb, int B, int H, int W
                 DPT_TRY(hive_vit_linear(ctx, cat, dt, rw, (const float *)rb, nullptr, maps[r]->p, B * n_patch, D, 2 * D, 1 /* GELU */));
             }
         }
+        drop(feat);  // the last stage's output fed the patch projection only
+        drop(pe);
+        d->release(tokens);
+        d->release(tap3);
+        d->release(tap4);
+        d->release(cat);
         Map t4;
         DPT_TRY(conv(map3, "pretrained.act_postprocess3.3.weight", "pretrained.act_postprocess3.3.bias", D, 1, 1, false, 0, nullptr, nullptr, false, &layer_3, nullptr));
+        drop(map3);
         DPT_TRY(conv(map4, "pretrained.act_postprocess4.3.weight", "pretrained.act_postprocess4.3.bias", D, 1, 1, false, 0, nullptr, nullptr, false, &t4, nullptr));
+        drop(map4);
         DPT_TRY(conv(t4, "pretrained.act_postprocess4.4.weight", "pretrained.act_postprocess4.4.bias", D, 3, 2, false, 0, nullptr, nullptr, false, &layer_4, nullptr));
+        drop(t4);
         return HIVE_OK;
     };
     // ---- DPT-Large backbone (timm vit_large_patch16_384 as isl-org/DPT hooks it: blocks 5 / 11 / 17 / 23) -------------------------
@@ -277,26 +359,45 @@ int run_forward(hive_dpt *d, bool dry, const uint8_t *d_rgb, int B, int H, int W
                 DPT_TRY(hive_vit_linear(ctx, cat, dt, rw, (const float *)rb, nullptr, maps[r].p, B * n_patch, D, 2 * D, 1 /* GELU */));
             }
         }
+        d->release(xin);
+        d->release(cols);
+        d->release(pe);
+        d->release(tokens);
+        d->release(cat);
+        for (int r = 0; r < 4; ++r) d->release(tapb[r]);
         // ConvTranspose2d(C, C, s, s) = 1 x 1 convolution to s s C channels ((dy, dx, co) rows of the re-laid-out weight) + scatter + bias
         auto conv_transpose = [&](const Map &x, const std::string &prefix, int s_, Map *out) -> int {
             Map tmp{d->alloc((size_t)B * x.H * x.W * s_ * s_ * x.C), x.H, x.W, s_ * s_ * x.C};
             *out = Map{d->alloc((size_t)B * x.H * x.W * s_ * s_ * x.C), s_ * x.H, s_ * x.W, x.C};
-            if (dry) return HIVE_OK;
+            if (dry) {
+                drop(tmp);
+                return HIVE_OK;
+            }
             const void *wr, *bias;
             DPT_TRY(need(prefix + ".weight.rows", &wr));
             DPT_TRY(need(prefix + ".bias", &bias));
             DPT_TRY(hive_nhwc_conv(ctx, x.p, dt, B, x.H, x.W, x.C, s_ * s_ * x.C, 1, 1, 0, 0, x.H, x.W, wr, nullptr, 0, nullptr, nullptr, tmp.p, nullptr));
-            return hive_nhwc_pixel_shuffle_bias(ctx, tmp.p, bias, dt, B, x.H, x.W, x.C, s_, out->p);
+            const int rc = hive_nhwc_pixel_shuffle_bias(ctx, tmp.p, bias, dt, B, x.H, x.W, x.C, s_, out->p);
+            drop(tmp);
+            return rc;
         };
         const std::string pp = "pretrained.act_postprocess";
         Map t;
         DPT_TRY(conv(maps[0], pp + "1.3.weight", (pp + "1.3.bias").c_str(), 256, 1, 1, false, 0, nullptr, nullptr, false, &t, nullptr));
+        drop(maps[0]);
         DPT_TRY(conv_transpose(t, pp + "1.4", 4, &layer_1));
+        drop(t);
         DPT_TRY(conv(maps[1], pp + "2.3.weight", (pp + "2.3.bias").c_str(), 512, 1, 1, false, 0, nullptr, nullptr, false, &t, nullptr));
+        drop(maps[1]);
         DPT_TRY(conv_transpose(t, pp + "2.4", 2, &layer_2));
+        drop(t);
         DPT_TRY(conv(maps[2], pp + "3.3.weight", (pp + "3.3.bias").c_str(), 1024, 1, 1, false, 0, nullptr, nullptr, false, &layer_3, nullptr));
+        drop(maps[2]);
         DPT_TRY(conv(maps[3], pp + "4.3.weight", (pp + "4.3.bias").c_str(), 1024, 1, 1, false, 0, nullptr, nullptr, false, &t, nullptr));
-        return conv(t, pp + "4.4.weight", (pp + "4.4.bias").c_str(), 1024, 3, 2, false, 0, nullptr, nullptr, false, &layer_4, nullptr);
+        drop(maps[3]);
+        DPT_TRY(conv(t, pp + "4.4.weight", (pp + "4.4.bias").c_str(), 1024, 3, 2, false, 0, nullptr, nullptr, false, &layer_4, nullptr));
+        drop(t);
+        return HIVE_OK;
     };
 
     DPT_TRY(d->cfg.backbone == 0 ? hybrid_backbone() : large_backbone());
@@ -309,30 +410,44 @@ int run_forward(hive_dpt *d, bool dry, const uint8_t *d_rgb, int B, int H, int W
             DPT_TRY(conv(lrn_relu, pre + "resConfUnit1.conv1.weight", (pre + "resConfUnit1.conv1.bias").c_str(), 256, 3, 1, false, 1, nullptr, nullptr, false, &t,
                          nullptr));
             DPT_TRY(conv(t, pre + "resConfUnit1.conv2.weight", (pre + "resConfUnit1.conv2.bias").c_str(), 256, 3, 1, false, 0, lrn.p, path->p, true, &o, &o_relu));
+            drop(t);
         }
-        Map u, low;
-        DPT_TRY(conv(o_relu, pre + "resConfUnit2.conv1.weight", (pre + "resConfUnit2.conv1.bias").c_str(), 256, 3, 1, false, 1, nullptr, nullptr, false, &t, nullptr));
-        DPT_TRY(conv(t, pre + "resConfUnit2.conv2.weight", (pre + "resConfUnit2.conv2.bias").c_str(), 256, 3, 1, false, 0, o.p, nullptr, false, &u, nullptr));
+        Map u, low, t2;
+        DPT_TRY(conv(o_relu, pre + "resConfUnit2.conv1.weight", (pre + "resConfUnit2.conv1.bias").c_str(), 256, 3, 1, false, 1, nullptr, nullptr, false, &t2, nullptr));
+        DPT_TRY(conv(t2, pre + "resConfUnit2.conv2.weight", (pre + "resConfUnit2.conv2.bias").c_str(), 256, 3, 1, false, 0, o.p, nullptr, false, &u, nullptr));
+        drop(t2);
+        if (o.p != lrn.p) drop(o);  // (with a path, o / o_relu are resConfUnit1's outputs; without, they ARE lrn / lrn_relu, dropped by the caller)
+        if (o_relu.p != lrn_relu.p) drop(o_relu);
         // the 1x1 out_conv commutes with the bilinear interpolation: it runs on a quarter of the pixels, its bias is added on load
         DPT_TRY(conv(u, pre + "out_conv.weight", nullptr, 256, 1, 1, false, 0, nullptr, nullptr, false, &low, nullptr));
+        drop(u);
         *out = Map{d->alloc((size_t)B * 4 * low.H * low.W * 256), 2 * low.H, 2 * low.W, 256};
-        if (dry) return HIVE_OK;
-        const void *ob;
-        DPT_TRY(need(pre + "out_conv.bias", &ob));
-        return hive_nhwc_upsample2x(ctx, low.p, ob, dt, B, low.H, low.W, 256, out->p);
+        int rc = HIVE_OK;
+        if (!dry) {
+            const void *ob;
+            DPT_TRY(need(pre + "out_conv.bias", &ob));
+            rc = hive_nhwc_upsample2x(ctx, low.p, ob, dt, B, low.H, low.W, 256, out->p);
+        }
+        drop(low);
+        return rc;
     };
     const Map *layers[4] = {&layer_1, &layer_2, &layer_3, &layer_4};
     Map path{}, prev{};
     for (int n = 4; n >= 1; --n) {
         Map lrn, lrn_relu;
         DPT_TRY(conv(*layers[n - 1], "scratch.layer" + std::to_string(n) + "_rn.weight", nullptr, 256, 3, 1, false, 0, nullptr, nullptr, true, &lrn, &lrn_relu));
+        d->release(layers[n - 1]->p);  // layer_n fed its layer_rn convolution only
         DPT_TRY(refinenet(n, n == 4 ? nullptr : &prev, lrn, lrn_relu, &path));
+        drop(lrn);
+        drop(lrn_relu);
+        if (n != 4) drop(prev);
         prev = path;
     }
 
     // ---- depth head: conv 256 -> 128 (+ bias, in its epilogue), x2 upsample + conv 128 -> 32 + ReLU + 1x1 + ReLU + inversion
     Map lo;
     DPT_TRY(conv(path, "scratch.output_conv.0.weight", "scratch.output_conv.0.bias", 128, 3, 1, false, 0, nullptr, nullptr, false, &lo, nullptr));
+    drop(path);
     if (dry) return HIVE_OK;
     const void *w3;
     DPT_TRY(need("scratch.output_conv.2.weight", &w3));  // [ky][kx][32][128]
@@ -394,14 +509,20 @@ int hive_dpt_forward(hive_dpt *d, const uint8_t *d_rgb, int B, int H, int W, con
     // size the activation arena with a dry run of the same allocation sequence, then launch
     void *arena = d->arena;
     d->arena = nullptr;
-    d->arena_used = 0;
+    d->reset_arena();
     int rc = run_forward(d, true, d_rgb, B, H, W, d_pos_embed, d_depth, max_depth, d_out_mm, d_out_m);
     d->arena = arena;
     if (rc) return rc;
-    const size_t need = d->arena_used;
+    const size_t need = d->arena_used;  // the high-water mark of the dry run
     if ((rc = hive_reserve_device(ctx, &d->arena, &d->arena_bytes, need))) return rc;
-    d->arena_used = 0;
+    d->reset_arena();
     return run_forward(d, false, d_rgb, B, H, W, d_pos_embed, d_depth, max_depth, d_out_mm, d_out_m);
+}
+
+int hive_dpt_arena_bytes(hive_dpt *d, int64_t *bytes) {
+    if (!d || !bytes) return hive_fail(d ? d->ctx : nullptr, HIVE_ERR_INVALID, "hive_dpt_arena_bytes: NULL argument");
+    *bytes = (int64_t)d->arena_bytes;
+    return HIVE_OK;
 }
 
 int hive_dpt_destroy(hive_dpt *d) {

@@ -120,6 +120,12 @@ class NativeDPT:
                                                      float(max_depth or 0.0), _lib.ptr(mm), _lib.ptr(m)))
         return depth, mm, m
 
+    def arena_bytes(self):
+        """Bytes of the activation arena (high-water mark of the largest forward so far)."""
+        n = ctypes.c_int64(0)
+        self.ctx.check(self.ctx.lib.hive_dpt_arena_bytes(self.handle, ctypes.byref(n)))
+        return int(n.value)
+
     def close(self):
         if getattr(self, "handle", None) and _lib.alive():
             self.ctx.lib.hive_dpt_destroy(self.handle)

@@ -457,6 +457,9 @@ int hive_dpt_create(hive_ctx *ctx, const hive_dpt_config *config, const hive_dpt
  * all): d_depth f32 metres; d_out_mm = uint16(depth * 1000); d_out_m = mm / 1000 with > max_depth -> 0. */
 int hive_dpt_forward(hive_dpt *dpt, const uint8_t *d_rgb, int B, int H, int W, const void *d_pos_embed, float *d_depth, float max_depth,
                      uint16_t *d_out_mm, float *d_out_m);
+/* Bytes of the activation arena (grown to the largest forward seen: the high-water mark of its maps, which are released behind
+ * their last consumer -- ~10 GB for 96 frames of 480 x 640, where the maps total 38 GB). */
+int hive_dpt_arena_bytes(hive_dpt *dpt, int64_t *bytes);
 int hive_dpt_destroy(hive_dpt *dpt);
 
 #ifdef __cplusplus
