@@ -6,7 +6,7 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-The job: K * B frames of the seeded 150-frame synthetic sequence (wrapping), B = --batch (96).  A step = one batch of B
+The job: K * B frames of the seeded 150-frame synthetic sequence (wrapping), B = --batch (107: fills the GEMMs' tile rounds).  A step = one batch of B
 frames: uint8 frames start in PINNED HOST memory and are uploaded inside the timed region (double-buffered on a copy stream,
 SURVEY.md 8d) -> preprocess -> DPT-Hybrid (seeded random weights of the real architecture: depth maps of 1-7 m, so the TSDF scene
 has surfaces inside the volume; bf16 or --dtype fp16, HIP engine) -> f32 depth tail
@@ -40,7 +40,10 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=96, help="frames per step (final code: 64 -> 1074, 96 -> 1104, 128 -> 1102 frames/s on one box)")
+    ap.add_argument("--batch", type=int, default=107,
+                    help="frames per step.  107 frames x 1216 padded tokens = 508.25 row tiles of 256: the N = 768 / 1536 / 3072 GEMMs then have 1527 / 3054 / "
+                         "6108 tiles = 5.96 / 11.93 / 23.86 rounds of the 256 CUs (96 frames: 5.34 rounds, the sixth a third full).  Same box: 96 -> 1175, "
+                         "107 -> 1207, 125 -> 1194, 143 -> 1208 frames/s")
     ap.add_argument("--frames", type=int, default=150, help="length of the synthetic sequence")
     ap.add_argument("--voxel", type=float, default=0.01, help="0.01 -> 512^3 over the 5.12 m volume")
     ap.add_argument("--engine", default="hip", choices=["hip", "torch"], help="'torch' = PyTorch-op ViT blocks (comparison only)")

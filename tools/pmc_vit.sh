@@ -4,7 +4,7 @@
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmcvit_$1
 rm -rf $OUT && mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-P="python3 $GRAFT_REPO_ROOT/bench.py --timed-only --no-overlap --steps 2 --warmup 1 --batch ${2:-96}"
+P="python3 $GRAFT_REPO_ROOT/bench.py --timed-only --no-overlap --steps 2 --warmup 1 --batch ${2:-107}"
 $P > $OUT/warm.log 2>&1
 pass() { n=$1; shift; timeout -k 10 300 rocprofv3 --pmc "$@" --output-format csv -d $OUT/p$n -- $P > $OUT/p$n.log 2>&1 || echo "pass $n failed"; }
 pass A SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE SQ_WAVES

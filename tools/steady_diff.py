@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """profiles/<tag>_steady_step.csv: per-step kernel time of the bench in steady state = (stats of the 16-step
-run - stats of the 6-step run) / 10 (96 frames per step), from tools/steady_profile.sh."""
+run - stats of the 6-step run) / 10 (bench.py's default frames per step), from tools/steady_profile.sh."""
 import csv, glob, os, sys
 tag = sys.argv[1]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
