@@ -13,7 +13,7 @@ pass C SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INST_CYCLES_VM
 python3 - <<PY
 import csv, glob, collections, json, re
 # kernel families by name pattern (rocprofv3 prints some template instantiations demangled, some mangled: both forms)
-kernels = [(r"gemm256p_kernel(<[^,>]*, 0>|I[^L]*Li0E)", "gemm q|k (bias; 256 x 256 tiles)"), (r"gemm256p_kernel(<[^,>]*, 1>|I[^L]*Li1E)", "gemm fc1 + GELU, readout (256 x 256 tiles)"),
+kernels = [(r"gemm256p_kernel(<[^,>]*, 0>|I[^L]*Li0E)", "gemm q|k (bias; 256 x 256 tiles)"), (r"gemm256p_kernel(<[^,>]*, 1>|I[^L]*Li1E|<bool _Accum, int, E>)", "gemm fc1 + GELU, readout (256 x 256 tiles)"),  # (rocprofv3 garbles this one instantiation's demangled name)
            (r"gemm256p_kernel(<[^,>]*, 2>|I[^L]*Li2E)", "gemm proj / fc2 + residual (256 x 256 tiles)"), (r"gemm256p_kernel(<[^,>]*, 3>|I[^L]*Li3E)", "gemm v^T (256 x 256 tiles)"),
            (r"gemm_kernel", "gemm (128 x 128 tiles)"), (r"attention_kernel", "attention"), (r"head_conv_kernel", "fused depth head"),
            (r"conv_kernel(<[^,>]*, 256, 256, 0>|I[^L]*Li256ELi256ELi0E)", "conv -> 256-channel tiles (decoder RCUs, layer_rn)"),
