@@ -66,11 +66,11 @@ struct ConvParams {
 // per lane on whole 128-byte lines; a lane gets 8 consecutive output channels (always the same ones) of one pixel; everything in
 // f32, one rounding
 //
-// GN (the ResNetV2 convolutions, each followed by a GroupNorm): the statistics pass of that GroupNorm is folded in.  The lane adds
-// the outputs it stores (after the rounding: the values the GroupNorm will read) and their squares per channel, separately for the
-// two images a tile of TM <= Ho Wo rows can touch (rows below / from `boundary`); the 8 lanes that share its channels are added by
-// xor-shuffles, the waves of the tile through LDS in wave order -- a fixed order, run-to-run identical -- and the tile's row of
-// `gn_partial` is written.  hive_nhwc_group_norm_stats (dpt_ops.hip) finishes from there: no pass over the tensor for statistics.
+// GN == 1 (the ResNetV2 convolutions, each followed by a GroupNorm): the statistics pass of that GroupNorm is folded in -- the sums of the
+// stored (rounded) outputs and of their squares per channel, separately for the two images a tile of TM <= Ho Wo rows can touch (rows
+// below / from `boundary`), taken from the accumulators (gn_sums_from_acc below), added over the waves of the tile through LDS in wave
+// order -- a fixed order, run-to-run identical -- and written as the tile's row of `gn_partial`.  hive_nhwc_group_norm_stats (dpt_ops.hip)
+// finishes from there: no pass over the tensor for statistics.  GN == 1 is launched for plain epilogues only (bias at most).
 // y = x * (rstd * gamma) + (beta - mean * (rstd * gamma)) with every operation rounded on its own, as gn_apply_kernel (dpt_ops.hip, built
 // with -ffp-contract=off) computes it (HIP's __fmul_rn / __fadd_rn are plain operators and contract to an FMA in this file)
 __device__ __forceinline__ float gn_affine_exact(float x, float rstd, float gamma, float beta, float mean) {
@@ -82,7 +82,10 @@ __device__ __forceinline__ float gn_affine_exact(float x, float rstd, float gamm
 
 template <typename T, int MT, int GN>
 __device__ __forceinline__ void conv_epilogue(const ConvParams<T> &p, f32x4 (&acc)[4][MT], int m_base, int n_base, unsigned char *stage, int lane,
-                                              int boundary, bool straddles, float (&gsum)[2][8], float (&gsq)[2][8]) {
+                                              int boundary) {
+    // `lane` made opaque per tile: otherwise the compiler computes every lane-constant of the epilogue (row numbers, LDS addresses) once in
+    // front of the persistent tile loop, runs out of registers over the K loop and SPILLS them -- reloads between the hand-placed LDS-DMA
+    asm volatile("" : "+v"(lane));
     const int n = n_base + (lane & 7) * 8;
     float b[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (p.bias) {
@@ -100,24 +103,36 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams<T> &p, f32x4 (&ac
         gmean[0] = st[0], grstd[0] = st[1];
         if (img0 + 1 < n_img) gmean[1] = st[2 * p.gn_G], grstd[1] = st[2 * p.gn_G + 1];
     }
-    hive_mfma::staged_rows<MT>(stage, acc, lane, [&](int r, int, const f32x4 &lo, const f32x4 &hi) {
+    // the shortcut / skip rows: loaded one fragment row AHEAD of their use (two register sets), so that a load's trip to memory runs under
+    // the previous fragment row's turn through LDS instead of in front of every store (as gemm_store_rows in vit.hip; measured on the
+    // second pass of the ResNetV2 conv3 at 120 x 160: 660 -> see DESIGN 5.3).  A residual may BE the output: every element is read by
+    // the lane that later writes it and rows of mt + 1 are read before rows of mt are written.
+    vec<T, 8> rs1[2][2], rs2[2][2];
+    const int row_in_frag = lane >> 3;
+    auto pre = [&](int mt, int j) {
+        const int m = min(m_base + mt * 16 + 8 * j + row_in_frag, p.M - 1);
+        const size_t off = (size_t)m * p.Cout + n;
+        if (GN != 1 && p.res1) rs1[mt & 1][j] = *reinterpret_cast<const vec<T, 8> *>(p.res1 + off);
+        if (GN == 0 && p.res2) rs2[mt & 1][j] = *reinterpret_cast<const vec<T, 8> *>(p.res2 + off);
+    };
+    hive_mfma::staged_rows<MT>(stage, acc, lane, pre, [&](int r, int, const f32x4 &lo, const f32x4 &hi, int mt, int jrow) {
         const int m = m_base + r;
         if (m >= p.M) return;
         const size_t o_off = (size_t)m * p.Cout + n;
         float o[8];
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] = lo[j] + b[j], o[4 + j] = hi[j] + b[4 + j];
-        if (GN != 2 && p.res1) {
-            const vec<T, 8> rs = *reinterpret_cast<const vec<T, 8> *>(p.res1 + o_off);
+        if (GN == 0 && p.res1) {
+            const vec<T, 8> rs = rs1[mt & 1][jrow];
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] += (float)rs[j];
         }
-        if (GN != 2 && p.res2) {
-            const vec<T, 8> rs = *reinterpret_cast<const vec<T, 8> *>(p.res2 + o_off);
+        if (GN == 0 && p.res2) {
+            const vec<T, 8> rs = rs2[mt & 1][jrow];
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] += (float)rs[j];
         }
-        if (GN != 2 && p.relu) {
+        if (GN == 0 && p.relu) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = fmaxf(o[j], 0.0f);
         }
@@ -132,7 +147,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams<T> &p, f32x4 (&ac
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = gn_affine_exact((float)ov[j], rstd, ggam[j], gbet[j], mean);
             if (p.res1) {
-                const vec<T, 8> rs = *reinterpret_cast<const vec<T, 8> *>(p.res1 + o_off);
+                const vec<T, 8> rs = rs1[mt & 1][jrow];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) o[j] = (float)(T)o[j] + (float)rs[j];
             }
@@ -146,27 +161,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams<T> &p, f32x4 (&ac
             return;
         }
         if (GN != 1 || !p.stats_only) *reinterpret_cast<vec<T, 8> *>(p.out + o_off) = ov;
-        if (GN == 1) {
-            if (!straddles) {  // (workgroup-uniform) the whole tile lies in one sample: one set of sums
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float v = (float)ov[j];
-                    gsum[0][j] += v;
-                    gsq[0][j] += v * v;
-                }
-            } else {
-                const bool second = m >= boundary;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float v = (float)ov[j], v0 = second ? 0.f : v, v1 = second ? v : 0.f;
-                    gsum[0][j] += v0;
-                    gsum[1][j] += v1;
-                    gsq[0][j] += v0 * v0;
-                    gsq[1][j] += v1 * v1;
-                }
-            }
-        }
-        if (p.out_relu) {
+        if (GN == 0 && p.out_relu) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) ov[j] = (T)fmaxf(o[j], 0.0f);
             *reinterpret_cast<vec<T, 8> *>(p.out_relu + o_off) = ov;
@@ -174,7 +169,104 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams<T> &p, f32x4 (&ac
     });
 }
 
+// GroupNorm sums straight from the accumulators (GN == 1 where the epilogue has no shortcut / ReLU: every ResNetV2 convolution).  In the
+// MFMA layout a lane holds 4 consecutive channels (x 4 fragments along N) of pixel `fr` of each of its MT fragment rows: it rounds them to
+// T (the values the GroupNorm will read), and adds them and their squares with packed f32 instructions -- 2.5 VALU instructions per
+// output instead of the ~11 of the path through the LDS turn-around (measured: the statistics-only pass of conv3 at 120 x 160 spent
+// 245 of its 322 us there).  The 16 pixels of a fragment row sit in the 16 lanes of a DPP row: four row_ror additions leave the row's
+// total in each of its lanes (no LDS, unlike the ds_bpermute behind __shfl_xor); a fixed order, run-to-run identical.
+// wsum[(h 2 + k) 64 + c]: sums (k = 0) / sums of squares (k = 1) of channel n_base + c over the wave's rows of the tile's first (h = 0: rows
+// below `boundary`) and second image -- written AFTER the epilogue's stores (the accumulators are still there; the wave's 4 KiB of LDS is free).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float dpp_row_total(float v) {
+#define HIVE_ROR_ADD(ctrl) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, false))
+    HIVE_ROR_ADD(0x128);  // row_ror:8
+    HIVE_ROR_ADD(0x124);
+    HIVE_ROR_ADD(0x122);
+    HIVE_ROR_ADD(0x121);
+#undef HIVE_ROR_ADD
+    return v;
+}
+template <typename T, int MT>
+__device__ __forceinline__ void gn_sums_from_acc(const ConvParams<T> &p, const f32x4 (&acc)[4][MT], int m_base, int n_base, int lane, int boundary,
+                                                 float *wsum) {
+    asm volatile("" : "+v"(lane));  // (as in conv_epilogue)
+    const int fr = lane & 15, fq = lane >> 4;
+    const f32x2 zero2 = f32x2{0.f, 0.f};
+    const int m_end = m_base + MT * 16;                                                     // (wave-uniform, as everything below that decides a branch)
+    const bool one_image = m_end <= p.M && (m_end <= boundary || m_base >= boundary);  // every row of the wave is stored and lies in ONE image: no masks
+    const bool second = m_base >= boundary;
+    // one fragment column (16 channels) at a time, so that only its sums are live beside the accumulators
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        f32x4 bias = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p.bias) {
+            const vec<T, 4> bv = *reinterpret_cast<const vec<T, 4> *>(p.bias + n_base + nt * 16 + fq * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bias[e] = (float)bv[e];
+        }
+        f32x2 s2[2][2] = {{zero2, zero2}, {zero2, zero2}}, q2[2][2] = {{zero2, zero2}, {zero2, zero2}};  // [image][channel pair]
+        if (one_image) {
+            f32x2 ts[2] = {zero2, zero2}, tq[2] = {zero2, zero2};
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const f32x4 a = acc[nt][mt] + bias;
+                const f32x2 lo = f32x2{(float)(T)a[0], (float)(T)a[1]}, hi = f32x2{(float)(T)a[2], (float)(T)a[3]};
+                ts[0] += lo;
+                ts[1] += hi;
+                tq[0] = __builtin_elementwise_fma(lo, lo, tq[0]);
+                tq[1] = __builtin_elementwise_fma(hi, hi, tq[1]);
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                s2[0][k] = second ? zero2 : ts[k];
+                s2[1][k] = second ? ts[k] : zero2;
+                q2[0][k] = second ? zero2 : tq[k];
+                q2[1][k] = second ? tq[k] : zero2;
+            }
+        } else {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int m = m_base + mt * 16 + fr;
+                const bool in0 = m < boundary && m < p.M, in1 = m >= boundary && m < p.M;
+                const f32x4 a = acc[nt][mt] + bias;
+                const f32x2 lo = f32x2{(float)(T)a[0], (float)(T)a[1]}, hi = f32x2{(float)(T)a[2], (float)(T)a[3]};
+                const f32x2 lo0 = in0 ? lo : zero2, hi0 = in0 ? hi : zero2, lo1 = in1 ? lo : zero2, hi1 = in1 ? hi : zero2;
+                s2[0][0] += lo0;
+                s2[0][1] += hi0;
+                s2[1][0] += lo1;
+                s2[1][1] += hi1;
+                q2[0][0] = __builtin_elementwise_fma(lo0, lo0, q2[0][0]);
+                q2[0][1] = __builtin_elementwise_fma(hi0, hi0, q2[0][1]);
+                q2[1][0] = __builtin_elementwise_fma(lo1, lo1, q2[1][0]);
+                q2[1][1] = __builtin_elementwise_fma(hi1, hi1, q2[1][1]);
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            f32x4 st = f32x4{0.f, 0.f, 0.f, 0.f}, qt = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (h == 0 || m_end > boundary) {  // (the wave reaches into the second image at all)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    st[e] = dpp_row_total(s2[h][e >> 1][e & 1]);
+                    qt[e] = dpp_row_total(q2[h][e >> 1][e & 1]);
+                }
+            }
+            if (fr == 0) {  // a row's total is in each of its lanes: lane 16 fq writes channels nt 16 + fq 4 + (0..3)
+                *reinterpret_cast<f32x4 *>(wsum + (h * 2 + 0) * 64 + nt * 16 + fq * 4) = st;
+                *reinterpret_cast<f32x4 *>(wsum + (h * 2 + 1) * 64 + nt * 16 + fq * 4) = qt;
+            }
+        }
+    }
+}
+
 constexpr int BK = 64;
+
+// tuning builds only (make ablate_conv; tools/probe_resnet.py): phases of conv_kernel left out -- 1: the epilogue's turn through LDS and its
+// stores, 2: the MFMAs (the stage pieces are still issued), 4: the LDS-DMA, 8: the GroupNorm sums' reduction and their store
+#ifndef HIVE_CONV_ABLATE
+#define HIVE_CONV_ABLATE 0
+#endif
 
 template <typename T, int TM, int TN, int GN>
 __global__ __launch_bounds__(512, 1) void conv_kernel(ConvParams<T> p) {
@@ -230,6 +322,7 @@ __global__ __launch_bounds__(512, 1) void conv_kernel(ConvParams<T> p) {
     // one LDS-DMA wave-instruction of a stage: j < A_PW an A group (8 output pixels x 128 B of one tap), else a W group
     auto issue_piece = [&](const Tile &tile, int stage, int tap, int cc, int j) {
         unsigned char *st = lds + stage * STAGE_BYTES;
+        if (HIVE_CONV_ABLATE & 4) return;
         if (j < A_PW) {
             const int dy = tap / p.S, dx = tap - dy * p.S;
             const long long shift = ((long long)dy * p.W + dx) * p.Cin + cc * BK;
@@ -284,42 +377,19 @@ __global__ __launch_bounds__(512, 1) void conv_kernel(ConvParams<T> p) {
             }
             if (++nx_tap == p.taps) nx_tap = 0, ++nx_cc;
             const unsigned char *a_t = lds + buf * STAGE_BYTES, *w_t = a_t + A_GROUPS * 1024;
-            hive_mfma::kstep64<T, MT, false>(a_t, w_t, wr * RW, wc * 64, fr, fq, acc, PER_WAVE, [&](int j) { issue_piece(tile, buf ^ 1, is_tap, is_cc, j); });
+            if (HIVE_CONV_ABLATE & 2) {
+                for (int j = 0; j < PER_WAVE; ++j) issue_piece(tile, buf ^ 1, is_tap, is_cc, j);
+            } else {
+                hive_mfma::kstep64<T, MT, false>(a_t, w_t, wr * RW, wc * 64, fr, fq, acc, PER_WAVE, [&](int j) { issue_piece(tile, buf ^ 1, is_tap, is_cc, j); });
+            }
             buf ^= 1;
         }
         unsigned char *stage = lds + 2 * STAGE_BYTES + wave * 4096;
-        float gsum[2][8], gsq[2][8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) gsum[0][j] = gsum[1][j] = gsq[0][j] = gsq[1][j] = 0.f;
         const int hw = p.Ho * p.Wo, boundary = (em0 / hw + 1) * hw;  // first row of the tile's second image
-        const bool straddles = boundary < em0 + TM && boundary < p.M;  // the tile reaches into a second sample
-        conv_epilogue<T, MT, GN>(p, acc, em0 + wr * RW, en0 + wc * 64, stage, lane, boundary, straddles, gsum, gsq);
-        if (GN == 1) {
-            // the 8 lanes with the same channels (lane bits 3..5), then the WM waves of the tile in wave order
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    if (h == 1 && !straddles) continue;  // all zero
-                    float a = gsum[h][j], q = gsq[h][j];
-#pragma unroll
-                    for (int off = 8; off < 64; off <<= 1) {
-                        a += __shfl_xor(a, off);
-                        q += __shfl_xor(q, off);
-                    }
-                    gsum[h][j] = a;
-                    gsq[h][j] = q;
-                }
-            float *wsum = reinterpret_cast<float *>(stage);  // [image h][sum, sq][64 channels of this wave]
-            if (lane < 8) {
-#pragma unroll
-                for (int h = 0; h < 2; ++h)
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        wsum[(h * 2 + 0) * 64 + lane * 8 + j] = gsum[h][j];
-                        wsum[(h * 2 + 1) * 64 + lane * 8 + j] = gsq[h][j];
-                    }
-            }
+        if (!(HIVE_CONV_ABLATE & 1) && !(GN == 1 && p.stats_only)) conv_epilogue<T, MT, GN>(p, acc, em0 + wr * RW, en0 + wc * 64, stage, lane, boundary);
+        if (GN == 1 && !(HIVE_CONV_ABLATE & 8)) {
+            __builtin_amdgcn_wave_barrier();  // behind the epilogue's last reads of this LDS
+            gn_sums_from_acc<T, MT>(p, acc, em0 + wr * RW, en0 + wc * 64, lane, boundary, reinterpret_cast<float *>(stage));
             __syncthreads();
             const int tile_m = em0 / TM;
             for (int t = tid; t < 4 * TN; t += 512) {
@@ -419,7 +489,8 @@ int launch_conv_t(hive_ctx *ctx, const char *what, const void *d_x, int N, int H
         p.gn_cpg = gn_mode->gn_cpg;
     }
     // GroupNorm statistics from the epilogue: a tile may touch two images at most (tm <= Ho Wo); smaller maps keep the stand-alone pass
-    if (d_gn_partial && gn_tile_rows && (long long)Ho * Wo >= tm) {
+    // (and plain epilogues: with a shortcut / ReLU in the epilogue no statistics are left and *gn_tile_rows stays 0)
+    if (d_gn_partial && gn_tile_rows && (long long)Ho * Wo >= tm && !relu && !d_residual && !d_residual2 && !d_out_relu) {
         HIVE_REQUIRE(ctx, (long long)((p.M + tm - 1) / tm) * 4 * C_out <= gn_partial_floats, "%s: gn_partial holds %lld floats, %lld needed", what,
                      gn_partial_floats, (long long)((p.M + tm - 1) / tm) * 4 * C_out);
         p.gn_partial = (float *)d_gn_partial;

@@ -370,7 +370,8 @@ int hive_nhwc_conv(hive_ctx *ctx, const void *d_x, int dtype, int N, int H, int 
  * convolution of the hybrid backbone) folded into the epilogue: per tile of *gn_tile_rows output pixels (all C_out channels) the sum
  * and the sum of squares of the stored outputs, per channel, split between the two samples the tile may touch, are left in
  * d_gn_partial (float, >= hive_nhwc_conv_gn_partial_floats(N * H_out * W_out, C_out) elements).  *gn_tile_rows = 0 when the map is
- * smaller than a tile: nothing was written and the GroupNorm makes its own pass.  hive_nhwc_group_norm_stats = hive_nhwc_group_norm
+ * smaller than a tile or the epilogue is more than a store (relu / a residual / d_out_relu given): nothing was written and the
+ * GroupNorm makes its own pass.  hive_nhwc_group_norm_stats = hive_nhwc_group_norm
  * taking its statistics from there (d_gn_partial NULL or gn_tile_rows 0: identical to hive_nhwc_group_norm). */
 int64_t hive_nhwc_conv_gn_partial_floats(int64_t n_px, int C_out);
 int hive_nhwc_conv_gn(hive_ctx *ctx, const void *d_x, int dtype, int N, int H, int W, int C_in, int C_out, int kernel, int stride,
