@@ -34,6 +34,15 @@
 
 #include <algorithm>
 
+// tuning builds only (make ablate_conv; tools/probe_resnet.py): phases of conv_kernel left out -- 1: the epilogue's turn through LDS and its
+// stores, 2: the MFMAs (the stage pieces are still issued), 4: the LDS-DMA, 8: the GroupNorm sums' reduction and their store
+#ifndef HIVE_CONV_ABLATE
+#define HIVE_CONV_ABLATE 0
+#endif
+#ifndef HIVE_CONV_AHEAD
+#define HIVE_CONV_AHEAD 2  // fragment rows the shortcut loads of the epilogue run ahead
+#endif
+
 using hive_mfma::f32x4;
 using hive_mfma::vec;  // vec<T, 8>: 8 elements of the 16-bit type T (__bf16 or _Float16), one 16-byte register quad
 
@@ -107,15 +116,16 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams<T> &p, f32x4 (&ac
     // the previous fragment row's turn through LDS instead of in front of every store (as gemm_store_rows in vit.hip; measured on the
     // second pass of the ResNetV2 conv3 at 120 x 160: 660 -> see DESIGN 5.3).  A residual may BE the output: every element is read by
     // the lane that later writes it and rows of mt + 1 are read before rows of mt are written.
-    vec<T, 8> rs1[2][2], rs2[2][2];
+    constexpr int AHEAD = HIVE_CONV_AHEAD;
+    vec<T, 8> rs1[AHEAD + 1][2], rs2[AHEAD + 1][2];
     const int row_in_frag = lane >> 3;
     auto pre = [&](int mt, int j) {
         const int m = min(m_base + mt * 16 + 8 * j + row_in_frag, p.M - 1);
         const size_t off = (size_t)m * p.Cout + n;
-        if (GN != 1 && p.res1) rs1[mt & 1][j] = *reinterpret_cast<const vec<T, 8> *>(p.res1 + off);
-        if (GN == 0 && p.res2) rs2[mt & 1][j] = *reinterpret_cast<const vec<T, 8> *>(p.res2 + off);
+        if (GN != 1 && p.res1) rs1[mt % (AHEAD + 1)][j] = *reinterpret_cast<const vec<T, 8> *>(p.res1 + off);
+        if (GN == 0 && p.res2) rs2[mt % (AHEAD + 1)][j] = *reinterpret_cast<const vec<T, 8> *>(p.res2 + off);
     };
-    hive_mfma::staged_rows<MT>(stage, acc, lane, pre, [&](int r, int, const f32x4 &lo, const f32x4 &hi, int mt, int jrow) {
+    hive_mfma::staged_rows<MT, AHEAD>(stage, acc, lane, pre, [&](int r, int, const f32x4 &lo, const f32x4 &hi, int mt, int jrow) {
         const int m = m_base + r;
         if (m >= p.M) return;
         const size_t o_off = (size_t)m * p.Cout + n;
@@ -123,12 +133,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams<T> &p, f32x4 (&ac
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] = lo[j] + b[j], o[4 + j] = hi[j] + b[4 + j];
         if (GN == 0 && p.res1) {
-            const vec<T, 8> rs = rs1[mt & 1][jrow];
+            const vec<T, 8> rs = rs1[mt % (AHEAD + 1)][jrow];
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] += (float)rs[j];
         }
         if (GN == 0 && p.res2) {
-            const vec<T, 8> rs = rs2[mt & 1][jrow];
+            const vec<T, 8> rs = rs2[mt % (AHEAD + 1)][jrow];
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] += (float)rs[j];
         }
@@ -147,7 +157,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams<T> &p, f32x4 (&ac
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = gn_affine_exact((float)ov[j], rstd, ggam[j], gbet[j], mean);
             if (p.res1) {
-                const vec<T, 8> rs = rs1[mt & 1][jrow];
+                const vec<T, 8> rs = rs1[mt % (AHEAD + 1)][jrow];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) o[j] = (float)(T)o[j] + (float)rs[j];
             }
@@ -171,13 +181,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams<T> &p, f32x4 (&ac
 
 // GroupNorm sums straight from the accumulators (GN == 1 where the epilogue has no shortcut / ReLU: every ResNetV2 convolution).  In the
 // MFMA layout a lane holds 4 consecutive channels (x 4 fragments along N) of pixel `fr` of each of its MT fragment rows: it rounds them to
-// T (the values the GroupNorm will read), and adds them and their squares with packed f32 instructions -- 2.5 VALU instructions per
+// T (the values the GroupNorm will read), and adds them and their squares with dot instructions -- 1.5 VALU instructions per
 // output instead of the ~11 of the path through the LDS turn-around (measured: the statistics-only pass of conv3 at 120 x 160 spent
 // 245 of its 322 us there).  The 16 pixels of a fragment row sit in the 16 lanes of a DPP row: four row_ror additions leave the row's
 // total in each of its lanes (no LDS, unlike the ds_bpermute behind __shfl_xor); a fixed order, run-to-run identical.
 // wsum[(h 2 + k) 64 + c]: sums (k = 0) / sums of squares (k = 1) of channel n_base + c over the wave's rows of the tile's first (h = 0: rows
 // below `boundary`) and second image -- written AFTER the epilogue's stores (the accumulators are still there; the wave's 4 KiB of LDS is free).
-typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float dot2acc(vec<__bf16, 2> a, vec<__bf16, 2> b, float c) { return __builtin_amdgcn_fdot2_f32_bf16(a, b, c, false); }
+__device__ __forceinline__ float dot2acc(vec<_Float16, 2> a, vec<_Float16, 2> b, float c) { return __builtin_amdgcn_fdot2(a, b, c, false); }
 __device__ __forceinline__ float dpp_row_total(float v) {
 #define HIVE_ROR_ADD(ctrl) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, false))
     HIVE_ROR_ADD(0x128);  // row_ror:8
@@ -192,11 +203,14 @@ __device__ __forceinline__ void gn_sums_from_acc(const ConvParams<T> &p, const f
                                                  float *wsum) {
     asm volatile("" : "+v"(lane));  // (as in conv_epilogue)
     const int fr = lane & 15, fq = lane >> 4;
-    const f32x2 zero2 = f32x2{0.f, 0.f};
     const int m_end = m_base + MT * 16;                                                     // (wave-uniform, as everything below that decides a branch)
     const bool one_image = m_end <= p.M && (m_end <= boundary || m_base >= boundary);  // every row of the wave is stored and lies in ONE image: no masks
     const bool second = m_base >= boundary;
-    // one fragment column (16 channels) at a time, so that only its sums are live beside the accumulators
+    // one fragment column (16 channels) at a time, so that only its sums are live beside the accumulators.  Two pixels of one channel are
+    // rounded into one packed register (v_cvt_pk) and v_dot2c_f32_{bf16,f16} adds both (against packed ones) and both squares (against
+    // itself) into the f32 sums: 1.5 instructions per output.
+    vec<T, 2> ones;
+    ones[0] = ones[1] = (T)1.0f;
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
         f32x4 bias = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -205,41 +219,42 @@ __device__ __forceinline__ void gn_sums_from_acc(const ConvParams<T> &p, const f
 #pragma unroll
             for (int e = 0; e < 4; ++e) bias[e] = (float)bv[e];
         }
-        f32x2 s2[2][2] = {{zero2, zero2}, {zero2, zero2}}, q2[2][2] = {{zero2, zero2}, {zero2, zero2}};  // [image][channel pair]
+        f32x4 sv[2], qv[2];  // [image][channel]
+        sv[0] = sv[1] = qv[0] = qv[1] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (one_image) {
-            f32x2 ts[2] = {zero2, zero2}, tq[2] = {zero2, zero2};
+            f32x4 ts = f32x4{0.f, 0.f, 0.f, 0.f}, tq = ts;
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const f32x4 a = acc[nt][mt] + bias;
-                const f32x2 lo = f32x2{(float)(T)a[0], (float)(T)a[1]}, hi = f32x2{(float)(T)a[2], (float)(T)a[3]};
-                ts[0] += lo;
-                ts[1] += hi;
-                tq[0] = __builtin_elementwise_fma(lo, lo, tq[0]);
-                tq[1] = __builtin_elementwise_fma(hi, hi, tq[1]);
-            }
+            for (int mt = 0; mt < MT; mt += 2) {
+                const f32x4 a0 = acc[nt][mt] + bias, a1 = acc[nt][mt + 1] + bias;
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                s2[0][k] = second ? zero2 : ts[k];
-                s2[1][k] = second ? ts[k] : zero2;
-                q2[0][k] = second ? zero2 : tq[k];
-                q2[1][k] = second ? tq[k] : zero2;
+                for (int e = 0; e < 4; ++e) {
+                    vec<T, 2> y;
+                    y[0] = (T)a0[e], y[1] = (T)a1[e];
+                    ts[e] = dot2acc(y, ones, ts[e]);
+                    tq[e] = dot2acc(y, y, tq[e]);
+                }
             }
+            const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+            sv[0] = second ? zero4 : ts;
+            sv[1] = second ? ts : zero4;
+            qv[0] = second ? zero4 : tq;
+            qv[1] = second ? tq : zero4;
         } else {
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const int m = m_base + mt * 16 + fr;
-                const bool in0 = m < boundary && m < p.M, in1 = m >= boundary && m < p.M;
-                const f32x4 a = acc[nt][mt] + bias;
-                const f32x2 lo = f32x2{(float)(T)a[0], (float)(T)a[1]}, hi = f32x2{(float)(T)a[2], (float)(T)a[3]};
-                const f32x2 lo0 = in0 ? lo : zero2, hi0 = in0 ? hi : zero2, lo1 = in1 ? lo : zero2, hi1 = in1 ? hi : zero2;
-                s2[0][0] += lo0;
-                s2[0][1] += hi0;
-                s2[1][0] += lo1;
-                s2[1][1] += hi1;
-                q2[0][0] = __builtin_elementwise_fma(lo0, lo0, q2[0][0]);
-                q2[0][1] = __builtin_elementwise_fma(hi0, hi0, q2[0][1]);
-                q2[1][0] = __builtin_elementwise_fma(lo1, lo1, q2[1][0]);
-                q2[1][1] = __builtin_elementwise_fma(hi1, hi1, q2[1][1]);
+            for (int mt = 0; mt < MT; mt += 2) {
+                const int m0 = m_base + mt * 16 + fr, m1 = m0 + 16;
+                const bool v0 = m0 < p.M, v1 = m1 < p.M, s0 = m0 >= boundary, s1 = m1 >= boundary;
+                const f32x4 a0 = acc[nt][mt] + bias, a1 = acc[nt][mt + 1] + bias;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    vec<T, 2> y, z;  // the pair's members of the first / second image, zero otherwise
+                    y[0] = (T)(v0 && !s0 ? a0[e] : 0.f), y[1] = (T)(v1 && !s1 ? a1[e] : 0.f);
+                    z[0] = (T)(v0 && s0 ? a0[e] : 0.f), z[1] = (T)(v1 && s1 ? a1[e] : 0.f);
+                    sv[0][e] = dot2acc(y, ones, sv[0][e]);
+                    qv[0][e] = dot2acc(y, y, qv[0][e]);
+                    sv[1][e] = dot2acc(z, ones, sv[1][e]);
+                    qv[1][e] = dot2acc(z, z, qv[1][e]);
+                }
             }
         }
 #pragma unroll
@@ -248,8 +263,8 @@ __device__ __forceinline__ void gn_sums_from_acc(const ConvParams<T> &p, const f
             if (h == 0 || m_end > boundary) {  // (the wave reaches into the second image at all)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    st[e] = dpp_row_total(s2[h][e >> 1][e & 1]);
-                    qt[e] = dpp_row_total(q2[h][e >> 1][e & 1]);
+                    st[e] = dpp_row_total(sv[h][e]);
+                    qt[e] = dpp_row_total(qv[h][e]);
                 }
             }
             if (fr == 0) {  // a row's total is in each of its lanes: lane 16 fq writes channels nt 16 + fq 4 + (0..3)
@@ -262,11 +277,6 @@ __device__ __forceinline__ void gn_sums_from_acc(const ConvParams<T> &p, const f
 
 constexpr int BK = 64;
 
-// tuning builds only (make ablate_conv; tools/probe_resnet.py): phases of conv_kernel left out -- 1: the epilogue's turn through LDS and its
-// stores, 2: the MFMAs (the stage pieces are still issued), 4: the LDS-DMA, 8: the GroupNorm sums' reduction and their store
-#ifndef HIVE_CONV_ABLATE
-#define HIVE_CONV_ABLATE 0
-#endif
 
 template <typename T, int TM, int TN, int GN>
 __global__ __launch_bounds__(512, 1) void conv_kernel(ConvParams<T> p) {

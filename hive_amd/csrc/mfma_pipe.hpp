@@ -145,12 +145,17 @@ struct KPipe {
 // `pre(mt, j)` (optional) is called one fragment row AHEAD of `finish(row, col, lo, hi, mt, j)`: the place to issue the global loads
 // (residual rows) that finish will consume, so that they fly during the previous fragment row's turn-around instead of being
 // waited for in front of every store.
-template <int MT, typename Acc, typename Pre, typename Finish>
+// AHEAD = 2: `pre` runs two fragment rows ahead (three register sets in the caller): a row's turn takes ~0.5 us, less than a trip to HBM
+// under load.
+template <int MT, int AHEAD = 1, typename Acc, typename Pre, typename Finish>
 __device__ __forceinline__ void staged_rows(unsigned char *stage, const Acc &acc, int lane, Pre &&pre, Finish &&finish) {
     const int fr = lane & 15, fq = lane >> 4;
     const int rr = lane >> 3, c0 = 2 * (lane & 7);
-    pre(0, 0);
-    pre(0, 1);
+#pragma unroll
+    for (int a = 0; a < AHEAD && a < MT; ++a) {
+        pre(a, 0);
+        pre(a, 1);
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -158,9 +163,9 @@ __device__ __forceinline__ void staged_rows(unsigned char *stage, const Acc &acc
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (mt + 1 < MT) {
-            pre(mt + 1, 0);
-            pre(mt + 1, 1);
+        if (mt + AHEAD < MT) {
+            pre(mt + AHEAD, 0);
+            pre(mt + AHEAD, 1);
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -175,7 +180,7 @@ __device__ __forceinline__ void staged_rows(unsigned char *stage, const Acc &acc
 
 template <int MT, typename Acc, typename Finish>
 __device__ __forceinline__ void staged_rows(unsigned char *stage, const Acc &acc, int lane, Finish &&finish) {
-    staged_rows<MT>(stage, acc, lane, [](int, int) {}, [&](int r, int c, const f32x4 &lo, const f32x4 &hi, int, int) { finish(r, c, lo, hi); });
+    staged_rows<MT, 1>(stage, acc, lane, [](int, int) {}, [&](int r, int c, const f32x4 &lo, const f32x4 &hi, int, int) { finish(r, c, lo, hi); });
 }
 
 constexpr int STAGED_ROWS_LDS = 8 * 4096;  // 8 waves

@@ -48,6 +48,12 @@ def case(name, h, w, cin, cout, k, mode):
         def fn():
             ctx.check(lib.hive_nhwc_conv_gn_apply(ctx.handle, x.data_ptr(), _lib.BF16, B, h, w, cin, cout, k, 1, pad, pad, h, w, wt.data_ptr(), 32, gamma.data_ptr(),
                                                   beta.data_ptr(), 1e-5, res.data_ptr(), 1, out.data_ptr(), scratch.data_ptr(), nfl, ctypes.byref(fused)))
+    elif mode == "rcu":  # decoder: conv2 of a residual unit, out = conv + x + skip, and relu(out) beside it
+        res2, out2 = res.clone(), torch.empty_like(out)
+
+        def fn():
+            ctx.check(lib.hive_nhwc_conv(ctx.handle, x.data_ptr(), _lib.BF16, B, h, w, cin, cout, k, 1, pad, pad, h, w, wt.data_ptr(), None, 0, res.data_ptr(),
+                                         res2.data_ptr(), out.data_ptr(), out2.data_ptr()))
     else:  # plain convolution with bias-less epilogue
         def fn():
             ctx.check(lib.hive_nhwc_conv(ctx.handle, x.data_ptr(), _lib.BF16, B, h, w, cin, cout, k, 1, pad, pad, h, w, wt.data_ptr(), None, 0, None, None,
@@ -64,6 +70,8 @@ case("stage1 conv1 1x1 256->64", 120, 160, 256, 64, 1, "stats")
 case("stage1 conv2 3x3 64->64", 120, 160, 64, 64, 3, "stats")
 case("stage1 conv3 1x1 64->256", 120, 160, 64, 256, 1, "two_pass")
 case("stage1 conv3 1x1 64->256", 120, 160, 64, 256, 1, "plain")
+case("refinenet1 3x3 256->256", 120, 160, 256, 256, 3, "plain")
+case("refinenet1 3x3 256->256", 120, 160, 256, 256, 3, "rcu")
 case("stage2 conv1 1x1 512->128", 60, 80, 512, 128, 1, "stats")
 case("stage2 conv2 3x3 128->128", 60, 80, 128, 128, 3, "stats")
 case("stage2 conv3 1x1 128->512", 60, 80, 128, 512, 1, "two_pass")
