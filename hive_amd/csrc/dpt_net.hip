@@ -238,20 +238,24 @@ int run_forward(hive_dpt *d, bool dry, const uint8_t *d_rgb, int B, int H, int W
         // ---- pre-processing + ResNetV2 stem -----------------------------------------------------------------------------------
         half_t *xin = d->alloc((size_t)B * H * W * 3);
         Map s0{d->alloc((size_t)B * same_out(H, 2) * same_out(W, 2) * 64), same_out(H, 2), same_out(W, 2), 64};
+        const int64_t stem_floats = hive_nhwc_conv_gn_partial_floats((int64_t)B * s0.H * s0.W, 64);
+        s0.gn = (float *)d->alloc((size_t)stem_floats * 2);  // the GroupNorm's sums, left by the convolution's epilogue
         if (!dry) {
             DPT_TRY(hive_dpt_preprocess(ctx, d_rgb, (int64_t)B * H * W * 3, 0.5f, 0.5f, dt, xin));
             const void *sw;
             DPT_TRY(need(bb + "stem.conv.weight", &sw));
-            DPT_TRY(hive_resnet_stem_conv(ctx, xin, dt, B, H, W, sw, s0.p));
+            DPT_TRY(hive_resnet_stem_conv_gn(ctx, xin, dt, B, H, W, sw, s0.p, s0.gn, stem_floats, &s0.gn_tm));
         }
         d->release(xin);
-        Map s1, feat;
-        DPT_TRY(group_norm(s0, bb + "stem.norm", nullptr, 1, &s1));
+        // GroupNorm + ReLU + MaxPool2dSame(3, 2) in one pass: the normalised 64-channel map at half resolution never reaches memory
+        Map feat{d->alloc((size_t)B * same_out(s0.H, 2) * same_out(s0.W, 2) * 64), same_out(s0.H, 2), same_out(s0.W, 2), 64};
+        if (!dry) {
+            const void *g, *b;
+            DPT_TRY(need(bb + "stem.norm.weight", &g));
+            DPT_TRY(need(bb + "stem.norm.bias", &b));
+            DPT_TRY(hive_nhwc_group_norm_relu_maxpool(ctx, s0.p, dt, B, s0.H, s0.W, 64, 32, g, b, d->cfg.gn_eps, feat.p, s0.gn_tm ? s0.gn : nullptr, s0.gn_tm));
+        }
         drop(s0);
-        feat = Map{d->alloc((size_t)B * same_out(s1.H, 2) * same_out(s1.W, 2) * 64), same_out(s1.H, 2), same_out(s1.W, 2), 64};
-        if (!dry) DPT_TRY(hive_nhwc_maxpool3x3s2(ctx, s1.p, dt, B, s1.H, s1.W, 64, feat.p));
-        drop(s1);
-
         // ---- ResNetV2 stages: non pre-activation bottlenecks, GroupNorm behind every convolution ------------------------------
         const int depths[3] = {3, 4, 9}, chans[3] = {256, 512, 1024};
         Map hook[2] = {Map{nullptr, 0, 0, 0}, Map{nullptr, 0, 0, 0}};

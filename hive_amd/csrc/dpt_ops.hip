@@ -381,6 +381,52 @@ __global__ __launch_bounds__(256) void pixel_shuffle_bias_kernel(const T *__rest
     }
 }
 
+// MaxPool2dSame(3, 2)(relu(GroupNorm(x))) in one pass (the ResNetV2 stem behind its convolution): out[n][oy][ox][c] = the maximum over the
+// 3 x 3 / 2 window (TensorFlow "SAME" padding: padded positions never win) of the normalised, rectified and ROUNDED values -- rounding and
+// ReLU are monotonic, so max(round(relu(y))) == round(relu(max(y))): bit-identical to gn_apply_kernel followed by the pooling kernel, without
+// the normalised map (1.05 GB at 107 frames of 480 x 640) ever reaching memory.  A thread: one output pixel x 8 channels.
+template <typename T>
+__global__ __launch_bounds__(256) void gn_relu_maxpool_kernel(const T *__restrict__ x, const T *__restrict__ gamma, const T *__restrict__ beta,
+                                                              const float *__restrict__ stats, T *__restrict__ out, int H, int W, int C, int G, int Ho,
+                                                              int Wo, int pad_t, int pad_l) {
+    const int VC = C >> 3, cpg = C / G;
+    const int n = blockIdx.y;
+    const long long total = (long long)Ho * Wo * VC;
+    const int v = threadIdx.x % VC;  // VC (a power of two <= 256) divides the stride of the loop below: a thread keeps its channels
+    float a[8], b[8];
+    {
+        float gm[8], bt[8];
+        load8(gamma + v * 8, gm);
+        load8(beta + v * 8, bt);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int g = (v * 8 + j) / cpg;
+            const float mean = stats[2 * (n * G + g)], rstd = stats[2 * (n * G + g) + 1];
+            a[j] = rstd * gm[j];
+            b[j] = bt[j] - mean * a[j];
+        }
+    }
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int pix = (int)(i / VC), ox = pix % Wo, oy = pix / Wo;
+        float m[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m[j] = 0.f;  // the ReLU's floor: every window holds at least one real pixel
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int iy = 2 * oy + ky - pad_t, ix = 2 * ox + kx - pad_l;
+                if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+                    float f[8];
+                    load8(x + (((size_t)n * H + iy) * W + ix) * C + v * 8, f);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) m[j] = fmaxf(m[j], f[j] * a[j] + b[j]);
+                }
+            }
+        store8(out + (((size_t)n * Ho + oy) * Wo + ox) * C + v * 8, m);
+    }
+}
+
 static bool pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
 
 int hive_gn_finalize_tiles(hive_ctx *ctx, const float *d_partial, int N, int HW, int C, int G, int tile_rows, float eps, float *d_stats) {
@@ -439,6 +485,48 @@ int hive_nhwc_group_norm_stats(hive_ctx *ctx, const void *d_x, int dtype, int N,
     HIVE_ENTER(ctx);
     if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
     return group_norm_impl(ctx, d_x, dtype, N, HW, C, G, d_gamma, d_beta, eps, d_residual, relu, d_out, d_gn_partial, gn_tile_rows);
+}
+
+int hive_nhwc_group_norm_relu_maxpool(hive_ctx *ctx, const void *d_x, int dtype, int N, int H, int W, int C, int G, const void *d_gamma, const void *d_beta,
+                                      float eps, void *d_out, const void *d_gn_partial, int gn_tile_rows) {
+    HIVE_ENTER(ctx);
+    if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
+    HIVE_REQUIRE(ctx, d_x && d_gamma && d_beta && d_out && d_out != d_x, "group_norm_relu_maxpool: bad pointers");
+    HIVE_REQUIRE(ctx, N > 0 && N <= 65535 && H > 0 && W > 0 && C >= 8 && C <= 2048 && pow2(C) && G > 0 && C % G == 0,
+                 "group_norm_relu_maxpool: need C a power of two in [8, 2048], C %% G == 0, N <= 65535 (N=%d H=%d W=%d C=%d G=%d)", N, H, W, C, G);
+    HIVE_REQUIRE(ctx, dtype == HIVE_BF16 || dtype == HIVE_F16, "group_norm_relu_maxpool: dtype must be HIVE_F16 or HIVE_BF16");
+    const int HW = H * W;
+    const bool from_tiles = d_gn_partial && gn_tile_rows > 0;
+    HIVE_REQUIRE(ctx, !from_tiles || gn_tile_rows <= HW, "group_norm_relu_maxpool: tiles of %d rows on samples of %d", gn_tile_rows, HW);
+    const int VC = C / 8, PP = 256 / VC;
+    const int slabs = std::max(1, std::min(64, std::min(HW / (4 * PP) + 1, (ctx->num_cus * 8 + N - 1) / N)));
+    const size_t partial_floats = from_tiles ? 0 : (size_t)N * slabs * 2 * C, stats_floats = (size_t)N * G * 2;
+    int rc = hive_reserve_device(ctx, &ctx->d_scratch, &ctx->scratch_bytes, (partial_floats + stats_floats) * sizeof(float));
+    if (rc) return rc;
+    float *partial = (float *)ctx->d_scratch, *stats = partial + partial_floats;
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+    const int pad_t = std::max((Ho - 1) * 2 + 3 - H, 0) / 2, pad_l = std::max((Wo - 1) * 2 + 3 - W, 0) / 2;
+    const long long per_img = (long long)Ho * Wo * VC;
+    const dim3 g1(slabs, N), gp((unsigned)std::max<long long>(1, std::min<long long>((per_img + 255) / 256, ((long long)ctx->num_cus * 32 + N - 1) / N)), N);
+    if (from_tiles)
+        hipLaunchKernelGGL(gn_finalize_tiles_kernel, dim3(N * G), dim3(256), 0, ctx->stream, (const float *)d_gn_partial, C, G, gn_tile_rows, HW, eps, stats, N * G);
+    if (dtype == HIVE_BF16) {
+        if (!from_tiles) {
+            hipLaunchKernelGGL(gn_partial_kernel<bf16>, g1, dim3(256), 0, ctx->stream, (const bf16 *)d_x, HW, C, slabs, partial);
+            hipLaunchKernelGGL(gn_finalize_kernel, dim3(N * G), dim3(256), 0, ctx->stream, partial, C, G, slabs, HW, eps, stats, N * G);
+        }
+        hipLaunchKernelGGL(gn_relu_maxpool_kernel<bf16>, gp, dim3(256), 0, ctx->stream, (const bf16 *)d_x, (const bf16 *)d_gamma, (const bf16 *)d_beta, stats,
+                           (bf16 *)d_out, H, W, C, G, Ho, Wo, pad_t, pad_l);
+    } else {
+        if (!from_tiles) {
+            hipLaunchKernelGGL(gn_partial_kernel<_Float16>, g1, dim3(256), 0, ctx->stream, (const _Float16 *)d_x, HW, C, slabs, partial);
+            hipLaunchKernelGGL(gn_finalize_kernel, dim3(N * G), dim3(256), 0, ctx->stream, partial, C, G, slabs, HW, eps, stats, N * G);
+        }
+        hipLaunchKernelGGL(gn_relu_maxpool_kernel<_Float16>, gp, dim3(256), 0, ctx->stream, (const _Float16 *)d_x, (const _Float16 *)d_gamma,
+                           (const _Float16 *)d_beta, stats, (_Float16 *)d_out, H, W, C, G, Ho, Wo, pad_t, pad_l);
+    }
+    HIVE_CHECK_HIP(ctx, hipGetLastError());
+    return HIVE_OK;
 }
 
 int hive_nhwc_bias_act(hive_ctx *ctx, const void *d_x, int dtype, int64_t n_px, int C, const void *d_bias, int relu,

@@ -8,7 +8,8 @@
 // (21 taps + 11 zero weights): the A fragment of a pixel for k-step ky is 32 consecutive bf16 of input row 2 oy + ky - pad starting
 // at column 2 ox - pad (the 11 extra values belong to the neighbouring pixels and meet zero weights).  A workgroup owns an 8 x 32
 // output tile: its 21 x 69 x 3 input patch and the 64 x 224 weight matrix sit in LDS; four waves x (4 x 4) accumulators of
-// v_mfma_f32_16x16x32_bf16.  HBM-bound: 1.8 MB in, 9.8 MB out per 480 x 640 frame.
+// v_mfma_f32_16x16x32_bf16.  HBM-bound: 1.8 MB in, 9.8 MB out per 480 x 640 frame.  hive_resnet_stem_conv_gn also leaves the sums the
+// GroupNorm behind the convolution needs (per 256-pixel tile, from the accumulators: as conv.hip's gn_sums_from_acc).
 #include "hive_internal.hpp"
 
 #include <algorithm>
@@ -22,8 +23,12 @@ namespace {
 
 constexpr int ST_TH = 8, ST_TW = 32;                      // output tile
 constexpr int ST_PH = 2 * ST_TH + 5, ST_PW = 2 * ST_TW + 5;  // input patch 21 x 69 pixels
-constexpr int ST_ROW = 240;                               // patch row pitch in bf16 (69 x 3 = 207, + slack for the 32-wide k-steps; 480 B)
+constexpr int ST_ROW = 240;                               // patch row pitch in elements (69 x 3 = 207, + slack for the 32-wide k-steps; 480 B)
+constexpr int ST_RD = 104;                                // dwords of a patch row that are loaded (208 elements >= 207)
 constexpr int ST_K = 7 * 32;                              // padded K
+constexpr int ST_WP = ST_K + 8;                           // weight row pitch in LDS: 464 B = 116 dwords, 116 mod 64 = 52 -> the 16 rows of a fragment
+                                                          // read (16 B per lane) start in 16 distinct 4-dword bank groups (pitch 448 B: 4-way conflicts)
+constexpr int ST_LOADS = (ST_PH * ST_RD + 255) / 256;     // dword loads per thread and patch (9)
 
 template <typename T>
 struct StemParams {
@@ -31,70 +36,162 @@ struct StemParams {
     const T *w;   // [64][7][32]: (ky, (kx, c) padded from 21 to 32 with zeros)
     T *out;       // [N][Ho][Wo][64]
     int H, W, Ho, Wo, pad_t, pad_l;
+    int tiles_x, tiles_y, n_tiles;
+    float *gn_partial;  // or nullptr: [tile][2][2][64] sums / sums of squares of the tile's (rounded) outputs -- the layout of conv.hip's
+                        // GroupNorm partials with 256-pixel "tiles" (hive_nhwc_group_norm_stats reads them); only whole tiles (Ho % 8 == 0, Wo % 32 == 0)
 };
 
+__device__ __forceinline__ float stem_dot2(vec<__bf16, 2> a, vec<__bf16, 2> b, float c) { return __builtin_amdgcn_fdot2_f32_bf16(a, b, c, false); }
+__device__ __forceinline__ float stem_dot2(vec<_Float16, 2> a, vec<_Float16, 2> b, float c) { return __builtin_amdgcn_fdot2(a, b, c, false); }
+__device__ __forceinline__ float stem_row_total(float v) {  // sum over the 16 lanes of a DPP row, left in every lane
+#define HIVE_ROR_ADD(ctrl) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, false))
+    HIVE_ROR_ADD(0x128);
+    HIVE_ROR_ADD(0x124);
+    HIVE_ROR_ADD(0x122);
+    HIVE_ROR_ADD(0x121);
+#undef HIVE_ROR_ADD
+    return v;
+}
+
+// PERSISTENT workgroups (as many as fit: 3 per CU by LDS): the weights go to LDS once; per tile the patch of the NEXT tile is loaded into
+// registers (dwords: a patch row is 414 contiguous bytes of the frame, 4-byte aligned when W and the left padding are even -- `fast`;
+// otherwise, and for tiles that touch the frame's border, element by element with the bounds tests) while the MFMAs and the stores of the
+// current one run.  Round 3: 729 -> see DESIGN 5.6 (one workgroup per tile, weights re-read per tile, 2-byte patch loads, 4-way LDS
+// conflicts on the weight fragments).
 template <typename T>
 __global__ __launch_bounds__(256) void stem_conv_kernel(StemParams<T> p) {
     __shared__ __attribute__((aligned(16))) T patch[ST_PH * ST_ROW + 64];
-    __shared__ __attribute__((aligned(16))) T wl[64 * ST_K];
+    __shared__ __attribute__((aligned(16))) T wl[64 * ST_WP];
+    __shared__ float wsum[4][2][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tiles_x = (p.Wo + ST_TW - 1) / ST_TW, tiles_y = (p.Ho + ST_TH - 1) / ST_TH;
-    const int img = blockIdx.x / (tiles_x * tiles_y), t = blockIdx.x % (tiles_x * tiles_y);
-    const int oy0 = (t / tiles_x) * ST_TH, ox0 = (t % tiles_x) * ST_TW;
-    const int iy0 = 2 * oy0 - p.pad_t, ix0 = 2 * ox0 - p.pad_l;
-    // weights: 64 x 224 bf16 = 28 KiB, 16 bytes per thread and pass
-    for (int i = tid; i < 64 * ST_K / 8; i += 256) reinterpret_cast<uint4 *>(wl)[i] = reinterpret_cast<const uint4 *>(p.w)[i];
-    // patch: rows iy0 .. iy0 + 20, columns ix0 .. ix0 + 68, 3 channels; zero outside the frame.  One bf16 per thread and step
-    // (a patch row starts 2 * pad_l pixels left of a 384-byte boundary: element granularity keeps it simple; 9 KB per tile)
-    const T *xin = p.x + (size_t)img * p.H * p.W * 3;
-    for (int i = tid; i < ST_PH * ST_ROW; i += 256) {
-        const int r = i / ST_ROW, e = i - r * ST_ROW;  // element e = (col, c)
-        const int col = e / 3, c = e - col * 3;
-        const int iy = iy0 + r, ix = ix0 + col;
-        T v = (T)0.0f;
-        if (e < ST_PW * 3 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) v = xin[((size_t)iy * p.W + ix) * 3 + c];
-        patch[i] = v;
+    for (int i = tid; i < 64 * ST_K / 8; i += 256) {  // weights: 64 x 224 = 28 KiB, 16 bytes per thread and pass
+        const int row = i / (ST_K / 8), c8 = i - row * (ST_K / 8);
+        *reinterpret_cast<uint4 *>(wl + row * ST_WP + c8 * 8) = reinterpret_cast<const uint4 *>(p.w)[i];
     }
     if (tid < 64) patch[ST_PH * ST_ROW + tid] = (T)0.0f;
-    __syncthreads();
+    // elements 208 .. 239 of every patch row are never loaded but are read (against zero weights): zero, not whatever LDS held
+    for (int i = tid; i < ST_PH * (ST_ROW / 2 - ST_RD); i += 256) {
+        const int r = i / (ST_ROW / 2 - ST_RD), d = i - r * (ST_ROW / 2 - ST_RD);
+        reinterpret_cast<uint32_t *>(patch)[r * (ST_ROW / 2) + ST_RD + d] = 0u;
+    }
+    const bool even = (p.W % 2 == 0) && (p.pad_l % 2 == 0);  // dword-aligned patch rows
+    const int per_img = p.tiles_x * p.tiles_y;
+    uint32_t regs[ST_LOADS];
+    auto fetch = [&](int tile) {  // the tile's patch -> registers (dword i of the patch: row i / 104, elements 2 (i % 104), + 1)
+        const int img = tile / per_img, t = tile - img * per_img;
+        const int oy0 = (t / p.tiles_x) * ST_TH, ox0 = (t % p.tiles_x) * ST_TW;
+        const int iy0 = 2 * oy0 - p.pad_t, ix0 = 2 * ox0 - p.pad_l;
+        const T *xin = p.x + (size_t)img * p.H * p.W * 3;
+        const bool inside = iy0 >= 0 && iy0 + ST_PH <= p.H && ix0 >= 0 && ix0 + (2 * ST_RD + 2) / 3 <= p.W;  // (workgroup-uniform)
+        if (even && inside) {
+            const uint32_t *base = reinterpret_cast<const uint32_t *>(xin + ((size_t)iy0 * p.W + ix0) * 3);
+            const int row_dwords = p.W * 3 / 2;
+#pragma unroll
+            for (int k = 0; k < ST_LOADS; ++k) {
+                const int i = tid + 256 * k, r = i / ST_RD, d = i - r * ST_RD;
+                regs[k] = (k + 1 < ST_LOADS || i < ST_PH * ST_RD) ? base[(size_t)r * row_dwords + d] : 0u;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < ST_LOADS; ++k) {
+                const int i = tid + 256 * k, r = i / ST_RD, d = i - r * ST_RD;
+                T v[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int e = 2 * d + h, col = e / 3, c = e - col * 3;
+                    const int iy = iy0 + r, ix = ix0 + col;
+                    v[h] = (T)0.0f;
+                    if (r < ST_PH && e < ST_PW * 3 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) v[h] = xin[((size_t)iy * p.W + ix) * 3 + c];
+                }
+                regs[k] = *reinterpret_cast<const uint32_t *>(v);
+            }
+        }
+    };
+    int tile = blockIdx.x;
+    if (tile < p.n_tiles) fetch(tile);
     const int fr = lane & 15, fq = lane >> 4;
-    // wave w: output rows 2 w, 2 w + 1 of the tile; m fragment mt: row 2 w + (mt >> 1), columns 16 (mt & 1) .. + 15
-    f32x4 acc[4][4];
+    for (; tile < p.n_tiles; tile += gridDim.x) {
+        __syncthreads();  // everyone finished with the previous tile's patch (and, the first time, the weights are in LDS)
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+        for (int k = 0; k < ST_LOADS; ++k) {
+            const int i = tid + 256 * k, r = i / ST_RD, d = i - r * ST_RD;
+            if (k + 1 < ST_LOADS || i < ST_PH * ST_RD) reinterpret_cast<uint32_t *>(patch)[r * (ST_ROW / 2) + d] = regs[k];
+        }
+        __syncthreads();
+        if (tile + (int)gridDim.x < p.n_tiles) fetch(tile + gridDim.x);  // in flight during the MFMAs and the stores below
+        const int img = tile / per_img, t = tile - img * per_img;
+        const int oy0 = (t / p.tiles_x) * ST_TH, ox0 = (t % p.tiles_x) * ST_TW;
+        // wave w: output rows 2 w, 2 w + 1 of the tile; m fragment mt: row 2 w + (mt >> 1), columns 16 (mt & 1) .. + 15
+        f32x4 acc[4][4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int ky = 0; ky < 7; ++ky) {
-        vec<T, 8> wf[4], af[4];
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) wf[nt] = *reinterpret_cast<const vec<T, 8> *>(wl + (nt * 16 + fr) * ST_K + ky * 32 + fq * 8);
+        for (int ky = 0; ky < 7; ++ky) {
+            vec<T, 8> wf[4], af[4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) wf[nt] = *reinterpret_cast<const vec<T, 8> *>(wl + (nt * 16 + fr) * ST_WP + ky * 32 + fq * 8);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const int oy = 2 * wave + (mt >> 1), ox = 16 * (mt & 1) + fr;
+                const T *src = patch + (2 * oy + ky) * ST_ROW + 6 * ox + fq * 8;  // 4-byte aligned: 12 ox + 16 fq bytes
+                uint32_t raw[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) raw[q] = reinterpret_cast<const uint32_t *>(src)[q];
+                af[mt] = *reinterpret_cast<const vec<T, 8> *>(raw);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) acc[nt][mt] = hive_mfma::mfma16(wf[nt], af[mt], acc[nt][mt]);
+        }
+        // a lane owns 4 consecutive channels (16 nt + 4 fq ..) of pixel (2 w + (mt >> 1), 16 (mt & 1) + fr)
+        T *out = p.out + (size_t)img * p.Ho * p.Wo * 64;
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
-            const int oy = 2 * wave + (mt >> 1), ox = 16 * (mt & 1) + fr;
-            const T *src = patch + (2 * oy + ky) * ST_ROW + 6 * ox + fq * 8;  // 4-byte aligned: 12 ox + 16 fq bytes
-            uint32_t raw[4];
+            const int oy = oy0 + 2 * wave + (mt >> 1), ox = ox0 + 16 * (mt & 1) + fr;
+            if (oy < p.Ho && ox < p.Wo) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) raw[q] = reinterpret_cast<const uint32_t *>(src)[q];
-            af[mt] = *reinterpret_cast<const vec<T, 8> *>(raw);
+                for (int nt = 0; nt < 4; ++nt) {
+                    vec<T, 4> ov;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) ov[j] = (T)acc[nt][mt][j];
+                    *reinterpret_cast<vec<T, 4> *>(out + ((size_t)oy * p.Wo + ox) * 64 + nt * 16 + fq * 4) = ov;
+                }
+            }
         }
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) acc[nt][mt] = hive_mfma::mfma16(wf[nt], af[mt], acc[nt][mt]);
-    }
-    // a lane owns 4 consecutive channels (16 nt + 4 fq ..) of pixel (2 w + (mt >> 1), 16 (mt & 1) + fr)
-    T *out = p.out + (size_t)img * p.Ho * p.Wo * 64;
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        const int oy = oy0 + 2 * wave + (mt >> 1), ox = ox0 + 16 * (mt & 1) + fr;
-        if (oy < p.Ho && ox < p.Wo) {
+        if (p.gn_partial) {  // (whole tiles only: every accumulator is a stored output)
+            vec<T, 2> ones;
+            ones[0] = ones[1] = (T)1.0f;
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
-                vec<T, 4> ov;
+                f32x4 sv = f32x4{0.f, 0.f, 0.f, 0.f}, qv = sv;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) ov[j] = (T)acc[nt][mt][j];
-                *reinterpret_cast<vec<T, 4> *>(out + ((size_t)oy * p.Wo + ox) * 64 + nt * 16 + fq * 4) = ov;
+                for (int mt = 0; mt < 4; mt += 2)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        vec<T, 2> y;
+                        y[0] = (T)acc[nt][mt][e], y[1] = (T)acc[nt][mt + 1][e];
+                        sv[e] = stem_dot2(y, ones, sv[e]);
+                        qv[e] = stem_dot2(y, y, qv[e]);
+                    }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    sv[e] = stem_row_total(sv[e]);
+                    qv[e] = stem_row_total(qv[e]);
+                }
+                if (fr == 0) {
+                    *reinterpret_cast<f32x4 *>(&wsum[wave][0][nt * 16 + fq * 4]) = sv;
+                    *reinterpret_cast<f32x4 *>(&wsum[wave][1][nt * 16 + fq * 4]) = qv;
+                }
+            }
+            __syncthreads();
+            if (tid < 128) {
+                const int which = tid >> 6, c = tid & 63;
+                const float a = ((wsum[0][which][c] + wsum[1][which][c]) + wsum[2][which][c]) + wsum[3][which][c];
+                p.gn_partial[((size_t)tile * 4 + which) * 64 + c] = a;       // h = 0: the tile's (only) image
+                p.gn_partial[((size_t)tile * 4 + 2 + which) * 64 + c] = 0.f;  // h = 1
             }
         }
     }
@@ -132,7 +229,8 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const T *__restrict__
 }
 
 template <typename T>
-int launch_stem(hive_ctx *ctx, const void *d_x, int N, int H, int W, const void *d_w, void *d_out) {
+int launch_stem(hive_ctx *ctx, const void *d_x, int N, int H, int W, const void *d_w, void *d_out, float *d_gn_partial, long long gn_partial_floats,
+                int *gn_tile_rows) {
     StemParams<T> p{};
     p.x = (const T *)d_x;
     p.w = (const T *)d_w;
@@ -143,8 +241,19 @@ int launch_stem(hive_ctx *ctx, const void *d_x, int N, int H, int W, const void 
     p.Wo = (W + 1) / 2;
     p.pad_t = std::max((p.Ho - 1) * 2 + 7 - H, 0) / 2;  // TensorFlow "SAME": the odd pixel goes to the bottom / right
     p.pad_l = std::max((p.Wo - 1) * 2 + 7 - W, 0) / 2;
-    const long long tiles = (long long)N * ((p.Ho + ST_TH - 1) / ST_TH) * ((p.Wo + ST_TW - 1) / ST_TW);
-    hipLaunchKernelGGL(stem_conv_kernel<T>, dim3((unsigned)tiles), dim3(256), 0, ctx->stream, p);
+    p.tiles_x = (p.Wo + ST_TW - 1) / ST_TW;
+    p.tiles_y = (p.Ho + ST_TH - 1) / ST_TH;
+    const long long tiles = (long long)N * p.tiles_x * p.tiles_y;
+    HIVE_REQUIRE(ctx, tiles < (1ll << 31), "resnet_stem_conv: %lld tiles", tiles);
+    p.n_tiles = (int)tiles;
+    if (gn_tile_rows) *gn_tile_rows = 0;
+    if (d_gn_partial && gn_tile_rows && p.Ho % ST_TH == 0 && p.Wo % ST_TW == 0) {  // whole tiles: a tile is 256 pixels of ONE image
+        HIVE_REQUIRE(ctx, tiles * 4 * 64 <= gn_partial_floats, "resnet_stem_conv_gn: gn_partial holds %lld floats, %lld needed", gn_partial_floats, tiles * 4 * 64);
+        p.gn_partial = d_gn_partial;
+        *gn_tile_rows = ST_TH * ST_TW;
+    }
+    const unsigned grid = (unsigned)std::min<long long>(tiles, (long long)ctx->num_cus * 3);  // persistent: 3 workgroups of 41 KB LDS per CU
+    hipLaunchKernelGGL(stem_conv_kernel<T>, dim3(grid), dim3(256), 0, ctx->stream, p);
     HIVE_CHECK_HIP(ctx, hipGetLastError());
     return HIVE_OK;
 }
@@ -153,13 +262,27 @@ int launch_stem(hive_ctx *ctx, const void *d_x, int N, int H, int W, const void 
 
 extern "C" {
 
-int hive_resnet_stem_conv(hive_ctx *ctx, const void *d_x, int dtype, int N, int H, int W, const void *d_w, void *d_out) {
-    HIVE_ENTER(ctx);
-    if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
+static int stem_entry(hive_ctx *ctx, const void *d_x, int dtype, int N, int H, int W, const void *d_w, void *d_out, void *d_gn_partial, int64_t gn_partial_floats,
+                      int *gn_tile_rows) {
     HIVE_REQUIRE(ctx, d_x && d_w && d_out, "resnet_stem_conv: NULL argument");
     HIVE_REQUIRE(ctx, dtype == HIVE_BF16 || dtype == HIVE_F16, "resnet_stem_conv: dtype must be HIVE_F16 or HIVE_BF16");
     HIVE_REQUIRE(ctx, N > 0 && H >= 7 && W >= 7 && (long long)N * H * W < (1ll << 31), "resnet_stem_conv: bad sizes %d x %d x %d", N, H, W);
-    return dtype == HIVE_BF16 ? launch_stem<__bf16>(ctx, d_x, N, H, W, d_w, d_out) : launch_stem<_Float16>(ctx, d_x, N, H, W, d_w, d_out);
+    return dtype == HIVE_BF16 ? launch_stem<__bf16>(ctx, d_x, N, H, W, d_w, d_out, (float *)d_gn_partial, gn_partial_floats, gn_tile_rows)
+                              : launch_stem<_Float16>(ctx, d_x, N, H, W, d_w, d_out, (float *)d_gn_partial, gn_partial_floats, gn_tile_rows);
+}
+
+int hive_resnet_stem_conv(hive_ctx *ctx, const void *d_x, int dtype, int N, int H, int W, const void *d_w, void *d_out) {
+    HIVE_ENTER(ctx);
+    if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
+    return stem_entry(ctx, d_x, dtype, N, H, W, d_w, d_out, nullptr, 0, nullptr);
+}
+
+int hive_resnet_stem_conv_gn(hive_ctx *ctx, const void *d_x, int dtype, int N, int H, int W, const void *d_w, void *d_out, void *d_gn_partial,
+                             int64_t gn_partial_floats, int *gn_tile_rows) {
+    HIVE_ENTER(ctx);
+    if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
+    HIVE_REQUIRE(ctx, d_gn_partial && gn_tile_rows, "resnet_stem_conv_gn: NULL argument");
+    return stem_entry(ctx, d_x, dtype, N, H, W, d_w, d_out, d_gn_partial, gn_partial_floats, gn_tile_rows);
 }
 
 int hive_nhwc_maxpool3x3s2(hive_ctx *ctx, const void *d_x, int dtype, int N, int H, int W, int C, void *d_out) {

@@ -176,6 +176,13 @@ class ResNetV2Stem(nn.Sequential):
         self.norm = GroupNormAct(out_chs)
         self.pool = MaxPool2dSame(3, 2)
 
+    def forward(self, x):
+        if self.conv.engine == "hip" and self.norm.engine == "hip" and self.pool.engine == "hip" and (self.pool.k, self.pool.s) == (3, 2) and self.norm.apply_act:
+            # GroupNorm + ReLU + max pool in one pass behind the convolution (bit-identical to the three modules in sequence)
+            y = self.conv(x)
+            return dpt_ops.group_norm_relu_maxpool(y, self.norm, stats=getattr(y, "hive_gn_stats", None))
+        return super().forward(x)
+
 
 class ResNetV2(nn.Module):
     def __init__(self, layers=(3, 4, 9), channels=(256, 512, 1024)):

@@ -284,9 +284,35 @@ def stem_conv(x, conv, weight):
         w[:, :, :21] = weight.detach().permute(0, 2, 3, 1).reshape(64, 7, 21)  # (ky, (kx, c)), a kernel row padded to 32
         hit = cache["stem"] = (stamp, w.contiguous())
     n, _, h, w_ = x.shape
-    out = torch.empty((n, 64, (h + 1) // 2, (w_ + 1) // 2), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    oh, ow = (h + 1) // 2, (w_ + 1) // 2
+    out = torch.empty((n, 64, oh, ow), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
     ctx = _lib.default_context(x.device.index or 0)
-    ctx.check(ctx.lib.hive_resnet_stem_conv(ctx.handle, x.data_ptr(), _code(x.dtype), n, h, w_, hit[1].data_ptr(), out.data_ptr()))
+    # the statistics of the GroupNorm behind the convolution come out of its epilogue (hive_resnet_stem_conv_gn), as for every other
+    # StdConv2dSame; they ride on the tensor as ``out.hive_gn_stats = (partial, tile_rows)`` (tile_rows 0: none were written)
+    import ctypes
+    partial = torch.empty(int(ctx.lib.hive_nhwc_conv_gn_partial_floats(n * oh * ow, 64)), dtype=torch.float32, device=x.device)
+    tile_rows = ctypes.c_int(0)
+    ctx.check(ctx.lib.hive_resnet_stem_conv_gn(ctx.handle, x.data_ptr(), _code(x.dtype), n, h, w_, hit[1].data_ptr(), out.data_ptr(), partial.data_ptr(),
+                                               partial.numel(), ctypes.byref(tile_rows)))
+    if tile_rows.value:
+        out.hive_gn_stats = (partial, tile_rows.value)
+    return out
+
+
+def group_norm_relu_maxpool(x, norm, stats=None):
+    """MaxPool2dSame(3, 2)(relu(norm(x))) in one pass (hive_nhwc_group_norm_relu_maxpool): the ResNetV2 stem behind its convolution.
+    ``stats``: ``x.hive_gn_stats`` of the convolution that wrote ``x``, or None (own statistics pass)."""
+    why = _why_not_map(x) or (None if norm.weight.dtype == x.dtype else f"affine parameters are {norm.weight.dtype}, the tensor {x.dtype}")
+    n, c, h, w = x.shape
+    if not why and ((c & (c - 1)) or c > 2048):
+        why = f"{c} channels: a power of two <= 2048 is needed"
+    if why:
+        not_covered("group_norm + max pool", why)
+    out = torch.empty((n, c, (h + 1) // 2, (w + 1) // 2), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    ctx = _lib.default_context(x.device.index or 0)
+    partial, tile_rows = stats if stats is not None else (None, 0)
+    ctx.check(ctx.lib.hive_nhwc_group_norm_relu_maxpool(ctx.handle, x.data_ptr(), _code(x.dtype), n, h, w, c, norm.num_groups, norm.weight.data_ptr(),
+                                                        norm.bias.data_ptr(), float(norm.eps), out.data_ptr(), _lib.ptr(partial), int(tile_rows)))
     return out
 
 

@@ -410,6 +410,15 @@ int hive_nhwc_pixel_shuffle_bias(hive_ctx *ctx, const void *d_in, const void *d_
  * 32 with zeros).  And MaxPool2dSame(3, 2): [N][H][W][C] -> [N][ceil(H/2)][ceil(W/2)][C], C % 8 == 0. */
 int hive_resnet_stem_conv(hive_ctx *ctx, const void *d_x, int dtype, int N, int H, int W, const void *d_w, void *d_out);
 int hive_nhwc_maxpool3x3s2(hive_ctx *ctx, const void *d_x, int dtype, int N, int H, int W, int C, void *d_out);
+/* The stem as the network object runs it (same results as the three calls above with hive_nhwc_group_norm between them):
+ * hive_resnet_stem_conv_gn = the convolution, leaving the statistics of the GroupNorm behind it as hive_nhwc_conv_gn does (per 256-pixel
+ * tile; d_gn_partial >= hive_nhwc_conv_gn_partial_floats(N * H_out * W_out, 64) floats; *gn_tile_rows = 0 -- nothing written -- unless
+ * H_out % 8 == 0 and W_out % 32 == 0); hive_nhwc_group_norm_relu_maxpool = MaxPool2dSame(3, 2)(relu(GroupNorm(x))) in one pass over
+ * x [N][H][W][C] -> [N][ceil(H/2)][ceil(W/2)][C] (d_gn_partial / gn_tile_rows as hive_nhwc_group_norm_stats; NULL / 0: own statistics). */
+int hive_resnet_stem_conv_gn(hive_ctx *ctx, const void *d_x, int dtype, int N, int H, int W, const void *d_w, void *d_out, void *d_gn_partial,
+                             int64_t gn_partial_floats, int *gn_tile_rows);
+int hive_nhwc_group_norm_relu_maxpool(hive_ctx *ctx, const void *d_x, int dtype, int N, int H, int W, int C, int G, const void *d_gamma,
+                                      const void *d_beta, float eps, void *d_out, const void *d_gn_partial, int gn_tile_rows);
 
 /* ---- the whole DPT-Hybrid network behind one handle ------------------------------------------------------------------------
  * dpt.models.DPTDepthModel(path, scale, shift, invert, backbone="vitb_rn50_384", non_negative) + .forward(), with the frame

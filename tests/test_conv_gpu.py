@@ -187,6 +187,33 @@ def test_stem_conv_and_maxpool_match_torch(gpu_ctx, half, n, h, w):
     got_p = pool(y)
     assert got_p.shape == ref_p.shape and got_p.is_contiguous(memory_format=torch.channels_last)
     assert torch.equal(got_p.float(), ref_p), "max pooling is exact"
+    # the stem as the network runs it: the GroupNorm's sums out of the convolution's epilogue (whole 8 x 32 tiles only), and
+    # GroupNorm + ReLU + max pool as ONE pass -- bit-identical to the three kernels in sequence on the same statistics
+    from hive_amd.dpt import ops
+    from hive_amd.dpt.models import GroupNormAct
+    norm = GroupNormAct(64)
+    with torch.no_grad():
+        norm.weight.copy_(torch.rand(64, generator=g) + 0.5)
+        norm.bias.copy_(torch.randn(64, generator=g) * 0.2)
+    norm = norm.to(half).cuda().eval()
+    norm.engine = "hip"
+    stats = getattr(out, "hive_gn_stats", None)
+    assert (stats is not None) == (oh % 8 == 0 and ow % 32 == 0), "sums from the epilogue exactly when the map is whole tiles"
+    if stats is not None:
+        partial, tile_rows = stats
+        assert tile_rows == 256
+        rows = out.permute(0, 2, 3, 1).float()  # [n][oh][ow][64]
+        got = partial[: n * (oh // 8) * (ow // 32) * 4 * 64].view(n, oh // 8, ow // 32, 2, 2, 64).double()
+        tiles = rows.double().view(n, oh // 8, 8, ow // 32, 32, 64)
+        assert torch.allclose(got[:, :, :, 0, 0], tiles.sum((2, 4)), rtol=1e-5, atol=1e-2) and torch.allclose(got[:, :, :, 0, 1], (tiles ** 2).sum((2, 4)), rtol=1e-5, atol=1e-2)
+        assert got[:, :, :, 1].abs().max().item() == 0.0
+    with torch.no_grad():
+        for st in ({None, None} if stats is None else (stats, None)):
+            seq = pool(ops.group_norm_act(out, 32, norm.weight, norm.bias, norm.eps, relu=True, engine="hip", stats=st))
+            one = ops.group_norm_relu_maxpool(out, norm, stats=st)
+            assert torch.equal(one, seq), "fused GroupNorm + ReLU + max pool vs the separate kernels"
+        ref_n = pool.__class__(3, 2)(F.relu(F.group_norm(out.float(), 32, norm.weight.float(), norm.bias.float(), norm.eps)))
+    assert (one.float() - ref_n).abs().max().item() <= 4 * _ulp(half) * max(ref_n.abs().max().item(), 1.0)
 
 
 @pytest.mark.parametrize("n,cin,cout,k,stride,h,w", [
