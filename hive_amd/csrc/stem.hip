@@ -21,6 +21,9 @@ using hive_mfma::vec;  // T = __bf16 or _Float16 (the reference's model.half())
 
 namespace {
 
+#ifndef HIVE_STEM_ABLATE
+#define HIVE_STEM_ABLATE 0  // tuning builds: 1 no output stores, 2 no patch loads, 4 no MFMAs
+#endif
 constexpr int ST_TH = 8, ST_TW = 32;                      // output tile
 constexpr int ST_PH = 2 * ST_TH + 5, ST_PW = 2 * ST_TW + 5;  // input patch 21 x 69 pixels
 constexpr int ST_ROW = 240;                               // patch row pitch in elements (69 x 3 = 207, + slack for the 32-wide k-steps; 480 B)
@@ -28,7 +31,8 @@ constexpr int ST_RD = 104;                                // dwords of a patch r
 constexpr int ST_K = 7 * 32;                              // padded K
 constexpr int ST_WP = ST_K + 8;                           // weight row pitch in LDS: 464 B = 116 dwords, 116 mod 64 = 52 -> the 16 rows of a fragment
                                                           // read (16 B per lane) start in 16 distinct 4-dword bank groups (pitch 448 B: 4-way conflicts)
-constexpr int ST_LOADS = (ST_PH * ST_RD + 255) / 256;     // dword loads per thread and patch (9)
+constexpr int ST_RQ = ST_RD / 4;                          // 16-byte quads of a patch row (26)
+constexpr int ST_LOADS = (ST_PH * ST_RQ + 255) / 256;     // 16-byte loads per thread and patch (3)
 
 template <typename T>
 struct StemParams {
@@ -37,6 +41,7 @@ struct StemParams {
     T *out;       // [N][Ho][Wo][64]
     int H, W, Ho, Wo, pad_t, pad_l;
     int tiles_x, tiles_y, n_tiles;
+    int run;            // consecutive tiles a workgroup takes at a time (and sums before it writes a row of gn_partial): divides tiles_x * tiles_y
     float *gn_partial;  // or nullptr: [tile][2][2][64] sums / sums of squares of the tile's (rounded) outputs -- the layout of conv.hip's
                         // GroupNorm partials with 256-pixel "tiles" (hive_nhwc_group_norm_stats reads them); only whole tiles (Ho % 8 == 0, Wo % 32 == 0)
 };
@@ -59,14 +64,20 @@ __device__ __forceinline__ float stem_row_total(float v) {  // sum over the 16 l
 // current one run.  Round 3: 729 -> see DESIGN 5.6 (one workgroup per tile, weights re-read per tile, 2-byte patch loads, 4-way LDS
 // conflicts on the weight fragments).
 template <typename T>
-__global__ __launch_bounds__(256) void stem_conv_kernel(StemParams<T> p) {
+__global__ __launch_bounds__(256, 3) void stem_conv_kernel(StemParams<T> p) {  // 3 waves per SIMD: three workgroups per CU (41 KB of LDS each)
     __shared__ __attribute__((aligned(16))) T patch[ST_PH * ST_ROW + 64];
     __shared__ __attribute__((aligned(16))) T wl[64 * ST_WP];
     __shared__ float wsum[4][2][64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x;
+    // Output channel of accumulator row (nt, fq, e) -- row nt 16 + fq 4 + e of the weight tile in LDS: (nt >> 1) 32 + fq 8 + (nt & 1) 4 + e.
+    // With this permutation of the weight rows a lane holds 8 CONSECUTIVE channels per fragment pair (nt = 2 a, 2 a + 1) and the four
+    // lanes fq of a pixel 64 contiguous bytes: the tile leaves in 8 stores of 16 bytes per lane on whole 64-byte sectors instead of 16
+    // of 8 bytes on half sectors (the kernel is bound by its vector-memory instructions: tools/probe_stem.py with the tuning builds).
     for (int i = tid; i < 64 * ST_K / 8; i += 256) {  // weights: 64 x 224 = 28 KiB, 16 bytes per thread and pass
         const int row = i / (ST_K / 8), c8 = i - row * (ST_K / 8);
-        *reinterpret_cast<uint4 *>(wl + row * ST_WP + c8 * 8) = reinterpret_cast<const uint4 *>(p.w)[i];
+        const int nt = row >> 4, f4 = (row >> 2) & 3, e = row & 3;
+        const int ch = (nt >> 1) * 32 + f4 * 8 + (nt & 1) * 4 + e;
+        *reinterpret_cast<uint4 *>(wl + row * ST_WP + c8 * 8) = reinterpret_cast<const uint4 *>(p.w)[ch * (ST_K / 8) + c8];
     }
     if (tid < 64) patch[ST_PH * ST_ROW + tid] = (T)0.0f;
     // elements 208 .. 239 of every patch row are never loaded but are read (against zero weights): zero, not whatever LDS held
@@ -76,49 +87,79 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(StemParams<T> p) {
     }
     const bool even = (p.W % 2 == 0) && (p.pad_l % 2 == 0);  // dword-aligned patch rows
     const int per_img = p.tiles_x * p.tiles_y;
-    uint32_t regs[ST_LOADS];
-    auto fetch = [&](int tile) {  // the tile's patch -> registers (dword i of the patch: row i / 104, elements 2 (i % 104), + 1)
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    typedef uint32_t u4u __attribute__((ext_vector_type(4), aligned(4)));  // global_load_dwordx4 needs dword alignment only
+    u4 regs[ST_LOADS];
+    auto fetch = [&](int tile) {  // the tile's patch -> registers: quad i = row i / 26, dwords 4 (i % 26) .. + 3 (elements 8 (i % 26) .. + 7)
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));  // (opaque per call: see the tile loop)
         const int img = tile / per_img, t = tile - img * per_img;
         const int oy0 = (t / p.tiles_x) * ST_TH, ox0 = (t % p.tiles_x) * ST_TW;
         const int iy0 = 2 * oy0 - p.pad_t, ix0 = 2 * ox0 - p.pad_l;
         const T *xin = p.x + (size_t)img * p.H * p.W * 3;
         const bool inside = iy0 >= 0 && iy0 + ST_PH <= p.H && ix0 >= 0 && ix0 + (2 * ST_RD + 2) / 3 <= p.W;  // (workgroup-uniform)
-        if (even && inside) {
+        if (HIVE_STEM_ABLATE & 2) {
+#pragma unroll
+            for (int k = 0; k < ST_LOADS; ++k) regs[k] = u4{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
+        } else if (even && inside) {
             const uint32_t *base = reinterpret_cast<const uint32_t *>(xin + ((size_t)iy0 * p.W + ix0) * 3);
             const int row_dwords = p.W * 3 / 2;
 #pragma unroll
             for (int k = 0; k < ST_LOADS; ++k) {
-                const int i = tid + 256 * k, r = i / ST_RD, d = i - r * ST_RD;
-                regs[k] = (k + 1 < ST_LOADS || i < ST_PH * ST_RD) ? base[(size_t)r * row_dwords + d] : 0u;
+                const int i = tid + 256 * k, r = i / ST_RQ, d = i - r * ST_RQ;
+                regs[k] = u4{0u, 0u, 0u, 0u};
+                if (k + 1 < ST_LOADS || i < ST_PH * ST_RQ) regs[k] = *reinterpret_cast<const u4u *>(base + (size_t)r * row_dwords + 4 * d);
             }
         } else {
 #pragma unroll
             for (int k = 0; k < ST_LOADS; ++k) {
-                const int i = tid + 256 * k, r = i / ST_RD, d = i - r * ST_RD;
-                T v[2];
+                const int i = tid + 256 * k, r = i / ST_RQ, d = i - r * ST_RQ;
+                T v[8];
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int e = 2 * d + h, col = e / 3, c = e - col * 3;
+                for (int h = 0; h < 8; ++h) {
+                    const int e = 8 * d + h, col = e / 3, c = e - col * 3;
                     const int iy = iy0 + r, ix = ix0 + col;
                     v[h] = (T)0.0f;
                     if (r < ST_PH && e < ST_PW * 3 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) v[h] = xin[((size_t)iy * p.W + ix) * 3 + c];
                 }
-                regs[k] = *reinterpret_cast<const uint32_t *>(v);
+                regs[k] = *reinterpret_cast<const u4 *>(v);
             }
         }
     };
-    int tile = blockIdx.x;
-    if (tile < p.n_tiles) fetch(tile);
-    const int fr = lane & 15, fq = lane >> 4;
-    for (; tile < p.n_tiles; tile += gridDim.x) {
+    auto flush_sums = [&](int run_idx) {  // the four waves' sums of a run of tiles (in wsum since its last tile's MFMAs) -> its row of gn_partial
+        if (tid < 128) {
+            const int which = tid >> 6, c = tid & 63;
+            const float a = ((wsum[0][which][c] + wsum[1][which][c]) + wsum[2][which][c]) + wsum[3][which][c];
+            p.gn_partial[((size_t)run_idx * 4 + which) * 64 + c] = a;       // h = 0: the run's (only) image
+            p.gn_partial[((size_t)run_idx * 4 + 2 + which) * 64 + c] = 0.f;  // h = 1
+        }
+    };
+    // tiles in runs of p.run consecutive ones (same image); the workgroup walks runs blockIdx.x, + gridDim.x, ...
+    const int n_runs = p.n_tiles / p.run;
+    int run_idx = blockIdx.x, in_run = 0, pending = -1;
+    if (run_idx < n_runs) fetch(run_idx * p.run);
+    f32x4 rs[4], rq[4];  // this lane's running sums over the run: channels of accumulator rows (nt, fq, 0..3), its pixels
+    for (; run_idx < n_runs;) {
+        const int tile = run_idx * p.run + in_run;
+        const bool last_of_run = in_run + 1 == p.run;
+        const int next_tile = last_of_run ? (run_idx + (int)gridDim.x) * p.run : tile + 1;
+        // the thread index made opaque per tile: otherwise every lane-constant below (LDS and store addresses) is computed once in front of
+        // the loop and spilled (40 registers at three waves per SIMD)
+        int tix = tid;
+        asm volatile("" : "+v"(tix));
+        const int lane = tix & 63, wave = __builtin_amdgcn_readfirstlane(tix >> 6), fr = lane & 15, fq = lane >> 4;
         __syncthreads();  // everyone finished with the previous tile's patch (and, the first time, the weights are in LDS)
 #pragma unroll
         for (int k = 0; k < ST_LOADS; ++k) {
-            const int i = tid + 256 * k, r = i / ST_RD, d = i - r * ST_RD;
-            if (k + 1 < ST_LOADS || i < ST_PH * ST_RD) reinterpret_cast<uint32_t *>(patch)[r * (ST_ROW / 2) + d] = regs[k];
+            const int i = tix + 256 * k, r = i / ST_RQ, d = i - r * ST_RQ;
+            if (k + 1 < ST_LOADS || i < ST_PH * ST_RQ) *reinterpret_cast<u4 *>(reinterpret_cast<uint32_t *>(patch) + r * (ST_ROW / 2) + 4 * d) = regs[k];
+        }
+        if (pending >= 0) {  // between the two barriers: wsum is complete and nobody writes it yet
+            flush_sums(pending);
+            pending = -1;
         }
         __syncthreads();
-        if (tile + (int)gridDim.x < p.n_tiles) fetch(tile + gridDim.x);  // in flight during the MFMAs and the stores below
+        if (next_tile < p.n_tiles) fetch(next_tile);  // in flight during the MFMAs and the stores below
         const int img = tile / per_img, t = tile - img * per_img;
         const int oy0 = (t / p.tiles_x) * ST_TH, ox0 = (t % p.tiles_x) * ST_TW;
         // wave w: output rows 2 w, 2 w + 1 of the tile; m fragment mt: row 2 w + (mt >> 1), columns 16 (mt & 1) .. + 15
@@ -127,7 +168,7 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(StemParams<T> p) {
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
+#pragma unroll 1  // (unrolled, the compiler reads all seven kernel rows' fragments ahead: 247 registers, or 82 spilled at three waves per SIMD)
         for (int ky = 0; ky < 7; ++ky) {
             vec<T, 8> wf[4], af[4];
 #pragma unroll
@@ -144,20 +185,25 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(StemParams<T> p) {
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) acc[nt][mt] = hive_mfma::mfma16(wf[nt], af[mt], acc[nt][mt]);
+                for (int nt = 0; nt < 4; ++nt) {
+                    if (HIVE_STEM_ABLATE & 4)
+                        acc[nt][mt][0] += (float)wf[nt][0] + (float)af[mt][0];
+                    else
+                        acc[nt][mt] = hive_mfma::mfma16(wf[nt], af[mt], acc[nt][mt]);
+                }
         }
-        // a lane owns 4 consecutive channels (16 nt + 4 fq ..) of pixel (2 w + (mt >> 1), 16 (mt & 1) + fr)
+        // a lane owns channels 32 a + 8 fq .. + 7 (a = 0, 1: accumulators nt = 2 a, 2 a + 1) of pixel (2 w + (mt >> 1), 16 (mt & 1) + fr)
         T *out = p.out + (size_t)img * p.Ho * p.Wo * 64;
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
             const int oy = oy0 + 2 * wave + (mt >> 1), ox = ox0 + 16 * (mt & 1) + fr;
-            if (oy < p.Ho && ox < p.Wo) {
+            if (oy < p.Ho && ox < p.Wo && (!(HIVE_STEM_ABLATE & 1) || acc[0][mt][0] == 12345.678f)) {
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
-                    vec<T, 4> ov;
+                for (int a = 0; a < 2; ++a) {
+                    vec<T, 8> ov;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) ov[j] = (T)acc[nt][mt][j];
-                    *reinterpret_cast<vec<T, 4> *>(out + ((size_t)oy * p.Wo + ox) * 64 + nt * 16 + fq * 4) = ov;
+                    for (int j = 0; j < 4; ++j) ov[j] = (T)acc[2 * a][mt][j], ov[4 + j] = (T)acc[2 * a + 1][mt][j];
+                    *reinterpret_cast<vec<T, 8> *>(out + ((size_t)oy * p.Wo + ox) * 64 + a * 32 + fq * 8) = ov;
                 }
             }
         }
@@ -166,34 +212,45 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(StemParams<T> p) {
             ones[0] = ones[1] = (T)1.0f;
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
-                f32x4 sv = f32x4{0.f, 0.f, 0.f, 0.f}, qv = sv;
+                if (in_run == 0) rs[nt] = rq[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int mt = 0; mt < 4; mt += 2)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         vec<T, 2> y;
                         y[0] = (T)acc[nt][mt][e], y[1] = (T)acc[nt][mt + 1][e];
-                        sv[e] = stem_dot2(y, ones, sv[e]);
-                        qv[e] = stem_dot2(y, y, qv[e]);
+                        rs[nt][e] = stem_dot2(y, ones, rs[nt][e]);
+                        rq[nt][e] = stem_dot2(y, y, rq[nt][e]);
                     }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    sv[e] = stem_row_total(sv[e]);
-                    qv[e] = stem_row_total(qv[e]);
-                }
-                if (fr == 0) {
-                    *reinterpret_cast<f32x4 *>(&wsum[wave][0][nt * 16 + fq * 4]) = sv;
-                    *reinterpret_cast<f32x4 *>(&wsum[wave][1][nt * 16 + fq * 4]) = qv;
-                }
             }
-            __syncthreads();
-            if (tid < 128) {
-                const int which = tid >> 6, c = tid & 63;
-                const float a = ((wsum[0][which][c] + wsum[1][which][c]) + wsum[2][which][c]) + wsum[3][which][c];
-                p.gn_partial[((size_t)tile * 4 + which) * 64 + c] = a;       // h = 0: the tile's (only) image
-                p.gn_partial[((size_t)tile * 4 + 2 + which) * 64 + c] = 0.f;  // h = 1
+            if (last_of_run) {  // (workgroup-uniform) the 16 pixel lanes of a row, then -- behind the next barrier -- the four waves
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    f32x4 sv, qv;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        sv[e] = stem_row_total(rs[nt][e]);
+                        qv[e] = stem_row_total(rq[nt][e]);
+                    }
+                    if (fr == 0) {
+                        const int ch = (nt >> 1) * 32 + fq * 8 + (nt & 1) * 4;
+                        *reinterpret_cast<f32x4 *>(&wsum[wave][0][ch]) = sv;
+                        *reinterpret_cast<f32x4 *>(&wsum[wave][1][ch]) = qv;
+                    }
+                }
+                pending = run_idx;
             }
         }
+        if (last_of_run) {
+            run_idx += gridDim.x;
+            in_run = 0;
+        } else {
+            ++in_run;
+        }
+    }
+    if (pending >= 0) {
+        __syncthreads();
+        flush_sums(pending);
     }
 }
 
@@ -247,12 +304,15 @@ int launch_stem(hive_ctx *ctx, const void *d_x, int N, int H, int W, const void 
     HIVE_REQUIRE(ctx, tiles < (1ll << 31), "resnet_stem_conv: %lld tiles", tiles);
     p.n_tiles = (int)tiles;
     if (gn_tile_rows) *gn_tile_rows = 0;
-    if (d_gn_partial && gn_tile_rows && p.Ho % ST_TH == 0 && p.Wo % ST_TW == 0) {  // whole tiles: a tile is 256 pixels of ONE image
-        HIVE_REQUIRE(ctx, tiles * 4 * 64 <= gn_partial_floats, "resnet_stem_conv_gn: gn_partial holds %lld floats, %lld needed", gn_partial_floats, tiles * 4 * 64);
+    const int per_img = p.tiles_x * p.tiles_y;
+    p.run = per_img % 4 == 0 ? 4 : (per_img % 2 == 0 ? 2 : 1);  // the sums' cross-lane reduction once per run: it cost a quarter of the kernel per tile
+    if (d_gn_partial && gn_tile_rows && p.Ho % ST_TH == 0 && p.Wo % ST_TW == 0) {  // whole tiles: a run is 256 * run pixels of ONE image
+        HIVE_REQUIRE(ctx, tiles / p.run * 4 * 64 <= gn_partial_floats, "resnet_stem_conv_gn: gn_partial holds %lld floats, %lld needed", gn_partial_floats,
+                     tiles / p.run * 4 * 64);
         p.gn_partial = d_gn_partial;
-        *gn_tile_rows = ST_TH * ST_TW;
+        *gn_tile_rows = ST_TH * ST_TW * p.run;
     }
-    const unsigned grid = (unsigned)std::min<long long>(tiles, (long long)ctx->num_cus * 3);  // persistent: 3 workgroups of 41 KB LDS per CU
+    const unsigned grid = (unsigned)std::min<long long>(tiles / p.run, (long long)ctx->num_cus * 3);  // persistent: 3 workgroups of 41 KB LDS per CU
     hipLaunchKernelGGL(stem_conv_kernel<T>, dim3(grid), dim3(256), 0, ctx->stream, p);
     HIVE_CHECK_HIP(ctx, hipGetLastError());
     return HIVE_OK;
