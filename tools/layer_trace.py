@@ -53,8 +53,31 @@ def parse(out):
     print(f"{len(seq)} launches, {tot / 1e3:.2f} ms of kernels, {span / 1e3:.2f} ms first start -> last end")
 
 
+
+
+def gaps(trace_csv, tail_ms=400.0):
+    """Idle intervals of the device (no kernel of any stream running) over the last `tail_ms` of a kernel trace: where a step loses time
+    to the host.  Usage: python tools/layer_trace.py gaps <kernel_trace.csv> [tail_ms]"""
+    rows = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(trace_csv))))
+    t_end = max(r[1] for r in rows)
+    rows = [r for r in rows if r[0] >= t_end - tail_ms * 1e6]
+    busy_until, idle, big = rows[0][0], 0, []
+    for s, e, name in rows:
+        if s > busy_until:
+            idle += s - busy_until
+            if s - busy_until > 20000:
+                big.append(((s - busy_until) / 1e3, short(name)))
+        busy_until = max(busy_until, e)
+    span = (rows[-1][1] - rows[0][0]) / 1e6
+    print(f"last {span:.1f} ms: idle {idle / 1e6:.2f} ms ({100 * idle / 1e6 / span:.1f} %), {len(big)} gaps > 20 us")
+    for g, n in sorted(big, reverse=True)[:15]:
+        print(f"  {g:8.1f} us before {n}")
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "run":
         run(int(sys.argv[2]), sys.argv[3])
+    elif sys.argv[1] == "gaps":
+        gaps(sys.argv[2], float(sys.argv[3]) if len(sys.argv) > 3 else 400.0)
     else:
         parse(sys.argv[2])
