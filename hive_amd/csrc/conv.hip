@@ -40,7 +40,7 @@
 #define HIVE_CONV_ABLATE 0
 #endif
 #ifndef HIVE_CONV_AHEAD
-#define HIVE_CONV_AHEAD 2  // fragment rows the shortcut loads of the epilogue run ahead
+#define HIVE_CONV_AHEAD 4  // fragment rows the shortcut loads of the epilogue run ahead (ONE shortcut; with two: half as many)
 #endif
 
 using hive_mfma::f32x4;
@@ -89,7 +89,7 @@ __device__ __forceinline__ float gn_affine_exact(float x, float rstd, float gamm
     return x * a + b;
 }
 
-template <typename T, int MT, int GN>
+template <typename T, int MT, int GN, int NRES = 1>
 __device__ __forceinline__ void conv_epilogue(const ConvParams<T> &p, f32x4 (&acc)[4][MT], int m_base, int n_base, unsigned char *stage, int lane,
                                               int boundary) {
     // `lane` made opaque per tile: otherwise the compiler computes every lane-constant of the epilogue (row numbers, LDS addresses) once in
@@ -112,18 +112,20 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams<T> &p, f32x4 (&ac
         gmean[0] = st[0], grstd[0] = st[1];
         if (img0 + 1 < n_img) gmean[1] = st[2 * p.gn_G], grstd[1] = st[2 * p.gn_G + 1];
     }
-    // the shortcut / skip rows: loaded one fragment row AHEAD of their use (two register sets), so that a load's trip to memory runs under
-    // the previous fragment row's turn through LDS instead of in front of every store (as gemm_store_rows in vit.hip; measured on the
-    // second pass of the ResNetV2 conv3 at 120 x 160: 660 -> see DESIGN 5.3).  A residual may BE the output: every element is read by
-    // the lane that later writes it and rows of mt + 1 are read before rows of mt are written.
-    constexpr int AHEAD = HIVE_CONV_AHEAD;
-    vec<T, 8> rs1[AHEAD + 1][2], rs2[AHEAD + 1][2];
+    // the shortcut / skip rows: loaded AHEAD fragment rows before their use (AHEAD + 1 register sets), so that a load's trip to memory runs
+    // under the previous rows' turns through LDS instead of in front of every store (as gemm_store_rows in vit.hip).  A fragment row's turn
+    // is ~0.5 us, a trip to HBM under load 2 us: with one row ahead the second pass of conv3 at 120 x 160 took 660 us, with two 600, with
+    // FOUR (8 KiB per wave, 16 MB over the chip in flight) 500.  NRES = 2 (the residual unit that adds its input AND the path from above:
+    // twice the bytes per row) runs two ahead -- its six register sets are what four ahead costs with one shortcut.  A residual may BE the
+    // output: every element is read by the lane that later writes it and rows of mt + AHEAD are read before rows of mt are written.
+    constexpr int AHEAD = NRES == 2 ? HIVE_CONV_AHEAD / 2 : HIVE_CONV_AHEAD;
+    vec<T, 8> rs1[AHEAD + 1][2], rs2[NRES == 2 ? AHEAD + 1 : 1][2];
     const int row_in_frag = lane >> 3;
     auto pre = [&](int mt, int j) {
         const int m = min(m_base + mt * 16 + 8 * j + row_in_frag, p.M - 1);
         const size_t off = (size_t)m * p.Cout + n;
         if (GN != 1 && p.res1) rs1[mt % (AHEAD + 1)][j] = *reinterpret_cast<const vec<T, 8> *>(p.res1 + off);
-        if (GN == 0 && p.res2) rs2[mt % (AHEAD + 1)][j] = *reinterpret_cast<const vec<T, 8> *>(p.res2 + off);
+        if (GN == 0 && NRES == 2) rs2[mt % (AHEAD + 1)][j] = *reinterpret_cast<const vec<T, 8> *>(p.res2 + off);
     };
     hive_mfma::staged_rows<MT, AHEAD>(stage, acc, lane, pre, [&](int r, int, const f32x4 &lo, const f32x4 &hi, int mt, int jrow) {
         const int m = m_base + r;
@@ -137,7 +139,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams<T> &p, f32x4 (&ac
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] += (float)rs[j];
         }
-        if (GN == 0 && p.res2) {
+        if (GN == 0 && NRES == 2) {
             const vec<T, 8> rs = rs2[mt % (AHEAD + 1)][jrow];
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] += (float)rs[j];
@@ -285,7 +287,9 @@ __global__ __launch_bounds__(512, 1) void conv_kernel(ConvParams<T> p) {
     constexpr int W_GROUPS = TN / 8, GROUPS = A_GROUPS + W_GROUPS, PER_WAVE = GROUPS / 8;
     constexpr int STAGE_BYTES = GROUPS * 1024;
     constexpr int WN = TN / 64, WM = 8 / WN, RW = TM / WM, MT = RW / 16;  // waves along N / M, rows per wave, M fragments (TN = 64: 8 x 1 waves of 32 x 64)
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x;
+    int lane = tid & 63;  // made opaque once per tile (top of the tile loop): the lane-constants of the stage pieces are then recomputed per tile
+                          // instead of living -- spilled, with both skip connections' register sets in the epilogue -- across the whole loop
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave / WN, wc = wave % WN;
     // PERSISTENT workgroups, XCD-aware (one per CU: the two stages take 96-128 KiB of LDS): the grid is a multiple of 8;
@@ -308,11 +312,14 @@ __global__ __launch_bounds__(512, 1) void conv_kernel(ConvParams<T> p) {
         const T *pbase[A_PW];
     };
     int a_chunk[A_PW];
+    auto lane_constants = [&]() {
 #pragma unroll
-    for (int j = 0; j < A_PW; ++j) {
-        const int row = (wave + 8 * j) * 8 + (lane >> 3);
-        a_chunk[j] = ((lane & 7) ^ ((row >> 1) & 7)) * 8;  // source-side swizzle: LDS slot (lane & 7) receives this chunk
-    }
+        for (int j = 0; j < A_PW; ++j) {
+            const int row = (wave + 8 * j) * 8 + (lane >> 3);
+            a_chunk[j] = ((lane & 7) ^ ((row >> 1) & 7)) * 8;  // source-side swizzle: LDS slot (lane & 7) receives this chunk
+        }
+    };
+    lane_constants();
     auto setup = [&](int t, Tile &tile) {
         tile.m0 = (t / tiles_n) * TM;
         tile.n0 = (t % tiles_n) * TN;
@@ -327,7 +334,6 @@ __global__ __launch_bounds__(512, 1) void conv_kernel(ConvParams<T> p) {
             tile.pbase[j] = p.x + (((long long)img * p.H + tile.py[j]) * p.W + tile.px[j]) * p.Cin + a_chunk[j];  // may point before the image: used only when inside
         }
     };
-    const int w_lane_row = lane >> 3;
 
     // one LDS-DMA wave-instruction of a stage: j < A_PW an A group (8 output pixels x 128 B of one tap), else a W group
     auto issue_piece = [&](const Tile &tile, int stage, int tap, int cc, int j) {
@@ -341,7 +347,7 @@ __global__ __launch_bounds__(512, 1) void conv_kernel(ConvParams<T> p) {
             __builtin_amdgcn_global_load_lds((const void *)g, (__attribute__((address_space(3))) void *)(st + (wave + 8 * j) * 1024), 16, 0, 0);
         } else {
             const int grp = wave + 8 * (j - A_PW);  // W group: rows grp * 8 .. + 7 of the weight tile
-            const int row = grp * 8 + w_lane_row;
+            const int row = grp * 8 + (lane >> 3);
             const int chunk = (lane & 7) ^ ((row >> 1) & 7);
             const T *g = p.w + (size_t)(tile.n0 + row) * K + tap * p.Cin + cc * BK + chunk * 8;
             __builtin_amdgcn_global_load_lds((const void *)g, (__attribute__((address_space(3))) void *)(st + (A_GROUPS + grp) * 1024), 16, 0, 0);
@@ -357,9 +363,11 @@ __global__ __launch_bounds__(512, 1) void conv_kernel(ConvParams<T> p) {
     setup(run0 + tl, tile);
 #pragma unroll
     for (int j = 0; j < PER_WAVE; ++j) issue_piece(tile, 0, 0, 0, j);
-    const int fr = lane & 15, fq = lane >> 4;
     int buf = 0;  // LDS stage of the current K-step (alternates along the whole stream)
     for (;;) {
+        asm volatile("" : "+v"(lane));
+        lane_constants();
+        const int fr = lane & 15, fq = lane >> 4;
         const bool has_next = tl + per_xcd < run_n;
         const int em0 = tile.m0, en0 = tile.n0;  // the tile being multiplied (for its epilogue)
         f32x4 acc[4][MT];  // acc[nt][mt] = W_frag . A_frag^T : rows = output channel, cols = pixel
@@ -396,7 +404,12 @@ __global__ __launch_bounds__(512, 1) void conv_kernel(ConvParams<T> p) {
         }
         unsigned char *stage = lds + 2 * STAGE_BYTES + wave * 4096;
         const int hw = p.Ho * p.Wo, boundary = (em0 / hw + 1) * hw;  // first row of the tile's second image
-        if (!(HIVE_CONV_ABLATE & 1) && !(GN == 1 && p.stats_only)) conv_epilogue<T, MT, GN>(p, acc, em0 + wr * RW, en0 + wc * 64, stage, lane, boundary);
+        if (!(HIVE_CONV_ABLATE & 1) && !(GN == 1 && p.stats_only)) {
+            if (GN == 0 && p.res2)  // (kernel-uniform) both skip connections
+                conv_epilogue<T, MT, GN, 2>(p, acc, em0 + wr * RW, en0 + wc * 64, stage, lane, boundary);
+            else
+                conv_epilogue<T, MT, GN, 1>(p, acc, em0 + wr * RW, en0 + wc * 64, stage, lane, boundary);
+        }
         if (GN == 1 && !(HIVE_CONV_ABLATE & 8)) {
             __builtin_amdgcn_wave_barrier();  // behind the epilogue's last reads of this LDS
             gn_sums_from_acc<T, MT>(p, acc, em0 + wr * RW, en0 + wc * 64, lane, boundary, reinterpret_cast<float *>(stage));

@@ -1,5 +1,7 @@
 #!/bin/bash
-# Round-3 profile set (GPU box: gpurun -- bash tools/profile_r03.sh [parts]); parts = any of: trace pmc valu small mfma (default: all but mfma)
+# Round-3 profile set (GPU box: gpurun -- bash tools/profile_r03.sh [parts]); parts = any of: trace pmc valu small fp16 layers (default: trace pmc valu small)
+#   fp16 : the default bench command with --dtype fp16 (the reference's model.half())                                        -> .../fp16.log
+#   layers: launch-ordered kernel times of one forward at the bench batch (tools/layer_trace.sh)                              -> gpurun_out/layer_trace/forward.csv
 #   trace: rocprofv3 --kernel-trace --stats of the default bench command, and of the same with --no-overlap  -> gpurun_out/prof_r03/trace{,_no_overlap}
 #   pmc  : FETCH_SIZE / WRITE_SIZE of the integrate kernels, separate passes, bench scene (DPT depth) and room scene (analytic depth,
 #          consecutive frames: tools/probe_integrate.py --yaw-step 2.4)                          -> gpurun_out/prof_r03/pmc_{fetch,write}_{bench,room}
@@ -37,5 +39,7 @@ if has small; then
   timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/small -- python3 $GRAFT_REPO_ROOT/tools/probe_small_kernels.py > $OUT/small.json 2> $OUT/small.err || echo "small failed"
   find $OUT/small -name "*kernel_trace.csv" -delete
 fi
+if has fp16; then timeout -k 10 400 python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --dtype fp16 > $OUT/fp16.log 2>&1 || echo "fp16 failed"; fi
+if has layers; then timeout -k 10 300 bash $GRAFT_REPO_ROOT/tools/layer_trace.sh 107 bf16 || echo "layers failed"; fi
 for f in $(find $OUT -name "*counter_collection.csv"); do (head -1 $f; grep -E "integrate_kernel|integrate_multi_kernel" $f) > $f.tmp && mv $f.tmp $f; done
 du -sh $OUT; echo profile done

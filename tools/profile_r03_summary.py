@@ -51,7 +51,7 @@ def counters(sub):
 stats = newest("trace", "*kernel_stats.csv")
 if stats:
     shutil.copy(stats, os.path.join(dst, "r03_kernel_stats.csv"))
-for log, name in (("trace.log", "r03_bench_line.json"), ("trace_no_overlap.log", "r03_bench_line_no_overlap.json")):
+for log, name in (("trace.log", "r03_bench_line.json"), ("trace_no_overlap.log", "r03_bench_line_no_overlap.json"), ("fp16.log", "r03_bench_line_fp16.json")):
     lp = os.path.join(src, log)
     if os.path.exists(lp):
         lines = [l for l in open(lp) if l.startswith('{"metric"')]
@@ -101,3 +101,7 @@ if small:
 sj = os.path.join(src, "small.json")
 if os.path.exists(sj) and os.path.getsize(sj) > 0:
     shutil.copy(sj, os.path.join(dst, "r03_small_kernels.json"))
+
+for srcf, name in ((os.path.join(root, "gpurun_out", "pmc_vit_r03.json"), "r03_mfma_pmc.json"), (os.path.join(root, "gpurun_out", "layer_trace", "forward.csv"), "r03_forward_trace.csv")):
+    if os.path.exists(srcf) and os.path.getsize(srcf) > 0 and os.path.getmtime(srcf) > os.path.getmtime(os.path.join(dst, name)) if os.path.exists(os.path.join(dst, name)) else os.path.exists(srcf):
+        shutil.copy(srcf, os.path.join(dst, name))
