@@ -35,6 +35,9 @@ using hive_mfma::f32x16;
 using hive_mfma::vec;  // vec<T, 8>: 8 elements of the 16-bit element type T = __bf16 (north_star's contract) or _Float16 (what the
                        // reference runs, /root/reference/hive/dataset_adaptors.py:1394-1401, 1415-1417): same MFMA shapes and rates
 
+#ifndef HIVE_GEMM_AHEAD
+#define HIVE_GEMM_AHEAD 3
+#endif
 enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RESIDUAL = 2, EPI_QKV = 3 };
 
 // v^T key order.  The attention's P.V step holds the probabilities of a lane in accumulator order: its 8 k-slots of one
@@ -154,14 +157,15 @@ __device__ __forceinline__ void gemm_store_rows(const GemmParams<T> &p, const f3
     // residual rows: loaded one fragment row ahead (two register sets), not in front of each store.  The residual may BE the output
     // (x += proj(...)): every element is read by the lane that later writes it, rows of fragment row mt + 1 are read before rows of
     // mt are written -- no hazard, but the compiler cannot know, so the order is set by hand.
-    vec<T, 8> rs[2][2];
+    constexpr int AHEAD = HIVE_GEMM_AHEAD;  // fragment rows the residual loads run ahead (a row's turn is ~0.5 us, a trip to HBM under load 2 us: conv.hip)
+    vec<T, 8> rs[AHEAD + 1][2];
     auto pre = [&](int mt, int j) {
         if (EPI == EPI_BIAS_RESIDUAL) {
             const int m = min(m_base + mt * 16 + 8 * j + rr, p.M - 1);
-            rs[mt & 1][j] = *reinterpret_cast<const vec<T, 8> *>(p.residual + (size_t)m * p.ldc + n);
+            rs[mt % (AHEAD + 1)][j] = *reinterpret_cast<const vec<T, 8> *>(p.residual + (size_t)m * p.ldc + n);
         }
     };
-    hive_mfma::staged_rows<MT>(stage, acc, lane, pre, [&](int r, int, const f32x4 &lo, const f32x4 &hi, int mt, int j) {
+    hive_mfma::staged_rows<MT, AHEAD>(stage, acc, lane, pre, [&](int r, int, const f32x4 &lo, const f32x4 &hi, int mt, int j) {
         const int m = m_base + r;
         if (m >= p.M) return;
         float o[8] = {lo[0] + b0.x, lo[1] + b0.y, lo[2] + b0.z, lo[3] + b0.w, hi[0] + b1.x, hi[1] + b1.y, hi[2] + b1.z, hi[3] + b1.w};
@@ -179,7 +183,7 @@ __device__ __forceinline__ void gemm_store_rows(const GemmParams<T> &p, const f3
         }
         if (EPI == EPI_BIAS_RESIDUAL) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) o[k] += (float)rs[mt & 1][j][k];
+            for (int k = 0; k < 8; ++k) o[k] += (float)rs[mt % (AHEAD + 1)][j][k];
         }
         vec<T, 8> ov;
 #pragma unroll
