@@ -384,7 +384,7 @@ def main():
         dpt_ms = e0.elapsed_time(e1) / reps
         flops = count_flops(H, W)
         tflops = flops["total"] * fr.shape[0] / (dpt_ms * 1e-3) / 1e12
-        dpt_roof = {"kernel": "hive_dpt_forward (190 launches: MFMA GEMM / attention / implicit-GEMM convolutions + glue)", "bound": "mfma", "achieved": tflops, "peak": 2500.0,
+        dpt_roof = {"kernel": "hive_dpt_forward (293 launches at 480 x 640: MFMA GEMM / attention / implicit-GEMM convolutions + glue)", "bound": "mfma", "achieved": tflops, "peak": 2500.0,
                     "unit": "TFLOP/s", "frac": tflops / 2500.0, "dtype": args.dtype, "flops_per_frame": flops["total"], "frames": int(fr.shape[0]), "ms_per_batch": dpt_ms,
                     "ms_per_frame": dpt_ms / fr.shape[0], "note": "algorithmic FLOPs (2 x MACs, hive_amd.dpt.models.count_flops) x frames / time of the whole network, "
                     "glue kernels included; per-kernel mfma_busy: profiles/r03_mfma_pmc.json"}
