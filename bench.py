@@ -12,14 +12,17 @@ SURVEY.md 8d) -> preprocess -> DPT-Hybrid (seeded random weights of the real arc
 has surfaces inside the volume; bf16 or --dtype fp16, HIP engine) -> f32 depth tail
 + uint16-mm hand-off -> TSDF integrate.
 
-N > 1 (BASELINE configs[2]: the SAME sequence frame-sharded; `--scaling strong`, default): the K * B frames are split in
-contiguous blocks over the ranks, identical per-frame work to N = 1, then the shared static-scene volume is merged INSIDE the
-timed region:
+N > 1 (BASELINE configs[2]: the same sequence frame-sharded over the ranks, one merge of the shared static-scene volume): the frames
+are independent units, so the default is WEAK scaling -- the job grows with N: N * K * B frames of the wrapping sequence, rank r
+takes the contiguous block [r K B, (r + 1) K B) in K steps of B frames (per-GPU work = the N = 1 job), no collective on the data
+path, and the shared volume is merged ONCE, inside the timed region ("scaling": "weak"; value = N K B / time).  `--scaling strong`
+splits the SAME K * B frames in contiguous blocks over the ranks instead (config 3 literally: fixed total work; the merge then weighs
+more the shorter the per-rank share).  The merge:
   --merge sum   (default; north_star's design): every rank fuses its block into its own volume; reduce-scatter of the 5
                 accumulator planes -> every rank folds its 1 / N of the voxels -> all-gather of the 3 result planes.
   --merge exact (bit-identical to one GPU): depth + colour frames are all-gathered, every rank integrates all frames in
                 sequence order into its x-slab of the volume, the slabs are all-gathered.
-`--scaling weak` keeps the round-1 mode (every rank runs K full steps on its own sequence, one merge at the end).
+(`--merge exact` is a strong-scaling mode by construction: every rank integrates every frame.)
 Rank 0 prints one JSON line.
 """
 import argparse
@@ -47,7 +50,8 @@ def parse_args():
     ap.add_argument("--frames", type=int, default=150, help="length of the synthetic sequence")
     ap.add_argument("--voxel", type=float, default=0.01, help="0.01 -> 512^3 over the 5.12 m volume")
     ap.add_argument("--engine", default="hip", choices=["hip", "torch"], help="'torch' = PyTorch-op ViT blocks (comparison only)")
-    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"], help="N > 1: shard the same job (strong) or repeat it per rank (weak)")
+    ap.add_argument("--scaling", default="weak", choices=["strong", "weak"],
+                    help="N > 1: weak (default) = N x K x B frames, a contiguous block of K steps per rank; strong = the same K x B frames split over the ranks")
     ap.add_argument("--merge", default="sum", choices=["sum", "exact"], help="N > 1: how the shared volume is merged")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"], help="16-bit type of the network (north_star: bf16; the reference runs fp16)")
     ap.add_argument("--no-overlap", action="store_true", help="TSDF sweeps on the network's stream (default: on a second stream, under the next batch's network)")
@@ -159,10 +163,10 @@ def main():
     torch.backends.cudnn.benchmark = True
 
     H, W, B, T = 480, 640, args.batch, args.frames
-    strong = world > 1 and args.scaling == "strong"
     exact = world > 1 and args.merge == "exact"
-    # the synthetic sequence (every rank generates the same one in strong mode; its own in weak mode)
-    seq = synthetic.make_sequence(num_frames=T, height=H, width=W, seed=1234 + (0 if strong or world == 1 else rank), yaw_step_deg=360.0 / T)
+    strong = world > 1 and (args.scaling == "strong" or exact)  # (exact: every rank integrates every frame -- fixed total work by construction)
+    # the synthetic sequence: the same one on every rank (the job is a stretch of its wrapping frame index)
+    seq = synthetic.make_sequence(num_frames=T, height=H, width=W, seed=1234, yaw_step_deg=360.0 / T)
     K = seq["K"]
     poses = seq["poses"]
     frames_host = torch.from_numpy(seq["color"]).pin_memory()  # uint8 [T, H, W, 3]
@@ -183,12 +187,15 @@ def main():
     stream = depth_mod.DepthFusionStream(model, volume, K, overlap=overlap)
     feeder = FrameFeeder(frames_host, B, device)
 
-    # the job: frames job[0 .. K * B) of the wrapping sequence; this rank's contiguous block of it
+    # strong: the job is frames [0, K B) of the wrapping sequence, this rank takes its contiguous share of every stretch asked for;
+    # weak: the job is frames [0, N (W + K) B), this rank owns the contiguous block [rank (W + K) B, + (W + K) B) (W warm-up steps first)
     def job_frames(first_step, n_steps):
-        ids = [(first_step * B + j) % T for j in range(n_steps * B)]
         if strong:
+            ids = [(first_step * B + j) % T for j in range(n_steps * B)]
             lo, hi = hdist.shard_range(len(ids), rank, world)
             return ids[lo:hi], [b - a for a, b in (hdist.shard_range(len(ids), r, world) for r in range(world))]
+        base = (rank * (args.warmup + args.steps) + first_step) * B
+        ids = [(base + j) % T for j in range(n_steps * B)]
         return ids, [len(ids)] * world
 
     def batches(ids):
@@ -412,8 +419,11 @@ def main():
     dims = "x".join(str(int(d)) for d in (merger.dims if exact else volume.vol_dim))
     merge_note = ""
     if world > 1:
-        merge_note = (", frames all-gathered, every rank integrates all frames into its x-slab (bit-identical to 1 GPU), slabs all-gathered"
-                      if exact else ", frame-sharded, shared volume merged by reduce-scatter of the 5 accumulator planes + all-gather of the 3 volumes (RCCL)")
+        share = (f"the same {args.steps} x {B} frames split in contiguous blocks over the ranks" if strong
+                 else f"{world} x {args.steps} x {B} frames, a contiguous block of {args.steps} steps per rank")
+        merge_note = (f", {share}, frames all-gathered, every rank integrates all frames into its x-slab (bit-identical to 1 GPU), slabs all-gathered"
+                      if exact else f", frame-sharded ({share}), shared volume merged once by reduce-scatter of the 5 accumulator planes + all-gather of the 3 "
+                                    f"volumes (RCCL), inside the timed region")
     out = {
         "metric": "frames/sec (depth+TSDF integrate) @640x480, 512^3 vol",
         "value": total_frames / elapsed,
