@@ -283,6 +283,50 @@ def test_conv_epilogue_group_norm_statistics(gpu_ctx, half, n, cin, cout, k, str
     assert torch.equal(again.hive_gn_stats[0][:used], partial[:used]), "the epilogue sums are run-to-run identical"
 
 
+def test_conv_gn_leaves_no_sums_behind_a_fused_epilogue(gpu_ctx, half):
+    """hive_nhwc_conv_gn writes the GroupNorm sums for PLAIN epilogues (bias at most): with a ReLU or a shortcut fused into the epilogue it
+    reports tile_rows 0 (the GroupNorm then makes its own pass) and is the ordinary convolution; with a bias the sums are those of the
+    stored (biased, rounded) outputs."""
+    import ctypes
+    from hive_amd import _lib
+    g = torch.Generator(device="cpu").manual_seed(5)
+    n, h, w, cin, cout = 2, 24, 32, 64, 128
+    x = torch.randn(n, h, w, cin, generator=g).to(half).cuda()
+    wt = (torch.randn(cout, 1, 1, cin, generator=g) * 0.2).to(half).cuda()
+    bias = torch.randn(cout, generator=g).to(half).cuda()
+    res = torch.randn(n, h, w, cout, generator=g).to(half).cuda()
+    lib, hnd, code = gpu_ctx.lib, gpu_ctx.handle, _lib.dtype_code(half)
+    nfl = int(lib.hive_nhwc_conv_gn_partial_floats(n * h * w, cout))
+    ref = torch.einsum("nhwc,oc->nhwo", x.float(), wt.view(cout, cin).float())
+    for relu, residual, b in ((0, None, None), (0, None, bias), (1, None, None), (0, res, None)):
+        out = torch.empty(n, h, w, cout, dtype=half, device="cuda")
+        partial = torch.full((nfl,), float("nan"), dtype=torch.float32, device="cuda")
+        rows = ctypes.c_int(-1)
+        gpu_ctx.check(lib.hive_nhwc_conv_gn(hnd, x.data_ptr(), code, n, h, w, cin, cout, 1, 1, 0, 0, h, w, wt.data_ptr(), _lib.ptr(b), relu, _lib.ptr(residual), None,
+                                            out.data_ptr(), None, partial.data_ptr(), nfl, ctypes.byref(rows)))
+        want = ref + (b.float() if b is not None else 0.0) + (residual.float() if residual is not None else 0.0)
+        want = want.clamp_min(0.0) if relu else want
+        assert (out.float() - want).abs().max().item() <= 4 * _ulp(half) * max(want.abs().max().item(), 1.0)
+        if relu or residual is not None:
+            assert rows.value == 0 and torch.isnan(partial).all(), "no sums (and nothing written) behind a fused ReLU / shortcut"
+        else:
+            assert rows.value in (128, 256)
+            tiles = (n * h * w + rows.value - 1) // rows.value
+            got = partial[: tiles * 4 * cout].view(tiles, 2, 2, cout).double()
+            flat = out.float().view(-1, cout).double()
+            per_img = h * w
+            s_ref = torch.zeros(n, cout, dtype=torch.float64, device="cuda")
+            s_got = torch.zeros_like(s_ref)
+            for t in range(tiles):
+                first = (t * rows.value) // per_img
+                s_got[first] += got[t, 0, 0]
+                if first + 1 < n:
+                    s_got[first + 1] += got[t, 1, 0]
+            for i in range(n):
+                s_ref[i] = flat[i * per_img:(i + 1) * per_img].sum(0)
+            assert torch.allclose(s_got, s_ref, rtol=1e-5, atol=1e-2)
+
+
 @pytest.mark.parametrize("n,cin,cout,stride,h,w,with_residual", [
     (3, 64, 256, 1, 20, 24, True),      # conv3 of a stage-1 block: tiles straddle the samples
     (2, 256, 1024, 1, 30, 40, True),    # four N tiles
