@@ -11,6 +11,7 @@
 #include "hive_internal.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 
 typedef __bf16 bf16;
 
@@ -33,6 +34,14 @@ __device__ __forceinline__ void store8(T *p, const float (&f)[8]) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) o.v[j] = (T)f[j];
     *reinterpret_cast<uint4 *>(p) = *reinterpret_cast<const uint4 *>(&o);
+}
+template <typename T>
+__device__ __forceinline__ void store8_nt(T *p, const float (&f)[8]) {  // streaming store (the x2 upsampling's 4 GB output)
+    Vec8<T> o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o.v[j] = (T)f[j];
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    __builtin_nontemporal_store(*reinterpret_cast<const u4 *>(&o), reinterpret_cast<u4 *>(p));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -286,6 +295,85 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const T *__restrict__ i
                     o[e] = h0 * (w0 * v00 + w1 * v01) + h1 * (w0 * v10 + w1 * v11);
                 }
                 store8(out + ((((size_t)n * OH + 2 * k + a) * OW) + 2 * j + b) * C + v * 8, o);
+            }
+        }
+    }
+}
+
+// The same operation through an LDS tile (round 3; used for C <= 512): a workgroup produces UP_TY x UP_TX output 2 x 2 blocks (8 x 16 output
+// pixels, all channels) from the (UP_TY + 2) x (UP_TX + 2) input pixels they can touch.  The gather form above issues 9 loads per 4 stores
+// (13 vector-memory instructions per 64 bytes of output: it is bound by the CU's texture-address path, 3.7 TB/s of useful bytes); here every
+// input pixel is loaded ONCE per tile (0.47 loaded bytes per output byte instead of 2.25), the bias is added once per input element, and
+// the four taps of an output come from LDS without selects.  Same operands, same formula: bit-identical (tests/test_vit_gpu.py).
+constexpr int UP_TY = 4, UP_TX = 8;
+template <typename T>
+__global__ __launch_bounds__(256) void upsample2x_lds_kernel(const T *__restrict__ in, const T *__restrict__ bias, T *__restrict__ out, int N, int H,
+                                                             int W, int C) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char up_lds[];
+    T *tile = reinterpret_cast<T *>(up_lds);  // [(UP_TY + 2)][(UP_TX + 2)][C]
+    constexpr int WR = UP_TY + 2, WC = UP_TX + 2;
+    const int VC = C >> 3;
+    const int OH = 2 * H, OW = 2 * W;
+    const float sh = OH > 1 ? (float)(H - 1) / (float)(OH - 1) : 0.f;
+    const float sw = OW > 1 ? (float)(W - 1) / (float)(OW - 1) : 0.f;
+    const int k0 = blockIdx.y * UP_TY, j0 = blockIdx.x * UP_TX, n = blockIdx.z;
+    const int ry0 = (int)(sh * (float)(2 * k0)), cx0 = (int)(sw * (float)(2 * j0));  // first source row / column of the tile
+    const T *src = in + (size_t)n * H * W * C;
+    // stage the window: row l holds source row min(ry0 + l, H - 1), column likewise (the clamps of the formula)
+    const int n_vec = WR * WC * VC;
+    for (int base = 0; base < n_vec; base += 256 * 4) {
+        uint4 raw[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = base + u * 256 + (int)threadIdx.x;
+            if (idx < n_vec) {
+                const int v = idx % VC, px = idx / VC, lc = px % WC, lr = px / WC;
+                const int gy = min(ry0 + lr, H - 1), gx = min(cx0 + lc, W - 1);
+                raw[u] = *reinterpret_cast<const uint4 *>(src + ((size_t)gy * W + gx) * C + v * 8);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = base + u * 256 + (int)threadIdx.x;
+            if (idx < n_vec) {
+                const int v = idx % VC;
+                if (bias) {  // (x + b) rounded to T, as the separate bias pass rounds it
+                    float f[8], bb[8];
+                    const T *t = reinterpret_cast<const T *>(&raw[u]);
+                    load8(bias + v * 8, bb);
+                    T r[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] = (float)t[e], r[e] = (T)(f[e] + bb[e]);
+                    raw[u] = *reinterpret_cast<const uint4 *>(r);
+                }
+                *reinterpret_cast<uint4 *>(tile + (size_t)idx * 8) = raw[u];
+            }
+        }
+    }
+    __syncthreads();
+    for (int item = threadIdx.x; item < UP_TY * UP_TX * VC; item += 256) {
+        const int v = item % VC, pair = item / VC, jl = pair % UP_TX, kl = pair / UP_TX;
+        const int k = k0 + kl, j = j0 + jl;
+        if (k >= H || j >= W) continue;
+        const float fy[2] = {sh * (float)(2 * k), sh * (float)(2 * k + 1)}, fx[2] = {sw * (float)(2 * j), sw * (float)(2 * j + 1)};
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int y0 = (int)fy[a];
+            const float h1 = fy[a] - (float)y0, h0 = 1.f - h1;
+            const int r0 = y0 - ry0;  // rows r0, r0 + 1 of the window: source rows y0, min(y0 + 1, H - 1)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int x0 = (int)fx[b];
+                const float w1 = fx[b] - (float)x0, w0 = 1.f - w1;
+                const int c0 = x0 - cx0;
+                float v00[8], v01[8], v10[8], v11[8], o[8];
+                load8(tile + ((size_t)(r0 * WC + c0) * VC + v) * 8, v00);
+                load8(tile + ((size_t)(r0 * WC + c0 + 1) * VC + v) * 8, v01);
+                load8(tile + ((size_t)((r0 + 1) * WC + c0) * VC + v) * 8, v10);
+                load8(tile + ((size_t)((r0 + 1) * WC + c0 + 1) * VC + v) * 8, v11);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = h0 * (w0 * v00[e] + w1 * v01[e]) + h1 * (w0 * v10[e] + w1 * v11[e]);
+                store8_nt(out + ((((size_t)n * OH + 2 * k + a) * OW) + 2 * j + b) * C + v * 8, o);
             }
         }
     }
@@ -555,6 +643,23 @@ int hive_nhwc_upsample2x(hive_ctx *ctx, const void *d_in, const void *d_bias, in
     HIVE_REQUIRE(ctx, d_in && d_out, "upsample2x: NULL argument");
     HIVE_REQUIRE(ctx, N > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "upsample2x: need C %% 8 == 0 (N=%d H=%d W=%d C=%d)", N, H, W, C);
     HIVE_REQUIRE(ctx, H <= 65535 && N <= 65535, "upsample2x: H %d / N %d too large for the launch grid", H, N);
+    const bool gather_only = getenv("HIVE_UPSAMPLE_GATHER") != nullptr;  // (A / B runs and the bit-identity test)
+    const size_t lds = (size_t)(UP_TY + 2) * (UP_TX + 2) * C * 2;
+    if (C <= 512 && !gather_only && (H + UP_TY - 1) / UP_TY <= 65535) {  // through an LDS tile
+        const dim3 tiles((unsigned)((W + UP_TX - 1) / UP_TX), (unsigned)((H + UP_TY - 1) / UP_TY), (unsigned)N);
+        if (dtype == HIVE_BF16) {
+            HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)upsample2x_lds_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+            hipLaunchKernelGGL(upsample2x_lds_kernel<bf16>, tiles, dim3(256), lds, ctx->stream, (const bf16 *)d_in, (const bf16 *)d_bias, (bf16 *)d_out, N, H, W, C);
+        } else if (dtype == HIVE_F16) {
+            HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)upsample2x_lds_kernel<_Float16>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+            hipLaunchKernelGGL(upsample2x_lds_kernel<_Float16>, tiles, dim3(256), lds, ctx->stream, (const _Float16 *)d_in, (const _Float16 *)d_bias, (_Float16 *)d_out,
+                               N, H, W, C);
+        } else {
+            return hive_fail(ctx, HIVE_ERR_INVALID, "upsample2x: dtype must be HIVE_F16 or HIVE_BF16");
+        }
+        HIVE_CHECK_HIP(ctx, hipGetLastError());
+        return HIVE_OK;
+    }
     const dim3 grid((unsigned)((W * (C / 8) + 255) / 256), (unsigned)H, (unsigned)N);  // a thread per 2 x 2 output pixels x 8 channels
     if (dtype == HIVE_BF16)
         hipLaunchKernelGGL(upsample2x_kernel<bf16>, grid, dim3(256), 0, ctx->stream, (const bf16 *)d_in, (const bf16 *)d_bias, (bf16 *)d_out, N, H, W, C);

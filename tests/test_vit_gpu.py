@@ -169,7 +169,7 @@ def test_group_norm_fused_matches_torch(gpu_ctx, half, N, C, H, W, relu, res):
     assert torch.equal(out, ops.group_norm_act(x, 32, g, b, 1e-5, relu=relu, residual=r, engine="hip"))
 
 
-@pytest.mark.parametrize("N,C,H,W", [(2, 256, 15, 20), (1, 128, 24, 32), (1, 8, 1, 1), (2, 32, 7, 5)])
+@pytest.mark.parametrize("N,C,H,W", [(2, 256, 15, 20), (1, 128, 24, 32), (1, 8, 1, 1), (2, 32, 7, 5), (3, 256, 30, 40), (1, 64, 9, 13), (1, 1024, 6, 5)])
 def test_upsample2x_matches_torch(gpu_ctx, half, N, C, H, W):
     import torch
     from hive_amd.dpt import ops
@@ -182,6 +182,13 @@ def test_upsample2x_matches_torch(gpu_ctx, half, N, C, H, W):
     xb = (x + b.view(1, -1, 1, 1)).contiguous(memory_format=torch.channels_last)
     assert torch.equal(ops.upsample2x(x, engine="hip", bias=b), ops.upsample2x(xb, engine="hip"))
     assert out.shape == ref.shape and out.is_contiguous(memory_format=torch.channels_last)
+    # the LDS-tiled kernel (C <= 512) and the gather kernel evaluate the same formula on the same operands: bit-identical
+    import os
+    os.environ["HIVE_UPSAMPLE_GATHER"] = "1"
+    try:
+        assert torch.equal(ops.upsample2x(x, engine="hip"), out) and torch.equal(ops.upsample2x(x, engine="hip", bias=b), ops.upsample2x(xb, engine="hip"))
+    finally:
+        del os.environ["HIVE_UPSAMPLE_GATHER"]
     # same formula evaluated in float: only the final rounding (half an ulp: 2^-9 relative for bfloat16, 2^-12 for float16)
     # differs from the fp32 reference
     ulp = 2.0 ** -8 if half == torch.bfloat16 else 2.0 ** -11
