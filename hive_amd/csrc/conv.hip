@@ -36,6 +36,9 @@
 
 // tuning builds only (make ablate_conv; tools/probe_resnet.py): phases of conv_kernel left out -- 1: the epilogue's turn through LDS and its
 // stores, 2: the MFMAs (the stage pieces are still issued), 4: the LDS-DMA, 8: the GroupNorm sums' reduction and their store
+#ifndef HIVE_CONV_AHEAD_GN2
+#define HIVE_CONV_AHEAD_GN2 4  // the same for the second pass of the two-pass GroupNorm convolutions (fewer live registers there)
+#endif
 #ifndef HIVE_CONV_ABLATE
 #define HIVE_CONV_ABLATE 0
 #endif
@@ -118,7 +121,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams<T> &p, f32x4 (&ac
     // FOUR (8 KiB per wave, 16 MB over the chip in flight) 500.  NRES = 2 (the residual unit that adds its input AND the path from above:
     // twice the bytes per row) runs two ahead -- its six register sets are what four ahead costs with one shortcut.  A residual may BE the
     // output: every element is read by the lane that later writes it and rows of mt + AHEAD are read before rows of mt are written.
-    constexpr int AHEAD = NRES == 2 ? HIVE_CONV_AHEAD / 2 : HIVE_CONV_AHEAD;
+    constexpr int AHEAD = GN == 2 ? HIVE_CONV_AHEAD_GN2 : (NRES == 2 ? HIVE_CONV_AHEAD / 2 : HIVE_CONV_AHEAD);
     vec<T, 8> rs1[AHEAD + 1][2], rs2[NRES == 2 ? AHEAD + 1 : 1][2];
     const int row_in_frag = lane >> 3;
     auto pre = [&](int mt, int j) {
