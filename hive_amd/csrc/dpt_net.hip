@@ -266,10 +266,31 @@ int run_forward(hive_dpt *d, bool dry, const uint8_t *d_rgb, int B, int H, int W
                 Map in = feat, shortcut = feat, t, u, t2, u2;
                 if (blk == 0) DPT_TRY(conv_norm(in, pre + "downsample.conv.weight", pre + "downsample.norm", cout, stride, nullptr, 0, &shortcut));
                 DPT_TRY(conv(in, pre + "conv1.weight", nullptr, mid, 1, 1, true, 0, nullptr, nullptr, false, &t, nullptr, true));
-                DPT_TRY(group_norm(t, pre + "norm1", nullptr, 1, &u));
-                drop(t);
-                DPT_TRY(conv(u, pre + "conv2.weight", nullptr, mid, 3, stride, true, 0, nullptr, nullptr, false, &t2, nullptr, true));
-                drop(u);
+                int bneck = 0;
+                // norm1 + ReLU applied while conv2 stages its input (csrc/bneck.hip): one kernel, no normalised map.  Needs conv1's sums, which its
+                // epilogue leaves for maps of at least one 256-pixel tile (smaller ones take the pair below)
+                if (mid == 64 && stride == 1 && (long long)t.H * t.W >= 256) {
+                    t2 = Map{d->alloc((size_t)B * t.H * t.W * 64), t.H, t.W, 64};
+                    const int64_t floats = hive_nhwc_conv_gn_partial_floats((int64_t)B * t.H * t.W, 64);
+                    t2.gn = (float *)d->alloc((size_t)floats * 2);
+                    if (dry) {
+                        bneck = 1;  // (the allocation sequence must not depend on the data: the launch below always fuses for these maps)
+                    } else {
+                        const void *g, *b, *w2;
+                        DPT_TRY(need(pre + "norm1.weight", &g));
+                        DPT_TRY(need(pre + "norm1.bias", &b));
+                        DPT_TRY(need(pre + "conv2.weight", &w2));
+                        DPT_TRY(hive_bneck_gn_conv3x3(ctx, t.p, dt, B, t.H, t.W, 64, t.gn, t.gn_tm, g, b, d->cfg.gn_eps, w2, t2.p, t2.gn, floats, &t2.gn_tm, &bneck));
+                        if (!bneck) return hive_fail(ctx, HIVE_ERR_INVALID, "hive_dpt: the 64-channel bottleneck convolution of '%s' was not fused", pre.c_str());
+                    }
+                    drop(t);
+                }
+                if (!bneck) {
+                    DPT_TRY(group_norm(t, pre + "norm1", nullptr, 1, &u));
+                    drop(t);
+                    DPT_TRY(conv(u, pre + "conv2.weight", nullptr, mid, 3, stride, true, 0, nullptr, nullptr, false, &t2, nullptr, true));
+                    drop(u);
+                }
                 DPT_TRY(group_norm(t2, pre + "norm2", nullptr, 1, &u2));
                 drop(t2);
                 DPT_TRY(conv_norm(u2, pre + "conv3.weight", pre + "norm3", cout, 1, shortcut.p, 1, &feat));  // relu(norm3(conv3(.)) + shortcut)

@@ -153,8 +153,12 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         shortcut = x if self.downsample is None else self.downsample(x)
-        x = self.norm1(self.conv1(x))
-        x = self.norm2(self.conv2(x))
+        t = self.conv1(x)
+        t2 = None
+        if self.conv1.engine == "hip" and self.norm1.engine == "hip" and self.conv2.engine == "hip":
+            # 64-channel bottlenecks: norm1 + ReLU applied while conv2 stages its input (one kernel; None elsewhere)
+            t2 = dpt_ops.bneck_gn_conv3x3(t, self.norm1, self.conv2, self.conv2.standardized_weight())
+        x = self.norm2(t2 if t2 is not None else self.conv2(self.norm1(t)))
         y = _conv_norm(self.conv3, self.norm3, x, residual=shortcut)
         return y if y is not None else self.norm3(self.conv3(x), residual=shortcut)  # relu(norm3(.) + shortcut)
 

@@ -299,6 +299,32 @@ def stem_conv(x, conv, weight):
     return out
 
 
+def bneck_gn_conv3x3(t, norm, conv, weight):
+    """conv(relu(norm(t))) for the 64-channel bottlenecks (hive_bneck_gn_conv3x3: the GroupNorm + ReLU applied while the 3 x 3 convolution
+    stages its input; csrc/bneck.hip), or None where it does not apply (then: ``group_norm_act`` + ``conv2d``).  ``t`` is conv1's output
+    with the sums its epilogue left (``t.hive_gn_stats``); ``weight``: conv's standardised [64, 64, 3, 3] weights.  The result carries
+    ``hive_gn_stats`` for the GroupNorm behind it."""
+    import ctypes
+    stats = getattr(t, "hive_gn_stats", None)
+    if (stats is None or _why_not_map(t) or t.shape[1] != 64 or conv.in_channels != 64 or conv.out_channels != 64 or tuple(conv.kernel_size) != (3, 3)
+            or tuple(conv.stride) != (1, 1) or conv.bias is not None or not norm.apply_act or norm.num_groups != 32 or norm.weight.dtype != t.dtype):
+        return None
+    w = weight if weight.is_contiguous(memory_format=torch.channels_last) else weight.contiguous(memory_format=torch.channels_last)
+    n, c, h, wd = t.shape
+    out = torch.empty_like(t)  # preserves channels_last
+    ctx = _lib.default_context(t.device.index or 0)
+    partial = torch.empty(int(ctx.lib.hive_nhwc_conv_gn_partial_floats(n * h * wd, 64)), dtype=torch.float32, device=t.device)
+    tile_rows, fused = ctypes.c_int(0), ctypes.c_int(0)
+    ctx.check(ctx.lib.hive_bneck_gn_conv3x3(ctx.handle, t.data_ptr(), _code(t.dtype), n, h, wd, c, stats[0].data_ptr(), int(stats[1]), norm.weight.data_ptr(),
+                                            norm.bias.data_ptr(), float(norm.eps), w.data_ptr(), out.data_ptr(), partial.data_ptr(), partial.numel(),
+                                            ctypes.byref(tile_rows), ctypes.byref(fused)))
+    if not fused.value:
+        return None
+    if tile_rows.value:
+        out.hive_gn_stats = (partial, tile_rows.value)
+    return out
+
+
 def group_norm_relu_maxpool(x, norm, stats=None):
     """MaxPool2dSame(3, 2)(relu(norm(x))) in one pass (hive_nhwc_group_norm_relu_maxpool): the ResNetV2 stem behind its convolution.
     ``stats``: ``x.hive_gn_stats`` of the convolution that wrote ``x``, or None (own statistics pass)."""

@@ -415,6 +415,14 @@ int hive_nhwc_maxpool3x3s2(hive_ctx *ctx, const void *d_x, int dtype, int N, int
  * tile; d_gn_partial >= hive_nhwc_conv_gn_partial_floats(N * H_out * W_out, 64) floats; *gn_tile_rows = 0 -- nothing written -- unless
  * H_out % 8 == 0 and W_out % 32 == 0); hive_nhwc_group_norm_relu_maxpool = MaxPool2dSame(3, 2)(relu(GroupNorm(x))) in one pass over
  * x [N][H][W][C] -> [N][ceil(H/2)][ceil(W/2)][C] (d_gn_partial / gn_tile_rows as hive_nhwc_group_norm_stats; NULL / 0: own statistics). */
+/* t2 = conv2(relu(norm1(t))) of a 64-channel ResNetV2 bottleneck (timm Bottleneck: `x = norm1(conv1(x)); x = norm2(conv2(x))`) as one kernel:
+ * d_x [N][H][W][64] is conv1's raw output with the sums its epilogue left (d_in_partial, in_tile_rows: hive_nhwc_conv_gn), d_gamma / d_beta
+ * norm1's parameters, d_w conv2's standardised 3 x 3 weights [64][3][3][64]; d_out = conv2's raw output (bit-identical to
+ * hive_nhwc_conv on the separately normalised tensor), and the sums of norm2 as hive_nhwc_conv_gn leaves them (d_gn_partial,
+ * *gn_tile_rows; 0: none).  *fused = 0 and nothing done where it does not apply (C != 64, no sums from conv1): run the pair. */
+int hive_bneck_gn_conv3x3(hive_ctx *ctx, const void *d_x, int dtype, int N, int H, int W, int C, const void *d_in_partial, int in_tile_rows,
+                          const void *d_gamma, const void *d_beta, float eps, const void *d_w, void *d_out, void *d_gn_partial,
+                          int64_t gn_partial_floats, int *gn_tile_rows, int *fused);
 int hive_resnet_stem_conv_gn(hive_ctx *ctx, const void *d_x, int dtype, int N, int H, int W, const void *d_w, void *d_out, void *d_gn_partial,
                              int64_t gn_partial_floats, int *gn_tile_rows);
 int hive_nhwc_group_norm_relu_maxpool(hive_ctx *ctx, const void *d_x, int dtype, int N, int H, int W, int C, int G, const void *d_gamma,

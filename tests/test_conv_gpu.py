@@ -428,3 +428,45 @@ def test_new_entry_points_reject_bad_arguments(gpu_ctx, half):
         gpu_ctx.check(lib.hive_patch_rows(h, frame.data_ptr(), _lib.dtype_code(half), 1, 40, 48, 3, 16, out.data_ptr()))
     with pytest.raises(_lib.HiveError, match="pixel_shuffle_bias"):
         gpu_ctx.check(lib.hive_nhwc_pixel_shuffle_bias(h, out.data_ptr(), None, _lib.dtype_code(half), 1, 4, 4, 12, 2, x.data_ptr()))
+
+
+@pytest.mark.parametrize("n,h,w", [(3, 120, 160), (2, 24, 32), (2, 37, 45)])
+def test_bottleneck_gn_conv3x3_equals_the_pair(gpu_ctx, half, n, h, w):
+    """hive_bneck_gn_conv3x3 (csrc/bneck.hip): conv2(relu(norm1(t))) of a 64-channel bottleneck as one kernel is bit-identical to the GroupNorm
+    pass followed by the general convolution; the sums it leaves for norm2 are those of its stored outputs; maps that are not whole 32-wide
+    tiles leave none (norm2 then makes its own pass)."""
+    from hive_amd.dpt import ops
+    from hive_amd.dpt.models import GroupNormAct, StdConv2dSame
+    g = torch.Generator(device="cpu").manual_seed(h)
+    conv1, conv2 = StdConv2dSame(64, 64, 1), StdConv2dSame(64, 64, 3)
+    norm1 = GroupNormAct(64)
+    with torch.no_grad():
+        conv1.weight.copy_(torch.randn(conv1.weight.shape, generator=g))
+        conv2.weight.copy_(torch.randn(conv2.weight.shape, generator=g))
+        norm1.weight.copy_(torch.rand(64, generator=g) + 0.5)
+        norm1.bias.copy_(torch.randn(64, generator=g) * 0.3)
+    conv1 = conv1.to(memory_format=torch.channels_last).to(half).cuda().eval()
+    conv2 = conv2.to(memory_format=torch.channels_last).to(half).cuda().eval()
+    norm1 = norm1.to(half).cuda().eval()
+    norm1.engine = "hip"
+    x = (torch.randn(n, 64, h, w, generator=g) + 0.2).to(half).cuda().contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        t = ops.conv2d(x, conv1, weight=conv1.standardized_weight(), same_pad=True, gn_stats=True)
+        assert t.hive_gn_stats[1] > 0
+        u = ops.group_norm_act(t, 32, norm1.weight, norm1.bias, norm1.eps, relu=True, engine="hip", stats=t.hive_gn_stats)
+        pair = ops.conv2d(u, conv2, weight=conv2.standardized_weight(), same_pad=True, gn_stats=True)
+        one = ops.bneck_gn_conv3x3(t, norm1, conv2, conv2.standardized_weight())
+    assert one is not None and torch.equal(one, pair), float((one.float() - pair.float()).abs().max())
+    stats = getattr(one, "hive_gn_stats", None)
+    assert (stats is not None) == (w % 32 == 0 and (h * w) % (((h + 15) // 16) * (w // 32)) == 0)
+    if stats is not None:
+        partial, tile_rows = stats
+        per_img = ((h + 15) // 16) * (w // 32)
+        assert tile_rows == h * w // per_img
+        got = partial[: n * per_img * 4 * 64].view(n, per_img, 2, 2, 64).double().sum(1)  # per image
+        rows = one.permute(0, 2, 3, 1).reshape(n, h * w, 64).double()
+        assert torch.allclose(got[:, 0, 0], rows.sum(1), rtol=1e-5, atol=1e-2) and torch.allclose(got[:, 0, 1], (rows ** 2).sum(1), rtol=1e-5, atol=1e-2)
+        assert got[:, 1].abs().max().item() == 0.0
+    # not a 64-channel stride-1 bottleneck: does not apply
+    conv_s2 = StdConv2dSame(64, 64, 3, stride=2).to(memory_format=torch.channels_last).to(half).cuda().eval()
+    assert ops.bneck_gn_conv3x3(t, norm1, conv_s2, conv_s2.standardized_weight()) is None
