@@ -19,7 +19,7 @@ kernels = [(r"gemm256p_kernel(<[^,>]*, 0>|I[^L]*Li0E)", "gemm q|k (bias; 256 x 2
            (r"conv_kernel(<[^,>]*, 256, 256, 0>|I[^L]*Li256ELi256ELi0E)", "conv -> 256-channel tiles (decoder RCUs, layer_rn)"),
            (r"conv_kernel(<[^,>]*, 256, 256, 1>|I[^L]*Li256ELi256ELi1E)", "conv + GroupNorm statistics (ResNetV2, 256-channel tiles)"),
            (r"conv_kernel(<[^,>]*, 256, 256, 2>|I[^L]*Li256ELi256ELi2E)", "conv + GroupNorm apply, second pass (ResNetV2 conv3 / downsample)"),
-           (r"conv_kernel(<[^,>]*, 256, 128, 0>|I[^L]*Li256ELi128ELi0E)", "conv 3x3 256 -> 128 (output_conv[0])"), (r"stem_conv_kernel", "ResNetV2 stem 7x7/2")]
+           (r"conv_kernel(<[^,>]*, 256, 128, 0>|I[^L]*Li256ELi128ELi0E)", "conv 3x3 256 -> 128 (output_conv[0])"), (r"stem_conv_kernel", "ResNetV2 stem 7x7/2"), (r"bneck_conv3x3_kernel", "64-channel bottleneck 3x3 with GroupNorm on load (bneck.hip)")]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("$OUT/p?/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
