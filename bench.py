@@ -12,18 +12,21 @@ SURVEY.md 8d) -> preprocess -> DPT-Hybrid (seeded random weights of the real arc
 has surfaces inside the volume; bf16 or --dtype fp16, HIP engine) -> f32 depth tail
 + uint16-mm hand-off -> TSDF integrate.
 
-N > 1 (BASELINE configs[2]: the same sequence frame-sharded over the ranks, one merge of the shared static-scene volume): the frames
-are independent units, so the default is WEAK scaling -- the job grows with N: N * K * B frames of the wrapping sequence, rank r
-takes the contiguous block [r K B, (r + 1) K B) in K steps of B frames (per-GPU work = the N = 1 job), no collective on the data
-path, and the shared volume is merged ONCE, inside the timed region ("scaling": "weak"; value = N K B / time).  `--scaling strong`
-splits the SAME K * B frames in contiguous blocks over the ranks instead (config 3 literally: fixed total work; the merge then weighs
-more the shorter the per-rank share).  The merge:
+One run prints ONE JSON line that covers the BASELINE configurations this command can reach:
+  N = 1: the headline (configs[1], `value`), the same job in float16 -- the reference's own type -- as `value_fp16`, and a bounded `config4` leg
+         (configs[3]: 1920 x 1080 frames, DPT-Large at the reference's 864 x 480 network size, 1024^3 volume).
+  N > 1: frames are independent units.  The headline `value` is the WEAK job ("scaling": "weak": N * K * B frames, a contiguous block of K
+         steps per rank, per-GPU work = the N = 1 job, no collective on the data path, the shared volume merged ONCE inside the timed
+         region), and the same run also times BASELINE configs[2] literally under the key `strong`: the SAME K * B frames split in
+         contiguous blocks over the ranks, one merge (fixed total work; the merge weighs more the shorter the per-rank share).
+         `--scaling strong` swaps the two (headline = strong, the weak job under `weak`).
+The merge:
   --merge sum   (default; north_star's design): every rank fuses its block into its own volume; reduce-scatter of the 5
                 accumulator planes -> every rank folds its 1 / N of the voxels -> all-gather of the 3 result planes.
   --merge exact (bit-identical to one GPU): depth + colour frames are all-gathered, every rank integrates all frames in
                 sequence order into its x-slab of the volume, the slabs are all-gathered.
 (`--merge exact` is a strong-scaling mode by construction: every rank integrates every frame.)
-Rank 0 prints one JSON line.
+Rank 0 prints the line.
 """
 import argparse
 import json

@@ -43,6 +43,7 @@ SIGNATURES = {
     "hive_tsdf_destroy": (c_int, [c_void_p]),
     "hive_tsdf_set_round_mode": (c_int, [c_void_p, c_int]),
     "hive_tsdf_reset": (c_int, [c_void_p]),
+    "hive_tsdf_planes_modified": (c_int, [c_void_p]),
     "hive_tsdf_info": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, P(c_float), P(c_float)]),
     "hive_tsdf_device_ptrs": (c_int, [c_void_p, P(c_void_p), P(c_void_p), P(c_void_p)]),
     "hive_tsdf_integrate": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_float, c_int,
@@ -50,6 +51,7 @@ SIGNATURES = {
     "hive_tsdf_integrate_batch": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_float,
                                           c_int]),
     "hive_tsdf_last_batch_groups": (c_int, [c_void_p, c_void_p, c_int, P(c_int)]),
+    "hive_tsdf_last_sweep_items": (c_int, [c_void_p, P(ctypes.c_uint64), P(c_int)]),
     "hive_tsdf_get_volume": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "hive_tsdf_set_volume": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "hive_tsdf_extract_mesh": (c_int, [c_void_p, P(c_int64), P(c_int64)]),
@@ -77,6 +79,8 @@ SIGNATURES = {
     "hive_filter_faces": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_double, c_double, c_int, c_void_p, P(c_int64)]),
     "hive_texture_window": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_double, c_int, c_void_p, c_void_p]),
     "hive_dilate_mask": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "hive_dilate_mask_se": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "hive_depth_apply_mask_se": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "hive_vit_create": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, P(c_void_p)]),
     "hive_vit_destroy": (c_int, [c_void_p]),
     "hive_vit_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),

@@ -261,6 +261,40 @@ __global__ __launch_bounds__(256) void dilate_cols_apply_kernel(const uint8_t *_
     out[base + i] = m ? 0.0f : depth[base + i];
 }
 
+// cv2.dilate with an ARBITRARY structuring element (hive/options.py:245-268 lets the caller pass any `dilation_filter`), one iteration:
+// out(v, u) = OR over the set taps (j, i) of in(v + j - kh / 2, u + i - kw / 2); taps that fall outside the image contribute nothing
+// (cv2's default border for dilation).  blockIdx.y = frame.  `instance` applies to the FIRST iteration's input (instance ids -> set / clear).
+struct StructuringElement {
+    int kh, kw;
+    uint8_t m[32 * 32];
+};
+__global__ __launch_bounds__(256) void dilate_se_kernel(const uint8_t *__restrict__ in, int H, int W, StructuringElement se, int instance, int first,
+                                                        uint8_t *__restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= H * W) return;
+    const size_t base = (size_t)blockIdx.y * H * W;
+    const int v = i / W, u = i % W;
+    const int ay = se.kh / 2, ax = se.kw / 2;
+    uint8_t m = 0;
+    for (int j = 0; j < se.kh; ++j) {
+        const int vv = v + j - ay;
+        if (vv < 0 || vv >= H) continue;
+        for (int k = 0; k < se.kw; ++k) {
+            const int uu = u + k - ax;
+            if (!se.m[j * se.kw + k] || uu < 0 || uu >= W) continue;
+            const uint8_t s = in[base + (size_t)vv * W + uu];
+            m |= (first && instance) ? (s == instance) : (s != 0);
+        }
+    }
+    out[base + i] = m;
+}
+
+__global__ __launch_bounds__(256) void zero_under_mask_kernel(const uint8_t *__restrict__ mask, size_t n, const float *__restrict__ depth, float *__restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    out[i] = mask[i] ? 0.0f : depth[i];
+}
+
 __global__ __launch_bounds__(256) void keep_mask_kernel(const uint8_t *__restrict__ mask, size_t n, int instance,
                                                         const float *__restrict__ depth, float *__restrict__ out) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -418,6 +452,112 @@ int hive_depth_apply_mask(hive_ctx *ctx, const float *d_depth, const uint8_t *d_
         hipLaunchKernelGGL(dilate_rows_batch_kernel, grid, dim3(256), 0, ctx->stream, d_mask, H, W, iterations, instance_id, rows);
         hipLaunchKernelGGL(dilate_cols_apply_kernel, grid, dim3(256), 0, ctx->stream, (const uint8_t *)rows, H, W, iterations, d_depth, d_out);
     }
+    HIVE_CHECK_HIP(ctx, hipGetLastError());
+    return HIVE_OK;
+}
+
+// A structuring element that is a full rectangle of odd sides dilates, iterated n times, like ONE (n (kw - 1) + 1) x (n (kh - 1) + 1)
+// box maximum (the separable fast path); anything else is iterated literally.
+static bool se_is_full_odd_rect(const uint8_t *se, int kh, int kw) {
+    if (kh % 2 == 0 || kw % 2 == 0) return false;
+    for (int i = 0; i < kh * kw; ++i)
+        if (!se[i]) return false;
+    return true;
+}
+static int check_se(hive_ctx *ctx, const uint8_t *se, int kh, int kw, StructuringElement *out) {
+    HIVE_REQUIRE(ctx, se && kh >= 1 && kw >= 1 && kh <= 32 && kw <= 32, "dilate: structuring element must be 1x1 .. 32x32, got %dx%d", kh, kw);
+    bool any = false;
+    out->kh = kh;
+    out->kw = kw;
+    memset(out->m, 0, sizeof(out->m));
+    for (int i = 0; i < kh * kw; ++i) {
+        out->m[i] = se[i] ? 1 : 0;
+        any = any || se[i];
+    }
+    HIVE_REQUIRE(ctx, any, "dilate: the structuring element has no set element");
+    return HIVE_OK;
+}
+// `iterations` literal passes of the structuring element over n frames: d_in (instance ids on the first pass) -> result in *d_result
+// (one of the two scratch planes a, b; both n * H * W bytes)
+static int dilate_se_iterate(hive_ctx *ctx, const uint8_t *d_in, int n, int H, int W, const StructuringElement &se, int iterations, int instance, uint8_t *a,
+                             uint8_t *b, const uint8_t **d_result) {
+    const dim3 grid((unsigned)(((size_t)H * W + 255) / 256), n);
+    const uint8_t *src = d_in;
+    uint8_t *dst = a;
+    for (int it = 0; it < iterations; ++it) {
+        hipLaunchKernelGGL(dilate_se_kernel, grid, dim3(256), 0, ctx->stream, src, H, W, se, instance, it == 0 ? 1 : 0, dst);
+        src = dst;
+        dst = dst == a ? b : a;
+    }
+    HIVE_CHECK_HIP(ctx, hipGetLastError());
+    *d_result = src;
+    return HIVE_OK;
+}
+
+int hive_dilate_mask_se(hive_ctx *ctx, const uint8_t *mask, int H, int W, const uint8_t *se, int kh, int kw, int iterations, int mem, uint8_t *out) {
+    HIVE_ENTER(ctx);
+    if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
+    HIVE_REQUIRE(ctx, mask && out, "dilate_mask: NULL argument");
+    HIVE_REQUIRE(ctx, H > 0 && W > 0 && iterations >= 0, "dilate_mask: bad arguments %dx%d, %d iterations", H, W, iterations);
+    StructuringElement el;
+    int rc = check_se(ctx, se, kh, kw, &el);
+    if (rc) return rc;
+    const size_t n = (size_t)H * W;
+    const bool host = mem == HIVE_MEM_HOST;
+    // planes: [0] the input (host calls), [1], [2] ping-pong
+    if ((rc = hive_reserve_device(ctx, &ctx->d_in, &ctx->in_bytes, 3 * align256(n)))) return rc;
+    uint8_t *base = (uint8_t *)ctx->d_in;
+    const uint8_t *d_mask = mask;
+    if (host) {
+        const void *dm;
+        if ((rc = to_device(ctx, mask, n, 0, mem, &dm))) return rc;
+        d_mask = (const uint8_t *)dm;
+    }
+    uint8_t *a = base + align256(n), *b = base + 2 * align256(n);
+    const uint8_t *res;
+    if (se_is_full_odd_rect(se, kh, kw)) {
+        const dim3 grid((unsigned)((n + 255) / 256));
+        hipLaunchKernelGGL(dilate_rows_kernel, grid, dim3(256), 0, ctx->stream, d_mask, H, W, iterations * (kw / 2), a);
+        hipLaunchKernelGGL(dilate_cols_kernel, grid, dim3(256), 0, ctx->stream, (const uint8_t *)a, H, W, iterations * (kh / 2), b);
+        HIVE_CHECK_HIP(ctx, hipGetLastError());
+        res = b;
+    } else if (iterations == 0) {  // cv2.dilate(iterations=0) copies; astype(bool) on the way out
+        hipLaunchKernelGGL(dilate_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_mask, H, W, 0, a);
+        HIVE_CHECK_HIP(ctx, hipGetLastError());
+        res = a;
+    } else if ((rc = dilate_se_iterate(ctx, d_mask, 1, H, W, el, iterations, 0, a, b, &res))) {
+        return rc;
+    }
+    HIVE_CHECK_HIP(ctx, hipMemcpyAsync(out, res, n, host ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, ctx->stream));
+    if (host) HIVE_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return HIVE_OK;
+}
+
+int hive_depth_apply_mask_se(hive_ctx *ctx, const float *d_depth, const uint8_t *d_mask, int n, int H, int W, const uint8_t *se, int kh, int kw, int iterations,
+                             int mode, int instance_id, float *d_out) {
+    HIVE_ENTER(ctx);
+    if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
+    StructuringElement el;
+    int rc = check_se(ctx, se, kh, kw, &el);
+    if (rc) return rc;
+    if (mode == 1) return hive_depth_apply_mask(ctx, d_depth, d_mask, n, H, W, iterations, mode, instance_id, d_out);  // the foreground keeps the UNDILATED mask
+    HIVE_REQUIRE(ctx, d_depth && d_mask && d_out, "depth_apply_mask: NULL argument");
+    HIVE_REQUIRE(ctx, n > 0 && n <= 65535 && H > 0 && W > 0 && iterations >= 0, "depth_apply_mask: bad arguments n=%d %dx%d, %d iterations", n, H, W, iterations);
+    HIVE_REQUIRE(ctx, mode == 0, "depth_apply_mask: mode must be 0 (zero under the dilated mask) or 1 (keep the mask only)");
+    HIVE_REQUIRE(ctx, instance_id >= 0 && instance_id <= 255, "depth_apply_mask: instance id %d", instance_id);
+    if (kh % 2 == 1 && kh == kw && se_is_full_odd_rect(se, kh, kw))  // square box: the separable two-launch path (radius iterations * (k / 2))
+        return hive_depth_apply_mask(ctx, d_depth, d_mask, n, H, W, iterations * (kh / 2), mode, instance_id, d_out);
+    const size_t total = (size_t)H * W * (size_t)n;
+    if ((rc = hive_reserve_device(ctx, &ctx->d_scratch, &ctx->scratch_bytes, 2 * align256(total)))) return rc;
+    uint8_t *a = (uint8_t *)ctx->d_scratch, *b = a + align256(total);
+    const uint8_t *res;
+    // (at least one literal pass, so that instance ids become set / clear; zero iterations = the undilated mask: a 1x1 pass)
+    StructuringElement one;
+    one.kh = one.kw = 1;
+    memset(one.m, 0, sizeof(one.m));
+    one.m[0] = 1;
+    if ((rc = dilate_se_iterate(ctx, d_mask, n, H, W, iterations ? el : one, iterations ? iterations : 1, instance_id, a, b, &res))) return rc;
+    hipLaunchKernelGGL(zero_under_mask_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, res, total, d_depth, d_out);
     HIVE_CHECK_HIP(ctx, hipGetLastError());
     return HIVE_OK;
 }

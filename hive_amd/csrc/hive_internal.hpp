@@ -116,6 +116,13 @@ struct hive_tsdf {
     int round_mode = HIVE_ROUND_HALF_EVEN;
     // frames per sweep of the most recent hive_tsdf_integrate_batch (1 = the single-frame kernel), in launch order
     std::vector<int> last_groups;
+    // true while every weight of the volume is a whole number of unit observations: set by create / reset, kept by integrate calls with
+    // obs_weight == 1 (at most 65533 frames: unit_frames), cleared by anything else that writes the planes (other observation weights,
+    // set_volume / set_volume_range / accum_finalize, hive_tsdf_planes_modified).  Selects the division-free colour update (tsdf.hip).
+    bool unit_weights = true;
+    int64_t unit_frames = 0;
+    // device word holding the work-list length of the most recent sweep (valid until the next sweep but one on this context)
+    const unsigned *last_n_items = nullptr;
     // mesh extraction results (device)
     int64_t n_verts = -1, n_faces = -1;
     float *d_verts = nullptr, *d_norms = nullptr, *d_verts_vox = nullptr;

@@ -31,56 +31,63 @@ struct FrameParams {
     int X, Y, Z, H, W;
     int x_off;                      // x-slab volumes: voxel (x, y, z) of this volume is voxel (x + x_off, y, z) of the scene grid
     const uint2 *frame;             // {depth bits, r | g<<8 | b<<16}
-    const unsigned *max_depth_bits;  // float bits of max(depth) of this frame
+    const unsigned *tile_max;       // float bits of max(depth) per (32 << tile_shift)^2-pixel tile, [tiles_y][tiles_x] (prep_frame_kernel)
+    int tile_shift, tiles_x, tiles_y;
+    int row_far;                    // 1: a row's far cut comes from the tiles its projection crosses; 0: from the frame's max depth
+    int fast_colour;                // 1: obs_w == 1, roundf contract, every weight of the volume an integer < 65534: update_voxels FASTC
     unsigned long long *n_updated;
 };
 
 // ---------------------------------------------------------------------------------------------
-// pre-pass: fuse depth f32 + colour u8x3 into one 8-byte texel and reduce max(depth)
-// (4 pixels per lane: one 16-byte depth load, three 4-byte colour loads, two 16-byte stores; one
-// atomicMax per workgroup).  VEC = false is the scalar fallback for unaligned / ragged images.
+// pre-pass, one workgroup per (32 << tile_shift)^2-pixel tile of one frame (blockIdx.y = frame of a batch: frames are n pixels apart in
+// every buffer): depth f32 + colour u8x3 fused into one 8-byte texel, and max(depth) of the tile (the work list's per-row far cut,
+// below).  VEC: 4 pixels per lane (one 16-byte depth load, three 4-byte colour loads, two 16-byte stores -- needs W % 4 == 0, depth
+// 16-byte and colour 4-byte aligned); VEC = false is the scalar form for ragged / unaligned images.
 template <bool VEC>
-__global__ __launch_bounds__(256) void pack_frame_kernel(const float *__restrict__ depth, const uint8_t *__restrict__ color,
-                                                         int n, uint2 *__restrict__ out, unsigned *max_bits, unsigned *zero_next) {
+__global__ __launch_bounds__(256) void prep_frame_kernel(const float *__restrict__ depth, const uint8_t *__restrict__ color, int H, int W, int tile_shift,
+                                                         int tiles_x, uint2 *__restrict__ out, unsigned *__restrict__ tile_max, int tile_stride,
+                                                         unsigned *zero_next) {
     __shared__ unsigned wave_max[4];
-    // blockIdx.y = frame of a batch (launch_integrate_multi): frames are n pixels apart in all three buffers, one max-depth slot each
+    const int n = H * W;
     depth += (size_t)blockIdx.y * n;
     color += (size_t)blockIdx.y * n * 3;
     out += (size_t)blockIdx.y * n;
-    max_bits += blockIdx.y;
-    // the NEXT frame's scalar block (max depth, update count, work-list length) is cleared here instead of by a memset launch per
-    // frame: the blocks alternate, and this kernel runs after every kernel of the frame that used that block last (stream order)
-    if (blockIdx.x == 0 && threadIdx.x < 8) zero_next[threadIdx.x] = 0u;
-    const int i = (blockIdx.x * 256 + threadIdx.x) * (VEC ? 4 : 1);
+    tile_max += (size_t)blockIdx.y * tile_stride;
+    // the NEXT sweep's scalar block (work-list length, ...) is cleared here instead of by a memset launch per sweep: the blocks
+    // alternate, and this kernel runs after every kernel of the sweep that used that block last (stream order)
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 8) zero_next[threadIdx.x] = 0u;
+    const int TS = 32 << tile_shift;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x % tiles_x;
     // max over non-negative floats == max over their bit patterns; NaN / negatives are ignored (treated as 0)
     unsigned bits = 0;
-    if (VEC) {
-        if (i < n) {
+    const int per_row = VEC ? TS / 4 : TS;
+    for (int g = threadIdx.x; g < per_row * TS; g += 256) {
+        const int r = ty * TS + g / per_row, c = tx * TS + (g % per_row) * (VEC ? 4 : 1);
+        if (r >= H || c >= W) continue;
+        const int i = r * W + c;
+        if (VEC) {
             const float4 d = *reinterpret_cast<const float4 *>(depth + i);
-            const uint3 c = *reinterpret_cast<const uint3 *>(color + 3 * i);  // 12 bytes = 4 RGB pixels
-            const unsigned p0 = c.x & 0xffffffu;
-            const unsigned p1 = (c.x >> 24) | ((c.y & 0xffffu) << 8);
-            const unsigned p2 = (c.y >> 16) | ((c.z & 0xffu) << 16);
-            const unsigned p3 = c.z >> 8;
+            const uint3 cc = *reinterpret_cast<const uint3 *>(color + 3 * (size_t)i);  // 12 bytes = 4 RGB pixels
+            const unsigned p0 = cc.x & 0xffffffu;
+            const unsigned p1 = (cc.x >> 24) | ((cc.y & 0xffffu) << 8);
+            const unsigned p2 = (cc.y >> 16) | ((cc.z & 0xffu) << 16);
+            const unsigned p3 = cc.z >> 8;
             uint4 *o = reinterpret_cast<uint4 *>(out + i);
             o[0] = make_uint4(__float_as_uint(d.x), p0, __float_as_uint(d.y), p1);
             o[1] = make_uint4(__float_as_uint(d.z), p2, __float_as_uint(d.w), p3);
             const float m = fmaxf(fmaxf(d.x, d.y), fmaxf(d.z, d.w));
-            bits = (m > 0.f) ? __float_as_uint(m) : 0u;
+            bits = max(bits, (m > 0.f) ? __float_as_uint(m) : 0u);
+        } else {
+            const float d = depth[i];
+            const unsigned rr = color[3 * (size_t)i + 0], gg = color[3 * (size_t)i + 1], bb = color[3 * (size_t)i + 2];
+            out[i] = make_uint2(__float_as_uint(d), rr | (gg << 8) | (bb << 16));
+            bits = max(bits, (d > 0.f) ? __float_as_uint(d) : 0u);
         }
-    } else if (i < n) {
-        const float d = depth[i];
-        const unsigned r = color[3 * i + 0], g = color[3 * i + 1], b = color[3 * i + 2];
-        out[i] = make_uint2(__float_as_uint(d), r | (g << 8) | (b << 16));
-        bits = (d > 0.f) ? __float_as_uint(d) : 0u;
     }
     for (int off = 32; off > 0; off >>= 1) bits = max(bits, (unsigned)__shfl_xor((int)bits, off));
     if ((threadIdx.x & 63) == 0) wave_max[threadIdx.x >> 6] = bits;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        bits = max(max(wave_max[0], wave_max[1]), max(wave_max[2], wave_max[3]));
-        if (bits) atomicMax(max_bits, bits);
-    }
+    if (threadIdx.x == 0) tile_max[blockIdx.x] = max(max(wave_max[0], wave_max[1]), max(wave_max[2], wave_max[3]));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -102,16 +109,37 @@ constexpr int VPT = 4;  // consecutive z voxels per lane: one 16-byte access per
 constexpr int COUNT_SLOTS = 64, COUNT_STRIDE = 16;  // update counters of the COUNT kernels: 64 x u64, 128 bytes apart (hive_ctx::d_scalars + 128)
 struct WorkItem {
     unsigned xy;  // x | y << 16
-    unsigned zz;  // segment start z | interval end z << 16
+    unsigned zz;  // segment start z | voxels of the segment inside the row's interval (1 .. 64) << 16 | frames whose own interval meets the segment << 24
 };
 
 struct RowClip {
     int z0, z1;  // half-open voxel range that may pass the inclusion tests
 };
 
+// Per-tile depth maxima of a frame (prep_frame_kernel) -> LDS table of their 3 x 3-dilated values, and the frame's maximum.  A row of
+// voxels projects to a straight image segment; every pixel a voxel of the row can round to lies within one tile (in each axis) of a
+// sample taken every <= tile size along that segment, so the maximum of the DILATED table over the samples bounds the depth the row
+// can meet: voxels with cam_z > that + trunc fail `depth - cam_z >= -trunc` at every pixel they can reach.
+constexpr int MAX_TILES = 2048;
+__device__ __forceinline__ void load_dilated_tiles(const unsigned *__restrict__ raw, int tiles_x, int tiles_y, float *dil, unsigned *gmax, int tid, int nthreads) {
+    unsigned m_all = 0;
+    for (int t = tid; t < tiles_x * tiles_y; t += nthreads) {
+        const int ty = t / tiles_x, tx = t % tiles_x;
+        unsigned m = 0;
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int yy = min(max(ty + dy, 0), tiles_y - 1), xx = min(max(tx + dx, 0), tiles_x - 1);
+                m = max(m, raw[yy * tiles_x + xx]);
+            }
+        dil[t] = __uint_as_float(m);
+        m_all = max(m_all, m);
+    }
+    if (m_all) atomicMax(gmax, m_all);
+}
+
 // Clip the row cam(tz) = a + b*tz against the padded frustum.  Conservative: pixel bounds widened by
-// half a pixel, the result by 2 voxels on each side.
-__device__ __forceinline__ RowClip clip_row(const FrameParams &p, float ax, float ay, float az, float far_z) {
+// half a pixel, the result by 2 voxels on each side.  far_frame: max(depth) of the frame; dil (or null): the dilated tile table.
+__device__ __forceinline__ RowClip clip_row(const FrameParams &p, float ax, float ay, float az, float far_frame, const float *dil) {
     const float bx = p.R[6], by = p.R[7], bz = p.R[8];
     // tz range of the row: tz(z) = (oz + z*vs) - T2
     float lo = (p.oz - p.T[2]) - p.vs;
@@ -126,16 +154,42 @@ __device__ __forceinline__ RowClip clip_row(const FrameParams &p, float ax, floa
             empty = true;
         }
     };
-    cut(az, bz);                                                                       // cam_z >= 0
-    cut(far_z - az, -bz);                                                              // cam_z <= far
+    // The two depth cuts carry a slack of ~1e-5 of the distances involved: the kernel evaluates cam_z = az + bz tz and depth - cam_z in
+    // float32, where a row (nearly) PARALLEL to the image plane (|bz| ~ 1e-17 at a yaw of 90 degrees) absorbs bz tz entirely, while the
+    // cut position -alpha / beta amplifies any rounding of alpha by 1 / |bz|: with the far wall exactly at max depth, alpha = 0 cut
+    // such a row at tz <= 0 although every voxel of it sits ON the boundary and updates (found by the frame masks of round 4: the
+    // union of a sweep's clips used to hide it).  The slack moves a cut by less than 1e-3 voxel wherever |bz| is not tiny.
+    const float slack = 1.0e-5f * (1.0f + fabsf(az) + far_frame);
+    cut(az + slack, bz);                                                               // cam_z >= 0
+    cut((far_frame + p.trunc - az) + slack, -bz);                                      // cam_z <= max depth of the frame + trunc
     cut(p.fx * ax + (p.cx + 1.0f) * az, p.fx * bx + (p.cx + 1.0f) * bz);               // px >= -1
     cut(((float)p.W - p.cx) * az - p.fx * ax, ((float)p.W - p.cx) * bz - p.fx * bx);   // px <= W
     cut(p.fy * ay + (p.cy + 1.0f) * az, p.fy * by + (p.cy + 1.0f) * bz);               // py >= -1
     cut(((float)p.H - p.cy) * az - p.fy * ay, ((float)p.H - p.cy) * bz - p.fy * by);   // py <= H
     RowClip r;
-    if (empty || !(lo <= hi)) {
-        r.z0 = r.z1 = 0;
-        return r;
+    r.z0 = r.z1 = 0;
+    if (empty || !(lo <= hi)) return r;
+    if (dil) {
+        // the row's own far cut: the largest depth in the tiles its image segment crosses.  The segment's end points are the
+        // projections of the clipped interval's ends; an end closer than 5 cm to the camera plane projects with too little
+        // precision for this (such rows keep the frame's bound -- a handful of rows next to the camera).
+        const float z0 = az + bz * lo, z1 = az + bz * hi;
+        if (fminf(z0, z1) >= 0.05f) {
+            const float wmax = (float)(p.W - 1), hmax = (float)(p.H - 1);
+            const float u0 = fminf(fmaxf(p.fx * ((ax + bx * lo) / z0) + p.cx, 0.f), wmax), v0 = fminf(fmaxf(p.fy * ((ay + by * lo) / z0) + p.cy, 0.f), hmax);
+            const float u1 = fminf(fmaxf(p.fx * ((ax + bx * hi) / z1) + p.cx, 0.f), wmax), v1 = fminf(fmaxf(p.fy * ((ay + by * hi) / z1) + p.cy, 0.f), hmax);
+            const float ts = (float)(32 << p.tile_shift);
+            const int n = (int)(fmaxf(fabsf(u1 - u0), fabsf(v1 - v0)) / ts) + 1;  // samples 0 .. n, at most a tile apart in each axis
+            const float du = (u1 - u0) / (float)n, dv = (v1 - v0) / (float)n;
+            float m = 0.f;
+            for (int i = 0; i <= n; ++i) {
+                const int tx = min((int)(u0 + du * (float)i) >> (5 + p.tile_shift), p.tiles_x - 1);
+                const int ty = min((int)(v0 + dv * (float)i) >> (5 + p.tile_shift), p.tiles_y - 1);
+                m = fmaxf(m, dil[ty * p.tiles_x + tx]);
+            }
+            cut((m + p.trunc - az) + slack, -bz);  // cam_z <= row bound + trunc
+            if (empty || !(lo <= hi)) return r;
+        }
     }
     const float inv = 1.0f / p.vs;
     float zf0 = floorf((lo + p.T[2] - p.oz) * inv) - 2.0f;
@@ -147,31 +201,9 @@ __device__ __forceinline__ RowClip clip_row(const FrameParams &p, float ax, floa
     return r;
 }
 
-__global__ __launch_bounds__(1024) void build_worklist_kernel(FrameParams p, WorkItem *__restrict__ items, unsigned *n_items) {
-    __shared__ unsigned wave_sum[16];
-    __shared__ unsigned block_base;
-    constexpr int CHUNK = SEG_LANES * VPT;
-    const long long row = (long long)blockIdx.x * 1024 + threadIdx.x;
+// block-wide exclusive scan of the rows' segment counts (1024 threads), one atomic per workgroup; returns the lane's first slot
+__device__ __forceinline__ unsigned worklist_slots(unsigned n_chunks, unsigned *n_items, unsigned *wave_sum, unsigned *block_base) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    unsigned n_chunks = 0;
-    int zstart = 0, z1 = 0, x = 0, y = 0;
-    if (row < (long long)p.X * p.Y) {
-        x = (int)(row / p.Y);
-        y = (int)(row % p.Y);
-        const float tx = (p.ox + (float)(x + p.x_off) * p.vs) - p.T[0];
-        const float ty = (p.oy + (float)y * p.vs) - p.T[1];
-        const float ax = p.R[0] * tx + p.R[3] * ty;
-        const float ay = p.R[1] * tx + p.R[4] * ty;
-        const float az = p.R[2] * tx + p.R[5] * ty;
-        const float far_z = __uint_as_float(*p.max_depth_bits) + p.trunc;
-        const RowClip clip = clip_row(p, ax, ay, az, far_z);
-        if (clip.z1 > clip.z0) {
-            zstart = (clip.z0 / VPT) * VPT;
-            z1 = clip.z1;
-            n_chunks = (unsigned)((z1 - zstart + CHUNK - 1) / CHUNK);
-        }
-    }
-    // block-wide exclusive scan of n_chunks, one atomic per workgroup
     unsigned inc = n_chunks;
     for (int off = 1; off < 64; off <<= 1) {
         const unsigned o = (unsigned)__shfl_up((int)inc, off);
@@ -186,14 +218,46 @@ __global__ __launch_bounds__(1024) void build_worklist_kernel(FrameParams p, Wor
             wave_sum[w] = total;
             total += s;
         }
-        block_base = total ? atomicAdd(n_items, total) : 0u;
+        *block_base = total ? atomicAdd(n_items, total) : 0u;
     }
     __syncthreads();
-    unsigned slot = block_base + wave_sum[wave] + inc - n_chunks;
+    return *block_base + wave_sum[wave] + inc - n_chunks;
+}
+
+__global__ __launch_bounds__(1024) void build_worklist_kernel(FrameParams p, WorkItem *__restrict__ items, unsigned *n_items) {
+    __shared__ unsigned wave_sum[16];
+    __shared__ unsigned block_base;
+    __shared__ float dil[MAX_TILES];
+    __shared__ unsigned gmax;
+    constexpr int CHUNK = SEG_LANES * VPT;
+    if (threadIdx.x == 0) gmax = 0u;
+    __syncthreads();
+    load_dilated_tiles(p.tile_max, p.tiles_x, p.tiles_y, dil, &gmax, threadIdx.x, 1024);
+    __syncthreads();
+    const long long row = (long long)blockIdx.x * 1024 + threadIdx.x;
+    unsigned n_chunks = 0;
+    int zstart = 0, z1 = 0, x = 0, y = 0;
+    if (row < (long long)p.X * p.Y) {
+        x = (int)(row / p.Y);
+        y = (int)(row % p.Y);
+        const float tx = (p.ox + (float)(x + p.x_off) * p.vs) - p.T[0];
+        const float ty = (p.oy + (float)y * p.vs) - p.T[1];
+        const float ax = p.R[0] * tx + p.R[3] * ty;
+        const float ay = p.R[1] * tx + p.R[4] * ty;
+        const float az = p.R[2] * tx + p.R[5] * ty;
+        const RowClip clip = clip_row(p, ax, ay, az, __uint_as_float(gmax), p.row_far ? dil : nullptr);
+        if (clip.z1 > clip.z0) {
+            zstart = (clip.z0 / VPT) * VPT;
+            z1 = clip.z1;
+            n_chunks = (unsigned)((z1 - zstart + CHUNK - 1) / CHUNK);
+        }
+    }
+    const unsigned slot = worklist_slots(n_chunks, n_items, wave_sum, &block_base);
     for (unsigned c = 0; c < n_chunks; ++c) {
+        const int zs = zstart + (int)c * CHUNK;
         WorkItem it;
         it.xy = (unsigned)x | ((unsigned)y << 16);
-        it.zz = (unsigned)(zstart + (int)c * CHUNK) | ((unsigned)z1 << 16);
+        it.zz = (unsigned)zs | ((unsigned)min(z1 - zs, CHUNK) << 16) | (1u << 24);
         items[slot + c] = it;
     }
 }
@@ -324,37 +388,83 @@ __device__ __forceinline__ V voxel_cam_z(const FrameParams &p, float az, int z) 
 
 // Running-average update of NV voxels; lanes / elements with ok == false keep their values.
 // UNIT: obs_weight == 1 (the reference's only call): ow * x == x exactly, the four multiplications are left out.
-template <int RM, typename V, int NV, bool UNIT = false>
-__device__ __forceinline__ void update_voxels(V &t, V &w, V &c, V dist, const unsigned (&rgb)[NV], const bool (&ok)[NV], float ow) {
-    const V w_old = w;
-    const V vow = v_splat(ow, w);
-    const V w_new = w_old + vow;
-    const V wr = refined_rcp(w_new);
-    const V t_new = div_exact(t * w_old + (UNIT ? dist : vow * dist), w_new, wr);
-    V or_, og, ob, nr, ng, nb;
+// The colour plane holds b 65536 + g 256 + r as a float (exact: an integer below 2^24).  The kernels keep the three channels as
+// floats while a voxel is in registers (the fused sweep: across all of its frames) and pack once before the store.
+template <typename V, int NV>
+__device__ __forceinline__ void unpack_colour(V c, V &r, V &g, V &b) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        const unsigned oc = (unsigned)v_get(c, i);  // exact: packed colour is an integer < 2^24
-        v_set(or_, i, (float)(oc & 255u));
-        v_set(og, i, (float)((oc >> 8) & 255u));
-        v_set(ob, i, (float)(oc >> 16));
+        const unsigned oc = (unsigned)v_get(c, i);
+        v_set(r, i, (float)(oc & 255u));
+        v_set(g, i, (float)((oc >> 8) & 255u));
+        v_set(b, i, (float)(oc >> 16));
+    }
+}
+template <typename V>
+__device__ __forceinline__ V pack_colour(V r, V g, V b) {  // (the oracle's own expression; two packed fma)
+    return v_fma(b, v_splat(65536.0f, r), v_fma(g, v_splat(256.0f, r), r));
+}
+__device__ __forceinline__ float v_floor(float x) { return floorf(x); }
+__device__ __forceinline__ f2 v_floor(f2 x) { return f2{floorf(x.x), floorf(x.y)}; }
+
+// Running-average update of NV voxels; lanes / elements with ok == false keep their values.
+// UNIT: obs_weight == 1 (the reference's only call): ow * x == x exactly, the four multiplications are left out.
+// FASTC (needs RM == 1, UNIT, and every weight of the volume an integer below 65534 -- the host tracks that: hive_tsdf::unit_weights):
+// the contract's colour update c' = min(255, roundf((c w + c_new) / (w + 1))) without its three divisions.  With n = c w + c_new and
+// d = w + 1 integers (both exact in float32 below 2^24), n / d = c + delta / d, delta = c_new - c in [-255, 255].  The correctly
+// rounded quotient fl(n / d) lies on the same side of every k + 1/2 as n / d itself -- a quotient that is not exactly k + 1/2 is at
+// least 1 / (2 d) > 2^-17 away from it, more than half an ulp of any float below 256 -- so roundf(fl(n / d)) = floor(n / d + 1/2)
+// = c + floor(delta / d + 1/2), and that is <= 255 by itself.  floor(delta / d + 1/2) is evaluated as floor(fma(delta, y, 1/2 + y / 4))
+// with y = the refined reciprocal of d: the bias y / 4 lifts exact ties (delta / d + 1/2 an integer) clear of the rounding errors
+// (<= 4.6e-5 / d + 7.5e-8, against 0.25 / d) and leaves every other value (at least 1 / (2 d) from an integer) on its side.
+// Exhaustively checked against the contract's expression on the CPU (tests/test_oracle_cpu.py::test_fast_colour_update_identity).
+template <int RM, typename V, int NV, bool UNIT, bool FASTC>
+__device__ __forceinline__ void update_voxels(V &t, V &w, V &r, V &g, V &b, V dist, const unsigned (&rgb)[NV], const bool (&ok)[NV], float ow) {
+    static_assert(!FASTC || (RM == 1 && UNIT), "the division-free colour update is the roundf / unit-weight contract's");
+    const V w_old = w;
+    V nr, ng, nb;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
         v_set(nr, i, (float)(rgb[i] & 255u));
         v_set(ng, i, (float)((rgb[i] >> 8) & 255u));
         v_set(nb, i, (float)((rgb[i] >> 16) & 255u));
     }
+    if (FASTC) {
+        const V w_new = w_old + v_splat(1.0f, w);
+        const V wr = refined_rcp(w_new);
+        const V t_new = div_exact(t * w_old + dist, w_new, wr);
+        V y, inc;  // elements that do not update: y = 0 -> floor(0 + 1/2) = 0 leaves the channels alone; weight + 0
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            v_set(y, i, ok[i] ? v_get(wr, i) : 0.0f);
+            v_set(inc, i, ok[i] ? 1.0f : 0.0f);
+        }
+        const V bias = v_fma(v_splat(0.25f, w), y, v_splat(0.5f, w));
+        r = r + v_floor(v_fma(nr - r, y, bias));
+        g = g + v_floor(v_fma(ng - g, y, bias));
+        b = b + v_floor(v_fma(nb - b, y, bias));
+        w = w_old + inc;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if (ok[i]) v_set(t, i, v_get(t_new, i));
+        return;
+    }
+    const V vow = v_splat(ow, w);
+    const V w_new = w_old + vow;
+    const V wr = refined_rcp(w_new);
+    const V t_new = div_exact(t * w_old + (UNIT ? dist : vow * dist), w_new, wr);
     const V lim = v_splat(255.0f, w);
-    const V r = v_min(v_round_nonneg<RM>(div_exact(or_ * w_old + (UNIT ? nr : vow * nr), w_new, wr)), lim);
-    const V g = v_min(v_round_nonneg<RM>(div_exact(og * w_old + (UNIT ? ng : vow * ng), w_new, wr)), lim);
-    const V b = v_min(v_round_nonneg<RM>(div_exact(ob * w_old + (UNIT ? nb : vow * nb), w_new, wr)), lim);
-    // b 65536 + g 256 + r: integers below 2^24, exact in float32 (the oracle's own expression); two packed fma instead of three
-    // conversions, two shift-ors and a conversion back per voxel
-    const V c_new = v_fma(b, v_splat(65536.0f, w), v_fma(g, v_splat(256.0f, w), r));
+    const V r_new = v_min(v_round_nonneg<RM>(div_exact(r * w_old + (UNIT ? nr : vow * nr), w_new, wr)), lim);
+    const V g_new = v_min(v_round_nonneg<RM>(div_exact(g * w_old + (UNIT ? ng : vow * ng), w_new, wr)), lim);
+    const V b_new = v_min(v_round_nonneg<RM>(div_exact(b * w_old + (UNIT ? nb : vow * nb), w_new, wr)), lim);
 #pragma unroll
     for (int i = 0; i < NV; ++i)
         if (ok[i]) {
             v_set(t, i, v_get(t_new, i));
             v_set(w, i, v_get(w_new, i));
-            v_set(c, i, v_get(c_new, i));
+            v_set(r, i, v_get(r_new, i));
+            v_set(g, i, v_get(g_new, i));
+            v_set(b, i, v_get(b_new, i));
         }
 }
 
@@ -461,7 +571,7 @@ __global__ __launch_bounds__(256) void integrate_kernel(FrameParams p, const Wor
         const int x = (int)(item.xy & 0xffffu), y = (int)(item.xy >> 16);
         const int zseg = (int)(item.zz & 0xffffu);
         const int zb = zseg + sl * VPT;  // volume role: this lane's first voxel
-        const bool live = zb < (int)(item.zz >> 16);
+        const bool live = sl * VPT < (int)((item.zz >> 16) & 0xffu);
         const int nrow = p.Z - zb;  // voxels of this quad inside the row (>= 4 except in the last quad of a row with Z % 4 != 0)
         const long long idx = ((long long)x * p.Y + y) * p.Z + zb;
         float t[VPT], w[VPT], c[VPT];  // ACCUM: planes 0..2
@@ -527,7 +637,7 @@ __global__ __launch_bounds__(256) void integrate_kernel(FrameParams p, const Wor
             if (!ACCUM) {
 #pragma unroll
                 for (int g = 0; g < Sh::NG; ++g) {
-                    V tv, wv, cv;
+                    V tv, wv, cv, rv, gv, bv;
                     unsigned rg[Sh::NV];
                     bool okg[Sh::NV];
 #pragma unroll
@@ -539,16 +649,21 @@ __global__ __launch_bounds__(256) void integrate_kernel(FrameParams p, const Wor
                         rg[i] = rgb[j];
                         okg[i] = ok[j];
                     }
-                    if (p.obs_w == 1.0f)  // (kernel-uniform)
-                        update_voxels<RM, V, Sh::NV, true>(tv, wv, cv, dist[g], rg, okg, p.obs_w);
+                    unpack_colour<V, Sh::NV>(cv, rv, gv, bv);
+                    // (kernel-uniform branches)
+                    if (RM == 1 && p.fast_colour)
+                        update_voxels<1, V, Sh::NV, true, true>(tv, wv, rv, gv, bv, dist[g], rg, okg, p.obs_w);
+                    else if (p.obs_w == 1.0f)
+                        update_voxels<RM, V, Sh::NV, true, false>(tv, wv, rv, gv, bv, dist[g], rg, okg, p.obs_w);
                     else
-                        update_voxels<RM, V, Sh::NV>(tv, wv, cv, dist[g], rg, okg, p.obs_w);
+                        update_voxels<RM, V, Sh::NV, false, false>(tv, wv, rv, gv, bv, dist[g], rg, okg, p.obs_w);
+                    const V cn = pack_colour(rv, gv, bv);
 #pragma unroll
                     for (int i = 0; i < Sh::NV; ++i) {
                         const int j = g * Sh::NV + i;
                         t[j] = v_get(tv, i);
                         w[j] = v_get(wv, i);
-                        c[j] = v_get(cv, i);
+                        if (ok[j]) c[j] = v_get(cn, i);  // (a voxel that does not update keeps its stored colour bits)
                         if (COUNT && ok[j]) ++n_upd;
                     }
                 }
@@ -606,25 +721,33 @@ __global__ __launch_bounds__(256) void integrate_kernel(FrameParams p, const Wor
 #endif
 constexpr int MAXF = HIVE_TSDF_MAXF;
 struct MultiParams {
-    FrameParams f[MAXF];  // the per-frame fields (R, T, frame, max_depth_bits) differ; the rest is the same in all
+    FrameParams f[MAXF];  // the per-frame fields (R, T, frame / depth / rgb, tile_max) differ; the rest is the same in all
     int nf;
+    int frame_skip;  // 1: a wave skips the frames whose clip excludes all of its segments (work item masks)
 };
 
 __global__ __launch_bounds__(1024) void build_worklist_multi_kernel(MultiParams mp, WorkItem *__restrict__ items, unsigned *n_items) {
     __shared__ unsigned wave_sum[16];
     __shared__ unsigned block_base;
+    __shared__ float dil[MAXF][MAX_TILES];
+    __shared__ unsigned gmax[MAXF];
     constexpr int CHUNK = SEG_LANES * VPT;
     const FrameParams &p = mp.f[0];
+    if (threadIdx.x < MAXF) gmax[threadIdx.x] = 0u;
+    __syncthreads();
+    for (int f = 0; f < mp.nf; ++f) load_dilated_tiles(mp.f[f].tile_max, p.tiles_x, p.tiles_y, dil[f], &gmax[f], threadIdx.x, 1024);
+    __syncthreads();
     const long long row = (long long)blockIdx.x * 1024 + threadIdx.x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned n_chunks = 0;
     int zstart = 0, z1 = 0, x = 0, y = 0;
+    int fz0[MAXF], fz1[MAXF];  // the frames' own intervals (empty: 0, 0)
     if (row < (long long)p.X * p.Y) {
         x = (int)(row / p.Y);
         y = (int)(row % p.Y);
         int lo = p.Z, hi = 0;
 #pragma unroll
-        for (int f = 0; f < MAXF; ++f)
+        for (int f = 0; f < MAXF; ++f) {
+            fz0[f] = fz1[f] = 0;
             if (f < mp.nf) {
                 const FrameParams &q = mp.f[f];
                 const float tx = (q.ox + (float)(x + q.x_off) * q.vs) - q.T[0];
@@ -632,47 +755,41 @@ __global__ __launch_bounds__(1024) void build_worklist_multi_kernel(MultiParams 
                 const float ax = q.R[0] * tx + q.R[3] * ty;
                 const float ay = q.R[1] * tx + q.R[4] * ty;
                 const float az = q.R[2] * tx + q.R[5] * ty;
-                const float far_z = __uint_as_float(*q.max_depth_bits) + q.trunc;
-                const RowClip clip = clip_row(q, ax, ay, az, far_z);
+                const RowClip clip = clip_row(q, ax, ay, az, __uint_as_float(gmax[f]), p.row_far ? dil[f] : nullptr);
                 if (clip.z1 > clip.z0) {
+                    fz0[f] = clip.z0, fz1[f] = clip.z1;
                     lo = min(lo, clip.z0);
                     hi = max(hi, clip.z1);
                 }
             }
+        }
         if (hi > lo) {
             zstart = (lo / VPT) * VPT;
             z1 = hi;
             n_chunks = (unsigned)((z1 - zstart + CHUNK - 1) / CHUNK);
         }
     }
-    unsigned inc = n_chunks;
-    for (int off = 1; off < 64; off <<= 1) {
-        const unsigned o = (unsigned)__shfl_up((int)inc, off);
-        if (lane >= off) inc += o;
-    }
-    if (lane == 63) wave_sum[wave] = inc;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned total = 0;
-        for (int w = 0; w < 16; ++w) {
-            const unsigned s = wave_sum[w];
-            wave_sum[w] = total;
-            total += s;
-        }
-        block_base = total ? atomicAdd(n_items, total) : 0u;
-    }
-    __syncthreads();
-    const unsigned slot = block_base + wave_sum[wave] + inc - n_chunks;
+    const unsigned slot = worklist_slots(n_chunks, n_items, wave_sum, &block_base);
     for (unsigned c = 0; c < n_chunks; ++c) {
+        const int zs = zstart + (int)c * CHUNK;
+        unsigned mask = 0;  // frames whose own interval meets [zs, zs + CHUNK): the others cannot update a voxel of this segment
+#pragma unroll
+        for (int f = 0; f < MAXF; ++f) mask |= (fz1[f] > zs && fz0[f] < zs + CHUNK) ? (1u << f) : 0u;
         WorkItem it;
         it.xy = (unsigned)x | ((unsigned)y << 16);
-        it.zz = (unsigned)(zstart + (int)c * CHUNK) | ((unsigned)z1 << 16);
+        it.zz = (unsigned)zs | ((unsigned)min(z1 - zs, CHUNK) << 16) | (mask << 24);
         items[slot + c] = it;
     }
 }
 
-template <int RM>
-__global__ __launch_bounds__(256) void integrate_multi_kernel(MultiParams mp, const WorkItem *__restrict__ items, const unsigned *__restrict__ n_items_ptr,
+// UPD: 0 = any observation weight, 1 = obs_weight == 1, 2 = obs_weight == 1 with the division-free colour update (update_voxels FASTC)
+#ifdef HIVE_TSDF_WAVES
+#define HIVE_TSDF_OCC __attribute__((amdgpu_waves_per_eu(HIVE_TSDF_WAVES, HIVE_TSDF_WAVES)))
+#else
+#define HIVE_TSDF_OCC
+#endif
+template <int RM, int UPD>
+__global__ __launch_bounds__(256) HIVE_TSDF_OCC void integrate_multi_kernel(MultiParams mp, const WorkItem *__restrict__ items, const unsigned *__restrict__ n_items_ptr,
                                                               float *__restrict__ v0, float *__restrict__ v1, float *__restrict__ v2) {
     constexpr int PER_WAVE = 64 / SEG_LANES, SEG_VOX = SEG_LANES * 4;
     typedef ItemShape Sh;
@@ -693,14 +810,22 @@ __global__ __launch_bounds__(256) void integrate_multi_kernel(MultiParams mp, co
         const int x = (int)(item.xy & 0xffffu), y = (int)(item.xy >> 16);
         const int zseg = (int)(item.zz & 0xffffu);
         const int zb = zseg + sl * VPT;
-        const bool live = zb < (int)(item.zz >> 16);
+        const bool live = sl * VPT < (int)((item.zz >> 16) & 0xffu);
         const int nrow = p0.Z - zb;  // voxels of this quad inside the row (< 4 only in the last quad of a row with Z % 4 != 0)
         const long long idx = ((long long)x * p0.Y + y) * p0.Z + zb;
-        float t[VPT], w[VPT], c[VPT];
+        // frames that can update a voxel of ANY of the wave's segments (build_worklist_multi_kernel): the others are skipped by the
+        // whole wave -- no projection, no gather, no tests.  (A skipped frame's own clip excludes every voxel of the segments, and the
+        // clip is conservative: skipping cannot change a result.)
+        unsigned wave_frames = item.zz >> 24;
+#pragma unroll
+        for (int o = SEG_LANES; o < 64; o <<= 1) wave_frames |= (unsigned)__shfl_xor((int)wave_frames, o);
+        wave_frames = mp.frame_skip ? (unsigned)__builtin_amdgcn_readfirstlane((int)wave_frames) : 0xffu;
+        float t[VPT], w[VPT], cr[VPT], cg[VPT], cb[VPT];  // the colour as three channels while the voxels are in registers
         bool loaded = false;
         uint2 *mine = xchg + ((threadIdx.x >> 6) * PER_WAVE + seg) * SEG_VOX;
 #pragma unroll 1  // one frame's parameters in scalar registers at a time (unrolled, the four sets spill 160 SGPRs)
         for (int f = 0; f < mp.nf; ++f) {
+            if (!((wave_frames >> f) & 1u)) continue;  // (wave-uniform)
             const FrameParams &p = mp.f[f];
             const float tx = (p.ox + (float)(x + p.x_off) * p.vs) - p.T[0];
             const float ty = (p.oy + (float)y * p.vs) - p.T[1];
@@ -708,6 +833,9 @@ __global__ __launch_bounds__(256) void integrate_multi_kernel(MultiParams mp, co
             const float ay = p.R[1] * tx + p.R[4] * ty;
             const float az = p.R[2] * tx + p.R[5] * ty;
             // gather role: voxels zseg + SEG_LANES k + sl, k = 0 .. 3
+            // (Round 4, measured and taken out: depth and colour as separate planes, the 4-byte depth gathered first, the depth tests run
+            // in the gather role and the colour fetched for the passing voxels only -- the second dependent round trip costs more than
+            // the lines it saves: 292 vs 224 us per four-frame launch on the room scene, 261 vs 219 on the bench scene.)
             uint2 tex[4];
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
@@ -738,14 +866,17 @@ __global__ __launch_bounds__(256) void integrate_multi_kernel(MultiParams mp, co
             const bool any = depth_tests<V>(p, trunc_rcp, depth_v, cam_z, live, nrow, dist, ok);
             if (any) {
                 if (!loaded) {  // the lane's first frame with an update: its voxels come in now and stay in registers
+                    float c[VPT];
                     vol_load4(t, v0 + idx, nrow);
                     vol_load4(w, v1 + idx, nrow);
                     vol_load4(c, v2 + idx, nrow);
+#pragma unroll
+                    for (int j = 0; j < VPT; ++j) unpack_colour<float, 1>(c[j], cr[j], cg[j], cb[j]);
                     loaded = true;
                 }
 #pragma unroll
                 for (int g = 0; g < Sh::NG; ++g) {
-                    V tv, wv, cv;
+                    V tv, wv, rv, gv, bv;
                     unsigned rg[Sh::NV];
                     bool okg[Sh::NV];
 #pragma unroll
@@ -753,25 +884,30 @@ __global__ __launch_bounds__(256) void integrate_multi_kernel(MultiParams mp, co
                         const int j = g * Sh::NV + i;
                         v_set(tv, i, t[j]);
                         v_set(wv, i, w[j]);
-                        v_set(cv, i, c[j]);
+                        v_set(rv, i, cr[j]);
+                        v_set(gv, i, cg[j]);
+                        v_set(bv, i, cb[j]);
                         rg[i] = rgb[j];
                         okg[i] = ok[j];
                     }
-                    if (p.obs_w == 1.0f)  // (kernel-uniform)
-                        update_voxels<RM, V, Sh::NV, true>(tv, wv, cv, dist[g], rg, okg, p.obs_w);
-                    else
-                        update_voxels<RM, V, Sh::NV>(tv, wv, cv, dist[g], rg, okg, p.obs_w);
+                    update_voxels<RM, V, Sh::NV, UPD >= 1, UPD == 2>(tv, wv, rv, gv, bv, dist[g], rg, okg, p.obs_w);
 #pragma unroll
                     for (int i = 0; i < Sh::NV; ++i) {
                         const int j = g * Sh::NV + i;
                         t[j] = v_get(tv, i);
                         w[j] = v_get(wv, i);
-                        c[j] = v_get(cv, i);
+                        cr[j] = v_get(rv, i);
+                        cg[j] = v_get(gv, i);
+                        cb[j] = v_get(bv, i);
                     }
                 }
             }
         }
         if (loaded) {
+            // (a voxel of the quad that no frame updated gets its colour back as pack(unpack(c)) = c: the plane holds integers below 2^24)
+            float c[VPT];
+#pragma unroll
+            for (int j = 0; j < VPT; ++j) c[j] = pack_colour(cr[j], cg[j], cb[j]);
             vol_store4(v0 + idx, t, nrow);
             vol_store4(v1 + idx, w, nrow);
             vol_store4(v2 + idx, c, nrow);
@@ -870,6 +1006,24 @@ static int fill_volume(hive_tsdf *v) {
 // the scalar block of the frame in flight: d_scalars[0..7] or d_scalars[48..55]
 static inline unsigned *tsdf_scalars(hive_ctx *ctx) { return ctx->d_scalars + (ctx->tsdf_scalars ? 48 : 0); }
 
+// tiles of (32 << shift)^2 pixels, the smallest shift with at most MAX_TILES tiles (the work-list kernels keep MAXF tables in LDS)
+struct TileGrid {
+    int shift, tiles_x, tiles_y;
+};
+static TileGrid tile_grid(int H, int W) {
+    TileGrid g;
+    for (g.shift = 0;; ++g.shift) {
+        const int ts = 32 << g.shift;
+        g.tiles_x = (W + ts - 1) / ts;
+        g.tiles_y = (H + ts - 1) / ts;
+        if ((long long)g.tiles_x * g.tiles_y <= MAX_TILES) return g;
+    }
+}
+static bool env_flag(const char *name, bool dflt) {  // tuning switches, read per call (A/B runs toggle them inside one process)
+    const char *e = getenv(name);
+    return e ? atoi(e) != 0 : dflt;
+}
+
 static int prepare_frame(hive_tsdf *v, const uint8_t *color, const float *depth, int H, int W, int mem,
                          const uint8_t **d_color, const float **d_depth) {
     hive_ctx *ctx = v->ctx;
@@ -887,19 +1041,23 @@ static int prepare_frame(hive_tsdf *v, const uint8_t *color, const float *depth,
         *d_depth = depth;
         *d_color = color;
     }
-    int rc = hive_reserve_device(ctx, &ctx->d_frame, &ctx->frame_bytes, npx * sizeof(uint2));
+    const TileGrid tg = tile_grid(H, W);
+    const size_t tex_bytes = (npx * sizeof(uint2) + 255) & ~(size_t)255;
+    int rc = hive_reserve_device(ctx, &ctx->d_frame, &ctx->frame_bytes, tex_bytes + MAX_TILES * sizeof(unsigned));
     if (rc) return rc;
-    // scalar block of this frame: [0] max depth bits, [4] work-list length (update counters: d_scalars + 128).  Two blocks alternate (both zero after
-    // hive_ctx_create); the pack kernel of a frame clears the block of the next one.
+    // scalar block of this frame: [4] work-list length (update counters: d_scalars + 128).  Two blocks alternate (both zero after
+    // hive_ctx_create); the prep kernel of a frame clears the block of the next one.
     ctx->tsdf_scalars ^= 1;
-    unsigned *mine = tsdf_scalars(ctx), *next = ctx->d_scalars + (ctx->tsdf_scalars ? 0 : 48);
-    const bool vec = npx % 4 == 0 && ((uintptr_t)*d_depth % 16 == 0) && ((uintptr_t)*d_color % 4 == 0);
+    unsigned *next = ctx->d_scalars + (ctx->tsdf_scalars ? 0 : 48);
+    unsigned *tiles = (unsigned *)((char *)ctx->d_frame + tex_bytes);
+    const bool vec = W % 4 == 0 && ((uintptr_t)*d_depth % 16 == 0) && ((uintptr_t)*d_color % 4 == 0);
+    const dim3 grid((unsigned)(tg.tiles_x * tg.tiles_y), 1);
     if (vec)
-        hipLaunchKernelGGL(pack_frame_kernel<true>, dim3((unsigned)((npx / 4 + 255) / 256)), dim3(256), 0, ctx->stream, *d_depth,
-                           *d_color, (int)npx, (uint2 *)ctx->d_frame, mine, next);
+        hipLaunchKernelGGL(prep_frame_kernel<true>, grid, dim3(256), 0, ctx->stream, *d_depth, *d_color, H, W, tg.shift, tg.tiles_x, (uint2 *)ctx->d_frame, tiles,
+                           MAX_TILES, next);
     else
-        hipLaunchKernelGGL(pack_frame_kernel<false>, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, ctx->stream, *d_depth,
-                           *d_color, (int)npx, (uint2 *)ctx->d_frame, mine, next);
+        hipLaunchKernelGGL(prep_frame_kernel<false>, grid, dim3(256), 0, ctx->stream, *d_depth, *d_color, H, W, tg.shift, tg.tiles_x, (uint2 *)ctx->d_frame, tiles,
+                           MAX_TILES, next);
     HIVE_CHECK_HIP(ctx, hipGetLastError());
     return HIVE_OK;
 }
@@ -925,40 +1083,75 @@ static void fill_frame_params(hive_tsdf *v, int H, int W, const float K[9], cons
     p.Z = (int)v->dim[2];
     p.H = H;
     p.W = W;
+    const TileGrid tg = tile_grid(H, W);
+    p.tile_shift = tg.shift;
+    p.tiles_x = tg.tiles_x;
+    p.tiles_y = tg.tiles_y;
+    p.row_far = env_flag("HIVE_TSDF_ROW_FAR", true) ? 1 : 0;
+    p.frame = nullptr;
+    p.tile_max = nullptr;
+    // the division-free colour update: the roundf contract, unit observation weight, and a volume whose weights are all integers
+    // below 65534 -- true as long as every integrate since the last reset had obs_weight == 1 (hive_tsdf::unit_weights / unit_frames)
+    p.fast_colour = (v->round_mode == HIVE_ROUND_HALF_AWAY && obs_weight == 1.0f && v->unit_weights && env_flag("HIVE_TSDF_FAST_COLOUR", true)) ? 1 : 0;
+    p.n_updated = nullptr;
 }
 
-// nf (2 .. MAXF) device-resident frames in ONE sweep (integrate_multi_kernel): nf pack launches, one work list over the union of the
-// frames' clips, one integrate launch.
+// nf (2 .. MAXF) device-resident frames in ONE sweep (integrate_multi_kernel): one prep launch for the nf frames (texels + tile
+// maxima), one work list over the union of the frames' clips, one integrate launch.
+// `prepared` (or null): the caller already holds the sweep's inputs -- the {depth, rgb} texels and the tile maxima of every frame
+// (hive_dpt_forward leaves both behind) -- and no prep launch is needed.
+struct PreparedFrames {
+    const uint2 *texels;       // [nf][H*W]
+    const unsigned *tile_max;  // [nf][tile_stride], tiles of (32 << tile_grid(H, W).shift)^2 pixels
+    int tile_stride;
+};
 static int launch_integrate_multi(hive_tsdf *v, int nf, const uint8_t *color, const float *depth, int H, int W, const float K[9], const double *poses,
-                                  float obs_weight) {
+                                  float obs_weight, const PreparedFrames *prepared) {
     hive_ctx *ctx = v->ctx;
     const size_t npx = (size_t)H * W;
-    int rc = hive_reserve_device(ctx, &ctx->d_frame, &ctx->frame_bytes, (size_t)nf * npx * sizeof(uint2));
-    if (rc) return rc;
-    // scalar block of this sweep: [f] = max depth of frame f, [MAXF] = work-list length.  Two blocks alternate (both zero after
-    // hive_ctx_create); this sweep's pack kernel clears the other one, which the previous sweep used (stream order) -- no memset launch
-    static_assert(MAXF + 1 <= 8, "pack_frame_kernel clears 8 words of the next block");
+    const TileGrid tg = tile_grid(H, W);
+    const size_t tex_bytes = ((size_t)nf * npx * sizeof(uint2) + 255) & ~(size_t)255;
+    int rc = HIVE_OK;
+    // scalar block of this sweep: [MAXF] = work-list length.  Two blocks alternate (both zero after hive_ctx_create); this sweep's
+    // first kernel clears the other one, which the previous sweep used (stream order) -- no memset launch
+    static_assert(MAXF + 1 <= 8, "prep_frame_kernel clears 8 words of the next block");
     ctx->tsdf_multi_scalars ^= 1;
     unsigned *sc = ctx->d_scalars + (ctx->tsdf_multi_scalars ? 80 : 64);
     unsigned *idle_block = ctx->d_scalars + (ctx->tsdf_multi_scalars ? 64 : 80);
+    const uint2 *texels = nullptr;
+    const unsigned *tiles = nullptr;
+    int tile_stride = MAX_TILES;
+    if (prepared) {
+        texels = prepared->texels;
+        tiles = prepared->tile_max;
+        tile_stride = prepared->tile_stride;
+        HIVE_CHECK_HIP(ctx, hipMemsetAsync(idle_block, 0, 8 * sizeof(unsigned), ctx->stream));
+    } else {
+        if ((rc = hive_reserve_device(ctx, &ctx->d_frame, &ctx->frame_bytes, tex_bytes + (size_t)MAXF * MAX_TILES * sizeof(unsigned)))) return rc;
+        unsigned *d_tiles = (unsigned *)((char *)ctx->d_frame + tex_bytes);
+        // the 4-pixels-per-lane form needs every frame's depth 16-byte and colour 4-byte aligned
+        const bool vec = W % 4 == 0 && (uintptr_t)depth % 16 == 0 && (uintptr_t)color % 4 == 0;
+        const dim3 grid((unsigned)(tg.tiles_x * tg.tiles_y), (unsigned)nf);
+        if (vec)
+            hipLaunchKernelGGL(prep_frame_kernel<true>, grid, dim3(256), 0, ctx->stream, depth, color, H, W, tg.shift, tg.tiles_x, (uint2 *)ctx->d_frame, d_tiles,
+                               MAX_TILES, idle_block);
+        else
+            hipLaunchKernelGGL(prep_frame_kernel<false>, grid, dim3(256), 0, ctx->stream, depth, color, H, W, tg.shift, tg.tiles_x, (uint2 *)ctx->d_frame, d_tiles,
+                               MAX_TILES, idle_block);
+        HIVE_CHECK_HIP(ctx, hipGetLastError());
+        texels = (const uint2 *)ctx->d_frame;
+        tiles = d_tiles;
+    }
     MultiParams mp;
     mp.nf = nf;
-    // all nf frames in one launch; the 4-pixels-per-lane form needs every frame's depth 16-byte and colour 4-byte aligned
-    if (npx % 4 == 0 && (uintptr_t)depth % 16 == 0 && (uintptr_t)color % 4 == 0)
-        hipLaunchKernelGGL(pack_frame_kernel<true>, dim3((unsigned)((npx / 4 + 255) / 256), (unsigned)nf), dim3(256), 0, ctx->stream, depth, color, (int)npx,
-                           (uint2 *)ctx->d_frame, sc, idle_block);
-    else
-        hipLaunchKernelGGL(pack_frame_kernel<false>, dim3((unsigned)((npx + 255) / 256), (unsigned)nf), dim3(256), 0, ctx->stream, depth, color, (int)npx,
-                           (uint2 *)ctx->d_frame, sc, idle_block);
+    mp.frame_skip = env_flag("HIVE_TSDF_FRAME_SKIP", true) ? 1 : 0;
     for (int f = 0; f < nf; ++f) {
-        uint2 *packed = (uint2 *)ctx->d_frame + (size_t)f * npx;
         fill_frame_params(v, H, W, K, poses + 16 * (size_t)f, obs_weight, mp.f[f]);
-        mp.f[f].frame = packed;
-        mp.f[f].max_depth_bits = sc + f;
-        mp.f[f].n_updated = nullptr;
+        mp.f[f].frame = texels + (size_t)f * npx;
+        mp.f[f].tile_max = tiles + (size_t)f * tile_stride;
+        if (env_flag("HIVE_TSDF_TIMING_SAME_TEXELS", false)) mp.f[f].frame = texels;  // TIMING EXPERIMENT ONLY (wrong results): every frame gathers from frame 0's texels
     }
     for (int f = nf; f < MAXF; ++f) mp.f[f] = mp.f[0];
-    HIVE_CHECK_HIP(ctx, hipGetLastError());
     const FrameParams &p = mp.f[0];
     const long long rows = (long long)p.X * p.Y;
     const long long seg = SEG_LANES * 4;
@@ -966,14 +1159,23 @@ static int launch_integrate_multi(hive_tsdf *v, int nf, const uint8_t *color, co
     if ((rc = hive_reserve_device(ctx, &ctx->d_scratch, &ctx->scratch_bytes, max_items * sizeof(WorkItem)))) return rc;
     WorkItem *items = (WorkItem *)ctx->d_scratch;
     unsigned *n_items = sc + MAXF;
+    v->last_n_items = n_items;
     hipLaunchKernelGGL(build_worklist_multi_kernel, dim3((unsigned)((rows + 1023) / 1024)), dim3(1024), 0, ctx->stream, mp, items, n_items);
     const long long max_trips = (long long)((max_items + 64 / SEG_LANES - 1) / (64 / SEG_LANES));
     const dim3 grid((unsigned)std::min<long long>((long long)ctx->num_cus * 8 * HIVE_GRID_MULT, (max_trips + 3) / 4)), block(256);
     if ((rc = hive_time_begin(ctx))) return rc;
-    if (v->round_mode)
-        hipLaunchKernelGGL((integrate_multi_kernel<1>), grid, block, 0, ctx->stream, mp, items, n_items, v->d_tsdf, v->d_weight, v->d_color);
-    else
-        hipLaunchKernelGGL((integrate_multi_kernel<0>), grid, block, 0, ctx->stream, mp, items, n_items, v->d_tsdf, v->d_weight, v->d_color);
+    const int upd = p.fast_colour ? 2 : (obs_weight == 1.0f ? 1 : 0);
+#define HIVE_LAUNCH(RM, UPD) \
+    hipLaunchKernelGGL((integrate_multi_kernel<RM, UPD>), grid, block, 0, ctx->stream, mp, items, n_items, v->d_tsdf, v->d_weight, v->d_color)
+    switch ((v->round_mode ? 3 : 0) + upd) {
+        case 0: HIVE_LAUNCH(0, 0); break;
+        case 1: HIVE_LAUNCH(0, 1); break;
+        case 3: HIVE_LAUNCH(1, 0); break;
+        case 4: HIVE_LAUNCH(1, 1); break;
+        case 5: HIVE_LAUNCH(1, 2); break;
+        default: return hive_fail(ctx, HIVE_ERR_STATE, "integrate: no kernel for round mode %d / update form %d", v->round_mode, upd);
+    }
+#undef HIVE_LAUNCH
     HIVE_CHECK_HIP(ctx, hipGetLastError());
     return hive_time_end(ctx);
 }
@@ -985,7 +1187,7 @@ static int launch_integrate(hive_tsdf *v, float *accum, int H, int W, const floa
     FrameParams p;
     fill_frame_params(v, H, W, K, pose, obs_weight, p);
     p.frame = (const uint2 *)ctx->d_frame;
-    p.max_depth_bits = tsdf_scalars(ctx);
+    p.tile_max = (const unsigned *)((const char *)ctx->d_frame + (((size_t)H * W * sizeof(uint2) + 255) & ~(size_t)255));
     p.n_updated = (unsigned long long *)(ctx->d_scalars + 128);
     if (count) HIVE_CHECK_HIP(ctx, hipMemsetAsync(p.n_updated, 0, COUNT_SLOTS * COUNT_STRIDE * sizeof(unsigned long long), ctx->stream));
     const long long rows = (long long)p.X * p.Y;
@@ -997,6 +1199,7 @@ static int launch_integrate(hive_tsdf *v, float *accum, int H, int W, const floa
     if (rc) return rc;
     WorkItem *items = (WorkItem *)ctx->d_scratch;
     unsigned *n_items = tsdf_scalars(ctx) + 4;
+    v->last_n_items = n_items;
     const dim3 wl_grid((unsigned)((rows + 1023) / 1024));
     hipLaunchKernelGGL(build_worklist_kernel, wl_grid, dim3(1024), 0, ctx->stream, p, items, n_items);
     // grid-stride sweep: HIVE_GRID_MULT (16) x the resident workgroup count (8 workgroups of 4 waves per CU), so that the
@@ -1017,6 +1220,13 @@ static int launch_integrate(hive_tsdf *v, float *accum, int H, int W, const floa
 #undef HIVE_LAUNCH
     HIVE_CHECK_HIP(ctx, hipGetLastError());
     return hive_time_end(ctx);
+}
+
+// bookkeeping behind hive_tsdf::unit_weights: n more observations of weight obs_w are about to be integrated
+static void note_observations(hive_tsdf *v, float obs_w, int64_t n) {
+    if (obs_w != 1.0f) v->unit_weights = false;
+    v->unit_frames += n;
+    if (v->unit_frames > 65533) v->unit_weights = false;  // (w + 1 stays below 65536: the bound of the division-free colour update)
 }
 
 static double voxel_extent(const hive_tsdf *v) {  // longest side of the whole grid in metres
@@ -1133,7 +1343,16 @@ int hive_tsdf_set_round_mode(hive_tsdf *v, int mode) {
 int hive_tsdf_reset(hive_tsdf *v) {
     HIVE_ENTER(v ? v->ctx : nullptr);
     if (!v) return hive_fail(nullptr, HIVE_ERR_INVALID, "vol is NULL");
+    v->unit_weights = true;
+    v->unit_frames = 0;
     return fill_volume(v);
+}
+
+int hive_tsdf_planes_modified(hive_tsdf *v) {
+    if (!v) return hive_fail(nullptr, HIVE_ERR_INVALID, "vol is NULL");
+    v->unit_weights = false;
+    v->n_verts = v->n_faces = -1;
+    return HIVE_OK;
 }
 
 int hive_tsdf_info(hive_tsdf *v, int64_t vol_dim[3], float origin[3], double vol_bnds[6], float *voxel_size,
@@ -1174,6 +1393,7 @@ int hive_tsdf_integrate(hive_tsdf *vol, const uint8_t *color, const float *depth
     hive_ctx *ctx = vol->ctx;
     const uint8_t *d_color;
     const float *d_depth;
+    note_observations(vol, obs_weight, 1);
     if ((rc = prepare_frame(vol, color, depth, H, W, mem, &d_color, &d_depth))) return rc;
     if ((rc = launch_integrate<false>(vol, nullptr, H, W, K, cam_pose, obs_weight, n_updated != nullptr))) return rc;
     vol->n_verts = vol->n_faces = -1;
@@ -1194,6 +1414,7 @@ int hive_tsdf_integrate_batch(hive_tsdf *vol, int n, const uint8_t *color, const
     int rc = check_frame_args(vol, color, depth, H, W, K, cam_poses, mem);
     if (rc) return rc;
     HIVE_REQUIRE(vol->ctx, n >= 0, "integrate_batch: n must be >= 0");
+    note_observations(vol, obs_weight, n);
     const size_t npx = (size_t)H * W;
     // device-resident frames on the vector path: groups of up to MAXF consecutive frames per sweep (bit-identical to one sweep each)
     static const char *frames_env = getenv("HIVE_TSDF_FRAMES_PER_LAUNCH");  // "1": the single-frame kernel (tuning / A-B)
@@ -1223,7 +1444,7 @@ int hive_tsdf_integrate_batch(hive_tsdf *vol, int n, const uint8_t *color, const
         if (multi)
             while (nf < group && f + nf < n && fusable(f, f + nf)) ++nf;
         if (nf > 1) {
-            if ((rc = launch_integrate_multi(vol, nf, color + f * npx * 3, depth + f * npx, H, W, K, cam_poses + 16 * (size_t)f, obs_weight))) return rc;
+            if ((rc = launch_integrate_multi(vol, nf, color + f * npx * 3, depth + f * npx, H, W, K, cam_poses + 16 * (size_t)f, obs_weight, nullptr))) return rc;
         } else {
             const uint8_t *d_color;
             const float *d_depth;
@@ -1242,6 +1463,20 @@ int hive_tsdf_last_batch_groups(hive_tsdf *vol, int *sizes, int capacity, int *n
     HIVE_REQUIRE(vol->ctx, n_groups && capacity >= 0 && (sizes || capacity == 0), "last_batch_groups: bad arguments");
     *n_groups = (int)vol->last_groups.size();
     for (int i = 0; i < capacity && i < *n_groups; ++i) sizes[i] = vol->last_groups[i];
+    return HIVE_OK;
+}
+
+int hive_tsdf_last_sweep_items(hive_tsdf *vol, uint64_t *n_items, int *segment_voxels) {
+    HIVE_ENTER(vol ? vol->ctx : nullptr);
+    if (!vol) return hive_fail(nullptr, HIVE_ERR_INVALID, "vol is NULL");
+    hive_ctx *ctx = vol->ctx;
+    HIVE_REQUIRE(ctx, n_items, "last_sweep_items: NULL argument");
+    HIVE_REQUIRE(ctx, vol->last_n_items, "last_sweep_items: no sweep has run on this volume");
+    unsigned n = 0;
+    HIVE_CHECK_HIP(ctx, hipMemcpyAsync(&n, vol->last_n_items, sizeof(n), hipMemcpyDeviceToHost, ctx->stream));
+    HIVE_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *n_items = n;
+    if (segment_voxels) *segment_voxels = SEG_LANES * VPT;
     return HIVE_OK;
 }
 
@@ -1267,6 +1502,7 @@ int hive_tsdf_set_volume(hive_tsdf *v, const float *h_tsdf, const float *h_color
     if (h_weight) HIVE_CHECK_HIP(ctx, hipMemcpyAsync(v->d_weight, h_weight, bytes, hipMemcpyDefault, ctx->stream));
     HIVE_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     v->n_verts = v->n_faces = -1;
+    v->unit_weights = false;
     return HIVE_OK;
 }
 
@@ -1326,6 +1562,7 @@ int hive_tsdf_set_volume_range(hive_tsdf *v, int64_t first, int64_t count, const
     if (d_weight) HIVE_CHECK_HIP(ctx, hipMemcpyAsync(v->d_weight + first, d_weight, bytes, hipMemcpyDefault, ctx->stream));
     if (d_color) HIVE_CHECK_HIP(ctx, hipMemcpyAsync(v->d_color + first, d_color, bytes, hipMemcpyDefault, ctx->stream));
     v->n_verts = v->n_faces = -1;
+    v->unit_weights = false;
     return HIVE_OK;
 }
 
@@ -1333,6 +1570,7 @@ int hive_tsdf_accum_finalize(hive_tsdf *v, const float *d_accum) {
     if (!v) return hive_fail(nullptr, HIVE_ERR_INVALID, "vol is NULL");
     int rc = hive_tsdf_accum_finalize_to(v, d_accum, v->n, v->n, v->d_tsdf, v->d_weight, v->d_color);
     v->n_verts = v->n_faces = -1;
+    v->unit_weights = false;
     return rc;
 }
 

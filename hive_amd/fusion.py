@@ -16,6 +16,7 @@ import numpy as np
 
 from hive_amd import _lib
 from hive_amd._lib import MEM_DEVICE, MEM_HOST, ptr
+from hive_amd.options import MaskDilationOptions
 
 
 def rigid_transform(xyz, transform):
@@ -161,6 +162,12 @@ class TSDFVolume:
         n = ctypes.c_int(0)
         self._ctx.check(self._ctx.lib.hive_tsdf_last_batch_groups(self._handle, ctypes.cast(sizes, ctypes.c_void_p), 4096, ctypes.byref(n)))
         return [int(sizes[i]) for i in range(min(n.value, 4096))]
+
+    def last_sweep_voxels(self):
+        """Voxels on the work list of the most recent sweep (segments x voxels per segment); forces a stream sync."""
+        n, seg = ctypes.c_uint64(0), ctypes.c_int(0)
+        self._ctx.check(self._ctx.lib.hive_tsdf_last_sweep_items(self._handle, ctypes.byref(n), ctypes.byref(seg)))
+        return int(n.value) * int(seg.value)
 
     def get_volume(self, with_weight=False):
         shape = tuple(int(v) for v in self._vol_dim)
@@ -333,18 +340,24 @@ class DeviceFrames:
             color = torch.empty((n, h, w, 3), dtype=torch.uint8, device="meta")  # shape only: the bounds pass never reads colour
         return cls(color, depth, poses, masks)
 
-    def masked_depth(self, iterations, mode=MASK_BACKGROUND, instance_id=0, ctx=None):
+    def masked_depth(self, iterations, mode=MASK_BACKGROUND, instance_id=0, ctx=None, dilation_filter=None):
         """Depth maps with the mask applied on the device: MASK_BACKGROUND = `depth[dilate(mask) > 0] = 0`
-        (hive/fusion.py:118-121), MASK_FOREGROUND = the complement (only pixels of the undilated mask keep their depth)."""
+        (hive/fusion.py:118-121), MASK_FOREGROUND = the complement (only pixels of the undilated mask keep their depth).
+        ``dilation_filter``: a structuring element other than the reference's 3x3 box (``MaskDilationOptions.filter``)."""
         import torch
         assert self.masks is not None, "this frame set was loaded without masks"
         ctx = ctx or _lib.default_context(self.depth.device.index or 0)
         out = torch.empty_like(self.depth)
         n, h, w = self.depth.shape
+        se = None if dilation_filter is None else MaskDilationOptions(int(iterations), dilation_filter).structuring_element()
         for a in range(0, n, MAX_BATCH_FRAMES):
             b = min(n, a + MAX_BATCH_FRAMES)
-            ctx.check(ctx.lib.hive_depth_apply_mask(ctx.handle, self.depth[a:b].data_ptr(), self.masks[a:b].data_ptr(), b - a, h, w, int(iterations),
-                                                    int(mode), int(instance_id), out[a:b].data_ptr()))
+            if se is None:
+                ctx.check(ctx.lib.hive_depth_apply_mask(ctx.handle, self.depth[a:b].data_ptr(), self.masks[a:b].data_ptr(), b - a, h, w, int(iterations),
+                                                        int(mode), int(instance_id), out[a:b].data_ptr()))
+            else:
+                ctx.check(ctx.lib.hive_depth_apply_mask_se(ctx.handle, self.depth[a:b].data_ptr(), self.masks[a:b].data_ptr(), b - a, h, w, ptr(se),
+                                                           se.shape[0], se.shape[1], int(iterations), int(mode), int(instance_id), out[a:b].data_ptr()))
         return out
 
 

@@ -118,6 +118,13 @@ class HiveDataset:
         self.mask_dataset = ImageFolderDataset(pjoin(self.base_path, self.mask_folder))
         self.inpainted_rgb_dataset, self.inpainted_depth_dataset = self._get_inpainted_frame_data()
 
+    @classmethod
+    def is_valid_folder_structure(cls, path) -> bool:
+        """True when `path` holds the files and folders of a HIVE dataset (io.py `InvalidDatasetFormatError` check)."""
+        path = str(path)
+        return (os.path.isdir(path) and all(os.path.isfile(pjoin(path, f)) for f in cls.required_files)
+                and all(os.path.isdir(pjoin(path, f)) for f in cls.required_folders))
+
     def _validate_dataset(self):
         if not os.path.isdir(self.base_path):
             raise RuntimeError(f"The folder {self.base_path} does not exist.")

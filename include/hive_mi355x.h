@@ -110,6 +110,10 @@ int hive_tsdf_destroy(hive_tsdf *vol);
  * (HIVE_ROUND_HALF_EVEN; `use_gpu=False`, BASELINE config 1). */
 int hive_tsdf_set_round_mode(hive_tsdf *vol, int mode);
 int hive_tsdf_reset(hive_tsdf *vol);
+/* Tell the library that the caller wrote the volume's planes itself (caller-owned storage of hive_tsdf_create): cached mesh results
+ * and the fast paths that rely on what the library knows about the planes' contents (every weight a whole number of unit
+ * observations since the last reset -- the division-free colour update of the sweep) are dropped until the next hive_tsdf_reset. */
+int hive_tsdf_planes_modified(hive_tsdf *vol);
 int hive_tsdf_info(hive_tsdf *vol, int64_t vol_dim[3], float origin[3], double vol_bnds[6],
                    float *voxel_size, float *trunc_margin);
 /* device pointers of the three volumes (for RCCL collectives / zero-copy views) */
@@ -132,6 +136,10 @@ int hive_tsdf_integrate_batch(hive_tsdf *vol, int n, const uint8_t *color, const
  * sweep i (1 = the single-frame kernel), in order; at most `capacity` sizes are written.  Diagnostic: the parity tests assert
  * with it that the fused sweep really ran (the semantics are those of hive/fusion.py:113-124's serial loop either way). */
 int hive_tsdf_last_batch_groups(hive_tsdf *vol, int *sizes, int capacity, int *n_groups);
+/* Length of the work list the most recent sweep on this volume ran over (segments of *segment_voxels consecutive z voxels
+ * that survive the per-row frustum / depth clip); forces a stream sync.  Diagnostic: n_items * segment_voxels against the voxels
+ * a sweep updates is the share of its arithmetic that can change a voxel (bench.py reports it). */
+int hive_tsdf_last_sweep_items(hive_tsdf *vol, uint64_t *n_items, int *segment_voxels);
 /* TSDFVolume.get_volume(): copies tsdf and colour (and weight) out (any may be NULL).  The destinations / sources of
  * get_volume / set_volume may be host OR device memory (unified addressing decides the copy direction). */
 int hive_tsdf_get_volume(hive_tsdf *vol, float *h_tsdf, float *h_color, float *h_weight);
@@ -239,11 +247,20 @@ int hive_texture_window(hive_ctx *ctx, const double *points, int64_t n, const do
 int hive_dilate_mask(hive_ctx *ctx, const uint8_t *mask, int H, int W, int iterations, int mem,
                      uint8_t *out);
 
+/* The same with the caller's structuring element (hive/options.py:245-268: `MaskDilationOptions(num_iterations, dilation_filter)`):
+ * se u8 [kh][kw] (host memory, 1x1 .. 32x32, non-zero = member, at least one member), cv2.dilate's definition -- anchor at
+ * (kw / 2, kh / 2), taps outside the image ignored, the pass repeated `iterations` times (0 = copy).  A full rectangle of odd sides
+ * takes the separable box-max path; anything else is iterated literally. */
+int hive_dilate_mask_se(hive_ctx *ctx, const uint8_t *mask, int H, int W, const uint8_t *se, int kh, int kw, int iterations, int mem,
+                        uint8_t *out);
+
 /* Masking of the depth maps of a frame set on the device (all pointers device memory; d_out may alias d_depth):
  *   mode 0 -- background volume, hive/fusion.py:118-121: `mask = dilate_mask(mask, iterations); depth[mask > 0] = 0`;
  *   mode 1 -- foreground volume (BASELINE config 5: the complement): depth is kept where the UNDILATED mask is set, 0 elsewhere.
  * d_mask u8 [n][H][W] instance ids (hive/io.py:214-218: 0 = background, 1..k = objects); instance_id > 0 restricts "set" to that
  * object, 0 = any object. */
+int hive_depth_apply_mask_se(hive_ctx *ctx, const float *d_depth, const uint8_t *d_mask, int n, int H, int W, const uint8_t *se, int kh,
+                             int kw, int iterations, int mode, int instance_id, float *d_out); /* the same, any structuring element (host) */
 int hive_depth_apply_mask(hive_ctx *ctx, const float *d_depth, const uint8_t *d_mask, int n, int H, int W, int iterations,
                           int mode, int instance_id, float *d_out);
 /* The loader's depth transform on the device (hive/io.py:1032-1039): uint16 millimetres -> float32 metres

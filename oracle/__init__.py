@@ -103,6 +103,15 @@ def dilate_mask(mask, iterations):
     return out.astype(bool)
 
 
+def dilate_mask_se(mask, se, iterations):
+    """Literal iterated cv2-style dilation with an arbitrary structuring element (centre anchor, outside ignored)."""
+    m = _c(np.asarray(mask) != 0, np.uint8)
+    se = _c(np.asarray(se) != 0, np.uint8)
+    out = np.zeros_like(m)
+    lib().oracle_dilate_mask_se(_p(m), m.shape[0], m.shape[1], _p(se), se.shape[0], se.shape[1], int(iterations), _p(out))
+    return out.astype(bool)
+
+
 def depth_quantize(depth_m, depth_scale=1.0 / 1000.0, max_depth=10.0, mask=None):
     d = _c(depth_m, np.float32)
     mm = np.zeros(d.shape, np.uint16)

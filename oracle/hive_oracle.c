@@ -248,6 +248,32 @@ void oracle_project(const double *points, int64_t n, const double K[9], const do
     }
 }
 
+/* hive/image_processing.py:30-45 dilate_mask with ANY structuring element (hive/options.py:245-268 `dilation_filter`), as cv2.dilate
+ * defines it: dst(v, u) = max over the set taps (j, i) of src(v + j - kh / 2, u + i - kw / 2), anchor at the element's centre
+ * (integer division), taps outside the image ignored, the pass repeated `iterations` times. */
+void oracle_dilate_mask_se(const uint8_t *mask, int H, int W, const uint8_t *se, int kh, int kw, int iterations, uint8_t *out) {
+    uint8_t *a = (uint8_t *)malloc((size_t)H * W), *b = (uint8_t *)malloc((size_t)H * W);
+    for (int64_t i = 0; i < (int64_t)H * W; ++i) a[i] = mask[i] ? 1 : 0;
+    for (int it = 0; it < iterations; ++it) {
+        for (int v = 0; v < H; ++v)
+            for (int u = 0; u < W; ++u) {
+                uint8_t m = 0;
+                for (int j = 0; j < kh; ++j)
+                    for (int i = 0; i < kw; ++i) {
+                        const int vv = v + j - kh / 2, uu = u + i - kw / 2;
+                        if (se[j * kw + i] && vv >= 0 && vv < H && uu >= 0 && uu < W && a[(int64_t)vv * W + uu]) m = 1;
+                    }
+                b[(int64_t)v * W + u] = m;
+            }
+        uint8_t *s = a;
+        a = b;
+        b = s;
+    }
+    memcpy(out, a, (size_t)H * W);
+    free(a);
+    free(b);
+}
+
 /* hive/image_processing.py:30-45 dilate_mask with the default 3x3 rectangle (hive/options.py:248),
  * applied `iterations` times, literally (one 3x3 max per iteration, outside pixels ignored). */
 void oracle_dilate_mask(const uint8_t *mask, int H, int W, int iterations, uint8_t *out) {

@@ -127,6 +127,35 @@ def test_dilate_mask_matches_oracle(gpu_ctx, oracle_lib):
         dilate_mask(np.zeros((2, 3, 4)), MaskDilationOptions(1))
 
 
+def test_dilate_mask_any_structuring_element_matches_oracle(gpu_ctx, oracle_lib):
+    """`MaskDilationOptions(num_iterations, dilation_filter)` with filters other than the default 3x3 box
+    (/root/reference/hive/options.py:245-268): cross, ellipse-like, asymmetric, even-sized, a non-square rectangle (separable path)
+    and an element without its own centre -- bit-exact vs the oracle's literal iterated cv2-style dilation."""
+    from hive_amd.image_processing import dilate_mask
+    from hive_amd.options import MaskDilationOptions
+    rng = np.random.default_rng(12)
+    cross = np.array([[0, 1, 0], [1, 1, 1], [0, 1, 0]], np.uint8)
+    ellipse5 = np.array([[0, 0, 1, 0, 0], [1, 1, 1, 1, 1], [1, 1, 1, 1, 1], [1, 1, 1, 1, 1], [0, 0, 1, 0, 0]], np.uint8)  # cv2.MORPH_ELLIPSE (5, 5)
+    lopsided = np.array([[1, 0, 0], [0, 0, 0], [0, 0, 1]], np.uint8)  # no centre: the mask itself is not part of its dilation
+    even = np.ones((2, 4), np.uint8)
+    rect = np.ones((3, 5), np.uint8)
+    ring = np.ones((7, 7), np.uint8)
+    ring[1:6, 1:6] = 0
+    for shape in ((48, 64), (37, 53)):
+        m = rng.random(shape) < 0.01
+        m[0, 0] = m[-1, -1] = m[0, shape[1] // 2] = True  # the image border
+        for se in (cross, ellipse5, lopsided, even, rect, ring, np.ones((1, 1), np.uint8)):
+            for it in (0, 1, 2, 5):
+                out = dilate_mask(m, MaskDilationOptions(num_iterations=it, dilation_filter=se))
+                assert out.dtype == bool and np.array_equal(out, oracle_lib.dilate_mask_se(m, se, it)), (se.shape, it)
+    box = np.ones((3, 3), np.uint8)
+    assert np.array_equal(dilate_mask(m, MaskDilationOptions(4, box)), oracle_lib.dilate_mask(m, 4))
+    with pytest.raises(ValueError):
+        dilate_mask(m, MaskDilationOptions(1, np.zeros((3, 3), np.uint8)))
+    with pytest.raises(ValueError):
+        dilate_mask(m, MaskDilationOptions(1, np.ones((33, 3), np.uint8)))
+
+
 def test_depth_quantize_matches_oracle(gpu_ctx, oracle_lib):
     import torch
     from hive_amd import _lib

@@ -158,3 +158,72 @@ def test_synthetic_sequence_is_seeded():
     from hive_amd.geometric import Trajectory
     back = Trajectory(rows.astype(np.float64)).inverse().to_homogenous_transforms()
     np.testing.assert_allclose(back, a["poses"], atol=1e-5)
+
+
+def test_option_groups_and_entrypoints_keep_the_reference_api(tmp_path):
+    """`north_star`: "keeping HIVE's hive.pipeline / hive.options entrypoints and dataset adaptors".  Names, constructor arguments, defaults and
+    CLI flags of /root/reference/hive/options.py:70-689, the adaptor names of dataset_adaptors.py:769,1023,1158 and
+    `Pipeline.from_command_line` (pipeline.py:100-141) -- API only for the stages outside the hot path."""
+    import argparse
+    from hive_amd import dataset_adaptors as da
+    from hive_amd.options import (BackgroundMeshOptions, COLMAPOptions, ForegroundTrajectorySmoothingOptions, InpaintingMode, MaskDilationOptions,
+                                  MeshDecimationOptions, MeshFilteringOptions, PipelineOptions, StorageOptions, WebXROptions)
+    from hive_amd.pipeline import Pipeline
+    # defaults as in the reference
+    p = PipelineOptions()
+    assert (p.num_frames, p.frame_step, p.estimate_pose, p.estimate_depth, p.background_only, p.static_camera, p.align_scene, p.billboard, p.log_file) == \
+        (-1, 15, False, False, False, False, False, False, 'logs.log') and p.inpainting_mode is InpaintingMode.Off
+    c = COLMAPOptions()
+    assert (c.is_single_camera, c.single_camera_per_folder, c.dense, c.quality, c.binary_path) == (True, False, False, 'low', '/usr/local/bin/colmap')
+    with pytest.raises(AssertionError):
+        COLMAPOptions(quality='ultra')
+    assert COLMAPOptions.from_json(c.to_json()) == c and c.copy() == c and c.copy() is not c
+    d = MeshDecimationOptions()
+    assert (d.num_faces_background, d.num_faces_object, d.max_error) == (2 ** 14, 2 ** 10, 0.001)
+    assert (ForegroundTrajectorySmoothingOptions().learning_rate, ForegroundTrajectorySmoothingOptions().num_epochs) == (1e-5, 0)
+    w = WebXROptions()
+    assert (w.webxr_path, w.webxr_url, w.webxr_run_server) == ('third_party/HIVE_Renderer/docs/video', 'localhost:8080', False)
+    assert [m.to_integer() for m in InpaintingMode.get_modes()] == [0, 1, 2, 3, 4] == InpaintingMode.get_modes_as_integer()
+    assert InpaintingMode.from_integer(2) is InpaintingMode.Lama_Image_CV2_Depth and InpaintingMode.get_name(4) == 'Lama_Image_Depth'
+    assert InpaintingMode.CV2_Image_Depth == InpaintingMode.CV2_Image | InpaintingMode.CV2_Depth
+    with pytest.raises(RuntimeError):
+        InpaintingMode.from_integer(7)
+    # the reference's command line parses into the same option objects
+    pipe = Pipeline.from_command_line(['--dataset_path', 'in', '--output_path', 'out', '--estimate_depth', '--background_only', '--num_frames', '50',
+                                       '--multiple_cameras', '--quality', 'high', '--inpainting_mode', '1', '--dilate_mask_iter', '3', '--sdf_voxel_size',
+                                       '0.02', '--num_faces_object', '512', '--webxr_add_sky_box', '--no_cache'])
+    assert (pipe.num_frames, pipe.estimate_depth, pipe.estimate_pose, pipe.options.background_only) == (50, True, False, True)
+    assert pipe.options.inpainting_mode is InpaintingMode.CV2_Image_Depth
+    assert (pipe.storage_options.dataset_path, pipe.storage_options.output_path, pipe.storage_options.no_cache, pipe.storage_options.overwrite_ok) == \
+        ('in', 'out', True, False)
+    assert (pipe.colmap_options.is_single_camera, pipe.colmap_options.quality) == (False, 'high')
+    assert pipe.dilation_options.num_iterations == 3 and pipe.background_mesh_options.sdf_voxel_size == 0.02
+    assert pipe.decimation_options.num_faces_object == 512 and pipe.webxr_options.webxr_add_sky_box and pipe.mesh_path == os.path.join('out', 'mesh')
+    with pytest.raises(SystemExit):  # --dataset_path / --output_path are required, as in the reference
+        Pipeline.from_command_line(['--num_frames', '3'])
+    # every group registers on a shared parser without flag clashes
+    parser = argparse.ArgumentParser()
+    for group in (PipelineOptions, StorageOptions, MaskDilationOptions, MeshFilteringOptions, MeshDecimationOptions, COLMAPOptions, BackgroundMeshOptions, WebXROptions,
+                  ForegroundTrajectorySmoothingOptions):
+        group.add_args(parser)
+    # adaptor names and get_dataset's dispatch by folder layout
+    for name in ('DatasetAdaptor', 'TUMAdaptor', 'UnrealAdaptor', 'VideoAdaptorBase', 'VideoAdaptor', 'StrayScannerAdaptor', 'DeviceOrientation', 'estimate_depth_dpt',
+                 'get_dataset'):
+        assert hasattr(da, name), name
+    unreal = tmp_path / 'unreal'
+    for folder in ('colour', 'depth'):
+        (unreal / folder).mkdir(parents=True)
+    for f in ('info.json', 'camera.txt', 'trajectory.txt'):
+        (unreal / f).write_text('')
+    assert da.UnrealAdaptor.is_valid_folder_structure(unreal) and not da.TUMAdaptor.is_valid_folder_structure(unreal)
+    with pytest.raises(NotImplementedError, match='outside the dense-compute path'):
+        da.get_dataset(StorageOptions(str(unreal), str(tmp_path / 'o1')), COLMAPOptions(), PipelineOptions())
+    video = tmp_path / 'clip.mp4'
+    video.write_bytes(b'')
+    assert da.VideoAdaptor.is_valid_folder_structure(video)
+    with pytest.raises(NotImplementedError):
+        da.get_dataset(StorageOptions(str(video), str(tmp_path / 'o2')))
+    with pytest.raises(RuntimeError, match='Could not recognise'):
+        da.get_dataset(StorageOptions(str(tmp_path), str(tmp_path / 'o3')))
+    with pytest.raises(RuntimeError, match='not a folder'):
+        da.get_dataset(StorageOptions(str(tmp_path / 'missing'), str(tmp_path / 'o4')))

@@ -13,6 +13,9 @@ def gold():
     return np.load(os.path.join(GOLDEN, "geometric_48x64.npz"))
 
 
+FULL_SWEEPS = bool(os.environ.get("HIVE_TEST_FULL"))  # exhaustive parameter sweeps (minutes) instead of the strided ones
+
+
 def kinv(K):
     return np.linalg.inv(K).astype(np.float64)
 
@@ -241,6 +244,66 @@ def test_dilate_equals_box_max(oracle_lib):
         for v, u in zip(*np.nonzero(m)):
             ref[max(0, v - it):v + it + 1, max(0, u - it):u + it + 1] = True
         assert np.array_equal(out, ref)
+
+
+def test_fast_colour_update_identity():
+    """The sweep's division-free colour update (hive_amd/csrc/tsdf.hip, update_voxels FASTC) against the contract's expression
+    c' = min(255, roundf((c w + c_new) / (w + 1))) evaluated in float32 operation by operation, on the CPU:
+      A. roundf(fl(n / d)) == floor((2 n + d) / (2 d)) for integers n <= 255 d, d < 65536 -- every (c, c_new) for a set of weights, and for
+         EVERY d the numerators next to each half-integer quotient (where a double rounding would show);
+      B. floor(fma(delta, y, 1/2 + y / 4)) == floor((2 delta + d) / (2 d)) for every delta in [-255, 255] and every d in [1, 65534], with
+         y = the float32 reciprocal of d and y moved by up to two ulps either way (the kernel's refined reciprocal is within one)."""
+    f32, f64 = np.float32, np.float64
+
+    def quotient_rounded(n, d):  # roundf of the correctly rounded float32 quotient (n, d: float32 integers; n / d >= 0)
+        q = (n.astype(f64) / d.astype(f64)).astype(f32)  # float64 quotient of float32 operands rounds to the correctly rounded float32 quotient
+        return np.minimum(np.floor(q.astype(f64) + 0.5), 255.0)
+
+    def fast(c, cn, d, ulps):
+        y = (1.0 / d.astype(f64)).astype(f32)
+        for _ in range(abs(ulps)):
+            y = np.nextafter(y, f32(np.inf) if ulps > 0 else f32(-np.inf))
+        bias = (0.25 * y.astype(f64) + 0.5).astype(f32)                                       # fma(0.25, y, 0.5): exact in float64, one rounding
+        t = ((cn - c).astype(f64) * y.astype(f64) + bias.astype(f64)).astype(f32)              # fma(delta, y, bias)
+        return c.astype(f64) + np.floor(t.astype(f64))
+
+    d = np.arange(1, 65535, dtype=np.int64)
+    for delta in range(-255, 256, 1 if FULL_SWEEPS else 3):
+        exact = np.floor_divide(2 * delta + d, 2 * d)
+        for ulps in (-2, 0, 2):
+            assert np.array_equal(fast(np.zeros(len(d), f32), np.full(len(d), delta, f32), d.astype(f32), ulps), exact), (delta, ulps)
+    for k in range(0, 255):  # numerators around (k + 1/2) d, every d
+        n_lo = ((2 * k + 1) * d) // 2
+        for n in (n_lo - 1, n_lo, n_lo + 1):
+            n = np.clip(n, 0, 255 * d)
+            assert np.array_equal(quotient_rounded(n.astype(f32), d.astype(f32)), np.floor_divide(2 * n + d, 2 * d)), k
+    cc, cn = (a.ravel().astype(f32) for a in np.meshgrid(np.arange(256), np.arange(256), indexing='ij'))
+    for w in list(range(0, 40)) + [255, 256, 1000, 4095, 4096, 32767, 32768, 65532, 65533]:
+        n = (cc * f32(w)).astype(f32) + cn  # the contract's numerator, exact below 2^24
+        ref = quotient_rounded(n.astype(f32), np.full(len(cc), w + 1, f32))
+        assert np.array_equal(fast(cc, cn, np.full(len(cc), w + 1, f32), 0), ref), w
+        assert np.array_equal(fast(cc, cn, np.full(len(cc), w + 1, f32), 1), ref), w
+
+
+def test_dilate_with_a_structuring_element(oracle_lib):
+    """Known answers of cv2.dilate's definition (anchor at the centre, outside ignored, iterated): a single pixel dilated once is the
+    element mirrored about its anchor; the 3x3 box gives the default path; an element without its centre moves the mask."""
+    m = np.zeros((9, 11), bool)
+    m[4, 5] = True
+    cross = np.array([[0, 1, 0], [1, 1, 1], [0, 1, 0]], np.uint8)
+    out = oracle_lib.dilate_mask_se(m, cross, 1)
+    assert out.sum() == 5 and out[3, 5] and out[5, 5] and out[4, 4] and out[4, 6] and out[4, 5]
+    out2 = oracle_lib.dilate_mask_se(m, cross, 2)  # the diamond of radius 2
+    vv, uu = np.mgrid[0:9, 0:11]
+    assert np.array_equal(out2, np.abs(vv - 4) + np.abs(uu - 5) <= 2)
+    corner = np.array([[1, 0, 0], [0, 0, 0], [0, 0, 0]], np.uint8)  # dst(v, u) = src(v - 1, u - 1): the mask moves down-right
+    moved = oracle_lib.dilate_mask_se(m, corner, 3)
+    assert moved.sum() == 1 and moved[7, 8]
+    rng = np.random.default_rng(6)
+    r = rng.random((40, 50)) < 0.02
+    for it in (0, 1, 4):
+        assert np.array_equal(oracle_lib.dilate_mask_se(r, np.ones((3, 3), np.uint8), it), oracle_lib.dilate_mask(r, it))
+    assert np.array_equal(oracle_lib.dilate_mask_se(r, cross, 0), r)
 
 
 def test_depth_quantize(oracle_lib):

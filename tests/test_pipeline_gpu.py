@@ -216,6 +216,18 @@ def test_depth_apply_mask_matches_oracle(gpu_ctx, oracle_lib, iterations):
         assert np.array_equal(fg[i], np.where(masks[i] > 0, depth[i], 0).astype(np.float32))
         assert np.array_equal(fg2[i], np.where(masks[i] == 2, depth[i], 0).astype(np.float32))
     assert (bg == 0).any() and (fg2 > 0).any()
+    # the same with structuring elements other than the 3 x 3 box (MaskDilationOptions.filter, hive/options.py:245-268), per instance too
+    cross = np.array([[0, 1, 0], [1, 1, 1], [0, 1, 0]], np.uint8)
+    for se in (cross, np.ones((5, 5), np.uint8), np.ones((2, 3), np.uint8), np.array([[1, 0, 0], [0, 0, 0], [0, 0, 1]], np.uint8)):
+        bg_se = frames.masked_depth(iterations, fusion.MASK_BACKGROUND, ctx=gpu_ctx, dilation_filter=se).cpu().numpy()
+        bg_se2 = frames.masked_depth(iterations, fusion.MASK_BACKGROUND, instance_id=2, ctx=gpu_ctx, dilation_filter=se).cpu().numpy()
+        for i in range(n):
+            expect = depth[i].copy()
+            expect[oracle_lib.dilate_mask_se(masks[i], se, iterations)] = 0.0
+            assert np.array_equal(bg_se[i], expect), f"frame {i}, element {se.shape}"
+            expect = depth[i].copy()
+            expect[oracle_lib.dilate_mask_se(masks[i] == 2, se, iterations)] = 0.0
+            assert np.array_equal(bg_se2[i], expect), f"frame {i}, element {se.shape}, instance 2"
 
 
 def test_fg_bg_volumes_match_oracle(gpu_ctx, oracle_lib):

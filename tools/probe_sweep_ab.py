@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""A/B of the fused TSDF sweep's switches in ONE process, on both scenes of bench.py (room: analytic depth; dpt: DPT-Hybrid depth of the
+seeded weights), 32 consecutive frames 2.4 degrees apart into 512^3:
+    HIVE_TSDF_ROW_FAR (per-row far cut from the depth tiles), HIVE_TSDF_FRAME_SKIP (work-item frame masks), HIVE_TSDF_FAST_COLOUR (division-free colour update)
+Per configuration: us per frame of the whole leg (prep + work list + sweep, HIP events), us per sweep launch (the library's own events), work-list
+voxels of the last sweep, and a check that the volume is bit-identical to configuration 0 0 0.  Usage: probe_sweep_ab.py [frames] [scene ...]"""
+import itertools
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from hive_amd import _lib, depth as depth_mod, fusion, synthetic  # noqa: E402
+
+frames = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+scenes = sys.argv[2:] or ["room", "dpt"]
+seq = synthetic.make_sequence(num_frames=frames, yaw_step_deg=2.4)
+ctx = _lib.default_context(0)
+n_vox = 512 ** 3
+storage = tuple(torch.empty(n_vox, dtype=torch.float32, device="cuda") for _ in range(3))
+vol = fusion.TSDFVolume(synthetic.room_bounds(), 0.01, ctx=ctx, storage=storage)
+color = torch.from_numpy(seq["color"]).cuda()
+depths = {}
+if "room" in scenes:
+    depths["room"] = torch.from_numpy(seq["depth"]).cuda()
+if "dpt" in scenes:
+    model = depth_mod.build_model(None, device=torch.device("cuda", 0), dtype=torch.bfloat16, engine="hip", init_seed=1234)
+    stream = depth_mod.DepthFusionStream(model, vol, seq["K"])
+    depths["dpt"] = stream.depth(color)[0].clone()
+    del model, stream
+out = {}
+configs = [c for c in itertools.product((0, 1), repeat=3)]
+if os.environ.get("PROBE_CONFIGS"):
+    configs = [tuple(int(ch) for ch in c) for c in os.environ["PROBE_CONFIGS"].split(",")]
+for scene, depth in depths.items():
+    # N_upd per frame (counting single-frame kernel) and N_union per sweep of four
+    vol.reset()
+    n_upd = [vol.integrate(color[i], depth[i], seq["K"], seq["poses"][i], return_n_updated=True) for i in range(min(frames, 8))]
+    ref = None
+    for cfg in configs:
+        os.environ["HIVE_TSDF_ROW_FAR"], os.environ["HIVE_TSDF_FRAME_SKIP"], os.environ["HIVE_TSDF_FAST_COLOUR"] = (str(v) for v in cfg)
+        leg, k_us = [], []
+        for rep in range(5):
+            vol.reset()
+            torch.cuda.synchronize()
+            ctx.set_timing(True)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            vol.integrate_batch(color, depth, seq["K"], seq["poses"])
+            b.record()
+            torch.cuda.synchronize()
+            n, ms = ctx.kernel_time_total()
+            ctx.set_timing(False)
+            leg.append(a.elapsed_time(b) * 1e3 / frames)
+            k_us.append(ms * 1e3 / max(n, 1))
+        wl = vol.last_sweep_voxels()
+        state = torch.stack([s.clone() for s in storage])
+        if ref is None:
+            ref = state
+            same = True
+        else:
+            same = bool(torch.equal(ref, state))
+        # N_union of the last sweep: weights that move across it
+        vol.reset()
+        groups = vol.last_batch_groups()
+        before = storage[1].clone()
+        nf = groups[-1]
+        vol.integrate_batch(color[frames - nf:], depth[frames - nf:], seq["K"], seq["poses"][frames - nf:])
+        n_union = int((storage[1] != before).sum().item())
+        wl_last = vol.last_sweep_voxels()
+        rec = {"row_far": cfg[0], "frame_skip": cfg[1], "fast_colour": cfg[2], "leg_us_per_frame_min": min(leg), "launch_us_min": min(k_us), "launch_us_all": [round(v, 1) for v in k_us],
+               "worklist_voxels_last_sweep": wl_last, "n_union_last_sweep": n_union, "frames_last_sweep": nf, "n_upd_mean": float(np.mean(n_upd)),
+               "bit_identical_to_first": same, "groups": groups[:3]}
+        out.setdefault(scene, []).append(rec)
+        print(scene, json.dumps(rec), flush=True)
+json.dump(out, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "sweep_ab.json"), "w"), indent=1)
