@@ -29,6 +29,7 @@ The merge:
 Rank 0 prints the line.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -54,12 +55,14 @@ def parse_args():
     ap.add_argument("--voxel", type=float, default=0.01, help="0.01 -> 512^3 over the 5.12 m volume")
     ap.add_argument("--engine", default="hip", choices=["hip", "torch"], help="'torch' = PyTorch-op ViT blocks (comparison only)")
     ap.add_argument("--scaling", default="weak", choices=["strong", "weak"],
-                    help="N > 1: weak (default) = N x K x B frames, a contiguous block of K steps per rank; strong = the same K x B frames split over the ranks")
+                    help="N > 1: which job is the headline `value` (the other one is timed too and reported under its own key).  weak = N x K x B frames, a "
+                         "contiguous block of K steps per rank; strong = BASELINE config 3 literally: the same K x B frames split over the ranks")
     ap.add_argument("--merge", default="sum", choices=["sum", "exact"], help="N > 1: how the shared volume is merged")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"], help="16-bit type of the network (north_star: bf16; the reference runs fp16)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"], help="16-bit type of the headline network (north_star: bf16; the reference runs fp16)")
     ap.add_argument("--no-overlap", action="store_true", help="TSDF sweeps on the network's stream (default: on a second stream, under the next batch's network)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--timed-only", action="store_true", help="profiling runs: skip the untimed roofline measurements behind the timed region")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the legs beside the headline job (fp16 job, config4, the other scaling mode at N > 1)")
+    ap.add_argument("--timed-only", action="store_true", help="profiling runs: only the headline timed job (no roofline / cpu_baseline / extra legs)")
     return ap.parse_args()
 
 
@@ -77,11 +80,12 @@ def host_cores():
     return int(env) if env else min(cores, 64)
 
 
-def cpu_baseline(seq, voxel, K):
-    """The CPU path timed on this box's host cores, on a bounded sample of the same workload: the fp32 torch-CPU DPT-Hybrid on
-    two frames (after one warm-up) and the C oracle's integrate -- the restatement of the reference library's loop, its x planes
-    spread over the same cores with OpenMP, as the library's own CPU fallback is `numba @njit(parallel=True)` -- on three 640 x 480
-    frames into the same 512^3 volume.  Both legs use every core the process may run on; the count is in `cores`."""
+def cpu_baseline(seq, voxel, K, budget_s=20.0):
+    """The CPU path timed on this box's host cores, on a bounded sample of the same workload (about `budget_s` seconds of CPU work):
+    the fp32 torch-CPU DPT-Hybrid on consecutive frames of the sequence (batches of 4, after a warm-up; as many batches as fit half the budget, at
+    most 16 frames), then the C oracle's integrate -- the restatement of the reference library's loop, its x planes spread over the same cores with
+    OpenMP, as the library's own CPU fallback is `numba @njit(parallel=True)` -- of exactly those frames, each with ITS OWN CPU depth map (after the
+    uint16-mm hand-off) and pose, into the same 512^3 volume.  Both legs use every core the process may run on; the count is in `cores`."""
     import oracle
     from hive_amd import synthetic
     from hive_amd.dpt.init import seeded_init
@@ -89,26 +93,32 @@ def cpu_baseline(seq, voxel, K):
     cores = host_cores()
     torch.set_num_threads(cores)
     model = seeded_init(DPTDepthModel(path=None, scale=0.000305, shift=0.1378, invert=True, engine="torch"), seed=1234).eval()
-    x = torch.from_numpy(seq["color"][:1].astype(np.float32) / 255.0 * 2.0 - 1.0).permute(0, 3, 1, 2).contiguous()
+    to_x = lambda ids: torch.from_numpy(seq["color"][ids].astype(np.float32) / 255.0 * 2.0 - 1.0).permute(0, 3, 1, 2).contiguous()
+    depths, t_dpt, n_dpt = [], 0.0, 0
     with torch.no_grad():
-        model(x)
-        t0 = time.time()
-        for _ in range(2):
-            depth = model(x)
-        t_dpt = (time.time() - t0) / 2
-    depth_np = depth[0].numpy().astype(np.float32)
+        model(to_x([0]))  # warm-up
+        while n_dpt < 16 and (n_dpt == 0 or t_dpt < budget_s / 2):
+            x = to_x(list(range(n_dpt, n_dpt + 4)))
+            t0 = time.time()
+            d = model(x)
+            t_dpt += time.time() - t0
+            depths.append(d.numpy().astype(np.float32))
+            n_dpt += 4
+    depth_np = np.concatenate(depths)
     depth_np = np.where(depth_np > 10.0, 0.0, np.trunc(depth_np * 1000.0) / 1000.0).astype(np.float32)  # the uint16-mm hand-off
     threads = oracle.set_threads(cores)
     ora = oracle.TSDFVolume(synthetic.room_bounds(), voxel)
-    n_frames, n_upd = 3, 0
+    n_upd = 0
     t0 = time.time()
-    for i in range(n_frames):
-        ora.integrate(seq["color"][i], depth_np, K, seq["poses"][i])
+    for i in range(n_dpt):
+        ora.integrate(seq["color"][i], depth_np[i], K, seq["poses"][i])
         n_upd += ora.last_n_updated
-    t_tsdf = (time.time() - t0) / n_frames
-    return {"value": 1.0 / (t_dpt + t_tsdf), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"2 frames DPT-Hybrid fp32 torch-CPU ({torch.get_num_threads()} threads, {t_dpt:.2f} s/frame) + {n_frames} frames C-oracle TSDF integrate "
-                      f"into {'x'.join(str(int(d)) for d in ora._vol_dim)} (OpenMP, {threads} threads, {t_tsdf:.2f} s/frame, mean N_upd {n_upd // n_frames})"}
+    t_tsdf = time.time() - t0
+    per_frame = (t_dpt + t_tsdf) / n_dpt
+    return {"value": 1.0 / per_frame, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"frames 0..{n_dpt - 1} of the sequence: DPT-Hybrid fp32 torch-CPU in batches of 4 ({torch.get_num_threads()} threads, {t_dpt / n_dpt:.2f} s/frame) + "
+                      f"C-oracle TSDF integrate of each frame's own depth map into {'x'.join(str(int(d)) for d in ora._vol_dim)} (OpenMP, {threads} threads, "
+                      f"{t_tsdf / n_dpt:.3f} s/frame, mean N_upd {n_upd // n_dpt}); {t_dpt + t_tsdf:.1f} s of CPU work in all"}
 
 
 class FrameFeeder:
@@ -151,6 +161,109 @@ class FrameFeeder:
         self.free[token[0]].record(stream or torch.cuda.current_stream())
 
 
+def source_stamp():
+    """sha256 of the TSDF kernel source: profiles/*_integrate_pmc.json carry the stamp of the source they were measured on, and the counter figures
+    are only merged into the line when it matches (a kernel change without a profile refresh must not mix generations)."""
+    h = hashlib.sha256()
+    for name in ("tsdf.hip", "hive_internal.hpp"):
+        with open(os.path.join(ROOT, "hive_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def load_profile(name):
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", name)))
+    except Exception:
+        return None
+
+
+def config4_leg(device, ctx, steps=2, batch=8):
+    """BASELINE configs[3], bounded: 1920 x 1080 frames (host-resident, uploaded in the timed region) -> the reference's resize rule (640 x 480 target, keep
+    aspect ratio, lower bound, multiple of 32: 864 x 480) -> DPT-Large depth (hive_dpt_forward, backbone vitl16_384, bf16, seeded weights) -> nearest
+    back to 1080p (estimate_depth_dpt's rule) -> uint16-mm hand-off -> integrate into a 1024^3 volume (5 mm voxels).  `steps` timed steps of
+    `batch` frames after one warm-up step; the sweep's roofline (SURVEY 8d bytes and must-move bytes) from the frames of the last step."""
+    from hive_amd import depth as depth_mod, fusion, synthetic
+    from hive_amd.dpt.init import seeded_init
+    from hive_amd.dpt.models import DPTDepthModel
+    from hive_amd.dpt.transforms import Resize
+    H, W, T = 1080, 1920, batch * (steps + 1)
+    net_w, net_h = Resize(640, 480, resize_target=None, keep_aspect_ratio=True, ensure_multiple_of=32, resize_method="lower_bound").get_size(W, H)
+    seq = synthetic.make_sequence(num_frames=T, height=H, width=W, yaw_step_deg=2.4)
+    model = DPTDepthModel(path=None, scale=depth_mod.DPT_SCALE, shift=depth_mod.DPT_SHIFT, invert=True, backbone="vitl16_384", engine="hip")
+    seeded_init(model, seed=1234)
+    model = model.eval().to(memory_format=torch.channels_last).to(torch.bfloat16).to(device)
+    storage = tuple(torch.empty(1024 ** 3, dtype=torch.float32, device=device) for _ in range(3))  # caller-owned planes: the weight plane is read below
+    vol = fusion.TSDFVolume(synthetic.room_bounds(), 0.005, ctx=ctx, storage=storage)
+    assert tuple(int(d) for d in vol.vol_dim) == (1024, 1024, 1024)
+    host = torch.from_numpy(seq["color"]).pin_memory()
+
+    def dpt(fr):
+        small = torch.nn.functional.interpolate(fr.permute(0, 3, 1, 2).float(), size=(net_h, net_w), mode="area").round().clamp(0, 255).to(torch.uint8)
+        d, _, _ = model.forward_frames(small.permute(0, 2, 3, 1).contiguous(), max_depth=None)
+        full = torch.nn.functional.interpolate(d[:, None], size=(H, W), mode="nearest")[:, 0]
+        m = (full * 1000.0).to(torch.int32).clamp(0, 65535).float() * (1.0 / 1000.0)
+        return torch.where(m > 10.0, torch.zeros_like(m), m).contiguous()
+
+    def step(i):
+        fr = host[i * batch:(i + 1) * batch].to(device, non_blocking=True)
+        dm = dpt(fr)
+        vol.integrate_batch(fr, dm, seq["K"], seq["poses"][i * batch:(i + 1) * batch])
+        return fr, dm
+
+    with torch.no_grad():
+        step(0)
+        torch.cuda.synchronize()
+        vol.reset()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(1, steps + 1):
+            fr, dm = step(i)
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        # the sweep alone, on the last step's frames: launch duration (HIP events inside the library), N_upd per frame (counting kernel), N_union per sweep
+        ids = list(range(steps * batch, (steps + 1) * batch))
+        n_upd = [vol.integrate(fr[j], dm[j], seq["K"], seq["poses"][i], return_n_updated=True) for j, i in enumerate(ids)]
+        ctx.set_timing(True)
+        vol.integrate_batch(fr, dm, seq["K"], seq["poses"][ids])
+        torch.cuda.synchronize()
+        n_launch, k_ms = ctx.kernel_time_total()
+        ctx.set_timing(False)
+        groups = vol.last_batch_groups()
+        wl = vol.last_sweep_voxels()
+        w_plane = storage[1]
+        w_before = w_plane.clone()
+        nf = groups[-1]
+        vol.integrate_batch(fr[-nf:], dm[-nf:], seq["K"], seq["poses"][ids[-nf:]])
+        n_union = int((w_plane != w_before).sum().item())
+        del w_before, w_plane
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(2):
+            dpt(fr)
+        e1.record()
+        e1.synchronize()
+        dpt_ms = e0.elapsed_time(e1) / 2
+    launch_us = k_ms / max(n_launch, 1) * 1e3
+    fpl = batch / max(len(groups), 1)
+    serial = (24.0 * float(np.mean(n_upd)) + 8.0 * H * W) * fpl
+    must = 24.0 * n_union + 8.0 * H * W * nf
+    out = {"workload": f"synthetic {W}x{H} RGB (room trajectory, 2.4 degrees per frame), DPT-Large (vitl16_384, bf16, seeded weights) at {net_w}x{net_h} + "
+                       f"{'x'.join(str(int(d)) for d in vol.vol_dim)} TSDF integrate, {steps} steps of {batch} frames, uploads in the timed region",
+           "value": steps * batch / elapsed, "unit": "frames/s", "ms_per_step": elapsed / steps * 1e3, "frames_per_step": batch, "steps": steps,
+           "dpt_ms_per_frame": dpt_ms / batch,
+           "roofline": {"kernel": "integrate_multi_kernel", "bound": "hbm", "achieved": serial / (launch_us * 1e-6) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                        "frac": serial / (launch_us * 1e-6) / 1e9 / 8000.0, "algorithmic_bytes_per_launch": serial, "frames_per_launch": fpl,
+                        "avg_launch_us": launch_us, "us_per_frame": launch_us / fpl, "n_upd_mean": float(np.mean(n_upd)),
+                        "must_move": {"bytes_per_launch": must, "gbs": must / (launch_us * 1e-6) / 1e9, "frac": must / (launch_us * 1e-6) / 1e9 / 8000.0,
+                                      "n_union_last_sweep": n_union},
+                        "worklist_voxels_last_sweep": wl}}
+    vol.close()
+    del model, vol, storage
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     args = parse_args()
     from hive_amd import _lib, depth as depth_mod, distributed as hdist, fusion, synthetic
@@ -167,7 +280,8 @@ def main():
 
     H, W, B, T = 480, 640, args.batch, args.frames
     exact = world > 1 and args.merge == "exact"
-    strong = world > 1 and (args.scaling == "strong" or exact)  # (exact: every rank integrates every frame -- fixed total work by construction)
+    headline_strong = world > 1 and (args.scaling == "strong" or exact)  # (exact: every rank integrates every frame -- fixed total work by construction)
+    extra_legs = not (args.no_extra_legs or args.timed_only)
     # the synthetic sequence: the same one on every rank (the job is a stretch of its wrapping frame index)
     seq = synthetic.make_sequence(num_frames=T, height=H, width=W, seed=1234, yaw_step_deg=360.0 / T)
     K = seq["K"]
@@ -177,22 +291,24 @@ def main():
     ctx = _lib.default_context(dev_index)
     overlap = not args.no_overlap and args.merge != "exact"  # (exact mode integrates after the all-gather: nothing to overlap)
     vctx = depth_mod.DepthFusionStream.side_stream_context(dev_index) if overlap else ctx  # the timed volume's context (and stream)
-    net_dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
-    # seeded non-degenerate weights (hive_amd/dpt/init.py): PyTorch's default initialisation predicts a constant 7.25 m, i.e. a
-    # TSDF scene with no surface (free space only); these give depth maps of 1-7 m with surfaces inside the volume
-    model = depth_mod.build_model(None, device=device, dtype=net_dtype, engine=args.engine, init_seed=1234)
+    torch_dtype = {"bf16": torch.bfloat16, "fp16": torch.float16}
     if exact:
         merger = hdist.ExactSlabFusion(synthetic.room_bounds(), args.voxel, ctx=ctx)
         volume = merger.slab
     else:
         merger = None
         volume = fusion.TSDFVolume(synthetic.room_bounds(), args.voxel, ctx=vctx)
-    stream = depth_mod.DepthFusionStream(model, volume, K, overlap=overlap)
     feeder = FrameFeeder(frames_host, B, device)
+
+    def make_stream(dtype_name):
+        # seeded non-degenerate weights (hive_amd/dpt/init.py): PyTorch's default initialisation predicts a constant 7.25 m, i.e. a
+        # TSDF scene with no surface (free space only); these give depth maps of 1-7 m with surfaces inside the volume
+        model = depth_mod.build_model(None, device=device, dtype=torch_dtype[dtype_name], engine=args.engine, init_seed=1234)
+        return depth_mod.DepthFusionStream(model, volume, K, overlap=overlap)
 
     # strong: the job is frames [0, K B) of the wrapping sequence, this rank takes its contiguous share of every stretch asked for;
     # weak: the job is frames [0, N (W + K) B), this rank owns the contiguous block [rank (W + K) B, + (W + K) B) (W warm-up steps first)
-    def job_frames(first_step, n_steps):
+    def job_frames(strong, first_step, n_steps):
         if strong:
             ids = [(first_step * B + j) % T for j in range(n_steps * B)]
             lo, hi = hdist.shard_range(len(ids), rank, world)
@@ -207,9 +323,9 @@ def main():
         cuts = [len(ids) * i // n_b for i in range(n_b + 1)]
         return [ids[a:b] for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
 
-    def run_job(first_step, n_steps, keep_depth=False):
+    def run_job(stream, strong, first_step, n_steps):
         """All of this rank's batches: upload (one batch ahead) -> depth -> integrate (or, exact mode, keep the depth maps)."""
-        ids, counts = job_frames(first_step, n_steps)
+        ids, counts = job_frames(strong, first_step, n_steps)
         todo = batches(ids)
         kept = []
         token = feeder.prefetch(todo[0]) if todo else None
@@ -220,9 +336,7 @@ def main():
                 depth_m, _ = stream.depth(fr)
                 kept.append((fr.clone(), depth_m))
             else:
-                depth_m = stream.step(fr, poses[batch_ids])
-                if keep_depth:
-                    kept.append((batch_ids, depth_m))
+                stream.step(fr, poses[batch_ids])
             feeder.release(token, stream.side if not exact else None)  # the buffer is free once the sweeps that read its colours are done
             token = nxt
         if exact:  # all-gather the frames, integrate every frame of the job in sequence order into this rank's x-slab
@@ -230,64 +344,81 @@ def main():
             depth = torch.cat([d for _, d in kept]) if kept else torch.empty((0, H, W), dtype=torch.float32, device=device)
             all_ids = [(first_step * B + j) % T for j in range(n_steps * B)]
             merger.integrate(color, depth, K, poses[all_ids], counts)
-        return kept
 
-    for s in range(0, args.warmup):
-        run_job(s, 1)
-    if strong and args.warmup > 0:  # the timed job's own batch sizes (this rank's share of K * B frames) also run once untimed:
-        warmed = {len(b) for s in range(args.warmup) for b in batches(job_frames(s, 1)[0])}  # first use sizes the activation arena
-        for size in sorted({len(b) for b in batches(job_frames(args.warmup, args.steps)[0])} - warmed):
-            ids = list(range(size))
-            tok = feeder.prefetch(ids)
-            stream.depth(feeder.acquire(tok))
-            feeder.release(tok)
-    if world > 1 and args.warmup > 0:  # warm-up of the collectives too (RCCL sets up its channels on the first large transfer)
-        if exact:
-            merger.gather()
+    def timed_job(stream, strong):
+        """W untimed warm-up steps, then EXACTLY K timed steps between barrier + synchronize on both sides; at N > 1 the one merge of the shared volume is
+        inside the timed region.  Returns (max-over-ranks seconds, frames of the whole job, sweep launches, sweep kernel ms of this rank)."""
+        for s in range(0, args.warmup):
+            run_job(stream, strong, s, 1)
+        if strong and args.warmup > 0:  # the timed job's own batch sizes (this rank's share of K * B frames) also run once untimed:
+            warmed = {len(b) for s in range(args.warmup) for b in batches(job_frames(strong, s, 1)[0])}  # first use sizes the activation arena
+            for size in sorted({len(b) for b in batches(job_frames(strong, args.warmup, args.steps)[0])} - warmed):
+                tok = feeder.prefetch(list(range(size)))
+                stream.depth(feeder.acquire(tok))
+                feeder.release(tok)
+        if world > 1 and args.warmup > 0:  # warm-up of the collectives too (RCCL sets up its channels on the first large transfer)
+            if exact:
+                merger.gather()
+            else:
+                stream.join()
+                hdist.fuse_sharded(volume)
+        torch.cuda.synchronize()
+        volume.reset()  # the timed job starts from an empty scene
+        torch.cuda.synchronize()
+        vctx.set_timing(True)
+        hdist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        if strong:
+            run_job(stream, True, args.warmup, args.steps)
         else:
-            hdist.fuse_sharded(volume)
-    torch.cuda.synchronize()
-    volume.reset()  # the timed job starts from an empty scene
-    torch.cuda.synchronize()
-    vctx.set_timing(True)
-    hdist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    if strong:
-        run_job(args.warmup, args.steps)
-    else:
-        for s in range(args.steps):
-            run_job(args.warmup + s, 1)
-    stream.join()  # the merge (and the end of the job) behind the last sweeps
-    if world > 1:
-        merged = merger.gather() if exact else hdist.fuse_sharded(volume)
-    torch.cuda.synchronize()
-    hdist.barrier()
-    elapsed = time.perf_counter() - t0
-    n_launch, kernel_ms = vctx.kernel_time_total()
-    vctx.set_timing(False)
-    elapsed = hdist.max_over_ranks(elapsed, device=device if world > 1 else "cpu")
-    if world > 1:
+            for s in range(args.steps):
+                run_job(stream, False, args.warmup + s, 1)
+        stream.join()  # the merge (and the end of the job) behind the last sweeps
+        merged = None
+        if world > 1:
+            merged = merger.gather() if exact else hdist.fuse_sharded(volume)
+        torch.cuda.synchronize()
+        hdist.barrier()
+        elapsed = time.perf_counter() - t0
+        n_launch, kernel_ms = vctx.kernel_time_total()
+        vctx.set_timing(False)
+        elapsed = hdist.max_over_ranks(elapsed, device=device if world > 1 else "cpu")
         del merged
+        total = args.steps * B * (1 if strong or world == 1 else world)
+        return elapsed, total, n_launch, kernel_ms
+
+    stream = make_stream(args.dtype)
+    elapsed, total_frames, n_launch, kernel_ms = timed_job(stream, headline_strong)
 
     if args.timed_only:
         if rank == 0:
-            print(json.dumps({"value": args.steps * B * (1 if strong or world == 1 else world) / elapsed, "unit": "frames/s", "ms_per_step": elapsed / args.steps * 1e3,
-                              "avg_integrate_us": kernel_ms / max(n_launch, 1) * 1e3, "note": "--timed-only: no roofline / cpu_baseline legs"}))
+            print(json.dumps({"value": total_frames / elapsed, "unit": "frames/s", "ms_per_step": elapsed / args.steps * 1e3,
+                              "avg_integrate_us": kernel_ms / max(n_launch, 1) * 1e3, "note": "--timed-only: no roofline / cpu_baseline / extra legs"}))
         return
 
+    # ---- the other scaling mode at N > 1 (BASELINE configs[2] literally when the headline is the weak job) -------------------------------------
+    other = None
+    if world > 1 and extra_legs and not exact:
+        o_elapsed, o_total, _, _ = timed_job(stream, not headline_strong)
+        other = {"scaling": "weak" if headline_strong else "strong", "value": o_total / o_elapsed, "unit": "frames/s", "frames_total": o_total,
+                 "ms_total": o_elapsed * 1e3, "steps": args.steps, "frames_per_step": B,
+                 "note": ("BASELINE configs[2] literally: the SAME K x B frames split in contiguous blocks over the ranks, one merge of the shared volume inside the timed "
+                          "region; value / (the N = 1 line's value) is the strong-scaling speed-up" if not headline_strong else
+                          "N x K x B frames, a contiguous block of K steps per rank, one merge inside the timed region")}
+
     # ---- untimed: what the timed launches processed --------------------------------------------------------------------
-    # A measurement volume of the same shape in caller-owned storage (its weight plane is read directly).  Per frame: N_upd, from the
-    # counting variant of the single-frame kernel.  Per sweep: N_union = voxels updated by ANY frame of the sweep = weights that moved
-    # across the launch (every update adds obs_weight > 0).  Both depend on depth + pose only, not on the volume's state.
+    # A measurement volume of the same shape.  Per frame: N_upd, from the counting variant of the single-frame kernel.  Per sweep: N_union = voxels
+    # updated by ANY frame of the sweep = weights that moved across the launch (every update adds obs_weight > 0), and the work list's length (the voxels
+    # the sweep ran its tests on).  All depend on depth + pose only, not on the volume's state.
     x_range = merger.x_ranges[rank] if exact else None
     n_vox = volume.num_voxels
-    storage = tuple(torch.empty(n_vox, dtype=torch.float32, device=device) for _ in range(3))
+    storage = tuple(torch.empty(n_vox, dtype=torch.float32, device=device) for _ in range(3))  # caller-owned planes: the weight plane is read directly
     mvol = fusion.TSDFVolume(synthetic.room_bounds(), args.voxel, ctx=ctx, storage=storage, x_range=x_range)
     w_plane = storage[1]
 
     def measure(frame_sets, depth_of, time_kernel=False):
-        """Over all frames: per-frame N_upd, per-sweep (frames, N_union), ms per frame of the TSDF leg (pack + work list + sweep), and
+        """Over all frames: per-frame N_upd, per-sweep (frames, N_union, work-list voxels), ms per frame of the TSDF leg (prep + work list + sweep), and
         with time_kernel the HIP-event time of the sweep launches."""
         n_upd, sweeps, leg_ms, k_ms, k_n = [], [], [], 0.0, 0
         for ids in frame_sets:
@@ -295,6 +426,7 @@ def main():
             depth_m = depth_of(fr, ids)
             for j, i in enumerate(ids):
                 n_upd.append(mvol.integrate(fr[j], depth_m[j], K, poses[i], return_n_updated=True))
+            mvol.reset()  # (also: every weight a whole number again -- the sweep's fast colour update, as in the timed job)
             if time_kernel:
                 ctx.set_timing(True)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -312,61 +444,66 @@ def main():
                 before = w_plane.clone()
                 mvol.integrate_batch(fr[a:a + nf], depth_m[a:a + nf], K, poses[ids[a:a + nf]])
                 assert mvol.last_batch_groups() == [nf]
-                sweeps.append((nf, int((w_plane != before).sum().item())))
+                sweeps.append((nf, int((w_plane != before).sum().item()), mvol.last_sweep_voxels()))
                 a += nf
         return n_upd, sweeps, float(np.mean(leg_ms)), (k_ms / max(k_n, 1) * 1e3, k_n)
 
-    def load_profile(name):
-        try:
-            return json.load(open(os.path.join(ROOT, "profiles", name)))
-        except Exception:
-            return None
+    stamp = source_stamp()
 
     def roofline(n_upd, sweeps, launch_us, scene_key):
-        """HBM roofline of the sweep kernel.  Bytes a launch MUST move: every voxel updated by any of its frames is read and written
-        once in three float planes (24 B x N_union) + one read of each frame's depth and colour (8 B x H x W x frames).  SURVEY 8(d)'s
-        per-frame figure (24 N_upd + 8 H W, one sweep per frame) times the frames of the launch is what the same work costs unfused;
-        it is reported separately as `serial_equivalent`: it is not a bandwidth and may exceed the HBM peak."""
-        frames = sum(nf for nf, _ in sweeps)
+        """HBM roofline of the sweep kernel.  `achieved` = SURVEY 8(d)'s ALGORITHMIC bytes per launch -- the per-frame figure 24 N_upd + 8 H W (every voxel a
+        frame updates read and written once in three float planes, one read of the frame's depth + colour) x the frames one launch integrates --
+        / the launch duration.  Four frames share one sweep, so a voxel all four update moves once where the per-frame figure counts it four times: the
+        bytes the fused launch MUST move (24 N_union + 8 H W x frames) are reported beside it as `must_move` -- the stricter figure."""
+        frames = sum(s[0] for s in sweeps)
         fpl = frames / max(len(sweeps), 1)
-        n_union = float(np.mean([u for _, u in sweeps]))
+        n_union = float(np.mean([s[1] for s in sweeps]))
+        wl = float(np.mean([s[2] for s in sweeps]))
         n_upd_mean = float(np.mean(n_upd))
-        alg = 24.0 * n_union + 8.0 * H * W * fpl
-        serial = (24.0 * n_upd_mean + 8.0 * H * W) * fpl
+        must = 24.0 * n_union + 8.0 * H * W * fpl
+        alg = (24.0 * n_upd_mean + 8.0 * H * W) * fpl
         achieved = alg / (launch_us * 1e-6) / 1e9
         out = {"kernel": "integrate_multi_kernel" if fpl > 1 else "integrate_kernel", "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-               "frac": achieved / 8000.0, "traffic": None, "algorithmic_bytes_per_launch": alg, "frames_per_launch": fpl, "avg_launch_us": launch_us,
-               "us_per_frame": launch_us / fpl, "n_union_mean": n_union, "n_upd_mean": n_upd_mean, "n_upd_fraction": n_upd_mean / n_vox,
-               "serial_equivalent": {"bytes_per_launch": serial, "gbs": serial / (launch_us * 1e-6) / 1e9,
-                                     "note": "SURVEY 8(d)'s one-sweep-per-frame bytes (24 N_upd + 8 H W) x frames per launch / avg_launch_us: what the fusion saves, not a bandwidth"}}
-        pmc = load_profile("r03_integrate_pmc.json")
+               "frac": achieved / 8000.0, "traffic": None, "algorithmic_bytes_per_launch": alg,
+               "algorithmic_bytes_note": "SURVEY 8(d): (24 N_upd + 8 H W) per frame x frames per launch",
+               "frames_per_launch": fpl, "avg_launch_us": launch_us, "us_per_frame": launch_us / fpl, "n_upd_mean": n_upd_mean, "n_upd_fraction": n_upd_mean / n_vox,
+               "must_move": {"bytes_per_launch": must, "gbs": must / (launch_us * 1e-6) / 1e9, "frac": must / (launch_us * 1e-6) / 1e9 / 8000.0, "n_union_mean": n_union,
+                             "note": "bytes a fused launch must move: 24 N_union + 8 H W x frames (a voxel updated by several of the launch's frames moves once)"},
+               "worklist": {"voxels_per_launch": wl, "updated_share": n_union / max(wl, 1.0),
+                            "note": "voxels on the sweep's work list (64-voxel segments that survive the per-row frustum / depth clip): every one runs every frame's projection, "
+                                    "texel gather and tests; updated_share = N_union / that"}}
+        pmc = load_profile("r04_integrate_pmc.json")
         if pmc and scene_key in pmc:
-            t = pmc[scene_key]
-            out["traffic"] = t.get("hbm_bytes_per_launch")
-            out["traffic_detail"] = {k: t.get(k) for k in ("read_bytes_lo", "read_bytes_hi", "write_bytes", "launches", "note") if k in t}
-            v = t.get("valu")
-            if v:  # the limiter the counters name: VALU issue.  A wave64 f32 VALU instruction holds its SIMD for 4 cycles (packed: 2 results in the same 4)
-                issue_us = v["SQ_INSTS_VALU"] * 4.0 / 1024.0 / (v["clock_ghz"] * 1e3)
-                out["valu_issue"] = {"insts_per_launch": v["SQ_INSTS_VALU"], "cycles_per_inst": 4, "simds": 1024, "clock_ghz": v["clock_ghz"], "min_us": issue_us,
-                                     "frac_of_launch": issue_us / launch_us, "simd_busy_valu": v.get("simd_busy_valu"),
-                                     "note": "profiles/r03_integrate_pmc.json (rocprofv3 --pmc of the same kernel and scene); min_us = instructions x 4 cycles / 1024 SIMDs at the measured clock"}
-                out["limiter"] = "valu-issue" if issue_us / launch_us > achieved / 6300.0 else "hbm"
+            if pmc.get("source_stamp") != stamp:
+                out["traffic_note"] = (f"profiles/r04_integrate_pmc.json was measured on TSDF kernel source {pmc.get('source_stamp')}, this build is {stamp}: "
+                                       f"counter figures withheld (refresh the profile: tools/profile_r04.sh)")
+            else:
+                t = pmc[scene_key]
+                out["traffic"] = t.get("hbm_bytes_per_launch")
+                out["traffic_detail"] = {k: t.get(k) for k in ("read_bytes_lo", "read_bytes_hi", "write_bytes", "launches", "note") if k in t}
+                v = t.get("valu")
+                if v:
+                    issue_us = v["SQ_INSTS_VALU"] * 4.0 / 1024.0 / (v["clock_ghz"] * 1e3)
+                    out["valu_issue"] = {"insts_per_launch": v["SQ_INSTS_VALU"], "cycles_per_inst": 4, "simds": 1024, "clock_ghz": v["clock_ghz"], "min_us": issue_us,
+                                         "frac_of_launch": issue_us / launch_us, "simd_busy_valu": v.get("simd_busy_valu"),
+                                         "note": "profiles/r04_integrate_pmc.json (rocprofv3 --pmc of the same kernel source and scene)"}
         return out
 
     with torch.no_grad():
         if exact:
             timed_sets = batches([(args.warmup * B + j) % T for j in range(args.steps * B)])
-        elif strong:
-            timed_sets = batches(job_frames(args.warmup, args.steps)[0])
+        elif headline_strong:
+            timed_sets = batches(job_frames(True, args.warmup, args.steps)[0])
         else:
-            timed_sets = [job_frames(args.warmup + s, 1)[0] for s in range(args.steps)]
+            timed_sets = [job_frames(False, args.warmup + s, 1)[0] for s in range(args.steps)]
+        timed_sets = timed_sets[:4]  # (the sequence wraps: a few steps cover every frame of it)
         n_upd_dpt, sweeps_dpt, leg_dpt, (us_dpt, _) = measure(timed_sets, lambda fr, ids: stream.depth(fr)[0], time_kernel=True)
         # the launch duration the roofline uses is the kernel's OWN (HIP events, the same frames swept again with nothing else on the GPU);
         # inside the timed job the sweeps share the chip with the next batch's network (second stream, lowest priority) and take longer
         main_roof = roofline(n_upd_dpt, sweeps_dpt, us_dpt, "bench")
         main_roof["launches"] = n_launch
         main_roof["avg_launch_us_in_job"] = kernel_ms / max(n_launch, 1) * 1e3
-        main_roof["overlap"] = ("the timed job runs the sweeps of batch i on a second, lowest-priority HIP stream under the network of batch i + 1 (+1.8 % frames/s): "
+        main_roof["overlap"] = ("the timed job runs the sweeps of batch i on a second, lowest-priority HIP stream under the network of batch i + 1: "
                                 "avg_launch_us_in_job is their duration there, avg_launch_us the kernel alone") if overlap else "none (--no-overlap / exact merge): the sweeps run on the network's stream"
         main_roof["tsdf_leg_us_per_frame"] = leg_dpt * 1e3
         main_roof["scene"] = "DPT-Hybrid depth (seeded weights) of the timed frames"
@@ -394,17 +531,18 @@ def main():
         dpt_ms = e0.elapsed_time(e1) / reps
         flops = count_flops(H, W)
         tflops = flops["total"] * fr.shape[0] / (dpt_ms * 1e-3) / 1e12
-        dpt_roof = {"kernel": "hive_dpt_forward (293 launches at 480 x 640: MFMA GEMM / attention / implicit-GEMM convolutions + glue)", "bound": "mfma", "achieved": tflops, "peak": 2500.0,
+        dpt_roof = {"kernel": "hive_dpt_forward (MFMA GEMM / attention / implicit-GEMM convolutions + glue, one C-ABI call)", "bound": "mfma", "achieved": tflops, "peak": 2500.0,
                     "unit": "TFLOP/s", "frac": tflops / 2500.0, "dtype": args.dtype, "flops_per_frame": flops["total"], "frames": int(fr.shape[0]), "ms_per_batch": dpt_ms,
                     "ms_per_frame": dpt_ms / fr.shape[0], "note": "algorithmic FLOPs (2 x MACs, hive_amd.dpt.models.count_flops) x frames / time of the whole network, "
-                    "glue kernels included; per-kernel mfma_busy: profiles/r03_mfma_pmc.json"}
-        busy = load_profile("r03_mfma_pmc.json")
+                    "glue kernels included; per-kernel mfma_busy: profiles/r04_mfma_pmc.json"}
+        busy = load_profile("r04_mfma_pmc.json") or load_profile("r03_mfma_pmc.json")
         if busy:
             dpt_roof["mfma_busy"] = busy.get("mfma_busy")
 
-        # ---- marching cubes once, on the room volume (reported separately) ----------------------------------------------
+        # ---- marching cubes once, on the room volume (reported separately; runs once per sequence) ----------------------------------------
         mesh = None
         if not exact:
+            mvol._extract()  # (a first call sizes the scratch and result buffers)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -413,22 +551,45 @@ def main():
             e1.synchronize()
             mc_bytes = 4.0 * n_vox + 36.0 * n_v + 12.0 * n_f + 4.0 * n_v
             mesh = {"mesh_ms": e0.elapsed_time(e1), "vertices": n_v, "faces": n_f, "algorithmic_bytes": mc_bytes, "gbs": mc_bytes / (e0.elapsed_time(e1) * 1e-3) / 1e9,
-                    "note": "hive_tsdf_extract_mesh on the room volume after the 32 frames above (device side, incl. its two count read-backs); bytes = 4 N + 36 V + 12 F + 4 V (SURVEY 8d)"}
-    del mvol, storage, w_plane
+                    "frac_of_hbm_peak": mc_bytes / (e0.elapsed_time(e1) * 1e-3) / 1e9 / 8000.0,
+                    "note": "hive_tsdf_extract_mesh on the room volume after the 32 frames above, end to end on the device side (its count read-back included; scratch and "
+                            "result buffers reused from the previous call); bytes = 4 N + 36 V + 12 F + 4 V (SURVEY 8d).  Runs once per sequence."}
+    mvol.close()
+    del mvol, w_plane, storage
+
+    # ---- the reference's dtype: the same timed job in float16 (N = 1) ------------------------------------------------------------------------
+    fp16 = None
+    if world == 1 and extra_legs and args.engine == "hip":
+        other_dtype = "fp16" if args.dtype == "bf16" else "bf16"
+        del stream
+        torch.cuda.empty_cache()
+        stream = make_stream(other_dtype)
+        f_elapsed, f_total, _, _ = timed_job(stream, False)
+        fp16 = {"dtype": other_dtype, "value": f_total / f_elapsed, "ms_per_step": f_elapsed / args.steps * 1e3}
+    del stream
+    torch.cuda.empty_cache()
+
+    # ---- BASELINE configs[3], bounded ----------------------------------------------------------------------------------------------------------
+    config4 = None
+    if world == 1 and extra_legs and args.engine == "hip":
+        try:
+            config4 = config4_leg(device, ctx)
+        except Exception as e:  # (a leg beside the headline must not take the line down with it)
+            config4 = {"error": f"{type(e).__name__}: {e}"}
 
     if rank != 0:
         return
-    total_frames = args.steps * B * (1 if strong or world == 1 else world)
     dims = "x".join(str(int(d)) for d in (merger.dims if exact else volume.vol_dim))
     merge_note = ""
+    scaling = None if world == 1 else ("strong" if headline_strong else "weak")
     if world > 1:
-        share = (f"the same {args.steps} x {B} frames split in contiguous blocks over the ranks" if strong
+        share = (f"the same {args.steps} x {B} frames split in contiguous blocks over the ranks" if headline_strong
                  else f"{world} x {args.steps} x {B} frames, a contiguous block of {args.steps} steps per rank")
         merge_note = (f", {share}, frames all-gathered, every rank integrates all frames into its x-slab (bit-identical to 1 GPU), slabs all-gathered"
                       if exact else f", frame-sharded ({share}), shared volume merged once by reduce-scatter of the 5 accumulator planes + all-gather of the 3 "
                                     f"volumes (RCCL), inside the timed region")
     out = {
-        "metric": "frames/sec (depth+TSDF integrate) @640x480, 512^3 vol",
+        "metric": "frames/sec (depth+TSDF integrate) @640x480, 512^3 vol" + ("" if world == 1 else f", {world} GPUs, {scaling} scaling ({total_frames} frames)"),
         "value": total_frames / elapsed,
         "unit": "frames/s",
         "n_gpus": world,
@@ -436,7 +597,7 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": None if world == 1 else ("strong" if strong else "weak"),
+        "scaling": scaling,
         "vs_baseline": None,
         "dtype": args.dtype,
         "data": "synthetic",
@@ -445,13 +606,21 @@ def main():
                         f"(seeded random weights: depth 1-7 m, {args.dtype}, {args.engine} engine) + {dims} TSDF integrate, {B} frames/step" + merge_note,
             "frames_per_step": B, "frames_total": total_frames, "image": [H, W], "volume": dims, "voxel_m": args.voxel,
             "n_upd_mean": main_roof["n_upd_mean"], "n_upd_fraction": main_roof["n_upd_fraction"], "merge": (args.merge if world > 1 else None),
-            "tsdf_overlap": overlap,
+            "tsdf_overlap": overlap, "scaling_mode": scaling,
         },
         "roofline": main_roof,
         "roofline_room": room_roof,
         "roofline_dpt": dpt_roof,
         "mesh": mesh,
+        "tsdf_source_stamp": stamp,
     }
+    if other is not None:
+        out[other["scaling"]] = other
+    if fp16 is not None:
+        out["value_" + fp16["dtype"]] = fp16["value"]
+        out["ms_per_step_" + fp16["dtype"]] = fp16["ms_per_step"]
+    if config4 is not None:
+        out["config4"] = config4
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(seq, args.voxel, K)
     print(json.dumps(out))

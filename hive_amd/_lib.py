@@ -251,6 +251,17 @@ class Context:
         self.check(self.lib.hive_ctx_get_stream(self.handle, ctypes.byref(h)))
         return int(h.value or 0)
 
+    def torch_stream(self):
+        """The torch stream object of a context that does NOT follow torch's current stream (a private or explicit hipStream_t):
+        whoever issues torch ops or collectives that must be ordered with this context's kernels runs them inside
+        ``with torch.cuda.stream(ctx.torch_stream())``.  None for a context that follows torch."""
+        if self._follow_torch:
+            return None
+        if self._side_stream is None:
+            import torch
+            self._side_stream = torch.cuda.ExternalStream(self.stream_handle(), device=self.device)
+        return self._side_stream
+
     def synchronize(self):
         self.check(self.lib.hive_ctx_synchronize(self.handle))
 

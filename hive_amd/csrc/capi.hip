@@ -120,9 +120,10 @@ int hive_ctx_create(int device_id, void *stream, hive_ctx **out) {
             ctx->stream = (hipStream_t)stream;  // NULL = the default stream
         }
     }
-    // [0, 128): scalar blocks of the kernels; [128, 128 + 2048): HIVE_COUNT_SLOTS update counters, one per 128-byte line (tsdf.hip)
-    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_scalars, (128 + 2048) * sizeof(unsigned));
-    if (e == hipSuccess) e = hipMemset(ctx->d_scalars, 0, (128 + 2048) * sizeof(unsigned));  // the TSDF scalar blocks start cleared (tsdf.hip prepare_frame)
+    // [0, 128): scalar blocks of the kernels; [128, 128 + 2048): HIVE_COUNT_SLOTS update counters, one per 128-byte line (tsdf.hip);
+    // [2304, 2304 + 2 x 512): the two scalar blocks of the fused sweep (tsdf.hip MS_BASE)
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_scalars, 4096 * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMemset(ctx->d_scalars, 0, 4096 * sizeof(unsigned));  // the TSDF scalar blocks start cleared (tsdf.hip prepare_frame)
     if (e == hipSuccess) e = hipMalloc(&ctx->d_zeros, 256);
     if (e == hipSuccess) e = hipMemset(ctx->d_zeros, 0, 256);
     if (e != hipSuccess) {
@@ -148,6 +149,7 @@ int hive_ctx_destroy(hive_ctx *ctx) {
     if (ctx->d_frame) (void)hipFree(ctx->d_frame);
     if (ctx->d_in) (void)hipFree(ctx->d_in);
     if (ctx->d_scalars) (void)hipFree(ctx->d_scalars);
+    if (ctx->h_pinned_small) (void)hipHostFree(ctx->h_pinned_small);
         if (ctx->d_zeros) (void)hipFree(ctx->d_zeros);
         if (ctx->owns_stream) (void)hipStreamDestroy(ctx->stream);
     }

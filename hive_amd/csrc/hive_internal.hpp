@@ -44,6 +44,7 @@ struct hive_ctx {
     int tsdf_scalars = 0;           // which of the two TSDF scalar blocks the frame in flight uses (tsdf.hip prepare_frame)
     int tsdf_multi_scalars = 0;     // the same for the multi-frame sweep's blocks (d_scalars + 64 / + 80)
     unsigned *d_scalars = nullptr;  // [0]=max depth bits, [2..3]=u64 counter, ...
+    void *h_pinned_small = nullptr;  // 256 bytes of pinned host memory for small read-backs (mesh totals)
     void *d_zeros = nullptr;        // 256 bytes of zeros: the source of padding taps in the implicit-GEMM convolutions
 
     // HIP-event timing of the dominant kernel
@@ -125,6 +126,7 @@ struct hive_tsdf {
     const unsigned *last_n_items = nullptr;
     // mesh extraction results (device)
     int64_t n_verts = -1, n_faces = -1;
+    int64_t cap_verts = 0, cap_faces = 0;  // capacity of the result arrays below (kept between extractions, grown on demand)
     float *d_verts = nullptr, *d_norms = nullptr, *d_verts_vox = nullptr;
     int32_t *d_faces = nullptr;
     uint8_t *d_vcolors = nullptr;

@@ -46,7 +46,7 @@ struct FrameParams {
 template <bool VEC>
 __global__ __launch_bounds__(256) void prep_frame_kernel(const float *__restrict__ depth, const uint8_t *__restrict__ color, int H, int W, int tile_shift,
                                                          int tiles_x, uint2 *__restrict__ out, unsigned *__restrict__ tile_max, int tile_stride,
-                                                         unsigned *zero_next) {
+                                                         unsigned *zero_next, int zero_words) {
     __shared__ unsigned wave_max[4];
     const int n = H * W;
     depth += (size_t)blockIdx.y * n;
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void prep_frame_kernel(const float *__restrict
     tile_max += (size_t)blockIdx.y * tile_stride;
     // the NEXT sweep's scalar block (work-list length, ...) is cleared here instead of by a memset launch per sweep: the blocks
     // alternate, and this kernel runs after every kernel of the sweep that used that block last (stream order)
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 8) zero_next[threadIdx.x] = 0u;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && (int)threadIdx.x < zero_words) zero_next[threadIdx.x] = 0u;
     const int TS = 32 << tile_shift;
     const int ty = blockIdx.x / tiles_x, tx = blockIdx.x % tiles_x;
     // max over non-negative floats == max over their bit patterns; NaN / negatives are ignored (treated as 0)
@@ -109,8 +109,12 @@ constexpr int VPT = 4;  // consecutive z voxels per lane: one 16-byte access per
 constexpr int COUNT_SLOTS = 64, COUNT_STRIDE = 16;  // update counters of the COUNT kernels: 64 x u64, 128 bytes apart (hive_ctx::d_scalars + 128)
 struct WorkItem {
     unsigned xy;  // x | y << 16
-    unsigned zz;  // segment start z | voxels of the segment inside the row's interval (1 .. 64) << 16 | frames whose own interval meets the segment << 24
+    unsigned zz;  // segment start z | (voxels of the segment inside the row's interval - 1) << 16 | frames whose own interval meets the segment << 22 | image band << 26
 };
+constexpr int ITEM_NLIVE_SHIFT = 16, ITEM_MASK_SHIFT = 22, ITEM_BIN_SHIFT = 26;
+constexpr int NBINS = 64;  // image bands (of the sweep's first frame) the fused sweep's work list is sorted by
+static_assert(HIVE_SEG_LANES * 4 <= 64, "a segment's live-voxel count - 1 takes 6 bits of WorkItem::zz");
+__device__ __forceinline__ int item_nlive(unsigned zz) { return ((zz >> ITEM_MASK_SHIFT) & 15u) ? (int)((zz >> ITEM_NLIVE_SHIFT) & 63u) + 1 : 0; }  // 0: a dead (all-zero) item
 
 struct RowClip {
     int z0, z1;  // half-open voxel range that may pass the inclusion tests
@@ -257,7 +261,7 @@ __global__ __launch_bounds__(1024) void build_worklist_kernel(FrameParams p, Wor
         const int zs = zstart + (int)c * CHUNK;
         WorkItem it;
         it.xy = (unsigned)x | ((unsigned)y << 16);
-        it.zz = (unsigned)zs | ((unsigned)min(z1 - zs, CHUNK) << 16) | (1u << 24);
+        it.zz = (unsigned)zs | ((unsigned)(min(z1 - zs, CHUNK) - 1) << ITEM_NLIVE_SHIFT) | (1u << ITEM_MASK_SHIFT);
         items[slot + c] = it;
     }
 }
@@ -324,16 +328,14 @@ __device__ __forceinline__ V div_exact(V a, V d, V y) {
 
 // Geometry half of the per-voxel work (no memory access) for NV consecutive z voxels starting at z:
 // camera depth and the pixel each voxel centre rounds to, or -1 (behind the camera / outside the image).
-template <int RM, typename V, int NV, int ZSTEP = 1>
-__device__ __forceinline__ void voxel_pixels(const FrameParams &p, float ax, float ay, float az, int z, V &cam_z, int (&pix)[NV]) {
-    V zf;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) v_set(zf, i, (float)(z + i * ZSTEP));
+// (row constants per ELEMENT: the elements of a packed pair may belong to different rows -- the fused sweep's gather role)
+template <int RM, typename V, int NV>
+__device__ __forceinline__ void voxel_pixels_rows(const FrameParams &p, V ax, V ay, V az, V zf, V &cam_z, int (&pix)[NV]) {
     const V pt_z = v_splat(p.oz, zf) + zf * v_splat(p.vs, zf);
     const V tz = pt_z - v_splat(p.T[2], zf);
-    const V cam_x = v_splat(ax, zf) + v_splat(p.R[6], zf) * tz;
-    const V cam_y = v_splat(ay, zf) + v_splat(p.R[7], zf) * tz;
-    cam_z = v_splat(az, zf) + v_splat(p.R[8], zf) * tz;
+    const V cam_x = ax + v_splat(p.R[6], zf) * tz;
+    const V cam_y = ay + v_splat(p.R[7], zf) * tz;
+    cam_z = az + v_splat(p.R[8], zf) * tz;
     bool tiny = false;
 #pragma unroll
     for (int i = 0; i < NV; ++i) tiny = tiny || fabsf(v_get(cam_z, i)) < 1.0e-18f;  // (one comparison; zero / negative depths take the full divisions too: same results)
@@ -373,6 +375,14 @@ __device__ __forceinline__ void voxel_pixels(const FrameParams &p, float ax, flo
             pix[i] = ok ? (__mul24((int)fy_, p.W) + (int)fx_) : -1;
         }
     }
+}
+
+template <int RM, typename V, int NV, int ZSTEP = 1>
+__device__ __forceinline__ void voxel_pixels(const FrameParams &p, float ax, float ay, float az, int z, V &cam_z, int (&pix)[NV]) {
+    V zf;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v_set(zf, i, (float)(z + i * ZSTEP));
+    voxel_pixels_rows<RM, V, NV>(p, v_splat(ax, zf), v_splat(ay, zf), v_splat(az, zf), zf, cam_z, pix);
 }
 
 // Camera depth of NV consecutive z voxels: the cam_z expressions of voxel_pixels, verbatim (bit-identical results).
@@ -571,7 +581,7 @@ __global__ __launch_bounds__(256) void integrate_kernel(FrameParams p, const Wor
         const int x = (int)(item.xy & 0xffffu), y = (int)(item.xy >> 16);
         const int zseg = (int)(item.zz & 0xffffu);
         const int zb = zseg + sl * VPT;  // volume role: this lane's first voxel
-        const bool live = sl * VPT < (int)((item.zz >> 16) & 0xffu);
+        const bool live = sl * VPT < item_nlive(item.zz);
         const int nrow = p.Z - zb;  // voxels of this quad inside the row (>= 4 except in the last quad of a row with Z % 4 != 0)
         const long long idx = ((long long)x * p.Y + y) * p.Z + zb;
         float t[VPT], w[VPT], c[VPT];  // ACCUM: planes 0..2
@@ -720,20 +730,28 @@ __global__ __launch_bounds__(256) void integrate_kernel(FrameParams p, const Wor
 #define HIVE_TSDF_MAXF 4
 #endif
 constexpr int MAXF = HIVE_TSDF_MAXF;
+static_assert(MAXF <= 4, "WorkItem::zz holds a 4-bit frame mask");
 struct MultiParams {
     FrameParams f[MAXF];  // the per-frame fields (R, T, frame / depth / rgb, tile_max) differ; the rest is the same in all
     int nf;
     int frame_skip;  // 1: a wave skips the frames whose clip excludes all of its segments (work item masks)
+    int xcd_split;   // 1: the (band-sorted) work list's eighths go to the eight XCDs; 0: one grid-stride sweep over the whole list
 };
 
-__global__ __launch_bounds__(1024) void build_worklist_multi_kernel(MultiParams mp, WorkItem *__restrict__ items, unsigned *n_items) {
+// scalar block of a fused sweep (two alternate, hive_ctx::d_scalars + MS_BASE + which * MS_STRIDE): [MS_NITEMS] work-list length, [MS_HIST ..] items
+// per image band, [MS_CURSOR ..] the sort's per-band write cursors; the sweep's first kernel clears the OTHER block's first MS_CLEAR words
+constexpr int MS_BASE = 2304, MS_STRIDE = 512, MS_NITEMS = MAXF, MS_HIST = 8, MS_CURSOR = MS_HIST + NBINS, MS_CLEAR = MS_CURSOR + NBINS;
+
+__global__ __launch_bounds__(1024) void build_worklist_multi_kernel(MultiParams mp, WorkItem *__restrict__ items, unsigned *n_items, unsigned *hist) {
     __shared__ unsigned wave_sum[16];
     __shared__ unsigned block_base;
     __shared__ float dil[MAXF][MAX_TILES];
     __shared__ unsigned gmax[MAXF];
+    __shared__ unsigned bin_count[NBINS];
     constexpr int CHUNK = SEG_LANES * VPT;
     const FrameParams &p = mp.f[0];
     if (threadIdx.x < MAXF) gmax[threadIdx.x] = 0u;
+    if (threadIdx.x < NBINS) bin_count[threadIdx.x] = 0u;
     __syncthreads();
     for (int f = 0; f < mp.nf; ++f) load_dilated_tiles(mp.f[f].tile_max, p.tiles_x, p.tiles_y, dil[f], &gmax[f], threadIdx.x, 1024);
     __syncthreads();
@@ -741,6 +759,13 @@ __global__ __launch_bounds__(1024) void build_worklist_multi_kernel(MultiParams 
     unsigned n_chunks = 0;
     int zstart = 0, z1 = 0, x = 0, y = 0;
     int fz0[MAXF], fz1[MAXF];  // the frames' own intervals (empty: 0, 0)
+    float ay0 = 0.f, az0 = 0.f;  // row constants of the sweep's first frame (image band of a segment)
+    auto frames_of = [&](int zs) {  // frames whose own interval meets [zs, zs + CHUNK): the others cannot update a voxel of this segment
+        unsigned mask = 0;
+#pragma unroll
+        for (int f = 0; f < MAXF; ++f) mask |= (fz1[f] > zs && fz0[f] < zs + CHUNK) ? (1u << f) : 0u;
+        return mask;
+    };
     if (row < (long long)p.X * p.Y) {
         x = (int)(row / p.Y);
         y = (int)(row % p.Y);
@@ -755,6 +780,7 @@ __global__ __launch_bounds__(1024) void build_worklist_multi_kernel(MultiParams 
                 const float ax = q.R[0] * tx + q.R[3] * ty;
                 const float ay = q.R[1] * tx + q.R[4] * ty;
                 const float az = q.R[2] * tx + q.R[5] * ty;
+                if (f == 0) ay0 = ay, az0 = az;
                 const RowClip clip = clip_row(q, ax, ay, az, __uint_as_float(gmax[f]), p.row_far ? dil[f] : nullptr);
                 if (clip.z1 > clip.z0) {
                     fz0[f] = clip.z0, fz1[f] = clip.z1;
@@ -766,20 +792,78 @@ __global__ __launch_bounds__(1024) void build_worklist_multi_kernel(MultiParams 
         if (hi > lo) {
             zstart = (lo / VPT) * VPT;
             z1 = hi;
-            n_chunks = (unsigned)((z1 - zstart + CHUNK - 1) / CHUNK);
+            // (a segment in a gap between the frames' intervals is in no frame's clip: it is not emitted)
+            for (int zs = zstart; zs < z1; zs += CHUNK) n_chunks += frames_of(zs) ? 1u : 0u;
         }
     }
-    const unsigned slot = worklist_slots(n_chunks, n_items, wave_sum, &block_base);
-    for (unsigned c = 0; c < n_chunks; ++c) {
-        const int zs = zstart + (int)c * CHUNK;
-        unsigned mask = 0;  // frames whose own interval meets [zs, zs + CHUNK): the others cannot update a voxel of this segment
-#pragma unroll
-        for (int f = 0; f < MAXF; ++f) mask |= (fz1[f] > zs && fz0[f] < zs + CHUNK) ? (1u << f) : 0u;
-        WorkItem it;
-        it.xy = (unsigned)x | ((unsigned)y << 16);
-        it.zz = (unsigned)zs | ((unsigned)min(z1 - zs, CHUNK) << 16) | (mask << 24);
-        items[slot + c] = it;
+    unsigned slot = worklist_slots(n_chunks, n_items, wave_sum, &block_base);
+    if (n_chunks)
+        for (int zs = zstart; zs < z1; zs += CHUNK) {
+            const unsigned mask = frames_of(zs);
+            if (!mask) continue;
+            // image band: the row v of the first frame the segment's middle projects to (clamped; any value is valid -- it only orders the list)
+            const float tz = (p.oz + (float)(zs + CHUNK / 2) * p.vs) - p.T[2];
+            const float cz = az0 + p.R[8] * tz;
+            const float v = cz > 1.0e-6f ? p.fy * ((ay0 + p.R[7] * tz) / cz) + p.cy : 0.f;
+            const int bin = min(max((int)(v * ((float)NBINS / (float)p.H)), 0), NBINS - 1);
+            atomicAdd(&bin_count[bin], 1u);
+            WorkItem it;
+            it.xy = (unsigned)x | ((unsigned)y << 16);
+            it.zz = (unsigned)zs | ((unsigned)(min(z1 - zs, CHUNK) - 1) << ITEM_NLIVE_SHIFT) | (mask << ITEM_MASK_SHIFT) | ((unsigned)bin << ITEM_BIN_SHIFT);
+            items[slot++] = it;
+        }
+    __syncthreads();
+    if (threadIdx.x < NBINS && bin_count[threadIdx.x]) atomicAdd(hist + threadIdx.x, bin_count[threadIdx.x]);
+}
+
+// Counting sort of the work list by image band (64 bands of the first frame's rows): the sorted list's eighths go to the eight XCDs
+// (integrate_multi_kernel), so that an XCD's waves gather from one stripe of each frame at a time -- four 2.46 MB frames of texels do
+// not fit a 4 MB L2 beside the volume stream when every XCD walks the whole image (round 3: L2 misses of the gathers several times
+// the volume traffic; with all four frames reading ONE frame's texels the launch took 186 instead of 222 us).  One workgroup per
+// 1024 consecutive items; inside a wave the items of a band keep their order (consecutive segments of a row stay neighbours).
+__global__ __launch_bounds__(1024) void sort_worklist_kernel(const WorkItem *__restrict__ tmp, WorkItem *__restrict__ out, const unsigned *__restrict__ n_items_ptr,
+                                                             const unsigned *__restrict__ hist, unsigned *cursor) {
+    __shared__ unsigned base[NBINS], cnt[NBINS], gofs[NBINS];
+    const unsigned n = *n_items_ptr;
+    const unsigned i0 = blockIdx.x * 1024u;
+    if (i0 >= n) return;
+    if (threadIdx.x < NBINS) cnt[threadIdx.x] = 0u;
+    if (threadIdx.x == 0) {
+        unsigned a = 0;
+        for (int b = 0; b < NBINS; ++b) {
+            base[b] = a;
+            a += hist[b];
+        }
     }
+    __syncthreads();
+    const unsigned i = i0 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    WorkItem it;
+    it.xy = it.zz = 0u;
+    unsigned bin = 0xffffffffu;
+    if (i < n) {
+        it = tmp[i];
+        bin = it.zz >> ITEM_BIN_SHIFT;
+    }
+    unsigned rank = 0, wave_base = 0;
+    unsigned long long todo = __ballot(i < n);
+    while (todo) {  // (wave-uniform: one round per distinct band of the wave's items)
+        const int leader = __ffsll((long long)todo) - 1;
+        const unsigned b = (unsigned)__shfl((int)bin, leader);
+        const unsigned long long m = __ballot(bin == b);
+        unsigned wb = 0;
+        if (lane == leader) wb = atomicAdd(&cnt[b], (unsigned)__popcll(m));
+        wb = (unsigned)__shfl((int)wb, leader);
+        if (bin == b) {
+            rank = (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+            wave_base = wb;
+        }
+        todo &= ~m;
+    }
+    __syncthreads();
+    if (threadIdx.x < NBINS && cnt[threadIdx.x]) gofs[threadIdx.x] = atomicAdd(cursor + threadIdx.x, cnt[threadIdx.x]);
+    __syncthreads();
+    if (i < n) out[base[bin] + gofs[bin] + wave_base + rank] = it;
 }
 
 // UPD: 0 = any observation weight, 1 = obs_weight == 1, 2 = obs_weight == 1 with the division-free colour update (update_voxels FASTC)
@@ -788,10 +872,17 @@ __global__ __launch_bounds__(1024) void build_worklist_multi_kernel(MultiParams 
 #else
 #define HIVE_TSDF_OCC
 #endif
-template <int RM, int UPD>
+// SEGK: how the gather role spreads a trip's 4 x 64 voxels over its four gather instructions.  false: instruction k takes voxels 16 k .. 16 k + 15
+// of EACH of the wave's four segments (four separate pixel runs per instruction); true: instruction k takes the 64 consecutive voxels of
+// segment k (ONE pixel run per instruction: 16 L + 4 instead of 16 L + 16 lines per trip and frame when 16 voxels span L lines -- the CU's
+// texture path pays per distinct 64-byte line).  Segment k's row is then the same for all lanes: its item comes from lane 16 k by readlane.
+// The work list is sorted by image band (sort_worklist_kernel) and the XCDs take the sorted list's eighths: workgroups with the same
+// blockIdx % 8 share an XCD (and its L2), so each XCD's gathers stay within one stripe of each frame.
+template <int RM, int UPD, bool SEGK>
 __global__ __launch_bounds__(256) HIVE_TSDF_OCC void integrate_multi_kernel(MultiParams mp, const WorkItem *__restrict__ items, const unsigned *__restrict__ n_items_ptr,
                                                               float *__restrict__ v0, float *__restrict__ v1, float *__restrict__ v2) {
     constexpr int PER_WAVE = 64 / SEG_LANES, SEG_VOX = SEG_LANES * 4;
+    static_assert(!SEGK || (PER_WAVE == 4 && SEG_VOX == 64), "SEGK: four 64-voxel segments per wave");
     typedef ItemShape Sh;
     typedef Sh::V V;
     __shared__ uint2 xchg[4 * PER_WAVE * SEG_VOX];
@@ -799,10 +890,15 @@ __global__ __launch_bounds__(256) HIVE_TSDF_OCC void integrate_multi_kernel(Mult
     const int seg = lane / SEG_LANES, sl = lane % SEG_LANES;
     const unsigned n_items = *n_items_ptr;
     const unsigned n_trips = (n_items + PER_WAVE - 1) / PER_WAVE;
-    const unsigned stride = gridDim.x * 4;
+    // XCD x = blockIdx % 8 sweeps trips [x per_xcd, (x + 1) per_xcd) with its gridDim / 8 workgroups (the host launches a multiple of 8)
+    const unsigned per_xcd = mp.xcd_split ? (n_trips + 7u) / 8u : n_trips;
+    const unsigned xcd = mp.xcd_split ? (blockIdx.x & 7u) : 0u;
+    const unsigned local_block = mp.xcd_split ? (blockIdx.x >> 3) : blockIdx.x;
+    const unsigned stride = (mp.xcd_split ? (gridDim.x >> 3) : gridDim.x) * 4;
+    const unsigned trip_end = min(n_trips, (xcd + 1u) * per_xcd);
     const FrameParams &p0 = mp.f[0];
     const float trunc_rcp = refined_rcp(p0.trunc);
-    for (unsigned trip = blockIdx.x * 4 + (threadIdx.x >> 6); trip < n_trips; trip += stride) {
+    for (unsigned trip = xcd * per_xcd + local_block * 4 + (threadIdx.x >> 6); trip < trip_end; trip += stride) {
         const unsigned ii = trip * PER_WAVE + (unsigned)seg;
         WorkItem item;
         item.xy = item.zz = 0u;
@@ -810,13 +906,22 @@ __global__ __launch_bounds__(256) HIVE_TSDF_OCC void integrate_multi_kernel(Mult
         const int x = (int)(item.xy & 0xffffu), y = (int)(item.xy >> 16);
         const int zseg = (int)(item.zz & 0xffffu);
         const int zb = zseg + sl * VPT;
-        const bool live = sl * VPT < (int)((item.zz >> 16) & 0xffu);
+        const bool live = sl * VPT < item_nlive(item.zz);
         const int nrow = p0.Z - zb;  // voxels of this quad inside the row (< 4 only in the last quad of a row with Z % 4 != 0)
         const long long idx = ((long long)x * p0.Y + y) * p0.Z + zb;
         // frames that can update a voxel of ANY of the wave's segments (build_worklist_multi_kernel): the others are skipped by the
         // whole wave -- no projection, no gather, no tests.  (A skipped frame's own clip excludes every voxel of the segments, and the
         // clip is conservative: skipping cannot change a result.)
-        unsigned wave_frames = item.zz >> 24;
+        unsigned wave_frames = (item.zz >> ITEM_MASK_SHIFT) & 15u;
+        // SEGK: the four segments' items as wave-uniform values
+        unsigned seg_xy[4], seg_zz[4];
+        if (SEGK) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                seg_xy[k] = (unsigned)__builtin_amdgcn_readlane((int)item.xy, SEG_LANES * k);
+                seg_zz[k] = (unsigned)__builtin_amdgcn_readlane((int)item.zz, SEG_LANES * k);
+            }
+        }
 #pragma unroll
         for (int o = SEG_LANES; o < 64; o <<= 1) wave_frames |= (unsigned)__shfl_xor((int)wave_frames, o);
         wave_frames = mp.frame_skip ? (unsigned)__builtin_amdgcn_readfirstlane((int)wave_frames) : 0xffu;
@@ -837,20 +942,58 @@ __global__ __launch_bounds__(256) HIVE_TSDF_OCC void integrate_multi_kernel(Mult
             // in the gather role and the colour fetched for the passing voxels only -- the second dependent round trip costs more than
             // the lines it saves: 292 vs 224 us per four-frame launch on the room scene, 261 vs 219 on the bench scene.)
             uint2 tex[4];
+            if (!SEGK) {
 #pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                V cz;
-                int pix[Sh::NV];
-                voxel_pixels<RM, V, Sh::NV, SEG_LANES>(p, ax, ay, az, zseg + sl + 2 * SEG_LANES * g, cz, pix);
+                for (int g = 0; g < 2; ++g) {
+                    V cz;
+                    int pix[Sh::NV];
+                    voxel_pixels<RM, V, Sh::NV, SEG_LANES>(p, ax, ay, az, zseg + sl + 2 * SEG_LANES * g, cz, pix);
 #pragma unroll
-                for (int i = 0; i < Sh::NV; ++i) {
-                    uint2 tx2 = p.frame[max(pix[i], 0)];
-                    if (pix[i] < 0) tx2.x = 0u;
-                    tex[g * Sh::NV + i] = tx2;
+                    for (int i = 0; i < Sh::NV; ++i) {
+                        uint2 tx2 = p.frame[max(pix[i], 0)];
+                        if (pix[i] < 0) tx2.x = 0u;
+                        tex[g * Sh::NV + i] = tx2;
+                    }
                 }
-            }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) mine[SEG_LANES * k + sl] = tex[k];
+                for (int k = 0; k < 4; ++k) mine[SEG_LANES * k + sl] = tex[k];
+            } else {
+                uint2 *wave_region = xchg + (threadIdx.x >> 6) * (PER_WAVE * SEG_VOX);
+                int pixk[4];
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    // pair (2 g, 2 g + 1): element i = voxel `lane` of segment 2 g + i, each with its own row's constants (the contract's operation order)
+                    V axv, ayv, azv, zf, cz;
+                    int pix[Sh::NV];
+#pragma unroll
+                    for (int i = 0; i < Sh::NV; ++i) {
+                        const int k = g * Sh::NV + i;
+                        const int xk = (int)(seg_xy[k] & 0xffffu), yk = (int)(seg_xy[k] >> 16), zk = (int)(seg_zz[k] & 0xffffu);
+                        const float txk = (p.ox + (float)(xk + p.x_off) * p.vs) - p.T[0];
+                        const float tyk = (p.oy + (float)yk * p.vs) - p.T[1];
+                        v_set(axv, i, p.R[0] * txk + p.R[3] * tyk);
+                        v_set(ayv, i, p.R[1] * txk + p.R[4] * tyk);
+                        v_set(azv, i, p.R[2] * txk + p.R[5] * tyk);
+                        v_set(zf, i, (float)(zk + lane));
+                    }
+                    voxel_pixels_rows<RM, V, Sh::NV>(p, axv, ayv, azv, zf, cz, pix);
+#pragma unroll
+                    for (int i = 0; i < Sh::NV; ++i) {
+                        const int k = g * Sh::NV + i;
+                        // a segment outside this frame's clip (or a dead one) is sent as depth 0, like a voxel outside the image; all four
+                        // gathers are issued back to back (no branch between them: a branch per gather serialised their round trips)
+                        const bool in_clip = !mp.frame_skip || ((seg_zz[k] >> (ITEM_MASK_SHIFT + f)) & 1u);
+                        pixk[k] = in_clip ? pix[i] : -1;
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    tex[k] = p.frame[max(pixk[k], 0)];
+                    if (pixk[k] < 0) tex[k].x = 0u;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) wave_region[SEG_VOX * k + lane] = tex[k];
+            }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1054,10 +1197,10 @@ static int prepare_frame(hive_tsdf *v, const uint8_t *color, const float *depth,
     const dim3 grid((unsigned)(tg.tiles_x * tg.tiles_y), 1);
     if (vec)
         hipLaunchKernelGGL(prep_frame_kernel<true>, grid, dim3(256), 0, ctx->stream, *d_depth, *d_color, H, W, tg.shift, tg.tiles_x, (uint2 *)ctx->d_frame, tiles,
-                           MAX_TILES, next);
+                           MAX_TILES, next, 8);
     else
         hipLaunchKernelGGL(prep_frame_kernel<false>, grid, dim3(256), 0, ctx->stream, *d_depth, *d_color, H, W, tg.shift, tg.tiles_x, (uint2 *)ctx->d_frame, tiles,
-                           MAX_TILES, next);
+                           MAX_TILES, next, 8);
     HIVE_CHECK_HIP(ctx, hipGetLastError());
     return HIVE_OK;
 }
@@ -1112,12 +1255,12 @@ static int launch_integrate_multi(hive_tsdf *v, int nf, const uint8_t *color, co
     const TileGrid tg = tile_grid(H, W);
     const size_t tex_bytes = ((size_t)nf * npx * sizeof(uint2) + 255) & ~(size_t)255;
     int rc = HIVE_OK;
-    // scalar block of this sweep: [MAXF] = work-list length.  Two blocks alternate (both zero after hive_ctx_create); this sweep's
-    // first kernel clears the other one, which the previous sweep used (stream order) -- no memset launch
-    static_assert(MAXF + 1 <= 8, "prep_frame_kernel clears 8 words of the next block");
+    // scalar block of this sweep (MS_* above).  Two blocks alternate (both zero after hive_ctx_create); this sweep's first kernel clears the
+    // other one, which the previous sweep used (stream order) -- no memset launch
+    static_assert(MS_CLEAR <= 256 && MS_CLEAR <= MS_STRIDE, "prep_frame_kernel clears the next block with one workgroup of 256 threads");
     ctx->tsdf_multi_scalars ^= 1;
-    unsigned *sc = ctx->d_scalars + (ctx->tsdf_multi_scalars ? 80 : 64);
-    unsigned *idle_block = ctx->d_scalars + (ctx->tsdf_multi_scalars ? 64 : 80);
+    unsigned *sc = ctx->d_scalars + MS_BASE + (ctx->tsdf_multi_scalars ? MS_STRIDE : 0);
+    unsigned *idle_block = ctx->d_scalars + MS_BASE + (ctx->tsdf_multi_scalars ? 0 : MS_STRIDE);
     const uint2 *texels = nullptr;
     const unsigned *tiles = nullptr;
     int tile_stride = MAX_TILES;
@@ -1125,7 +1268,7 @@ static int launch_integrate_multi(hive_tsdf *v, int nf, const uint8_t *color, co
         texels = prepared->texels;
         tiles = prepared->tile_max;
         tile_stride = prepared->tile_stride;
-        HIVE_CHECK_HIP(ctx, hipMemsetAsync(idle_block, 0, 8 * sizeof(unsigned), ctx->stream));
+        HIVE_CHECK_HIP(ctx, hipMemsetAsync(idle_block, 0, MS_CLEAR * sizeof(unsigned), ctx->stream));
     } else {
         if ((rc = hive_reserve_device(ctx, &ctx->d_frame, &ctx->frame_bytes, tex_bytes + (size_t)MAXF * MAX_TILES * sizeof(unsigned)))) return rc;
         unsigned *d_tiles = (unsigned *)((char *)ctx->d_frame + tex_bytes);
@@ -1134,17 +1277,20 @@ static int launch_integrate_multi(hive_tsdf *v, int nf, const uint8_t *color, co
         const dim3 grid((unsigned)(tg.tiles_x * tg.tiles_y), (unsigned)nf);
         if (vec)
             hipLaunchKernelGGL(prep_frame_kernel<true>, grid, dim3(256), 0, ctx->stream, depth, color, H, W, tg.shift, tg.tiles_x, (uint2 *)ctx->d_frame, d_tiles,
-                               MAX_TILES, idle_block);
+                               MAX_TILES, idle_block, MS_CLEAR);
         else
             hipLaunchKernelGGL(prep_frame_kernel<false>, grid, dim3(256), 0, ctx->stream, depth, color, H, W, tg.shift, tg.tiles_x, (uint2 *)ctx->d_frame, d_tiles,
-                               MAX_TILES, idle_block);
+                               MAX_TILES, idle_block, MS_CLEAR);
         HIVE_CHECK_HIP(ctx, hipGetLastError());
         texels = (const uint2 *)ctx->d_frame;
         tiles = d_tiles;
     }
+    const bool sorted = env_flag("HIVE_TSDF_SORT", true);  // work list sorted by image band, its eighths to the eight XCDs
+    const bool segk = env_flag("HIVE_TSDF_SEGK", true) && SEG_LANES == 16;
     MultiParams mp;
     mp.nf = nf;
     mp.frame_skip = env_flag("HIVE_TSDF_FRAME_SKIP", true) ? 1 : 0;
+    mp.xcd_split = sorted ? 1 : 0;
     for (int f = 0; f < nf; ++f) {
         fill_frame_params(v, H, W, K, poses + 16 * (size_t)f, obs_weight, mp.f[f]);
         mp.f[f].frame = texels + (size_t)f * npx;
@@ -1156,17 +1302,29 @@ static int launch_integrate_multi(hive_tsdf *v, int nf, const uint8_t *color, co
     const long long rows = (long long)p.X * p.Y;
     const long long seg = SEG_LANES * 4;
     const size_t max_items = (size_t)rows * (size_t)((p.Z + seg - 1) / seg);
-    if ((rc = hive_reserve_device(ctx, &ctx->d_scratch, &ctx->scratch_bytes, max_items * sizeof(WorkItem)))) return rc;
-    WorkItem *items = (WorkItem *)ctx->d_scratch;
-    unsigned *n_items = sc + MAXF;
+    // two lists: as built (row order), and sorted by image band
+    if ((rc = hive_reserve_device(ctx, &ctx->d_scratch, &ctx->scratch_bytes, 2 * max_items * sizeof(WorkItem)))) return rc;
+    WorkItem *built = (WorkItem *)ctx->d_scratch, *items = sorted ? built + max_items : built;
+    unsigned *n_items = sc + MS_NITEMS;
     v->last_n_items = n_items;
-    hipLaunchKernelGGL(build_worklist_multi_kernel, dim3((unsigned)((rows + 1023) / 1024)), dim3(1024), 0, ctx->stream, mp, items, n_items);
+    hipLaunchKernelGGL(build_worklist_multi_kernel, dim3((unsigned)((rows + 1023) / 1024)), dim3(1024), 0, ctx->stream, mp, built, n_items, sc + MS_HIST);
+    if (sorted)
+        hipLaunchKernelGGL(sort_worklist_kernel, dim3((unsigned)((max_items + 1023) / 1024)), dim3(1024), 0, ctx->stream, (const WorkItem *)built, items,
+                           (const unsigned *)n_items, (const unsigned *)(sc + MS_HIST), sc + MS_CURSOR);
     const long long max_trips = (long long)((max_items + 64 / SEG_LANES - 1) / (64 / SEG_LANES));
-    const dim3 grid((unsigned)std::min<long long>((long long)ctx->num_cus * 8 * HIVE_GRID_MULT, (max_trips + 3) / 4)), block(256);
+    const long long blocks = std::min<long long>((long long)ctx->num_cus * 8 * HIVE_GRID_MULT, (max_trips + 3) / 4);
+    const dim3 grid((unsigned)((blocks + 7) / 8 * 8)), block(256);  // (a multiple of 8: the XCDs' shares)
     if ((rc = hive_time_begin(ctx))) return rc;
     const int upd = p.fast_colour ? 2 : (obs_weight == 1.0f ? 1 : 0);
-#define HIVE_LAUNCH(RM, UPD) \
-    hipLaunchKernelGGL((integrate_multi_kernel<RM, UPD>), grid, block, 0, ctx->stream, mp, items, n_items, v->d_tsdf, v->d_weight, v->d_color)
+#define HIVE_LAUNCH(RM, UPD)                                                                                                                           \
+    do {                                                                                                                                               \
+        if (segk)                                                                                                                                      \
+            hipLaunchKernelGGL((integrate_multi_kernel<RM, UPD, true>), grid, block, 0, ctx->stream, mp, (const WorkItem *)items, (const unsigned *)n_items, v->d_tsdf, \
+                               v->d_weight, v->d_color);                                                                                               \
+        else                                                                                                                                           \
+            hipLaunchKernelGGL((integrate_multi_kernel<RM, UPD, false>), grid, block, 0, ctx->stream, mp, (const WorkItem *)items, (const unsigned *)n_items, v->d_tsdf, \
+                               v->d_weight, v->d_color);                                                                                               \
+    } while (0)
     switch ((v->round_mode ? 3 : 0) + upd) {
         case 0: HIVE_LAUNCH(0, 0); break;
         case 1: HIVE_LAUNCH(0, 1); break;

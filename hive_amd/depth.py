@@ -122,8 +122,10 @@ class DepthFusionStream:
         """``overlap=True``: the TSDF sweeps of batch i run on a second HIP stream while the network already works on batch
         i + 1.  The network's MFMA kernels leave the vector ALUs idle and whole CUs idle in the tails of their tile rounds; the sweep
         is vector-ALU work with 8 KB of LDS.  ``volume`` must then live on a context of that stream
-        (``side_stream_context()`` makes one); ``step`` returns an event that fires when its sweeps are done (for whoever recycles the
-        frame buffers) and ``join()`` orders the caller's stream behind the sweeps (before reading or merging the volume)."""
+        (``side_stream_context()`` makes one); ``step`` returns the depth maps, and ``self.last_done`` is an event that fires when the
+        sweeps of the MOST RECENT step are done (None before the first step and without overlap; overwritten by every step -- whoever
+        recycles frame buffers takes it right after the call); ``join()`` orders the caller's stream behind all sweeps queued so far
+        (before reading or merging the volume)."""
         self.model = model
         self.native = native  # run the network as one hive_dpt_forward call where it applies (frame size % 32 == 0)
         self.volume = volume
@@ -132,6 +134,7 @@ class DepthFusionStream:
         self.dtype = next(model.parameters()).dtype
         self.accum = None
         self.side = None
+        self.last_done = None
         if overlap:
             vctx = volume._ctx
             if vctx._follow_torch or not vctx._side_stream:
@@ -145,7 +148,7 @@ class DepthFusionStream:
     def side_stream_context(device=0):
         """A context (and its torch stream) for the volume of an overlapping stream: ``TSDFVolume(..., ctx=this)``."""
         ctx = _lib.Context(device, stream="own_low")  # lowest dispatch priority: the sweeps fill what the network leaves idle
-        ctx._side_stream = torch.cuda.ExternalStream(ctx.stream_handle(), device=device)
+        ctx.torch_stream()  # (creates ctx._side_stream, the torch view of that stream)
         return ctx
 
     def join(self):

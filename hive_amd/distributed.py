@@ -166,8 +166,10 @@ def fuse_sharded(volume, stream_or_accum=None):
     ``[tsdf * w, w, r * w, g * w, b * w]`` straight into the piece-major buffer.  Otherwise: the accumulators of a
     ``DepthFusionStream(accumulate=True)`` or a raw accumulator tensor filled with ``accum_integrate`` (sums of the raw
     observations, 40 B / voxel / frame)."""
-    side = getattr(volume._ctx, "_side_stream", None)  # a volume of an overlapping DepthFusionStream lives on its own stream:
-    if side is not None:                                # the collectives and the buffers go there too, in order with its kernels
+    # a volume whose context does not follow torch's current stream (the side stream of an overlapping DepthFusionStream, Context(stream="own"), an
+    # explicit hipStream_t) has its kernels on THAT stream: the collectives and the torch buffers go there too, in order with them
+    side = volume._ctx.torch_stream()
+    if side is not None:
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             _fuse_sharded(volume, stream_or_accum)

@@ -370,7 +370,7 @@ class _Staging:
     def __init__(self, capacity, h, w, device="cuda"):
         import torch
         self.capacity, self.device = int(capacity), device
-        self.color_h = torch.empty((capacity, h, w, 3), dtype=torch.uint8).pin_memory()
+        self.color_h = None  # pinned lazily, like the masks: the bounds pass of a chunked run (frame_chunks(with_color=False)) never touches colours
         self.depth_h = torch.empty((capacity, h, w), dtype=torch.float32).pin_memory()
         self.masks_h = None
         self.color_d = self.depth_d = self.masks_d = None
@@ -383,6 +383,8 @@ class _Staging:
             self.copied.synchronize()  # the previous chunk's upload has left the pinned buffers
         if with_masks and self.masks_h is None:
             self.masks_h = torch.empty(tuple(self.depth_h.shape), dtype=torch.uint8).pin_memory()
+        if with_color and self.color_h is None:
+            self.color_h = torch.empty(tuple(self.depth_h.shape) + (3,), dtype=torch.uint8).pin_memory()
         return (self.color_h[:n] if with_color else None), self.depth_h[:n], (self.masks_h[:n] if with_masks else None)
 
     def upload(self, n, with_color, with_masks):
@@ -403,15 +405,22 @@ class _Staging:
         return color, depth, masks
 
 
-def frame_chunks(dataset, frame_set, with_masks, chunk_frames, with_color=True):
-    """The frame set as ``DeviceFrames`` of at most ``chunk_frames`` frames each, in order, through ONE reused staging set."""
+def chunk_staging(dataset, frame_set, chunk_frames):
+    """The staging set of a chunked run over ``frame_set``: shared by its bounds pass and its integration pass (one set of pinned and
+    device buffers for the whole run: 9 bytes per pixel and resident frame once the colours and masks are in use)."""
     frame_set = list(frame_set)
-    staging = None
+    h, w = np.asarray(dataset.bg_depth_dataset[frame_set[0]]).shape
+    return _Staging(min(chunk_frames, len(frame_set)), h, w)
+
+
+def frame_chunks(dataset, frame_set, with_masks, chunk_frames, with_color=True, staging=None):
+    """The frame set as ``DeviceFrames`` of at most ``chunk_frames`` frames each, in order, through ONE reused staging set
+    (``staging``: the caller's, shared between passes; default: a set of this generator's own)."""
+    frame_set = list(frame_set)
     for a in range(0, len(frame_set), chunk_frames):
         ids = frame_set[a:a + chunk_frames]
         if staging is None:
-            h, w = np.asarray(dataset.bg_depth_dataset[ids[0]]).shape
-            staging = _Staging(min(chunk_frames, len(frame_set)), h, w)
+            staging = chunk_staging(dataset, frame_set, chunk_frames)
         yield DeviceFrames.from_dataset(dataset, ids, with_masks, with_color=with_color, staging=staging)
 
 
@@ -504,9 +513,10 @@ def tsdf_fusion(dataset, options=None, num_frames=-1, frame_set: Optional[List[i
         voxel_size, volume_bounds = adjust_voxel_size(dataset, options, frame_set, frames=frames)
         chunks = [frames]
     else:  # pass 1: depth maps only, running bounds; pass 2: everything, chunk by chunk, in sequence order
-        volume_bounds = scene_bounds(frame_chunks(dataset, frame_set, False, chunk_frames, with_color=False), dataset.camera_matrix)
+        staging = chunk_staging(dataset, frame_set, chunk_frames)  # one staging set for both passes
+        volume_bounds = scene_bounds(frame_chunks(dataset, frame_set, False, chunk_frames, with_color=False, staging=staging), dataset.camera_matrix)
         voxel_size = voxel_size_for_budget(volume_bounds, options)
-        chunks = frame_chunks(dataset, frame_set, needs_masks, chunk_frames)
+        chunks = frame_chunks(dataset, frame_set, needs_masks, chunk_frames, staging=staging)
     tsdf_vol = TSDFVolume(volume_bounds, voxel_size=voxel_size)
     for frames in chunks:
         depth = frames.masked_depth(options.depth_mask_dilation_iterations, MASK_BACKGROUND) if needs_masks else frames.depth
@@ -532,8 +542,9 @@ def tsdf_fusion_fg_bg(dataset, options=None, num_frames=-1, frame_set: Optional[
         chunks = [DeviceFrames.from_dataset(raw, frame_set, with_masks=True)]
         vol_bnds = scene_bounds(chunks[0], dataset.camera_matrix)
     else:
-        vol_bnds = scene_bounds(frame_chunks(raw, frame_set, False, chunk_frames, with_color=False), dataset.camera_matrix)
-        chunks = frame_chunks(raw, frame_set, True, chunk_frames)
+        staging = chunk_staging(raw, frame_set, chunk_frames)
+        vol_bnds = scene_bounds(frame_chunks(raw, frame_set, False, chunk_frames, with_color=False, staging=staging), dataset.camera_matrix)
+        chunks = frame_chunks(raw, frame_set, True, chunk_frames, staging=staging)
     voxel_size = voxel_size_for_budget(vol_bnds, options)
     modes = (("bg", MASK_BACKGROUND, options.depth_mask_dilation_iterations), ("fg", MASK_FOREGROUND, 0))
     volumes = {name: TSDFVolume(vol_bnds, voxel_size=voxel_size) for name, _, _ in modes}

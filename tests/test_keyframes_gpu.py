@@ -78,3 +78,45 @@ def test_select_key_frames_and_pipeline_on_tum_sequence(gpu_ctx, oracle_lib, tmp
     # the reconstructed room walls lie near the analytic room of the generator, expressed in the adaptor's frame:
     # all vertices within the 5.12 m cube's diagonal of the first camera
     assert np.linalg.norm(np.asarray(mesh.vertices), axis=1).max() < 9.0
+
+
+def test_config1_tum_layout_50_frames_256_cubed_numpy_rounding(gpu_ctx, oracle_lib, tmp_path):
+    """BASELINE.json configs[0] at its stated shape, on a synthetic TUM-layout folder (the TUM sequence itself is not in the container): 50 frames with
+    ground-truth poses and sensor depth (PNG scale 5000, /root/reference/hive/dataset_adaptors.py:574-766) -> `get_dataset` in the reference's call form ->
+    a FIXED 256^3 volume (2 cm voxels over a 5.12 m cube around the scene) with `TSDFVolume(..., use_gpu=False)`, i.e. the rounding of the reference
+    library's numpy path (np.round, ties to even) -> the fused sweeps.  Volume bits == the C oracle with round_mode 0, all three planes."""
+    import torch
+    from hive_amd import fusion
+    from hive_amd._lib import ROUND_HALF_EVEN
+    from hive_amd.dataset_adaptors import get_dataset
+    from hive_amd.options import COLMAPOptions, PipelineOptions, StorageOptions
+    tum, out = str(tmp_path / "tum"), str(tmp_path / "hive")
+    n = 50
+    write_tum_sequence(tum, num_frames=n, yaw_step_deg=360.0 / n)
+    ds = get_dataset(StorageOptions(dataset_path=tum, output_path=out), COLMAPOptions(), PipelineOptions(num_frames=n, frame_step=1))
+    assert ds.num_frames == n
+    frames = fusion.DeviceFrames.from_dataset(ds, list(range(n)), with_masks=False)
+    K = ds.camera_matrix
+    # the scene's bounds (union of the view frusta, as fusion.py:48-61) fix the centre of the cube; its side and the voxel size are the configuration's
+    bnds = fusion.scene_bounds(frames, K)
+    centre = np.round(bnds.mean(axis=1), 2)
+    lo = centre - 2.56
+    hi = lo + 5.12
+    for a in range(3):  # (hi - lo) / 0.02 must not round above 256 (the library takes the ceiling, as the reference's does)
+        while np.ceil((hi[a] - lo[a]) / 0.02) > 256:
+            hi[a] = np.nextafter(hi[a], -np.inf)
+    vol_bnds = np.stack([lo, hi], axis=1)
+    vol = fusion.TSDFVolume(vol_bnds, 0.02, use_gpu=False, ctx=gpu_ctx)
+    assert vol.round_mode == ROUND_HALF_EVEN and tuple(int(d) for d in vol.vol_dim) == (256, 256, 256)
+    vol.integrate_batch(frames.color, frames.depth, K, frames.poses)
+    assert max(vol.last_batch_groups()) > 1, "consecutive frames 7.2 degrees apart share sweeps"
+    ora = oracle_lib.TSDFVolume(vol_bnds, 0.02, round_mode=0)
+    color, depth = frames.color.cpu().numpy(), frames.depth.cpu().numpy()
+    for i in range(n):
+        ora.integrate(color[i], depth[i], K, frames.poses[i])
+    tsdf, col, weight = vol.get_volume(with_weight=True)
+    assert float(weight.max()) >= 10 and (tsdf < 0).any(), "the fusion saw surfaces"
+    assert np.array_equal(weight, ora._weight) and np.array_equal(tsdf, ora._tsdf) and np.array_equal(col, ora._color)
+    verts, faces, _, _ = vol.get_mesh()
+    o_verts, o_faces, _, _ = ora.get_mesh()
+    assert np.array_equal(faces, o_faces) and np.array_equal(verts, o_verts)

@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
 """A/B of the fused TSDF sweep's switches in ONE process, on both scenes of bench.py (room: analytic depth; dpt: DPT-Hybrid depth of the
-seeded weights), 32 consecutive frames 2.4 degrees apart into 512^3:
-    HIVE_TSDF_ROW_FAR (per-row far cut from the depth tiles), HIVE_TSDF_FRAME_SKIP (work-item frame masks), HIVE_TSDF_FAST_COLOUR (division-free colour update)
-Per configuration: us per frame of the whole leg (prep + work list + sweep, HIP events), us per sweep launch (the library's own events), work-list
-voxels of the last sweep, and a check that the volume is bit-identical to configuration 0 0 0.  Usage: probe_sweep_ab.py [frames] [scene ...]"""
-import itertools
+seeded weights), 32 consecutive frames 2.4 degrees apart into 512^3.  Switches (HIVE_TSDF_<name>, all default 1): ROW_FAR (per-row far cut from the
+depth tiles), FRAME_SKIP (work-item frame masks), FAST_COLOUR (division-free colour update), SORT (work list sorted by image band, eighths to the XCDs),
+SEGK (one segment per gather instruction).  PROBE_CONFIGS = ';'-separated configurations, each a ','-separated list of NAME=0/1 (the first is the
+reference the others' volumes are compared with); default: everything off, then everything on.
+Per configuration: us per frame of the whole leg (prep + work list + sort + sweep, HIP events), us per sweep launch (the library's own events), work-list
+voxels of the last sweep, and a check that the volume is bit-identical to the first configuration's.  Usage: probe_sweep_ab.py [frames] [scene ...]"""
 import json
 import os
 import sys
@@ -32,16 +33,17 @@ if "dpt" in scenes:
     depths["dpt"] = stream.depth(color)[0].clone()
     del model, stream
 out = {}
-configs = [c for c in itertools.product((0, 1), repeat=3)]
-if os.environ.get("PROBE_CONFIGS"):
-    configs = [tuple(int(ch) for ch in c) for c in os.environ["PROBE_CONFIGS"].split(",")]
+NAMES = ("ROW_FAR", "FRAME_SKIP", "FAST_COLOUR", "SORT", "SEGK")
+spec = os.environ.get("PROBE_CONFIGS") or (",".join(n + "=0" for n in NAMES) + ";" + ",".join(n + "=1" for n in NAMES))
+configs = [dict(kv.split("=") for kv in c.split(",") if kv) for c in spec.split(";")]
 for scene, depth in depths.items():
     # N_upd per frame (counting single-frame kernel) and N_union per sweep of four
     vol.reset()
     n_upd = [vol.integrate(color[i], depth[i], seq["K"], seq["poses"][i], return_n_updated=True) for i in range(min(frames, 8))]
     ref = None
     for cfg in configs:
-        os.environ["HIVE_TSDF_ROW_FAR"], os.environ["HIVE_TSDF_FRAME_SKIP"], os.environ["HIVE_TSDF_FAST_COLOUR"] = (str(v) for v in cfg)
+        for name in NAMES:
+            os.environ["HIVE_TSDF_" + name] = str(cfg.get(name, 1))
         leg, k_us = [], []
         for rep in range(5):
             vol.reset()
@@ -71,7 +73,7 @@ for scene, depth in depths.items():
         vol.integrate_batch(color[frames - nf:], depth[frames - nf:], seq["K"], seq["poses"][frames - nf:])
         n_union = int((storage[1] != before).sum().item())
         wl_last = vol.last_sweep_voxels()
-        rec = {"row_far": cfg[0], "frame_skip": cfg[1], "fast_colour": cfg[2], "leg_us_per_frame_min": min(leg), "launch_us_min": min(k_us), "launch_us_all": [round(v, 1) for v in k_us],
+        rec = {"config": {n: int(cfg.get(n, 1)) for n in NAMES}, "leg_us_per_frame_min": min(leg), "launch_us_min": min(k_us), "launch_us_all": [round(v, 1) for v in k_us],
                "worklist_voxels_last_sweep": wl_last, "n_union_last_sweep": n_union, "frames_last_sweep": nf, "n_upd_mean": float(np.mean(n_upd)),
                "bit_identical_to_first": same, "groups": groups[:3]}
         out.setdefault(scene, []).append(rec)
