@@ -147,6 +147,7 @@ int hive_ctx_destroy(hive_ctx *ctx) {
     for (auto ev : ctx->ev_pool) (void)hipEventDestroy(ev);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->d_frame) (void)hipFree(ctx->d_frame);
+    if (ctx->d_batch) (void)hipFree(ctx->d_batch);
     if (ctx->d_in) (void)hipFree(ctx->d_in);
     if (ctx->d_scalars) (void)hipFree(ctx->d_scalars);
     if (ctx->h_pinned_small) (void)hipHostFree(ctx->h_pinned_small);

@@ -8,10 +8,13 @@
 //                      gives the two halves of its unit square (fixed diagonal top-right / bottom-left), a block with exactly
 //                      three valid corners gives their triangle; no point set, no Qhull.  Faces index the rows of
 //                      point_cloud_from_depth's output (valid pixels in row-major order) and are wound like the reference's
-//                      reversed simplices (negative cross product in (u, v)).  What differs from Qhull's output (SURVEY.md 8f:
-//                      "face set after filtering, not Qhull's ordering"): the diagonal of a square is Qhull's arbitrary choice
-//                      among four co-circular points, and Qhull also bridges one-pixel holes with (sqrt 2, sqrt 2, 2)
-//                      triangles (2 of 566 faces on the test mask) -- tests/test_fgmesh_gpu.py quantifies both against scipy.
+//                      reversed simplices (negative cross product in (u, v)).  Delaunay of a lattice also BRIDGES an invalid pixel whose
+//                      4-neighbours are valid: the triangle through three of them has the hole as its circumcentre (radius 1, no valid
+//                      point inside) and sides (sqrt 2, sqrt 2, 2), which pass the default 2-pixel limit; with all four neighbours valid
+//                      the diamond is split along one of its diagonals (they are co-circular: Qhull's arbitrary choice, here west - east).
+//                      These are the only triangles of a lattice Delaunay whose sides are all <= 2: with them the face SET after the
+//                      filter equals the reference's up to the diagonal inside each co-circular unit square / diamond
+//                      (tests/test_fgmesh_gpu.py against scipy's Delaunay).
 //   hive_texture_window _get_mesh_texture_and_uv (:782-808): project the vertices (world2image, its default int32 pixels), their
 //                      bounding box (the crop of the frame that becomes the texture), uv relative to the box's corner.
 //
@@ -38,14 +41,11 @@ __device__ __forceinline__ bool edge_ok(const GridParams &p, const float *depth,
     return dist <= p.max_px && fabsf(depth[a] - depth[b]) <= p.max_depth;
 }
 
-// triangles of the 2 x 2 block whose top-left pixel is i = (v, u): corners a b / c d.  Returns the count and the corners.
-__device__ __forceinline__ int block_faces(const GridParams &p, const float *depth, const uint8_t *mask, int i, int (&tri)[2][3]) {
+// triangles that belong to pixel i = (v, u), in order: those of the 2 x 2 block whose top-left pixel it is (corners a b / c d), then, where
+// pixel i itself is invalid, the triangles that bridge it (4-neighbours n / w e / s).  Returns the count and the corners (pixel indices).
+constexpr int MAX_PIXEL_FACES = 4;
+__device__ __forceinline__ int pixel_faces(const GridParams &p, const float *depth, const uint8_t *mask, int i, int (&tri)[MAX_PIXEL_FACES][3]) {
     const int v = i / p.W, u = i - v * p.W;
-    if (v + 1 >= p.H || u + 1 >= p.W) return 0;
-    const int a = i, b = i + 1, c = i + p.W, d = i + p.W + 1;
-    const bool va = px_valid(depth, mask, a), vb = px_valid(depth, mask, b), vc = px_valid(depth, mask, c), vd = px_valid(depth, mask, d);
-    const int nv = va + vb + vc + vd;
-    if (nv < 3) return 0;
     int n = 0;
     // every triangle is listed clockwise-on-screen-with-v-down reversed, i.e. with a negative (u, v) cross product
     auto push = [&](int p0, int p1, int p2, bool ok) {
@@ -56,20 +56,44 @@ __device__ __forceinline__ int block_faces(const GridParams &p, const float *dep
             ++n;
         }
     };
-    const bool e_ab = va && vb && edge_ok(p, depth, a, b, 1, 0), e_ac = va && vc && edge_ok(p, depth, a, c, 0, 1);
-    const bool e_bd = vb && vd && edge_ok(p, depth, b, d, 0, 1), e_cd = vc && vd && edge_ok(p, depth, c, d, 1, 0);
-    const bool e_bc = vb && vc && edge_ok(p, depth, b, c, 1, 1), e_ad = va && vd && edge_ok(p, depth, a, d, 1, 1);
-    if (nv == 4) {            // diagonal b - c
-        push(a, c, b, e_ab && e_ac && e_bc);
-        push(b, c, d, e_bd && e_cd && e_bc);
-    } else if (!vd) {
-        push(a, c, b, e_ab && e_ac && e_bc);
-    } else if (!va) {
-        push(b, c, d, e_bd && e_cd && e_bc);
-    } else if (!vb) {
-        push(a, c, d, e_ac && e_cd && e_ad);
-    } else {  // !vc
-        push(a, d, b, e_ab && e_bd && e_ad);
+    if (v + 1 < p.H && u + 1 < p.W) {
+        const int a = i, b = i + 1, c = i + p.W, d = i + p.W + 1;
+        const bool va = px_valid(depth, mask, a), vb = px_valid(depth, mask, b), vc = px_valid(depth, mask, c), vd = px_valid(depth, mask, d);
+        const int nv = va + vb + vc + vd;
+        if (nv >= 3) {
+            const bool e_ab = va && vb && edge_ok(p, depth, a, b, 1, 0), e_ac = va && vc && edge_ok(p, depth, a, c, 0, 1);
+            const bool e_bd = vb && vd && edge_ok(p, depth, b, d, 0, 1), e_cd = vc && vd && edge_ok(p, depth, c, d, 1, 0);
+            const bool e_bc = vb && vc && edge_ok(p, depth, b, c, 1, 1), e_ad = va && vd && edge_ok(p, depth, a, d, 1, 1);
+            if (nv == 4) {            // diagonal b - c
+                push(a, c, b, e_ab && e_ac && e_bc);
+                push(b, c, d, e_bd && e_cd && e_bc);
+            } else if (!vd) {
+                push(a, c, b, e_ab && e_ac && e_bc);
+            } else if (!va) {
+                push(b, c, d, e_bd && e_cd && e_bc);
+            } else if (!vb) {
+                push(a, c, d, e_ac && e_cd && e_ad);
+            } else {  // !vc
+                push(a, d, b, e_ab && e_bd && e_ad);
+            }
+        }
+    }
+    if (!px_valid(depth, mask, i) && v > 0 && v + 1 < p.H && u > 0 && u + 1 < p.W) {  // a hole strictly inside the image
+        const int nn = i - p.W, ss = i + p.W, ww = i - 1, ee = i + 1;
+        const bool vn = px_valid(depth, mask, nn), vs = px_valid(depth, mask, ss), vw = px_valid(depth, mask, ww), ve = px_valid(depth, mask, ee);
+        if (vn + vs + vw + ve >= 3) {
+            const bool e_we = vw && ve && edge_ok(p, depth, ww, ee, 2, 0), e_ns = vn && vs && edge_ok(p, depth, nn, ss, 0, 2);
+            const bool e_wn = vw && vn && edge_ok(p, depth, ww, nn, 1, 1), e_ne = vn && ve && edge_ok(p, depth, nn, ee, 1, 1);
+            const bool e_ws = vw && vs && edge_ok(p, depth, ww, ss, 1, 1), e_se = vs && ve && edge_ok(p, depth, ss, ee, 1, 1);
+            if (vw && ve) {           // (all four valid: the west - east diagonal)
+                push(ww, ee, nn, vn && e_we && e_wn && e_ne);
+                push(ww, ss, ee, vs && e_we && e_ws && e_se);
+            } else if (!vw) {
+                push(nn, ss, ee, e_ns && e_ne && e_se);
+            } else {  // !ve
+                push(nn, ww, ss, e_ns && e_wn && e_ws);
+            }
+        }
     }
     return n;
 }
@@ -83,8 +107,8 @@ __global__ __launch_bounds__(256) void grid_count_kernel(const float *__restrict
         const int i = blockIdx.x * TILE + threadIdx.x * (TILE / 256) + j;
         if (i < n) {
             cv += px_valid(depth, mask, i);
-            int tri[2][3];
-            cf += (unsigned)block_faces(p, depth, mask, i, tri);
+            int tri[MAX_PIXEL_FACES][3];
+            cf += (unsigned)pixel_faces(p, depth, mask, i, tri);
         }
     }
     for (int off = 32; off > 0; off >>= 1) {
@@ -170,12 +194,12 @@ __global__ __launch_bounds__(256) void grid_faces_kernel(const float *__restrict
     __shared__ unsigned lds[4];
     const int n = p.H * p.W;
     const int base = blockIdx.x * TILE + threadIdx.x * (TILE / 256);
-    int tri[TILE / 256][2][3];
+    int tri[TILE / 256][MAX_PIXEL_FACES][3];
     int cnt[TILE / 256];
     unsigned c = 0;
 #pragma unroll
     for (int j = 0; j < TILE / 256; ++j) {
-        cnt[j] = base + j < n ? block_faces(p, depth, mask, base + j, tri[j]) : 0;
+        cnt[j] = base + j < n ? pixel_faces(p, depth, mask, base + j, tri[j]) : 0;
         c += (unsigned)cnt[j];
     }
     long long f = (long long)blk_faces[blockIdx.x] + block_exclusive(c, lds);

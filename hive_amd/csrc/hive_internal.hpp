@@ -39,6 +39,8 @@ struct hive_ctx {
     // packed frame {depth bits, rgb} + per-frame scalars
     void *d_frame = nullptr;
     size_t frame_bytes = 0;
+    void *d_batch = nullptr;  // texels + tile maxima of a prepared batch of frames (tsdf.hip prepare_batch)
+    size_t batch_bytes = 0;
     void *d_in = nullptr;  // device copy of host inputs
     size_t in_bytes = 0;
     int tsdf_scalars = 0;           // which of the two TSDF scalar blocks the frame in flight uses (tsdf.hip prepare_frame)

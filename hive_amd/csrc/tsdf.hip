@@ -736,6 +736,9 @@ struct MultiParams {
     int nf;
     int frame_skip;  // 1: a wave skips the frames whose clip excludes all of its segments (work item masks)
     int xcd_split;   // 1: the (band-sorted) work list's eighths go to the eight XCDs; 0: one grid-stride sweep over the whole list
+    unsigned *clear_next;  // the other scalar block: MS_CLEAR words to zero for the next sweep
+    int lanes_along_x;     // work-list kernel: 1 = its lanes (neighbouring rows) run along x, 0 = along y
+    int quad_interleave;   // work-list kernel: 1 = the segments of four neighbouring rows are interleaved
 };
 
 // scalar block of a fused sweep (two alternate, hive_ctx::d_scalars + MS_BASE + which * MS_STRIDE): [MS_NITEMS] work-list length, [MS_HIST ..] items
@@ -755,6 +758,9 @@ __global__ __launch_bounds__(1024) void build_worklist_multi_kernel(MultiParams 
     __syncthreads();
     for (int f = 0; f < mp.nf; ++f) load_dilated_tiles(mp.f[f].tile_max, p.tiles_x, p.tiles_y, dil[f], &gmax[f], threadIdx.x, 1024);
     __syncthreads();
+    // Lanes run along the volume axis (x or y) that lies most ACROSS the camera's vertical: neighbouring lanes' rows then project to
+    // horizontally neighbouring pixels -- the same 64-byte lines of the row-major texel planes -- and the work list interleaves the
+    // segments of four neighbouring rows (below), so that a wave's four segments gather from the same lines.
     const long long row = (long long)blockIdx.x * 1024 + threadIdx.x;
     unsigned n_chunks = 0;
     int zstart = 0, z1 = 0, x = 0, y = 0;
@@ -767,8 +773,13 @@ __global__ __launch_bounds__(1024) void build_worklist_multi_kernel(MultiParams 
         return mask;
     };
     if (row < (long long)p.X * p.Y) {
-        x = (int)(row / p.Y);
-        y = (int)(row % p.Y);
+        if (mp.lanes_along_x) {
+            y = (int)(row / p.X);
+            x = (int)(row % p.X);
+        } else {
+            x = (int)(row / p.Y);
+            y = (int)(row % p.Y);
+        }
         int lo = p.Z, hi = 0;
 #pragma unroll
         for (int f = 0; f < MAXF; ++f) {
@@ -796,11 +807,27 @@ __global__ __launch_bounds__(1024) void build_worklist_multi_kernel(MultiParams 
             for (int zs = zstart; zs < z1; zs += CHUNK) n_chunks += frames_of(zs) ? 1u : 0u;
         }
     }
-    unsigned slot = worklist_slots(n_chunks, n_items, wave_sum, &block_base);
+    const unsigned first = worklist_slots(n_chunks, n_items, wave_sum, &block_base);
+    // Quad interleave: the four lanes 4 q .. 4 q + 3 (four neighbouring rows) emit segment e of lane 0, of lane 1, ... then segment e + 1:
+    // item (lane j, e) goes to quad_first + sum_j' min(n_j', e) + #{j' < j : n_j' > e}.  A trip of the sweep takes four consecutive items.
+    const int lane = threadIdx.x & 63;
+    const unsigned quad_first = (unsigned)__shfl((int)first, lane & ~3);
+    unsigned nq[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) nq[j] = (unsigned)__shfl((int)n_chunks, (lane & ~3) + j);
+    unsigned e = 0;
     if (n_chunks)
         for (int zs = zstart; zs < z1; zs += CHUNK) {
             const unsigned mask = frames_of(zs);
             if (!mask) continue;
+            unsigned slot = quad_first;
+            if (mp.quad_interleave) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) slot += min(nq[j], e) + ((j < (lane & 3) && nq[j] > e) ? 1u : 0u);
+            } else {
+                slot = first + e;
+            }
+            ++e;
             // image band: the row v of the first frame the segment's middle projects to (clamped; any value is valid -- it only orders the list)
             const float tz = (p.oz + (float)(zs + CHUNK / 2) * p.vs) - p.T[2];
             const float cz = az0 + p.R[8] * tz;
@@ -810,7 +837,7 @@ __global__ __launch_bounds__(1024) void build_worklist_multi_kernel(MultiParams 
             WorkItem it;
             it.xy = (unsigned)x | ((unsigned)y << 16);
             it.zz = (unsigned)zs | ((unsigned)(min(z1 - zs, CHUNK) - 1) << ITEM_NLIVE_SHIFT) | (mask << ITEM_MASK_SHIFT) | ((unsigned)bin << ITEM_BIN_SHIFT);
-            items[slot++] = it;
+            items[slot] = it;
         }
     __syncthreads();
     if (threadIdx.x < NBINS && bin_count[threadIdx.x]) atomicAdd(hist + threadIdx.x, bin_count[threadIdx.x]);
@@ -872,17 +899,15 @@ __global__ __launch_bounds__(1024) void sort_worklist_kernel(const WorkItem *__r
 #else
 #define HIVE_TSDF_OCC
 #endif
-// SEGK: how the gather role spreads a trip's 4 x 64 voxels over its four gather instructions.  false: instruction k takes voxels 16 k .. 16 k + 15
-// of EACH of the wave's four segments (four separate pixel runs per instruction); true: instruction k takes the 64 consecutive voxels of
-// segment k (ONE pixel run per instruction: 16 L + 4 instead of 16 L + 16 lines per trip and frame when 16 voxels span L lines -- the CU's
-// texture path pays per distinct 64-byte line).  Segment k's row is then the same for all lanes: its item comes from lane 16 k by readlane.
 // The work list is sorted by image band (sort_worklist_kernel) and the XCDs take the sorted list's eighths: workgroups with the same
 // blockIdx % 8 share an XCD (and its L2), so each XCD's gathers stay within one stripe of each frame.
-template <int RM, int UPD, bool SEGK>
+// (Round 4, measured and taken out: gather instruction k covering the 64 consecutive voxels of segment k -- one pixel run per instruction
+// instead of four runs of 16 voxels, i.e. 12 fewer distinct 64-byte lines per trip and frame -- with segment k's row constants from readlane:
+// 210 vs 190 us per launch on the room scene, 198 vs 184 on the bench scene: the four rows' constants per frame cost more than the lines save.)
+template <int RM, int UPD>
 __global__ __launch_bounds__(256) HIVE_TSDF_OCC void integrate_multi_kernel(MultiParams mp, const WorkItem *__restrict__ items, const unsigned *__restrict__ n_items_ptr,
                                                               float *__restrict__ v0, float *__restrict__ v1, float *__restrict__ v2) {
     constexpr int PER_WAVE = 64 / SEG_LANES, SEG_VOX = SEG_LANES * 4;
-    static_assert(!SEGK || (PER_WAVE == 4 && SEG_VOX == 64), "SEGK: four 64-voxel segments per wave");
     typedef ItemShape Sh;
     typedef Sh::V V;
     __shared__ uint2 xchg[4 * PER_WAVE * SEG_VOX];
@@ -898,6 +923,9 @@ __global__ __launch_bounds__(256) HIVE_TSDF_OCC void integrate_multi_kernel(Mult
     const unsigned trip_end = min(n_trips, (xcd + 1u) * per_xcd);
     const FrameParams &p0 = mp.f[0];
     const float trunc_rcp = refined_rcp(p0.trunc);
+    // the NEXT sweep's scalar block (work-list length, band histogram, sort cursors) is cleared here instead of by a memset launch per
+    // sweep: the two blocks alternate, and every kernel of the sweep that used that block last has finished (stream order)
+    if (blockIdx.x == 0 && (int)threadIdx.x < MS_CLEAR) mp.clear_next[threadIdx.x] = 0u;
     for (unsigned trip = xcd * per_xcd + local_block * 4 + (threadIdx.x >> 6); trip < trip_end; trip += stride) {
         const unsigned ii = trip * PER_WAVE + (unsigned)seg;
         WorkItem item;
@@ -913,15 +941,6 @@ __global__ __launch_bounds__(256) HIVE_TSDF_OCC void integrate_multi_kernel(Mult
         // whole wave -- no projection, no gather, no tests.  (A skipped frame's own clip excludes every voxel of the segments, and the
         // clip is conservative: skipping cannot change a result.)
         unsigned wave_frames = (item.zz >> ITEM_MASK_SHIFT) & 15u;
-        // SEGK: the four segments' items as wave-uniform values
-        unsigned seg_xy[4], seg_zz[4];
-        if (SEGK) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                seg_xy[k] = (unsigned)__builtin_amdgcn_readlane((int)item.xy, SEG_LANES * k);
-                seg_zz[k] = (unsigned)__builtin_amdgcn_readlane((int)item.zz, SEG_LANES * k);
-            }
-        }
 #pragma unroll
         for (int o = SEG_LANES; o < 64; o <<= 1) wave_frames |= (unsigned)__shfl_xor((int)wave_frames, o);
         wave_frames = mp.frame_skip ? (unsigned)__builtin_amdgcn_readfirstlane((int)wave_frames) : 0xffu;
@@ -942,58 +961,20 @@ __global__ __launch_bounds__(256) HIVE_TSDF_OCC void integrate_multi_kernel(Mult
             // in the gather role and the colour fetched for the passing voxels only -- the second dependent round trip costs more than
             // the lines it saves: 292 vs 224 us per four-frame launch on the room scene, 261 vs 219 on the bench scene.)
             uint2 tex[4];
-            if (!SEGK) {
 #pragma unroll
-                for (int g = 0; g < 2; ++g) {
-                    V cz;
-                    int pix[Sh::NV];
-                    voxel_pixels<RM, V, Sh::NV, SEG_LANES>(p, ax, ay, az, zseg + sl + 2 * SEG_LANES * g, cz, pix);
+            for (int g = 0; g < 2; ++g) {
+                V cz;
+                int pix[Sh::NV];
+                voxel_pixels<RM, V, Sh::NV, SEG_LANES>(p, ax, ay, az, zseg + sl + 2 * SEG_LANES * g, cz, pix);
 #pragma unroll
-                    for (int i = 0; i < Sh::NV; ++i) {
-                        uint2 tx2 = p.frame[max(pix[i], 0)];
-                        if (pix[i] < 0) tx2.x = 0u;
-                        tex[g * Sh::NV + i] = tx2;
-                    }
+                for (int i = 0; i < Sh::NV; ++i) {
+                    uint2 tx2 = p.frame[max(pix[i], 0)];
+                    if (pix[i] < 0) tx2.x = 0u;
+                    tex[g * Sh::NV + i] = tx2;
                 }
-#pragma unroll
-                for (int k = 0; k < 4; ++k) mine[SEG_LANES * k + sl] = tex[k];
-            } else {
-                uint2 *wave_region = xchg + (threadIdx.x >> 6) * (PER_WAVE * SEG_VOX);
-                int pixk[4];
-#pragma unroll
-                for (int g = 0; g < 2; ++g) {
-                    // pair (2 g, 2 g + 1): element i = voxel `lane` of segment 2 g + i, each with its own row's constants (the contract's operation order)
-                    V axv, ayv, azv, zf, cz;
-                    int pix[Sh::NV];
-#pragma unroll
-                    for (int i = 0; i < Sh::NV; ++i) {
-                        const int k = g * Sh::NV + i;
-                        const int xk = (int)(seg_xy[k] & 0xffffu), yk = (int)(seg_xy[k] >> 16), zk = (int)(seg_zz[k] & 0xffffu);
-                        const float txk = (p.ox + (float)(xk + p.x_off) * p.vs) - p.T[0];
-                        const float tyk = (p.oy + (float)yk * p.vs) - p.T[1];
-                        v_set(axv, i, p.R[0] * txk + p.R[3] * tyk);
-                        v_set(ayv, i, p.R[1] * txk + p.R[4] * tyk);
-                        v_set(azv, i, p.R[2] * txk + p.R[5] * tyk);
-                        v_set(zf, i, (float)(zk + lane));
-                    }
-                    voxel_pixels_rows<RM, V, Sh::NV>(p, axv, ayv, azv, zf, cz, pix);
-#pragma unroll
-                    for (int i = 0; i < Sh::NV; ++i) {
-                        const int k = g * Sh::NV + i;
-                        // a segment outside this frame's clip (or a dead one) is sent as depth 0, like a voxel outside the image; all four
-                        // gathers are issued back to back (no branch between them: a branch per gather serialised their round trips)
-                        const bool in_clip = !mp.frame_skip || ((seg_zz[k] >> (ITEM_MASK_SHIFT + f)) & 1u);
-                        pixk[k] = in_clip ? pix[i] : -1;
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    tex[k] = p.frame[max(pixk[k], 0)];
-                    if (pixk[k] < 0) tex[k].x = 0u;
-                }
-#pragma unroll
-                for (int k = 0; k < 4; ++k) wave_region[SEG_VOX * k + lane] = tex[k];
             }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) mine[SEG_LANES * k + sl] = tex[k];
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1239,58 +1220,64 @@ static void fill_frame_params(hive_tsdf *v, int H, int W, const float K[9], cons
     p.n_updated = nullptr;
 }
 
-// nf (2 .. MAXF) device-resident frames in ONE sweep (integrate_multi_kernel): one prep launch for the nf frames (texels + tile
-// maxima), one work list over the union of the frames' clips, one integrate launch.
-// `prepared` (or null): the caller already holds the sweep's inputs -- the {depth, rgb} texels and the tile maxima of every frame
-// (hive_dpt_forward leaves both behind) -- and no prep launch is needed.
+// The fused sweep's inputs: the {depth, rgb} texels and the tile maxima of every frame (prep_frame_kernel; one launch for a whole batch of frames).
 struct PreparedFrames {
     const uint2 *texels;       // [nf][H*W]
     const unsigned *tile_max;  // [nf][tile_stride], tiles of (32 << tile_grid(H, W).shift)^2 pixels
     int tile_stride;
 };
-static int launch_integrate_multi(hive_tsdf *v, int nf, const uint8_t *color, const float *depth, int H, int W, const float K[9], const double *poses,
-                                  float obs_weight, const PreparedFrames *prepared) {
+// One prep launch for frames [0, n) of a device-resident batch into hive_ctx::d_batch (texels, then the tile maxima).
+static int prepare_batch(hive_tsdf *v, int n, const uint8_t *color, const float *depth, int H, int W, PreparedFrames *out) {
     hive_ctx *ctx = v->ctx;
     const size_t npx = (size_t)H * W;
     const TileGrid tg = tile_grid(H, W);
-    const size_t tex_bytes = ((size_t)nf * npx * sizeof(uint2) + 255) & ~(size_t)255;
+    const size_t tex_bytes = ((size_t)n * npx * sizeof(uint2) + 255) & ~(size_t)255;
+    int rc = hive_reserve_device(ctx, &ctx->d_batch, &ctx->batch_bytes, tex_bytes + (size_t)n * MAX_TILES * sizeof(unsigned));
+    if (rc) return rc;
+    unsigned *d_tiles = (unsigned *)((char *)ctx->d_batch + tex_bytes);
+    // the 4-pixels-per-lane form needs every frame's depth 16-byte and colour 4-byte aligned
+    const bool vec = W % 4 == 0 && (uintptr_t)depth % 16 == 0 && (uintptr_t)color % 4 == 0;
+    const dim3 grid((unsigned)(tg.tiles_x * tg.tiles_y), (unsigned)n);
+    if (vec)
+        hipLaunchKernelGGL(prep_frame_kernel<true>, grid, dim3(256), 0, ctx->stream, depth, color, H, W, tg.shift, tg.tiles_x, (uint2 *)ctx->d_batch, d_tiles, MAX_TILES,
+                           (unsigned *)nullptr, 0);
+    else
+        hipLaunchKernelGGL(prep_frame_kernel<false>, grid, dim3(256), 0, ctx->stream, depth, color, H, W, tg.shift, tg.tiles_x, (uint2 *)ctx->d_batch, d_tiles, MAX_TILES,
+                           (unsigned *)nullptr, 0);
+    HIVE_CHECK_HIP(ctx, hipGetLastError());
+    out->texels = (const uint2 *)ctx->d_batch;
+    out->tile_max = d_tiles;
+    out->tile_stride = MAX_TILES;
+    return HIVE_OK;
+}
+
+// nf (2 .. MAXF) prepared frames in ONE sweep (integrate_multi_kernel): one work list over the union of the frames' clips, sorted by image
+// band, one integrate launch.
+static int launch_integrate_multi(hive_tsdf *v, int nf, int H, int W, const float K[9], const double *poses, float obs_weight, const PreparedFrames &prepared) {
+    hive_ctx *ctx = v->ctx;
+    const size_t npx = (size_t)H * W;
     int rc = HIVE_OK;
-    // scalar block of this sweep (MS_* above).  Two blocks alternate (both zero after hive_ctx_create); this sweep's first kernel clears the
+    // scalar block of this sweep (MS_* above).  Two blocks alternate (both zero after hive_ctx_create); this sweep's integrate kernel clears the
     // other one, which the previous sweep used (stream order) -- no memset launch
-    static_assert(MS_CLEAR <= 256 && MS_CLEAR <= MS_STRIDE, "prep_frame_kernel clears the next block with one workgroup of 256 threads");
+    static_assert(MS_CLEAR <= 256 && MS_CLEAR <= MS_STRIDE, "integrate_multi_kernel clears the next block with one workgroup of 256 threads");
     ctx->tsdf_multi_scalars ^= 1;
     unsigned *sc = ctx->d_scalars + MS_BASE + (ctx->tsdf_multi_scalars ? MS_STRIDE : 0);
     unsigned *idle_block = ctx->d_scalars + MS_BASE + (ctx->tsdf_multi_scalars ? 0 : MS_STRIDE);
-    const uint2 *texels = nullptr;
-    const unsigned *tiles = nullptr;
-    int tile_stride = MAX_TILES;
-    if (prepared) {
-        texels = prepared->texels;
-        tiles = prepared->tile_max;
-        tile_stride = prepared->tile_stride;
-        HIVE_CHECK_HIP(ctx, hipMemsetAsync(idle_block, 0, MS_CLEAR * sizeof(unsigned), ctx->stream));
-    } else {
-        if ((rc = hive_reserve_device(ctx, &ctx->d_frame, &ctx->frame_bytes, tex_bytes + (size_t)MAXF * MAX_TILES * sizeof(unsigned)))) return rc;
-        unsigned *d_tiles = (unsigned *)((char *)ctx->d_frame + tex_bytes);
-        // the 4-pixels-per-lane form needs every frame's depth 16-byte and colour 4-byte aligned
-        const bool vec = W % 4 == 0 && (uintptr_t)depth % 16 == 0 && (uintptr_t)color % 4 == 0;
-        const dim3 grid((unsigned)(tg.tiles_x * tg.tiles_y), (unsigned)nf);
-        if (vec)
-            hipLaunchKernelGGL(prep_frame_kernel<true>, grid, dim3(256), 0, ctx->stream, depth, color, H, W, tg.shift, tg.tiles_x, (uint2 *)ctx->d_frame, d_tiles,
-                               MAX_TILES, idle_block, MS_CLEAR);
-        else
-            hipLaunchKernelGGL(prep_frame_kernel<false>, grid, dim3(256), 0, ctx->stream, depth, color, H, W, tg.shift, tg.tiles_x, (uint2 *)ctx->d_frame, d_tiles,
-                               MAX_TILES, idle_block, MS_CLEAR);
-        HIVE_CHECK_HIP(ctx, hipGetLastError());
-        texels = (const uint2 *)ctx->d_frame;
-        tiles = d_tiles;
-    }
+    const uint2 *texels = prepared.texels;
+    const unsigned *tiles = prepared.tile_max;
+    const int tile_stride = prepared.tile_stride;
     const bool sorted = env_flag("HIVE_TSDF_SORT", true);  // work list sorted by image band, its eighths to the eight XCDs
-    const bool segk = env_flag("HIVE_TSDF_SEGK", true) && SEG_LANES == 16;
     MultiParams mp;
     mp.nf = nf;
     mp.frame_skip = env_flag("HIVE_TSDF_FRAME_SKIP", true) ? 1 : 0;
     mp.xcd_split = sorted ? 1 : 0;
+    mp.clear_next = idle_block;
+    // the camera's "down" axis in world coordinates is column 1 of the pose's rotation: lanes run along the volume axis it has less of
+    const double *pose0 = poses;
+    const bool auto_x = fabs(pose0[0 * 4 + 1]) <= fabs(pose0[1 * 4 + 1]);
+    const char *lanes_env = getenv("HIVE_TSDF_LANES");  // tuning: "x" / "y" force the lane axis
+    mp.lanes_along_x = lanes_env ? (lanes_env[0] == 'x') : (auto_x ? 1 : 0);
+    mp.quad_interleave = env_flag("HIVE_TSDF_QUAD", true) ? 1 : 0;
     for (int f = 0; f < nf; ++f) {
         fill_frame_params(v, H, W, K, poses + 16 * (size_t)f, obs_weight, mp.f[f]);
         mp.f[f].frame = texels + (size_t)f * npx;
@@ -1316,15 +1303,8 @@ static int launch_integrate_multi(hive_tsdf *v, int nf, const uint8_t *color, co
     const dim3 grid((unsigned)((blocks + 7) / 8 * 8)), block(256);  // (a multiple of 8: the XCDs' shares)
     if ((rc = hive_time_begin(ctx))) return rc;
     const int upd = p.fast_colour ? 2 : (obs_weight == 1.0f ? 1 : 0);
-#define HIVE_LAUNCH(RM, UPD)                                                                                                                           \
-    do {                                                                                                                                               \
-        if (segk)                                                                                                                                      \
-            hipLaunchKernelGGL((integrate_multi_kernel<RM, UPD, true>), grid, block, 0, ctx->stream, mp, (const WorkItem *)items, (const unsigned *)n_items, v->d_tsdf, \
-                               v->d_weight, v->d_color);                                                                                               \
-        else                                                                                                                                           \
-            hipLaunchKernelGGL((integrate_multi_kernel<RM, UPD, false>), grid, block, 0, ctx->stream, mp, (const WorkItem *)items, (const unsigned *)n_items, v->d_tsdf, \
-                               v->d_weight, v->d_color);                                                                                               \
-    } while (0)
+#define HIVE_LAUNCH(RM, UPD) \
+    hipLaunchKernelGGL((integrate_multi_kernel<RM, UPD>), grid, block, 0, ctx->stream, mp, (const WorkItem *)items, (const unsigned *)n_items, v->d_tsdf, v->d_weight, v->d_color)
     switch ((v->round_mode ? 3 : 0) + upd) {
         case 0: HIVE_LAUNCH(0, 0); break;
         case 1: HIVE_LAUNCH(0, 1); break;
@@ -1596,13 +1576,26 @@ int hive_tsdf_integrate_batch(hive_tsdf *vol, int n, const uint8_t *color, const
         return dot >= fuse_cos * na * nb && dx * dx + dy * dy + dz * dz <= fuse_dist * fuse_dist * max_side * max_side;
     };
     vol->last_groups.clear();
+    // One prep launch (texels + tile maxima) serves up to PREP_CHUNK frames of the batch: at 4 frames per sweep a prep per sweep was 27 small
+    // launches per 107-frame step.  [prep_lo, prep_hi): the frames the current chunk holds.
+    constexpr int PREP_CHUNK = 128;
+    PreparedFrames chunk{nullptr, nullptr, 0};
+    int prep_lo = 0, prep_hi = 0;
     int f = 0;
     while (f < n) {
         int nf = 1;
         if (multi)
             while (nf < group && f + nf < n && fusable(f, f + nf)) ++nf;
         if (nf > 1) {
-            if ((rc = launch_integrate_multi(vol, nf, color + f * npx * 3, depth + f * npx, H, W, K, cam_poses + 16 * (size_t)f, obs_weight, nullptr))) return rc;
+            if (f + nf > prep_hi) {
+                prep_lo = f;
+                prep_hi = std::min(n, f + PREP_CHUNK);
+                if ((rc = prepare_batch(vol, prep_hi - prep_lo, color + (size_t)prep_lo * npx * 3, depth + (size_t)prep_lo * npx, H, W, &chunk))) return rc;
+            }
+            PreparedFrames mine = chunk;
+            mine.texels += (size_t)(f - prep_lo) * npx;
+            mine.tile_max += (size_t)(f - prep_lo) * chunk.tile_stride;
+            if ((rc = launch_integrate_multi(vol, nf, H, W, K, cam_poses + 16 * (size_t)f, obs_weight, mine))) return rc;
         } else {
             const uint8_t *d_color;
             const float *d_depth;

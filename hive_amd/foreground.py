@@ -8,9 +8,10 @@ face filter, the texture window and UV coordinates.  Decimation (openmesh), conn
   ``filter_faces``               ``Pipeline._filter_faces(points2d, depth, faces, options)`` (:670-694), any face list
   ``get_mesh_texture_and_uv``    ``Pipeline._get_mesh_texture_and_uv(...)`` (:782-808)
 
-The triangulation is the implicit one of the pixel grid (csrc/fgmesh.hip): the reference's Qhull Delaunay of the same lattice
-points differs from it only in which diagonal splits a unit square (arbitrary: four co-circular points) and in the faces
-that bridge one-pixel holes; tests/test_fgmesh_gpu.py measures both against scipy.
+The triangulation is the implicit one of the pixel grid (csrc/fgmesh.hip): unit squares and triangles of the valid pixels plus the
+(sqrt 2, sqrt 2, 2) triangles with which a lattice Delaunay bridges one-pixel holes -- after the reference's filter (sides <= 2 pixels by
+default) the face set equals the one the reference gets from Qhull, up to which diagonal splits four co-circular points (Qhull's
+arbitrary choice); tests/test_fgmesh_gpu.py checks that against scipy.
 """
 import ctypes
 

@@ -163,6 +163,11 @@ class TSDFVolume:
         self._ctx.check(self._ctx.lib.hive_tsdf_last_batch_groups(self._handle, ctypes.cast(sizes, ctypes.c_void_p), 4096, ctypes.byref(n)))
         return [int(sizes[i]) for i in range(min(n.value, 4096))]
 
+    def planes_modified(self):
+        """Tell the library that the caller wrote the volume's planes itself (caller-owned ``storage``): cached results and the fast paths that
+        rely on what the library knows about their contents are dropped until the next ``reset``."""
+        self._ctx.check(self._ctx.lib.hive_tsdf_planes_modified(self._handle))
+
     def last_sweep_voxels(self):
         """Voxels on the work list of the most recent sweep (segments x voxels per segment); forces a stream sync."""
         n, seg = ctypes.c_uint64(0), ctypes.c_int(0)

@@ -440,3 +440,77 @@ def test_multi_frame_sweep_on_x_slabs(gpu_ctx, oracle_lib, fusable_sequence):
     for k, ref in enumerate((ora._tsdf, ora._color, ora._weight)):
         assert np.array_equal(np.concatenate([p[k] for p in parts], axis=0), ref)
     assert ora._weight.max() >= 8
+
+
+def test_fast_colour_update_falls_back_when_weights_are_not_whole_numbers(gpu_ctx, oracle_lib, fusable_sequence):
+    """The sweep's division-free colour update (update_voxels FASTC) needs every weight of the volume to be a whole number of unit
+    observations; the library tracks that (hive_tsdf::unit_weights).  Each way of breaking it -- an observation weight other than 1, planes
+    written through hive_tsdf_set_volume, caller-owned planes written directly and announced with hive_tsdf_planes_modified -- must
+    send the NEXT unit-weight sweeps down the exact-division path: bit for bit against the oracle from the same starting planes; and a
+    reset restores the fast path (same bits either way, which is the point)."""
+    import torch
+    from hive_amd import fusion, synthetic
+    seq = fusable_sequence
+    color_d, depth_d = torch.from_numpy(seq["color"]).cuda(), torch.from_numpy(seq["depth"]).cuda()
+    bounds, voxel = synthetic.room_bounds(), 0.04
+
+    def run_oracle(ora, frames, w=1.0):
+        for i in frames:
+            ora.integrate(seq["color"][i], seq["depth"][i], seq["K"], seq["poses"][i], obs_weight=w)
+
+    # (a) a sweep with obs_weight 0.5 in between
+    vol, ora = fusion.TSDFVolume(bounds, voxel, ctx=gpu_ctx), oracle_lib.TSDFVolume(bounds, voxel)
+    vol.integrate_batch(color_d[:4], depth_d[:4], seq["K"], seq["poses"][:4])
+    vol.integrate_batch(color_d[4:6], depth_d[4:6], seq["K"], seq["poses"][4:6], obs_weight=0.5)
+    vol.integrate_batch(color_d[6:10], depth_d[6:10], seq["K"], seq["poses"][6:10])
+    run_oracle(ora, range(4)), run_oracle(ora, range(4, 6), 0.5), run_oracle(ora, range(6, 10))
+    _volumes_equal(vol, ora)
+    # (b) planes set by the caller: weights scaled by 0.75 (no longer whole numbers), through set_volume
+    t, c, w = vol.get_volume(with_weight=True)
+    vol.set_volume(tsdf=t, color=c, weight=w * np.float32(0.75))
+    ora._weight = (ora._weight * np.float32(0.75)).astype(np.float32)
+    vol.integrate_batch(color_d[:4], depth_d[:4], seq["K"], seq["poses"][:4])
+    run_oracle(ora, range(4))
+    _volumes_equal(vol, ora)
+    # (c) caller-owned planes written directly, announced with planes_modified
+    n = int(np.prod(vol.vol_dim))
+    storage = tuple(torch.empty(n, dtype=torch.float32, device="cuda") for _ in range(3))
+    ext, ora2 = fusion.TSDFVolume(bounds, voxel, ctx=gpu_ctx, storage=storage), oracle_lib.TSDFVolume(bounds, voxel)
+    ext.integrate_batch(color_d[:4], depth_d[:4], seq["K"], seq["poses"][:4])
+    run_oracle(ora2, range(4))
+    storage[1].mul_(0.5)
+    ext.planes_modified()
+    ora2._weight = (ora2._weight * np.float32(0.5)).astype(np.float32)
+    ext.integrate_batch(color_d[4:8], depth_d[4:8], seq["K"], seq["poses"][4:8])
+    run_oracle(ora2, range(4, 8))
+    _volumes_equal(ext, ora2)
+    # (d) reset: whole numbers again
+    ext.reset()
+    ora3 = oracle_lib.TSDFVolume(bounds, voxel)
+    ext.integrate_batch(color_d, depth_d, seq["K"], seq["poses"])
+    run_oracle(ora3, range(10))
+    _volumes_equal(ext, ora3)
+
+
+def test_clip_of_rows_parallel_to_the_image_plane(gpu_ctx, oracle_lib):
+    """Regression (round 4): at a yaw of exactly 90 degrees the voxel rows run parallel to the image plane (cam_z = az + 6e-17 tz), and with the
+    frame's deepest pixel on a wall exactly at max depth the far cut's alpha is 0: -alpha / beta cut those rows at tz <= 0 although all
+    of their voxels sit ON the truncation boundary and update.  Foreground-masked depth (sparse: small max depth) of frame 3 of the 30-degree
+    sequence into 512^3, single-frame kernel and a fused pair, N_upd and weights against the oracle."""
+    import torch
+    from hive_amd import fusion, synthetic
+    seq = synthetic.make_sequence(num_frames=6, yaw_step_deg=30.0)
+    masks = synthetic.ellipse_masks(6, 480, 640, num_objects=3, seed=9)
+    depth = np.where(masks > 0, seq["depth"], 0).astype(np.float32)
+    assert abs(seq["poses"][3][2, 2]) < 1e-15, "frame 3 looks along +x: rows along z are parallel to the image plane"
+    vol, ora = fusion.TSDFVolume(synthetic.room_bounds(), 0.01, ctx=gpu_ctx), oracle_lib.TSDFVolume(synthetic.room_bounds(), 0.01)
+    n = vol.integrate(seq["color"][3], depth[3], seq["K"], seq["poses"][3], return_n_updated=True)
+    ora.integrate(seq["color"][3], depth[3], seq["K"], seq["poses"][3])
+    assert n == ora.last_n_updated
+    pair = fusion.TSDFVolume(synthetic.room_bounds(), 0.01, ctx=gpu_ctx)
+    pair.integrate_batch(torch.from_numpy(seq["color"][2:4]).cuda(), torch.from_numpy(depth[2:4]).cuda(), seq["K"], seq["poses"][2:4])
+    assert pair.last_batch_groups() == [2]
+    ora_pair = oracle_lib.TSDFVolume(synthetic.room_bounds(), 0.01)
+    for i in (2, 3):
+        ora_pair.integrate(seq["color"][i], depth[i], seq["K"], seq["poses"][i])
+    assert np.array_equal(pair.get_volume(with_weight=True)[2], ora_pair._weight)

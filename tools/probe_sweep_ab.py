@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """A/B of the fused TSDF sweep's switches in ONE process, on both scenes of bench.py (room: analytic depth; dpt: DPT-Hybrid depth of the
 seeded weights), 32 consecutive frames 2.4 degrees apart into 512^3.  Switches (HIVE_TSDF_<name>, all default 1): ROW_FAR (per-row far cut from the
-depth tiles), FRAME_SKIP (work-item frame masks), FAST_COLOUR (division-free colour update), SORT (work list sorted by image band, eighths to the XCDs),
-SEGK (one segment per gather instruction).  PROBE_CONFIGS = ';'-separated configurations, each a ','-separated list of NAME=0/1 (the first is the
-reference the others' volumes are compared with); default: everything off, then everything on.
+depth tiles), FRAME_SKIP (work-item frame masks), FAST_COLOUR (division-free colour update), SORT (work list sorted by image band, eighths to the XCDs), QUAD (segments of four neighbouring rows interleaved); LANES=x|y forces the lane axis of the work-list kernel.
+PROBE_CONFIGS = ';'-separated configurations, each a ','-separated list of NAME=0/1 (the first is the reference the others' volumes are compared
+with); default: everything off, then everything on.
 Per configuration: us per frame of the whole leg (prep + work list + sort + sweep, HIP events), us per sweep launch (the library's own events), work-list
 voxels of the last sweep, and a check that the volume is bit-identical to the first configuration's.  Usage: probe_sweep_ab.py [frames] [scene ...]"""
 import json
@@ -33,7 +33,7 @@ if "dpt" in scenes:
     depths["dpt"] = stream.depth(color)[0].clone()
     del model, stream
 out = {}
-NAMES = ("ROW_FAR", "FRAME_SKIP", "FAST_COLOUR", "SORT", "SEGK")
+NAMES = ("ROW_FAR", "FRAME_SKIP", "FAST_COLOUR", "SORT", "QUAD")  # on / off switches (default on); any other HIVE_TSDF_<NAME>=value may be given too (LANES=x|y)
 spec = os.environ.get("PROBE_CONFIGS") or (",".join(n + "=0" for n in NAMES) + ";" + ",".join(n + "=1" for n in NAMES))
 configs = [dict(kv.split("=") for kv in c.split(",") if kv) for c in spec.split(";")]
 for scene, depth in depths.items():
@@ -42,8 +42,10 @@ for scene, depth in depths.items():
     n_upd = [vol.integrate(color[i], depth[i], seq["K"], seq["poses"][i], return_n_updated=True) for i in range(min(frames, 8))]
     ref = None
     for cfg in configs:
-        for name in NAMES:
-            os.environ["HIVE_TSDF_" + name] = str(cfg.get(name, 1))
+        for key in [k for k in os.environ if k.startswith("HIVE_TSDF_") and k != "HIVE_TSDF_TIMING_SAME_TEXELS"]:
+            del os.environ[key]
+        for name, value in cfg.items():
+            os.environ["HIVE_TSDF_" + name] = str(value)
         leg, k_us = [], []
         for rep in range(5):
             vol.reset()
@@ -73,7 +75,7 @@ for scene, depth in depths.items():
         vol.integrate_batch(color[frames - nf:], depth[frames - nf:], seq["K"], seq["poses"][frames - nf:])
         n_union = int((storage[1] != before).sum().item())
         wl_last = vol.last_sweep_voxels()
-        rec = {"config": {n: int(cfg.get(n, 1)) for n in NAMES}, "leg_us_per_frame_min": min(leg), "launch_us_min": min(k_us), "launch_us_all": [round(v, 1) for v in k_us],
+        rec = {"config": dict(cfg), "leg_us_per_frame_min": min(leg), "launch_us_min": min(k_us), "launch_us_all": [round(v, 1) for v in k_us],
                "worklist_voxels_last_sweep": wl_last, "n_union_last_sweep": n_union, "frames_last_sweep": nf, "n_upd_mean": float(np.mean(n_upd)),
                "bit_identical_to_first": same, "groups": groups[:3]}
         out.setdefault(scene, []).append(rec)
