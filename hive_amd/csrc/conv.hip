@@ -504,8 +504,15 @@ int launch_conv_t(hive_ctx *ctx, const char *what, const void *d_x, int N, int H
     int rc = ensure_conv_attrs<T>(ctx);
     if (rc) return rc;
     const int tn = C_out % 256 == 0 ? 256 : (C_out % 128 == 0 ? 128 : 64);
-    // 256 output pixels per tile, or 128 where that would leave CUs without a tile (30 x 40 and 15 x 20 maps: 113 / 29 tiles of 256)
-    const int tm = (tn >= 128 && (long long)((p.M + 255) / 256) * (C_out / tn) < ctx->num_cus) ? 128 : 256;
+    // 256 output pixels per tile, or 128 where that leaves fewer CU-rounds of work: one persistent workgroup per CU, so a launch costs
+    // rounds x tile size (a 128-row tile does ~0.85 of a 256-row tile's rate).  Large batches: thousands of tiles, 256 wins.  Small maps and
+    // small batches (30 x 40 / 15 x 20 maps: 113 / 29 tiles of 256; one 240 x 320 frame: 300 tiles = 2 rounds of 256 rows against 3 of 128).
+    int tm = 256;
+    if (tn >= 128) {
+        const long long per = C_out / tn, t256 = (long long)((p.M + 255) / 256) * per, t128 = (long long)((p.M + 127) / 128) * per;
+        const long long r256 = (t256 + ctx->num_cus - 1) / ctx->num_cus, r128 = (t128 + ctx->num_cus - 1) / ctx->num_cus;
+        if (t256 < ctx->num_cus || r128 * 128 * 100 < r256 * 256 * 85) tm = 128;
+    }
     if (gn_mode) {
         p.stats_only = gn_mode->stats_only;
         p.gn_stats = gn_mode->gn_stats;

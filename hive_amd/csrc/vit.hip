@@ -828,6 +828,7 @@ static int launch_layernorm(hive_ctx *ctx, const void *x, const float *g, const 
 
 constexpr int GEMM_TM = 128, GEMM_NST = 2;
 constexpr size_t GEMM_LDS = (size_t)GEMM_NST * (GEMM_TM / 8 + 16) * 1024 + (GEMM_TM / 32) * 4096;  // the stages + 4 KiB per wave for the epilogue: 80 KiB, two workgroups per CU
+constexpr size_t GEMM64_LDS = (size_t)GEMM_NST * (64 / 8 + 16) * 1024 + (64 / 32) * 4096;  // the 64-row tile of small batches: 56 KiB
 constexpr int GEMM256_LDS = 2 * T256_STAGE + hive_mfma::STAGED_ROWS_LDS;
 
 template <typename T>
@@ -874,6 +875,22 @@ static int launch_gemm(hive_ctx *ctx, int epi, const GemmParams<T> &p) {
     if ((epi != EPI_QKV || !one_tile_kernel) && p.N % T256 == 0 && ((force && force[0] == '2') || (!force && fills))) return launch_gemm256<T>(ctx, epi, p);
     // persistent workgroups: two per CU (64 KiB of LDS each), a multiple of 8 so that every XCD gets the same number
     const long long tiles = (long long)((p.M + GEMM_TM - 1) / GEMM_TM) * (p.N / BN);
+    // Small batches (the reference's literal loop is batch 1: M = 1216): with fewer 128-row tiles than CUs most of the chip idles (60 tiles for
+    // proj / fc2 at one frame); 64-row tiles (two waves, 56 KiB of LDS) double the workgroups.  HIVE_GEMM_SMALL=0: tuning override.
+    static const char *small_env = getenv("HIVE_GEMM_SMALL");
+    if (tiles <= ctx->num_cus && !(small_env && small_env[0] == '0')) {
+        const long long tiles64 = (long long)((p.M + 63) / 64) * (p.N / BN);
+        const dim3 grid64((unsigned)std::min<long long>((tiles64 + 7) / 8 * 8, (long long)(2 * ctx->num_cus) / 8 * 8)), block64(128);
+        switch (epi) {
+            case EPI_BIAS: hipLaunchKernelGGL((gemm_kernel<T, EPI_BIAS, 64, GEMM_NST>), grid64, block64, GEMM64_LDS, ctx->stream, p); break;
+            case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm_kernel<T, EPI_BIAS_GELU, 64, GEMM_NST>), grid64, block64, GEMM64_LDS, ctx->stream, p); break;
+            case EPI_BIAS_RESIDUAL: hipLaunchKernelGGL((gemm_kernel<T, EPI_BIAS_RESIDUAL, 64, GEMM_NST>), grid64, block64, GEMM64_LDS, ctx->stream, p); break;
+            case EPI_QKV: hipLaunchKernelGGL((gemm_kernel<T, EPI_QKV, 64, GEMM_NST>), grid64, block64, GEMM64_LDS, ctx->stream, p); break;
+            default: return hive_fail(ctx, HIVE_ERR_INVALID, "gemm: unknown epilogue %d", epi);
+        }
+        HIVE_CHECK_HIP(ctx, hipGetLastError());
+        return HIVE_OK;
+    }
     const dim3 grid((unsigned)std::min<long long>((tiles + 7) / 8 * 8, (long long)(2 * ctx->num_cus) / 8 * 8)), block(GEMM_TM * 2);
     switch (epi) {
         case EPI_BIAS: hipLaunchKernelGGL((gemm_kernel<T, EPI_BIAS, GEMM_TM, GEMM_NST>), grid, block, GEMM_LDS, ctx->stream, p); break;
@@ -892,6 +909,7 @@ static int ensure_gemm_attrs(hive_ctx *ctx) {
     if (ctx->device < 64 && set[ctx->device]) return HIVE_OK;
 #define HIVE_GEMM_ATTR(EPI_)                                                                                                                                  \
     HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)gemm_kernel<T, EPI_, GEMM_TM, GEMM_NST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS)); \
+    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)gemm_kernel<T, EPI_, 64, GEMM_NST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM64_LDS));      \
     HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)gemm256p_kernel<T, EPI_>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM256_LDS))
     HIVE_GEMM_ATTR(EPI_BIAS);
     HIVE_GEMM_ATTR(EPI_BIAS_GELU);
