@@ -10,9 +10,10 @@
 //   c' = min(255, round((c*w + ow*c_new)/w')) per channel.
 //
 // Kernel shape: voxel sweep over the part of the volume a frame can touch.  The volume is [X][Y][Z] with
-// z fastest.  pack_frame fuses depth + colour into 8-byte texels and reduces max(depth); build_worklist clips
-// every (x,y) row analytically against the view frustum (the camera-space position is affine in z; one LANE
-// per row) and emits one item per 64-voxel segment of the surviving z interval; integrate is a grid-stride
+// z fastest.  prep_frame fuses depth + colour into 8-byte texels and reduces max(depth) per 32 x 32-pixel tile; build_worklist clips
+// every (x,y) row analytically against the view frustum and the depth tiles its image segment crosses (the camera-space position is
+// affine in z; one LANE per row) and emits one item per 64-voxel segment of the surviving z interval; the fused sweep's list is then
+// sorted by image band (its eighths go to the eight XCDs: texel gathers stay in one L2); integrate is a grid-stride
 // sweep over that list: a wave takes 4 segments per trip (16 lanes x 4 consecutive z voxels = 16 bytes per
 // lane and volume, for rows of ANY length: the accesses need dword alignment only), packed-f32 arithmetic.  The clip is
 // padded and every voxel of a segment still runs the exact tests above, so results do not depend on it.

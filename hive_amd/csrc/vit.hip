@@ -110,6 +110,11 @@ struct GemmParams {
     int n_split;         // EPI_QKV: columns >= n_split are V columns
     int q_cols;          // EPI_BIAS: columns < q_cols (a multiple of 8) are multiplied by q_scale after the bias (the q part of q|k)
     float q_scale;
+    // LayerNorm folded into the GEMM that consumes it (hive_vit_forward): with W' = gamma o W stored as the weight, c1[n] = sum_k W'[n][k] and
+    // bias[n] = sum_k beta[k] W[n][k] + b[n], LayerNorm(x) W^T + b = rstd (x W'^T - mean c1) + bias -- the normalised tensor is never written.
+    const float *ln_stats;  // consumer: [M][2] = (mean, rstd) of the rows of A, or null: the plain epilogue
+    const float *ln_c1;     // consumer: [N]
+    float *ln_partial;      // producer (EPI_BIAS_RESIDUAL), or null: [M][N / 64][2] = per 64 stored columns of a row (their sum, the sum of squares about their own mean)
 };
 
 constexpr int BN = 128, BK = 64;
@@ -148,12 +153,30 @@ __device__ __forceinline__ void stage_group(const T *__restrict__ src, int ld, i
     __builtin_amdgcn_global_load_lds((const void *)g, (__attribute__((address_space(3))) void *)(tile + grp * 1024), 16, 0, 0);
 }
 
+// Sum over the 8 lanes 8 g .. 8 g + 7 (half of a 16-lane DPP row), left in all of them: two quad permutes and a half-row mirror, three DPP
+// additions on the VALU (the ds_bpermute behind __shfl_xor goes through the LDS pipe, which the epilogue's turn-around already keeps busy)
+__device__ __forceinline__ float dpp_oct_total(float v) {
+#define HIVE_DPP_ADD(ctrl) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, false))
+    HIVE_DPP_ADD(0xB1);   // quad_perm [1, 0, 3, 2]
+    HIVE_DPP_ADD(0x4E);   // quad_perm [2, 3, 0, 1]
+    HIVE_DPP_ADD(0x141);  // row_half_mirror: lane i of an 8-lane half reads lane 7 - i, which holds the other quad's sum
+#undef HIVE_DPP_ADD
+    return v;
+}
+
 // Epilogue of the A.W^T GEMM tiles (EPI_BIAS / _GELU / _RESIDUAL): bias, GELU or residual in f32, one rounding to bf16; through the
 // wave's 4 KiB of LDS (mfma_pipe.hpp staged_rows) so that the residual loads and the stores are 16 bytes per lane on whole lines.
 template <typename T, int EPI, int MT>
 __device__ __forceinline__ void gemm_store_rows(const GemmParams<T> &p, const f32x4 (&acc)[4][MT], int m_base, int n_base, unsigned char *stage, int lane) {
     const int n = n_base + (lane & 7) * 8, rr = lane >> 3;
     const float4 b0 = *reinterpret_cast<const float4 *>(p.bias + n), b1 = *reinterpret_cast<const float4 *>(p.bias + n + 4);
+    const bool ln_in = EPI != EPI_BIAS_RESIDUAL && p.ln_stats != nullptr;    // (kernel-uniform) the rows of A are normalised here, not by a LayerNorm pass
+    const bool ln_out = EPI == EPI_BIAS_RESIDUAL && p.ln_partial != nullptr;  // the stored rows' statistics are left for the GEMM that reads them next
+    float4 c0 = float4{0.f, 0.f, 0.f, 0.f}, c1 = c0;
+    if (ln_in) {
+        c0 = *reinterpret_cast<const float4 *>(p.ln_c1 + n);
+        c1 = *reinterpret_cast<const float4 *>(p.ln_c1 + n + 4);
+    }
     // residual rows: loaded one fragment row ahead (two register sets), not in front of each store.  The residual may BE the output
     // (x += proj(...)): every element is read by the lane that later writes it, rows of fragment row mt + 1 are read before rows of
     // mt are written -- no hazard, but the compiler cannot know, so the order is set by hand.
@@ -168,7 +191,17 @@ __device__ __forceinline__ void gemm_store_rows(const GemmParams<T> &p, const f3
     hive_mfma::staged_rows<MT, AHEAD>(stage, acc, lane, pre, [&](int r, int, const f32x4 &lo, const f32x4 &hi, int mt, int j) {
         const int m = m_base + r;
         if (m >= p.M) return;
-        float o[8] = {lo[0] + b0.x, lo[1] + b0.y, lo[2] + b0.z, lo[3] + b0.w, hi[0] + b1.x, hi[1] + b1.y, hi[2] + b1.z, hi[3] + b1.w};
+        float o[8];
+        if (ln_in) {
+            const float2 st = *reinterpret_cast<const float2 *>(p.ln_stats + 2 * (size_t)m);  // (mean, rstd) of row m
+            o[0] = st.y * (lo[0] - st.x * c0.x) + b0.x, o[1] = st.y * (lo[1] - st.x * c0.y) + b0.y;
+            o[2] = st.y * (lo[2] - st.x * c0.z) + b0.z, o[3] = st.y * (lo[3] - st.x * c0.w) + b0.w;
+            o[4] = st.y * (hi[0] - st.x * c1.x) + b1.x, o[5] = st.y * (hi[1] - st.x * c1.y) + b1.y;
+            o[6] = st.y * (hi[2] - st.x * c1.z) + b1.z, o[7] = st.y * (hi[3] - st.x * c1.w) + b1.w;
+        } else {
+            o[0] = lo[0] + b0.x, o[1] = lo[1] + b0.y, o[2] = lo[2] + b0.z, o[3] = lo[3] + b0.w;
+            o[4] = hi[0] + b1.x, o[5] = hi[1] + b1.y, o[6] = hi[2] + b1.z, o[7] = hi[3] + b1.w;
+        }
         if (EPI == EPI_BIAS && n < p.q_cols) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) o[k] *= p.q_scale;
@@ -189,7 +222,102 @@ __device__ __forceinline__ void gemm_store_rows(const GemmParams<T> &p, const f3
 #pragma unroll
         for (int k = 0; k < 8; ++k) ov[k] = (T)o[k];
         *reinterpret_cast<vec<T, 8> *>(p.C + (size_t)m * p.ldc + n) = ov;
+        if (ln_out) {
+            // statistics of the STORED (rounded) values of this row's 64 columns: the 8 lanes of the row sit side by side (lane & 7); the sum
+            // of squares is taken about the 64 values' own mean (ln_finalize_kernel merges the groups exactly: no E[x^2] - mean^2 cancellation)
+            float v[8], sum = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                v[k] = (float)ov[k];
+                sum += v[k];
+            }
+            sum = dpp_oct_total(sum);
+            const float mean = sum * (1.0f / 64.0f);
+            float m2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) m2 += (v[k] - mean) * (v[k] - mean);
+            m2 = dpp_oct_total(m2);
+            if ((lane & 7) == 0) *reinterpret_cast<float2 *>(p.ln_partial + 2 * ((size_t)m * (p.N >> 6) + (n_base >> 6))) = float2{sum, m2};
+        }
     });
+}
+
+// (mean, rstd) of every row of x [M][256 CH], exactly as layernorm_kernel computes them: the statistics of a ViT's first LayerNorm, whose input no
+// GEMM epilogue produced
+template <typename T, int CH>
+__global__ __launch_bounds__(256) void ln_row_stats_kernel(const T *__restrict__ x, float *__restrict__ stats, int M, float eps) {
+    constexpr int D = 256 * CH;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const T *xr = x + (size_t)row * D;
+    float v[4 * CH];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+        const vec<T, 4> t = *reinterpret_cast<const vec<T, 4> *>(xr + i * 256 + lane * 4);
+        for (int j = 0; j < 4; ++j) {
+            v[4 * i + j] = (float)t[j];
+            sum += v[4 * i + j];
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+    const float mean = sum / (float)D;
+    float var = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4 * CH; ++i) {
+        const float d = v[i] - mean;
+        var += d * d;
+    }
+    for (int off = 32; off > 0; off >>= 1) var += __shfl_xor(var, off);
+    if (lane == 0) *reinterpret_cast<float2 *>(stats + 2 * (size_t)row) = float2{mean, rsqrtf(var / (float)D + eps)};
+}
+
+// per-row groups (sum, M2 about the group's own mean) of 64 columns each -> (mean, rstd) of the row: Chan's pairwise merge, in group order
+__global__ __launch_bounds__(256) void ln_finalize_kernel(const float *__restrict__ partial, int M, int groups, float eps, float *__restrict__ stats) {
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= M) return;
+    const float2 *pr = reinterpret_cast<const float2 *>(partial) + (size_t)row * groups;
+    float sum = 0.f;
+    for (int g = 0; g < groups; ++g) sum += pr[g].x;
+    const float mean = sum / (float)(64 * groups);
+    float m2 = 0.f;
+    for (int g = 0; g < groups; ++g) {
+        const float d = pr[g].x * (1.0f / 64.0f) - mean;
+        m2 += pr[g].y + 64.0f * d * d;
+    }
+    *reinterpret_cast<float2 *>(stats + 2 * (size_t)row) = float2{mean, rsqrtf(m2 / (float)(64 * groups) + eps)};
+}
+
+// Weights of a GEMM with its LayerNorm folded in (one thread block per output column n): W'[n][k] = T(gamma[k] W[n][k]),
+// c1[n] = sum_k W'[n][k] (of the STORED values), c2[n] = sum_k beta[k] W[n][k] + b[n]; sums in float64.
+template <typename T>
+__global__ __launch_bounds__(256) void ln_fold_weights_kernel(const T *__restrict__ W, const float *__restrict__ bias, const float *__restrict__ gamma,
+                                                              const float *__restrict__ beta, int K, T *__restrict__ Wf, float *__restrict__ c1, float *__restrict__ c2) {
+    __shared__ double red[2][256];
+    const int n = blockIdx.x;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = threadIdx.x; k < K; k += 256) {
+        const float w = (float)W[(size_t)n * K + k];
+        const T wf = (T)(gamma[k] * w);
+        Wf[(size_t)n * K + k] = wf;
+        s1 += (double)(float)wf;
+        s2 += (double)beta[k] * (double)w;
+    }
+    red[0][threadIdx.x] = s1;
+    red[1][threadIdx.x] = s2;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            red[0][threadIdx.x] += red[0][threadIdx.x + off];
+            red[1][threadIdx.x] += red[1][threadIdx.x + off];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        c1[n] = (float)red[0][0];
+        c2[n] = (float)(red[1][0] + (double)bias[n]);
+    }
 }
 
 // C tile = TM x 128, K-step 64, TM/32 waves (each a 64 x 64 sub-tile = 4 x 4 MFMA 16x16x32 accumulators), an
@@ -280,11 +408,21 @@ __global__ __launch_bounds__(TM * 2, 1) void gemm_kernel(GemmParams<T> p) {
             for (int ntl = 0; ntl < 2; ++ntl) {
                 const int nt = half * 2 + ntl, row = ntl * 16 + fr;
                 const float b = p.bias[n0 + wc * 64 + nt * 16 + fr];
+                const float c1v = p.ln_stats ? p.ln_c1[n0 + wc * 64 + nt * 16 + fr] : 0.f;
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) {
                     vec<T, 4> ov;
+                    if (p.ln_stats) {  // (kernel-uniform) LayerNorm folded in: the lane's 4 tokens' (mean, rstd)
+                        const float *st = p.ln_stats + 2 * (size_t)min(mw + mt * 16 + fq * 4, p.M - 4);
+                        const float4 s0 = *reinterpret_cast<const float4 *>(st), s1 = *reinterpret_cast<const float4 *>(st + 4);
+                        ov[0] = (T)(s0.y * (acc[mt][nt][0] - s0.x * c1v) + b);
+                        ov[1] = (T)(s0.w * (acc[mt][nt][1] - s0.z * c1v) + b);
+                        ov[2] = (T)(s1.y * (acc[mt][nt][2] - s1.x * c1v) + b);
+                        ov[3] = (T)(s1.w * (acc[mt][nt][3] - s1.z * c1v) + b);
+                    } else {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) ov[j] = (T)(acc[mt][nt][j] + b);
+                        for (int j = 0; j < 4; ++j) ov[j] = (T)(acc[mt][nt][j] + b);
+                    }
                     *reinterpret_cast<vec<T, 4> *>(ot + row * 128 + (((mt * 2 + (fqs >> 1)) ^ (row & 7)) << 4) + (fqs & 1) * 8) = ov;
                 }
             }
@@ -505,9 +643,18 @@ __global__ __launch_bounds__(512, 1) void gemm256p_kernel(GemmParams<T> p) {
                     for (int ntl = 0; ntl < 2; ++ntl) {
                         const int nt = half * 2 + ntl, row = ntl * 16 + fr;
                         const float bv = p.bias[en0 + wc * 64 + nt * 16 + fr];
+                        const float c1v = p.ln_stats ? p.ln_c1[en0 + wc * 64 + nt * 16 + fr] : 0.f;
 #pragma unroll
                         for (int mtl = 0; mtl < 4; ++mtl) {
                             vec<T, 4> ov;
+                            if (p.ln_stats) {  // (kernel-uniform) LayerNorm folded in: the lane's 4 tokens' (mean, rstd)
+                                const float *st = p.ln_stats + 2 * (size_t)min(mw + mtl * 16 + fq * 4, p.M - 4);
+                                const float4 s0 = *reinterpret_cast<const float4 *>(st), s1 = *reinterpret_cast<const float4 *>(st + 4);
+                                ov[0] = (T)(s0.y * (acc[blk * 4 + mtl][nt][0] - s0.x * c1v) + bv);
+                                ov[1] = (T)(s0.w * (acc[blk * 4 + mtl][nt][1] - s0.z * c1v) + bv);
+                                ov[2] = (T)(s1.y * (acc[blk * 4 + mtl][nt][2] - s1.x * c1v) + bv);
+                                ov[3] = (T)(s1.w * (acc[blk * 4 + mtl][nt][3] - s1.z * c1v) + bv);
+                            } else
 #pragma unroll
                             for (int j = 0; j < 4; ++j) ov[j] = (T)(acc[blk * 4 + mtl][nt][j] + bv);
                             *reinterpret_cast<vec<T, 4> *>(ot + row * 128 + (((mtl * 2 + (fqs >> 1)) ^ (row & 7)) << 4) + (fqs & 1) * 8) = ov;
@@ -808,6 +955,14 @@ struct hive_vit {
     // workspace
     void *ws = nullptr;
     size_t ws_bytes = 0;
+    // LayerNorm folded into the q|k|v and fc1 GEMMs (hive_vit_forward): per block the weights gamma o W in the network's 16-bit type and the
+    // f32 columns c1 = sum_k W', c2 = sum_k beta W + b; one allocation
+    struct Folded {
+        const void *qkv_w = nullptr, *fc1_w = nullptr;
+        const float *qkv_c1 = nullptr, *qkv_c2 = nullptr, *fc1_c1 = nullptr, *fc1_c2 = nullptr;
+    };
+    std::vector<Folded> folded;
+    void *fold_mem = nullptr;
 };
 
 template <typename T>
@@ -828,7 +983,6 @@ static int launch_layernorm(hive_ctx *ctx, const void *x, const float *g, const 
 
 constexpr int GEMM_TM = 128, GEMM_NST = 2;
 constexpr size_t GEMM_LDS = (size_t)GEMM_NST * (GEMM_TM / 8 + 16) * 1024 + (GEMM_TM / 32) * 4096;  // the stages + 4 KiB per wave for the epilogue: 80 KiB, two workgroups per CU
-constexpr size_t GEMM64_LDS = (size_t)GEMM_NST * (64 / 8 + 16) * 1024 + (64 / 32) * 4096;  // the 64-row tile of small batches: 56 KiB
 constexpr int GEMM256_LDS = 2 * T256_STAGE + hive_mfma::STAGED_ROWS_LDS;
 
 template <typename T>
@@ -875,22 +1029,9 @@ static int launch_gemm(hive_ctx *ctx, int epi, const GemmParams<T> &p) {
     if ((epi != EPI_QKV || !one_tile_kernel) && p.N % T256 == 0 && ((force && force[0] == '2') || (!force && fills))) return launch_gemm256<T>(ctx, epi, p);
     // persistent workgroups: two per CU (64 KiB of LDS each), a multiple of 8 so that every XCD gets the same number
     const long long tiles = (long long)((p.M + GEMM_TM - 1) / GEMM_TM) * (p.N / BN);
-    // Small batches (the reference's literal loop is batch 1: M = 1216): with fewer 128-row tiles than CUs most of the chip idles (60 tiles for
-    // proj / fc2 at one frame); 64-row tiles (two waves, 56 KiB of LDS) double the workgroups.  HIVE_GEMM_SMALL=0: tuning override.
-    static const char *small_env = getenv("HIVE_GEMM_SMALL");
-    if (tiles <= ctx->num_cus && !(small_env && small_env[0] == '0')) {
-        const long long tiles64 = (long long)((p.M + 63) / 64) * (p.N / BN);
-        const dim3 grid64((unsigned)std::min<long long>((tiles64 + 7) / 8 * 8, (long long)(2 * ctx->num_cus) / 8 * 8)), block64(128);
-        switch (epi) {
-            case EPI_BIAS: hipLaunchKernelGGL((gemm_kernel<T, EPI_BIAS, 64, GEMM_NST>), grid64, block64, GEMM64_LDS, ctx->stream, p); break;
-            case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm_kernel<T, EPI_BIAS_GELU, 64, GEMM_NST>), grid64, block64, GEMM64_LDS, ctx->stream, p); break;
-            case EPI_BIAS_RESIDUAL: hipLaunchKernelGGL((gemm_kernel<T, EPI_BIAS_RESIDUAL, 64, GEMM_NST>), grid64, block64, GEMM64_LDS, ctx->stream, p); break;
-            case EPI_QKV: hipLaunchKernelGGL((gemm_kernel<T, EPI_QKV, 64, GEMM_NST>), grid64, block64, GEMM64_LDS, ctx->stream, p); break;
-            default: return hive_fail(ctx, HIVE_ERR_INVALID, "gemm: unknown epilogue %d", epi);
-        }
-        HIVE_CHECK_HIP(ctx, hipGetLastError());
-        return HIVE_OK;
-    }
+    // (Round 4, measured and taken out: 64-row tiles (two waves, 56 KiB of LDS) where fewer 128-row tiles than CUs exist -- the reference's literal
+    // loop is batch 1, M = 1216: 60 tiles for proj / fc2.  5.38 vs 5.35 ms per one-frame forward: at one tile per CU a GEMM is as long as its K loop
+    // (12-48 steps of ~0.8-1.5 us), whatever the tile's height; small batches want the K loop split, not the tile.)
     const dim3 grid((unsigned)std::min<long long>((tiles + 7) / 8 * 8, (long long)(2 * ctx->num_cus) / 8 * 8)), block(GEMM_TM * 2);
     switch (epi) {
         case EPI_BIAS: hipLaunchKernelGGL((gemm_kernel<T, EPI_BIAS, GEMM_TM, GEMM_NST>), grid, block, GEMM_LDS, ctx->stream, p); break;
@@ -909,7 +1050,6 @@ static int ensure_gemm_attrs(hive_ctx *ctx) {
     if (ctx->device < 64 && set[ctx->device]) return HIVE_OK;
 #define HIVE_GEMM_ATTR(EPI_)                                                                                                                                  \
     HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)gemm_kernel<T, EPI_, GEMM_TM, GEMM_NST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS)); \
-    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)gemm_kernel<T, EPI_, 64, GEMM_NST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM64_LDS));      \
     HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)gemm256p_kernel<T, EPI_>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM256_LDS))
     HIVE_GEMM_ATTR(EPI_BIAS);
     HIVE_GEMM_ATTR(EPI_BIAS_GELU);
@@ -925,8 +1065,14 @@ static int ensure_gemm_attrs(hive_ctx *ctx) {
 
 static inline int pad64(int n) { return (n + 63) / 64 * 64; }
 
+struct LnFold {  // LayerNorm folded into a GEMM: what the consumer reads (stats, c1) or the producer leaves (partial)
+    const float *stats = nullptr, *c1 = nullptr;
+    float *partial = nullptr;
+};
+
 template <typename T>
-static int linear_t(hive_ctx *ctx, const void *A, const void *W, const float *bias, const void *residual, void *C, int M, int N, int K, int epilogue) {
+static int linear_t(hive_ctx *ctx, const void *A, const void *W, const float *bias, const void *residual, void *C, int M, int N, int K, int epilogue,
+                    const LnFold &ln = LnFold()) {
     int rc = ensure_gemm_attrs<T>(ctx);
     if (rc) return rc;
     GemmParams<T> p{};
@@ -939,11 +1085,14 @@ static int linear_t(hive_ctx *ctx, const void *A, const void *W, const float *bi
     p.N = N;
     p.K = K;
     p.ldc = N;
+    p.ln_stats = ln.stats;
+    p.ln_c1 = ln.c1;
+    p.ln_partial = ln.partial;
     return launch_gemm<T>(ctx, epilogue, p);
 }
 
 template <typename T>
-static int qkv_t(hive_ctx *ctx, const void *x, const void *W, const float *bias, void *qk, void *vT, int B, int Np, int D, int H) {
+static int qkv_t(hive_ctx *ctx, const void *x, const void *W, const float *bias, void *qk, void *vT, int B, int Np, int D, int H, const LnFold &ln = LnFold()) {
     int rc = ensure_gemm_attrs<T>(ctx);
     if (rc) return rc;
     // q | k columns: plain bias epilogue into qk [M][2D]
@@ -958,6 +1107,8 @@ static int qkv_t(hive_ctx *ctx, const void *x, const void *W, const float *bias,
     p.ldc = 2 * D;
     p.q_cols = D;  // q leaves the GEMM in the softmax's base-2 exponent units: (x Wq + b) * head_dim^-0.5 * log2(e), rounded once
     p.q_scale = 0.125f * 1.44269504088896340736f;
+    p.ln_stats = ln.stats;
+    p.ln_c1 = ln.c1;
     if ((rc = launch_gemm<T>(ctx, EPI_BIAS, p))) return rc;
     // v columns: transposed store into vT [B][H][64][Np]
     GemmParams<T> pv{};
@@ -971,6 +1122,8 @@ static int qkv_t(hive_ctx *ctx, const void *x, const void *W, const float *bias,
     pv.ldc = D;
     pv.Np = Np;
     pv.H = H;
+    pv.ln_stats = ln.stats;
+    pv.ln_c1 = ln.c1 ? ln.c1 + 2 * D : nullptr;
     return launch_gemm<T>(ctx, EPI_QKV, pv);
 }
 
@@ -1108,6 +1261,46 @@ int hive_vit_create(hive_ctx *ctx, int dtype, int depth, int dim, int heads, int
     v->mlp = mlp_dim;
     v->eps = ln_eps;
     v->blocks.assign(blocks, blocks + depth);
+    // folded weights: per block (3 D + mlp) rows of D 16-bit values + 2 (3 D + mlp) floats
+    {
+        const size_t esz = sizeof(half_bits), rows = (size_t)3 * dim + mlp_dim;
+        const size_t w_bytes = (rows * dim * esz + 255) & ~(size_t)255, c_bytes = (2 * rows * sizeof(float) + 255) & ~(size_t)255;
+        hipError_t e = hipMalloc(&v->fold_mem, (size_t)depth * (w_bytes + c_bytes));
+        if (e != hipSuccess) {
+            int rc = hive_fail(ctx, HIVE_ERR_NOMEM, "vit_create: allocating the folded LayerNorm weights failed: %s", hipGetErrorString(e));
+            delete v;
+            return rc;
+        }
+        v->folded.resize(depth);
+        for (int i = 0; i < depth; ++i) {
+            char *base = (char *)v->fold_mem + (size_t)i * (w_bytes + c_bytes);
+            float *c = (float *)(base + w_bytes);
+            hive_vit::Folded &f = v->folded[i];
+            f.qkv_w = base;
+            f.fc1_w = base + (size_t)3 * dim * dim * esz;
+            f.qkv_c1 = c, f.qkv_c2 = c + 3 * dim, f.fc1_c1 = c + 6 * dim, f.fc1_c2 = c + 6 * dim + mlp_dim;
+            const hive_vit_block_weights &b = blocks[i];
+#define HIVE_FOLD(T_)                                                                                                                                   \
+    hipLaunchKernelGGL(ln_fold_weights_kernel<T_>, dim3(3 * dim), dim3(256), 0, ctx->stream, (const T_ *)b.qkv_w, (const float *)b.qkv_b, (const float *)b.ln1_g, \
+                       (const float *)b.ln1_b, dim, (T_ *)f.qkv_w, (float *)f.qkv_c1, (float *)f.qkv_c2);                                                \
+    hipLaunchKernelGGL(ln_fold_weights_kernel<T_>, dim3(mlp_dim), dim3(256), 0, ctx->stream, (const T_ *)b.fc1_w, (const float *)b.fc1_b, (const float *)b.ln2_g, \
+                       (const float *)b.ln2_b, dim, (T_ *)f.fc1_w, (float *)f.fc1_c1, (float *)f.fc1_c2)
+            if (dtype == HIVE_BF16) {
+                HIVE_FOLD(__bf16);
+            } else {
+                HIVE_FOLD(_Float16);
+            }
+#undef HIVE_FOLD
+        }
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // the caller may free or overwrite its weight tensors' temporaries after create
+        if (e != hipSuccess) {
+            int rc = hive_fail(ctx, HIVE_ERR_DEVICE, "vit_create: folding the LayerNorm weights failed: %s", hipGetErrorString(e));
+            (void)hipFree(v->fold_mem);
+            delete v;
+            return rc;
+        }
+    }
     *out = v;
     return HIVE_OK;
 }
@@ -1117,6 +1310,7 @@ int hive_vit_destroy(hive_vit *v) {
     if (!v) return HIVE_OK;
     (void)hipStreamSynchronize(v->ctx->stream);
     if (v->ws) (void)hipFree(v->ws);
+    if (v->fold_mem) (void)hipFree(v->fold_mem);
     delete v;
     return HIVE_OK;
 }
@@ -1130,25 +1324,71 @@ int hive_vit_forward(hive_vit *v, const void *x, int B, int N, const int *tap_bl
     int rc;
     const int D = v->dim, H = v->heads, Np = pad64(N), M = B * Np, dt = v->dtype;
     const size_t tok = (size_t)M * D * sizeof(half_bits);
-    // workspace: x (residual stream), ln, qk (2D), vT (D), attn, hidden (mlp)
+    // LayerNorm folded into the GEMMs that consume it (default; HIVE_LN_FOLD=0: a LayerNorm pass in front of q|k|v and of fc1, the normalised tensor
+    // written and read once more).  Folded: the proj / fc2 epilogues leave the statistics of the rows they store (per 64 columns), ln_finalize_kernel
+    // turns them into (mean, rstd) per row, and the q|k, v^T and fc1 epilogues apply them to x (gamma o W)^T: -24 LayerNorm launches (1.8 ms per 107-frame
+    // step) for 24 finalize launches of a few microseconds, and the token tensor makes one round trip less per half block.
+    const char *fold_env = getenv("HIVE_LN_FOLD");  // (read per call: tests toggle it inside one process)
+    const bool fold = !(fold_env && fold_env[0] == '0');
+    const int groups = D / 64;
+    // workspace: x (residual stream), ln, qk (2D), vT (D), attn, hidden (mlp), LayerNorm statistics (partial sums, (mean, rstd))
+    const size_t part_bytes = ((size_t)M * groups * 2 * sizeof(float) + 255) & ~(size_t)255, stat_bytes = ((size_t)M * 2 * sizeof(float) + 255) & ~(size_t)255;
     const size_t off_x = 0, off_ln = off_x + tok, off_qk = off_ln + tok, off_vt = off_qk + 2 * tok, off_attn = off_vt + tok,
-                 off_hid = off_attn + tok, total = off_hid + (size_t)M * v->mlp * sizeof(half_bits);
+                 off_hid = off_attn + tok, off_part = off_hid + (size_t)M * v->mlp * sizeof(half_bits), off_stat = off_part + part_bytes,
+                 total = off_stat + stat_bytes;
     if ((rc = hive_reserve_device(ctx, &v->ws, &v->ws_bytes, total))) return rc;
     char *ws = (char *)v->ws;
     half_bits *xs = (half_bits *)(ws + off_x), *ln = (half_bits *)(ws + off_ln), *qk = (half_bits *)(ws + off_qk), *vt = (half_bits *)(ws + off_vt),
               *attn = (half_bits *)(ws + off_attn), *hid = (half_bits *)(ws + off_hid);
+    float *part = (float *)(ws + off_part), *stats = (float *)(ws + off_stat);
     const int cp_blocks = std::min<int>((int)(((size_t)M * D / 8 + 255) / 256), ctx->num_cus * 8);
     hipLaunchKernelGGL(pad_tokens_kernel, dim3(cp_blocks), dim3(256), 0, ctx->stream, (const half_bits *)x, xs, B, N, Np, D, 1);
     HIVE_CHECK_HIP(ctx, hipGetLastError());
+    auto finalize = [&]() -> int {
+        hipLaunchKernelGGL(ln_finalize_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, ctx->stream, (const float *)part, M, groups, v->eps, stats);
+        HIVE_CHECK_HIP(ctx, hipGetLastError());
+        return HIVE_OK;
+    };
+    auto linear = [&](const void *A, const void *W, const float *bias, const void *residual, void *C, int Mm, int Nn, int Kk, int epi, const LnFold &lf) {
+        return dt == HIVE_BF16 ? linear_t<__bf16>(ctx, A, W, bias, residual, C, Mm, Nn, Kk, epi, lf) : linear_t<_Float16>(ctx, A, W, bias, residual, C, Mm, Nn, Kk, epi, lf);
+    };
     for (int i = 0; i < v->depth; ++i) {
         const hive_vit_block_weights &w = v->blocks[i];
-        if ((rc = hive_vit_layernorm(ctx, xs, dt, (const float *)w.ln1_g, (const float *)w.ln1_b, ln, M, D, v->eps))) return rc;
-        if ((rc = hive_vit_qkv(ctx, ln, dt, w.qkv_w, (const float *)w.qkv_b, qk, vt, B, Np, D, H))) return rc;
-        if ((rc = hive_vit_attention(ctx, qk, dt, vt, attn, B, N, Np, D, H))) return rc;
-        if ((rc = hive_vit_linear(ctx, attn, dt, w.proj_w, (const float *)w.proj_b, xs, xs, M, D, D, EPI_BIAS_RESIDUAL))) return rc;
-        if ((rc = hive_vit_layernorm(ctx, xs, dt, (const float *)w.ln2_g, (const float *)w.ln2_b, ln, M, D, v->eps))) return rc;
-        if ((rc = hive_vit_linear(ctx, ln, dt, w.fc1_w, (const float *)w.fc1_b, nullptr, hid, M, v->mlp, D, EPI_BIAS_GELU))) return rc;
-        if ((rc = hive_vit_linear(ctx, hid, dt, w.fc2_w, (const float *)w.fc2_b, xs, xs, M, D, v->mlp, EPI_BIAS_RESIDUAL))) return rc;
+        if (!fold) {
+            if ((rc = hive_vit_layernorm(ctx, xs, dt, (const float *)w.ln1_g, (const float *)w.ln1_b, ln, M, D, v->eps))) return rc;
+            if ((rc = hive_vit_qkv(ctx, ln, dt, w.qkv_w, (const float *)w.qkv_b, qk, vt, B, Np, D, H))) return rc;
+            if ((rc = hive_vit_attention(ctx, qk, dt, vt, attn, B, N, Np, D, H))) return rc;
+            if ((rc = hive_vit_linear(ctx, attn, dt, w.proj_w, (const float *)w.proj_b, xs, xs, M, D, D, EPI_BIAS_RESIDUAL))) return rc;
+            if ((rc = hive_vit_layernorm(ctx, xs, dt, (const float *)w.ln2_g, (const float *)w.ln2_b, ln, M, D, v->eps))) return rc;
+            if ((rc = hive_vit_linear(ctx, ln, dt, w.fc1_w, (const float *)w.fc1_b, nullptr, hid, M, v->mlp, D, EPI_BIAS_GELU))) return rc;
+            if ((rc = hive_vit_linear(ctx, hid, dt, w.fc2_w, (const float *)w.fc2_b, xs, xs, M, D, v->mlp, EPI_BIAS_RESIDUAL))) return rc;
+        } else {
+            const hive_vit::Folded &f = v->folded[i];
+            if (i == 0) {  // the first LayerNorm's input comes from no GEMM: its rows' statistics by a pass of their own
+                const dim3 grid((M + 3) / 4), block(256);
+#define HIVE_STATS(T_, CH_) hipLaunchKernelGGL((ln_row_stats_kernel<T_, CH_>), grid, block, 0, ctx->stream, (const T_ *)xs, stats, M, v->eps)
+                if (dt == HIVE_BF16) {
+                    switch (D / 256) { case 1: HIVE_STATS(__bf16, 1); break; case 2: HIVE_STATS(__bf16, 2); break; case 3: HIVE_STATS(__bf16, 3); break; default: HIVE_STATS(__bf16, 4); }
+                } else {
+                    switch (D / 256) { case 1: HIVE_STATS(_Float16, 1); break; case 2: HIVE_STATS(_Float16, 2); break; case 3: HIVE_STATS(_Float16, 3); break; default: HIVE_STATS(_Float16, 4); }
+                }
+#undef HIVE_STATS
+                HIVE_CHECK_HIP(ctx, hipGetLastError());
+            } else if ((rc = finalize())) {  // statistics of the rows the previous block's fc2 stored
+                return rc;
+            }
+            LnFold in1, in2, out;
+            in1.stats = stats, in1.c1 = f.qkv_c1;
+            in2.stats = stats, in2.c1 = f.fc1_c1;
+            out.partial = part;
+            rc = dt == HIVE_BF16 ? qkv_t<__bf16>(ctx, xs, f.qkv_w, f.qkv_c2, qk, vt, B, Np, D, H, in1) : qkv_t<_Float16>(ctx, xs, f.qkv_w, f.qkv_c2, qk, vt, B, Np, D, H, in1);
+            if (rc) return rc;
+            if ((rc = hive_vit_attention(ctx, qk, dt, vt, attn, B, N, Np, D, H))) return rc;
+            if ((rc = linear(attn, w.proj_w, (const float *)w.proj_b, xs, xs, M, D, D, EPI_BIAS_RESIDUAL, out))) return rc;
+            if ((rc = finalize())) return rc;
+            if ((rc = linear(xs, f.fc1_w, f.fc1_c2, nullptr, hid, M, v->mlp, D, EPI_BIAS_GELU, in2))) return rc;
+            if ((rc = linear(hid, w.fc2_w, (const float *)w.fc2_b, xs, xs, M, D, v->mlp, EPI_BIAS_RESIDUAL, i + 1 < v->depth ? out : LnFold()))) return rc;
+        }
         for (int t = 0; t < n_taps; ++t)
             if (tap_blocks[t] == i) {
                 hipLaunchKernelGGL(pad_tokens_kernel, dim3(cp_blocks), dim3(256), 0, ctx->stream, (const half_bits *)xs, (half_bits *)tap_out[t], B,

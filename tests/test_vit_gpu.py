@@ -230,6 +230,53 @@ def test_vit_forward_matches_fp32_blocks(gpu_ctx, half):
     assert t8.shape == (B, N, 768) and t8.dtype == half
 
 
+def test_vit_forward_layernorm_folded_into_the_gemms(gpu_ctx, half, monkeypatch):
+    """hive_vit_forward folds each LayerNorm into the GEMM that consumes it (x (gamma o W)^T with the rows' (mean, rstd) applied in the epilogue,
+    the statistics left by the proj / fc2 epilogues): against the same forward with a LayerNorm pass (HIVE_LN_FOLD=0) and against the fp32 blocks,
+    with LayerNorm gains / biases away from 1 / 0 and tokens whose mean is several times their spread (what the fold's mean c1 term has to cancel)."""
+    import copy
+    import torch
+    from hive_amd.dpt.models import VisionTransformerHybrid
+    from hive_amd.dpt.vit_engine import VitEngine
+    torch.manual_seed(11)
+    vit = VisionTransformerHybrid().eval()
+    with torch.no_grad():
+        for blk in vit.blocks:
+            for norm in (blk.norm1, blk.norm2):
+                norm.weight.copy_(1.0 + 0.5 * torch.randn_like(norm.weight))
+                norm.bias.copy_(0.3 * torch.randn_like(norm.bias))
+    for p in vit.blocks.parameters():
+        p.data = p.data.bfloat16().float()
+    vit = vit.cuda()
+    B, N = 2, 301
+    tokens = (torch.randn(B, N, 768, device="cuda") + 3.0 * torch.randn(B, N, 1, device="cuda")).to(half)  # per-token mean offsets of ~3 sigma
+    with torch.no_grad():
+        x = tokens.float()
+        refs = {}
+        for i, blk in enumerate(vit.blocks):
+            x = blk(x)
+            refs[i] = x
+    outs = {}
+    for fold in ("1", "0"):
+        monkeypatch.setenv("HIVE_LN_FOLD", fold)
+        eng = VitEngine(copy.deepcopy(vit).to(half), ctx=gpu_ctx)
+        outs[fold] = eng.forward(tokens, taps=(0, 8, 11))
+        del eng
+    tol = 2e-2 if half == torch.bfloat16 else 2.5e-3
+    for k, blk in enumerate((0, 8, 11)):
+        ref = refs[blk]
+        rel = {f: (outs[f][k].float() - ref).norm().item() / ref.norm().item() for f in outs}
+        assert torch.isfinite(outs["1"][k]).all() and rel["1"] < tol, f"block {blk}: folded {rel['1']:.4g}"
+        assert rel["1"] <= 1.25 * rel["0"] + 1e-4, f"block {blk}: folded {rel['1']:.4g} vs LayerNorm pass {rel['0']:.4g}"
+    # padded batch sizes / several batches reuse the statistics buffers: same result for the same tokens
+    monkeypatch.setenv("HIVE_LN_FOLD", "1")
+    eng = VitEngine(copy.deepcopy(vit).to(half), ctx=gpu_ctx)
+    a = eng.forward(tokens, taps=(11,))[0]
+    eng.forward(torch.cat([tokens, tokens]), taps=(11,))
+    b = eng.forward(tokens, taps=(11,))[0]
+    assert torch.equal(a, b)
+
+
 def test_dpt_hip_engine_matches_torch_engine(gpu_ctx, half):
     """Whole DPT-Hybrid at a small size (96 x 128), seeded non-degenerate weights (tests/dpt_weights.py): engine='hip' against
     the float32 model and against PyTorch's own bf16 operators, in millimetres of depth; and the device hand-off arithmetic
