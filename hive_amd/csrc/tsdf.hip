@@ -34,7 +34,7 @@ struct FrameParams {
     const uint2 *frame;             // {depth bits, r | g<<8 | b<<16}
     const unsigned *tile_max;       // float bits of max(depth) per (32 << tile_shift)^2-pixel tile, [tiles_y][tiles_x] (prep_frame_kernel)
     int tile_shift, tiles_x, tiles_y;
-    int row_far;                    // 1: a row's far cut comes from the tiles its projection crosses; 0: from the frame's max depth
+    int row_far;                    // a row's far cut comes from the tiles its image segment crosses: 0 never (the frame's max depth), 1 where the tile table says it pays, 2 always
     int fast_colour;                // 1: obs_w == 1, roundf contract, every weight of the volume an integer < 65534: update_voxels FASTC
     unsigned long long *n_updated;
 };
@@ -126,21 +126,40 @@ struct RowClip {
 // sample taken every <= tile size along that segment, so the maximum of the DILATED table over the samples bounds the depth the row
 // can meet: voxels with cam_z > that + trunc fail `depth - cam_z >= -trunc` at every pixel they can reach.
 constexpr int MAX_TILES = 2048;
-__device__ __forceinline__ void load_dilated_tiles(const unsigned *__restrict__ raw, int tiles_x, int tiles_y, float *dil, unsigned *gmax, int tid, int nthreads) {
-    unsigned m_all = 0;
-    for (int t = tid; t < tiles_x * tiles_y; t += nthreads) {
-        const int ty = t / tiles_x, tx = t % tiles_x;
-        unsigned m = 0;
-        for (int dy = -1; dy <= 1; ++dy)
-            for (int dx = -1; dx <= 1; ++dx) {
-                const int yy = min(max(ty + dy, 0), tiles_y - 1), xx = min(max(tx + dx, 0), tiles_x - 1);
-                m = max(m, raw[yy * tiles_x + xx]);
-            }
-        dil[t] = __uint_as_float(m);
-        m_all = max(m_all, m);
+// (every thread takes (tile, neighbour) pairs: one independent load each, folded into the table with LDS atomics -- a thread per tile doing its
+// nine loads in turn, frame after frame, kept the whole workgroup waiting for 36 round trips before the first row was clipped)
+__device__ __forceinline__ void load_dilated_tiles(const unsigned *__restrict__ raw, int tiles_x, int tiles_y, float *dil, unsigned *gmax, float *gsum, int tid, int nthreads) {
+    const int tiles = tiles_x * tiles_y;
+    unsigned *bits = reinterpret_cast<unsigned *>(dil);  // maxima of non-negative floats == maxima of their bit patterns
+    for (int t = tid; t < tiles; t += nthreads) bits[t] = 0u;
+    __syncthreads();
+    for (int i = tid; i < tiles * 9; i += nthreads) {
+        const int t = i / 9, k = i - t * 9;
+        const int ty = t / tiles_x, tx = t - ty * tiles_x;
+        const int yy = min(max(ty + k / 3 - 1, 0), tiles_y - 1), xx = min(max(tx + k % 3 - 1, 0), tiles_x - 1);
+        const unsigned v = raw[yy * tiles_x + xx];
+        if (v) atomicMax(&bits[t], v);
     }
-    if (m_all) atomicMax(gmax, m_all);
+    __syncthreads();
+    unsigned m_all = 0;
+    float sum = 0.f;
+    for (int t = tid; t < tiles; t += nthreads) {
+        m_all = max(m_all, bits[t]);
+        sum += dil[t];
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        m_all = max(m_all, (unsigned)__shfl_xor((int)m_all, off));
+        sum += __shfl_xor(sum, off);
+    }
+    if ((tid & 63) == 0 && m_all) {
+        atomicMax(gmax, m_all);
+        atomicAdd(gsum, sum);
+    }
 }
+// The per-row far cut pays where the depth map has large regions much nearer than its deepest pixel; walking a row's image segment over the tile
+// table costs ~9 us per four-frame sweep at 512^3 (a third of the work-list kernel), so a frame whose dilated tile maxima average above 85 % of its
+// maximum (nothing to cut: the benchmark's noise-like DPT maps, a room seen from inside) keeps the frame's bound for all rows.
+__device__ __forceinline__ bool row_far_pays(float gsum, unsigned gmax_bits, int tiles) { return gsum < 0.85f * (float)tiles * __uint_as_float(gmax_bits); }
 
 // Clip the row cam(tz) = a + b*tz against the padded frustum.  Conservative: pixel bounds widened by
 // half a pixel, the result by 2 voxels on each side.  far_frame: max(depth) of the frame; dil (or null): the dilated tile table.
@@ -234,11 +253,13 @@ __global__ __launch_bounds__(1024) void build_worklist_kernel(FrameParams p, Wor
     __shared__ unsigned block_base;
     __shared__ float dil[MAX_TILES];
     __shared__ unsigned gmax;
+    __shared__ float gsum;
     constexpr int CHUNK = SEG_LANES * VPT;
-    if (threadIdx.x == 0) gmax = 0u;
+    if (threadIdx.x == 0) gmax = 0u, gsum = 0.f;
     __syncthreads();
-    load_dilated_tiles(p.tile_max, p.tiles_x, p.tiles_y, dil, &gmax, threadIdx.x, 1024);
+    load_dilated_tiles(p.tile_max, p.tiles_x, p.tiles_y, dil, &gmax, &gsum, threadIdx.x, 1024);
     __syncthreads();
+    const bool row_far = p.row_far == 2 || (p.row_far == 1 && row_far_pays(gsum, gmax, p.tiles_x * p.tiles_y));
     const long long row = (long long)blockIdx.x * 1024 + threadIdx.x;
     unsigned n_chunks = 0;
     int zstart = 0, z1 = 0, x = 0, y = 0;
@@ -250,7 +271,7 @@ __global__ __launch_bounds__(1024) void build_worklist_kernel(FrameParams p, Wor
         const float ax = p.R[0] * tx + p.R[3] * ty;
         const float ay = p.R[1] * tx + p.R[4] * ty;
         const float az = p.R[2] * tx + p.R[5] * ty;
-        const RowClip clip = clip_row(p, ax, ay, az, __uint_as_float(gmax), p.row_far ? dil : nullptr);
+        const RowClip clip = clip_row(p, ax, ay, az, __uint_as_float(gmax), row_far ? dil : nullptr);
         if (clip.z1 > clip.z0) {
             zstart = (clip.z0 / VPT) * VPT;
             z1 = clip.z1;
@@ -751,13 +772,14 @@ __global__ __launch_bounds__(1024) void build_worklist_multi_kernel(MultiParams 
     __shared__ unsigned block_base;
     __shared__ float dil[MAXF][MAX_TILES];
     __shared__ unsigned gmax[MAXF];
+    __shared__ float gsum[MAXF];
     __shared__ unsigned bin_count[NBINS];
     constexpr int CHUNK = SEG_LANES * VPT;
     const FrameParams &p = mp.f[0];
-    if (threadIdx.x < MAXF) gmax[threadIdx.x] = 0u;
+    if (threadIdx.x < MAXF) gmax[threadIdx.x] = 0u, gsum[threadIdx.x] = 0.f;
     if (threadIdx.x < NBINS) bin_count[threadIdx.x] = 0u;
     __syncthreads();
-    for (int f = 0; f < mp.nf; ++f) load_dilated_tiles(mp.f[f].tile_max, p.tiles_x, p.tiles_y, dil[f], &gmax[f], threadIdx.x, 1024);
+    for (int f = 0; f < mp.nf; ++f) load_dilated_tiles(mp.f[f].tile_max, p.tiles_x, p.tiles_y, dil[f], &gmax[f], &gsum[f], threadIdx.x, 1024);
     __syncthreads();
     // Lanes run along the volume axis (x or y) that lies most ACROSS the camera's vertical: neighbouring lanes' rows then project to
     // horizontally neighbouring pixels -- the same 64-byte lines of the row-major texel planes -- and the work list interleaves the
@@ -793,7 +815,8 @@ __global__ __launch_bounds__(1024) void build_worklist_multi_kernel(MultiParams 
                 const float ay = q.R[1] * tx + q.R[4] * ty;
                 const float az = q.R[2] * tx + q.R[5] * ty;
                 if (f == 0) ay0 = ay, az0 = az;
-                const RowClip clip = clip_row(q, ax, ay, az, __uint_as_float(gmax[f]), p.row_far ? dil[f] : nullptr);
+                const bool row_far = p.row_far == 2 || (p.row_far == 1 && row_far_pays(gsum[f], gmax[f], p.tiles_x * p.tiles_y));  // (workgroup-uniform)
+                const RowClip clip = clip_row(q, ax, ay, az, __uint_as_float(gmax[f]), row_far ? dil[f] : nullptr);
                 if (clip.z1 > clip.z0) {
                     fz0[f] = clip.z0, fz1[f] = clip.z1;
                     lo = min(lo, clip.z0);
@@ -1212,7 +1235,10 @@ static void fill_frame_params(hive_tsdf *v, int H, int W, const float K[9], cons
     p.tile_shift = tg.shift;
     p.tiles_x = tg.tiles_x;
     p.tiles_y = tg.tiles_y;
-    p.row_far = env_flag("HIVE_TSDF_ROW_FAR", true) ? 1 : 0;
+    {
+        const char *e = getenv("HIVE_TSDF_ROW_FAR");  // tuning: 0 never / 1 adaptive (default) / 2 always
+        p.row_far = e ? std::min(2, std::max(0, atoi(e))) : 1;
+    }
     p.frame = nullptr;
     p.tile_max = nullptr;
     // the division-free colour update: the roundf contract, unit observation weight, and a volume whose weights are all integers

@@ -273,20 +273,25 @@ __global__ __launch_bounds__(256) void ln_row_stats_kernel(const T *__restrict__
     if (lane == 0) *reinterpret_cast<float2 *>(stats + 2 * (size_t)row) = float2{mean, rsqrtf(var / (float)D + eps)};
 }
 
-// per-row groups (sum, M2 about the group's own mean) of 64 columns each -> (mean, rstd) of the row: Chan's pairwise merge, in group order
+// per-row groups (sum, M2 about the group's own mean) of 64 columns each -> (mean, rstd) of the row: Chan's merge of the groups.  16 lanes per row
+// (a DPP row; groups <= 16, i.e. D <= 1024): lane g reads group g -- a row's partials are 8 `groups` contiguous bytes, four rows per wave-instruction.
+__device__ __forceinline__ float dpp_row16_total(float v) {
+#define HIVE_DPP_ADD(ctrl) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, false))
+    HIVE_DPP_ADD(0x128);  // row_ror:8
+    HIVE_DPP_ADD(0x124);  // row_ror:4
+    HIVE_DPP_ADD(0x122);  // row_ror:2
+    HIVE_DPP_ADD(0x121);  // row_ror:1
+#undef HIVE_DPP_ADD
+    return v;
+}
 __global__ __launch_bounds__(256) void ln_finalize_kernel(const float *__restrict__ partial, int M, int groups, float eps, float *__restrict__ stats) {
-    const int row = blockIdx.x * 256 + threadIdx.x;
-    if (row >= M) return;
-    const float2 *pr = reinterpret_cast<const float2 *>(partial) + (size_t)row * groups;
-    float sum = 0.f;
-    for (int g = 0; g < groups; ++g) sum += pr[g].x;
-    const float mean = sum / (float)(64 * groups);
-    float m2 = 0.f;
-    for (int g = 0; g < groups; ++g) {
-        const float d = pr[g].x * (1.0f / 64.0f) - mean;
-        m2 += pr[g].y + 64.0f * d * d;
-    }
-    *reinterpret_cast<float2 *>(stats + 2 * (size_t)row) = float2{mean, rsqrtf(m2 / (float)(64 * groups) + eps)};
+    const int row = blockIdx.x * 16 + (threadIdx.x >> 4), g = threadIdx.x & 15;
+    float2 pg = float2{0.f, 0.f};
+    if (row < M && g < groups) pg = reinterpret_cast<const float2 *>(partial)[(size_t)row * groups + g];
+    const float mean = dpp_row16_total(pg.x) / (float)(64 * groups);
+    const float d = pg.x * (1.0f / 64.0f) - mean;
+    const float m2 = dpp_row16_total(g < groups ? pg.y + 64.0f * d * d : 0.f);
+    if (row < M && g == 0) *reinterpret_cast<float2 *>(stats + 2 * (size_t)row) = float2{mean, rsqrtf(m2 / (float)(64 * groups) + eps)};
 }
 
 // Weights of a GEMM with its LayerNorm folded in (one thread block per output column n): W'[n][k] = T(gamma[k] W[n][k]),
@@ -1345,7 +1350,7 @@ int hive_vit_forward(hive_vit *v, const void *x, int B, int N, const int *tap_bl
     hipLaunchKernelGGL(pad_tokens_kernel, dim3(cp_blocks), dim3(256), 0, ctx->stream, (const half_bits *)x, xs, B, N, Np, D, 1);
     HIVE_CHECK_HIP(ctx, hipGetLastError());
     auto finalize = [&]() -> int {
-        hipLaunchKernelGGL(ln_finalize_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, ctx->stream, (const float *)part, M, groups, v->eps, stats);
+        hipLaunchKernelGGL(ln_finalize_kernel, dim3((unsigned)((M + 15) / 16)), dim3(256), 0, ctx->stream, (const float *)part, M, groups, v->eps, stats);
         HIVE_CHECK_HIP(ctx, hipGetLastError());
         return HIVE_OK;
     };

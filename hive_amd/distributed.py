@@ -198,6 +198,48 @@ def _fuse_sharded(volume, stream_or_accum):
     return volume
 
 
+def allreduce_bounds(vol_bnds):
+    """Union of every rank's scene bounds (3, 2): element-wise min of the lower and max of the upper corners -- exact in any order, so the
+    frame-sharded run gets the bounds (and with them the voxel size and the grid) of the one-GPU run over the whole frame set."""
+    import numpy as np
+    vol_bnds = np.asarray(vol_bnds, np.float64)
+    if not _collective():
+        return vol_bnds
+    device = "cpu" if _host_staged() else "cuda"
+    lo = torch.tensor(vol_bnds[:, 0], dtype=torch.float64, device=device)
+    hi = torch.tensor(vol_bnds[:, 1], dtype=torch.float64, device=device)
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    return np.stack([lo.cpu().numpy(), hi.cpu().numpy()], axis=1)
+
+
+def tsdf_fusion_fg_bg_sharded(dataset, options=None, num_frames=-1, frame_set=None, instance_id=0, chunk_frames=None):
+    """BASELINE config 5's multi-GPU form: the dynamic path (background volume = depth with the dilated instance masks zeroed, foreground volume
+    = the complement; ``hive_amd.fusion.tsdf_fusion_fg_bg``) with the frames sharded over the ranks.  Every rank decodes and fuses ITS contiguous
+    block of the frame set into its own pair of volumes -- on the grid of the whole set: the ranks' scene bounds are all-reduced (min / max, exact)
+    before the volumes are created -- and each of the two volumes is merged once with ``fuse_sharded`` (reduce-scatter of its sums, all-gather of
+    the result).  Returns {"bg": TSDFVolume, "fg": TSDFVolume}, the merged volumes, on every rank.  Parity with one GPU: as ``fuse_sharded``
+    (tsdf <= 1e-5, weights exact, colours +-2)."""
+    import numpy as np
+    from hive_amd import fusion
+    from hive_amd.options import BackgroundMeshOptions
+    options = options or BackgroundMeshOptions()
+    frame_set = fusion._resolve_frames(dataset, num_frames, frame_set)
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    lo, hi = shard_range(len(frame_set), rank, world)
+    mine = list(frame_set[lo:hi])
+    chunk = int(chunk_frames or fusion.CHUNK_FRAMES)
+    local = np.zeros((3, 2))  # (the reference starts from zeros: the origin is always inside, hive/fusion.py:48)
+    if mine:
+        local = fusion.scene_bounds(fusion.frame_chunks(fusion._RawFrames(dataset), mine, False, chunk, with_color=False), dataset.camera_matrix)
+    vol_bnds = allreduce_bounds(local)
+    volumes = fusion.tsdf_fusion_fg_bg(dataset, options, frame_set=mine, instance_id=instance_id, chunk_frames=chunk_frames, vol_bnds=vol_bnds)
+    for vol in volumes.values():
+        fuse_sharded(vol)
+    return volumes
+
+
 # ------------------------------------------------------------------------------------------------
 # Bit-exact mode (SURVEY.md §8e, the alternative): the FRAMES are all-gathered (2.15 MB each: 323 MB for 150 VGA frames),
 # the VOLUME is sharded in x-slabs, and every rank integrates every frame, in sequence order, into its slab.  A voxel's update

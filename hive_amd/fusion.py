@@ -531,7 +531,7 @@ def tsdf_fusion(dataset, options=None, num_frames=-1, frame_set: Optional[List[i
     return (mesh, tsdf_vol) if return_volume else mesh
 
 
-def tsdf_fusion_fg_bg(dataset, options=None, num_frames=-1, frame_set: Optional[List[int]] = None, instance_id=0, chunk_frames=None):
+def tsdf_fusion_fg_bg(dataset, options=None, num_frames=-1, frame_set: Optional[List[int]] = None, instance_id=0, chunk_frames=None, vol_bnds=None):
     """Dynamic-object variant (BASELINE config 5): two volumes over the same bounds and voxel size from one resident frame
     set -- background = depth with the dilated instance masks zeroed (exactly ``tsdf_fusion``'s volume, from
     ``dataset.depth_dataset`` / ``rgb_dataset``), foreground = the complement (depth kept only on the undilated masks, or on
@@ -543,13 +543,20 @@ def tsdf_fusion_fg_bg(dataset, options=None, num_frames=-1, frame_set: Optional[
     frame_set = _resolve_frames(dataset, num_frames, frame_set)
     raw = _RawFrames(dataset)
     chunk_frames = int(chunk_frames or CHUNK_FRAMES)
-    if len(frame_set) <= chunk_frames:
+    given_bounds = vol_bnds is not None  # (frame-sharded runs: the bounds of the WHOLE frame set, hive_amd.distributed.tsdf_fusion_fg_bg_sharded)
+    if len(frame_set) == 0:
+        assert given_bounds, "an empty frame set needs the scene's bounds"
+        chunks = []
+    elif len(frame_set) <= chunk_frames:
         chunks = [DeviceFrames.from_dataset(raw, frame_set, with_masks=True)]
-        vol_bnds = scene_bounds(chunks[0], dataset.camera_matrix)
+        if not given_bounds:
+            vol_bnds = scene_bounds(chunks[0], dataset.camera_matrix)
     else:
         staging = chunk_staging(raw, frame_set, chunk_frames)
-        vol_bnds = scene_bounds(frame_chunks(raw, frame_set, False, chunk_frames, with_color=False, staging=staging), dataset.camera_matrix)
+        if not given_bounds:
+            vol_bnds = scene_bounds(frame_chunks(raw, frame_set, False, chunk_frames, with_color=False, staging=staging), dataset.camera_matrix)
         chunks = frame_chunks(raw, frame_set, True, chunk_frames, staging=staging)
+    vol_bnds = np.asarray(vol_bnds, np.float64)
     voxel_size = voxel_size_for_budget(vol_bnds, options)
     modes = (("bg", MASK_BACKGROUND, options.depth_mask_dilation_iterations), ("fg", MASK_FOREGROUND, 0))
     volumes = {name: TSDFVolume(vol_bnds, voxel_size=voxel_size) for name, _, _ in modes}

@@ -193,3 +193,25 @@ def test_two_rank_exact_slab_mode_is_bit_identical_to_sequential(tmp_path, oracl
     assert tuple(got["dims"]) == tuple(int(d) for d in ref._vol_dim)
     for name, arr in (("tsdf", ref._tsdf), ("weight", ref._weight), ("color", ref._color)):
         assert np.array_equal(got[name], arr.reshape(-1)), f"{name}: the slab mode must be BIT-identical to the sequential fusion"
+
+
+def _bounds_worker(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    from hive_amd import distributed as hdist
+    hdist.init_from_env(backend="gloo")
+    local = np.array([[-1.5 - rank, 0.25 + rank], [0.0, 2.0 - 3.0 * rank], [-0.125 * (rank + 1), 7.0]])
+    merged = hdist.allreduce_bounds(local)
+    if rank == 0:
+        np.save(out_path, merged)
+    hdist.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_scene_bounds_union(tmp_path):
+    """`allreduce_bounds` (the frame-sharded dynamic path, hive_amd.distributed.tsdf_fusion_fg_bg_sharded): element-wise min / max over the ranks, exact."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "bounds.npy")
+    mp.start_processes(_bounds_worker, args=(2, _free_port(), out), nprocs=2, join=True, start_method="spawn")
+    assert np.array_equal(np.load(out), np.array([[-2.5, 1.25], [0.0, 2.0], [-0.25, 7.0]]))

@@ -114,3 +114,70 @@ def test_rccl_runs_the_merge_collectives(gpu_ctx, nccl_group, monkeypatch):
     assert fus.slab.last_batch_groups() == [4, 2]
     for a, b in zip(full.device_tensors(), want):
         assert torch.equal(a, b)
+
+
+# ---- BASELINE config 5's multi-GPU form: the dynamic path with the frames sharded over TWO ranks (both on this box's one GPU, collectives
+# through gloo: what is exercised is the sharding, the all-reduced bounds and the two merges, not RCCL) --------------------------------------
+class _ShardedFake:
+    """What tsdf_fusion_fg_bg reads of a HiveDataset, built from the seeded synthetic sequence in every rank."""
+
+    def __init__(self, n):
+        from hive_amd import synthetic
+        from hive_amd.geometric import Trajectory
+        self.seq = synthetic.make_sequence(num_frames=n, height=60, width=80, yaw_step_deg=25.0)
+        self.masks = list(synthetic.ellipse_masks(n, 60, 80, num_objects=2, seed=5))
+        self.num_frames = n
+        self.camera_matrix = self.seq["K"].astype(np.float64)
+        self.camera_trajectory = Trajectory(synthetic.trajectory_rows_world_to_cam(self.seq["poses"]).astype(np.float64))
+        self.has_inpainted_frame_data = False
+        self.mask_dataset = self.masks
+        self.rgb_dataset = self.bg_rgb_dataset = [c.copy() for c in self.seq["color"]]
+        self.depth_dataset = self.bg_depth_dataset = [d.copy() for d in self.seq["depth"]]
+
+
+def _fg_bg_worker(rank, world, port, out_path):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HIVE_DIST_BACKEND="gloo")
+    import torch
+    from hive_amd import distributed as hdist
+    from hive_amd.options import BackgroundMeshOptions
+    hdist.init_from_env()
+    torch.cuda.set_device(0)
+    options = BackgroundMeshOptions(sdf_voxel_size=0.05, sdf_max_voxels=400_000, depth_mask_dilation_iterations=2)
+    vols = hdist.tsdf_fusion_fg_bg_sharded(_ShardedFake(7), options)  # 7 frames: blocks of 4 + 3
+    if rank == 0:
+        out = {}
+        for name, vol in vols.items():
+            t, c, w = vol.get_volume(with_weight=True)
+            out[name + "_tsdf"], out[name + "_color"], out[name + "_weight"] = t, c, w
+            out[name + "_bnds"] = vol._vol_bnds
+        np.savez(out_path, **out)
+    hdist.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_dynamic_path_frame_sharded(gpu_ctx, tmp_path):
+    """`tsdf_fusion_fg_bg_sharded` on two ranks == `tsdf_fusion_fg_bg` on one (the same grid: bounds all-reduced exactly; weights exact,
+    tsdf <= 1e-5, colours +-2: the merge adds the ranks' sums where one GPU rounds after every frame)."""
+    import socket
+    import torch.multiprocessing as mp
+    from hive_amd import fusion
+    from hive_amd.options import BackgroundMeshOptions
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "sharded.npz")
+    mp.start_processes(_fg_bg_worker, args=(2, port, out), nprocs=2, join=True, start_method="spawn")
+    got = np.load(out)
+    options = BackgroundMeshOptions(sdf_voxel_size=0.05, sdf_max_voxels=400_000, depth_mask_dilation_iterations=2)
+    ref = fusion.tsdf_fusion_fg_bg(_ShardedFake(7), options)
+    for name in ("bg", "fg"):
+        t, c, w = ref[name].get_volume(with_weight=True)
+        assert np.array_equal(got[name + "_bnds"], ref[name]._vol_bnds) and got[name + "_tsdf"].shape == t.shape, name
+        assert np.array_equal(got[name + "_weight"], w), f"{name}: weights (and the observed set) must be exact"
+        assert np.abs(got[name + "_tsdf"] - t).max() <= 1e-5, name
+        for sh in (0, 8, 16):
+            a, b = (got[name + "_color"].astype(np.int64) >> sh) & 255, (c.astype(np.int64) >> sh) & 255
+            assert np.abs(a - b).max() <= 2, name
+    assert got["fg_weight"].max() > 0 and (got["bg_weight"] > 0).sum() > (got["fg_weight"] > 0).sum()
