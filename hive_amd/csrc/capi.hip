@@ -1,4 +1,6 @@
 // Context, error reporting, staging and timing plumbing of libhive_mi355x.so.
+#include <algorithm>
+
 #include "hive_internal.hpp"
 
 static thread_local std::string g_global_error;
@@ -28,6 +30,18 @@ int hive_reserve_device(hive_ctx *ctx, void **ptr, size_t *cur, size_t bytes) {
     }
     HIVE_CHECK_HIP(ctx, hipMalloc(ptr, bytes));
     *cur = bytes;
+    return HIVE_OK;
+}
+
+int hive_splitk_workspace(hive_ctx *ctx, size_t bytes, void **ws, unsigned **count) {
+    if (!ctx->d_splitk_count) {
+        HIVE_CHECK_HIP(ctx, hipMalloc((void **)&ctx->d_splitk_count, HIVE_SPLITK_TILES * sizeof(unsigned)));
+        HIVE_CHECK_HIP(ctx, hipMemsetAsync(ctx->d_splitk_count, 0, HIVE_SPLITK_TILES * sizeof(unsigned), ctx->stream));  // (the last arriver of a tile puts its counter back to 0)
+    }
+    int rc = hive_reserve_device(ctx, &ctx->d_splitk, &ctx->splitk_bytes, std::max(bytes, (size_t)32 << 20));
+    if (rc) return rc;
+    *ws = ctx->d_splitk;
+    *count = ctx->d_splitk_count;
     return HIVE_OK;
 }
 
@@ -148,6 +162,8 @@ int hive_ctx_destroy(hive_ctx *ctx) {
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->d_frame) (void)hipFree(ctx->d_frame);
     if (ctx->d_batch) (void)hipFree(ctx->d_batch);
+    if (ctx->d_splitk) (void)hipFree(ctx->d_splitk);
+    if (ctx->d_splitk_count) (void)hipFree(ctx->d_splitk_count);
     if (ctx->d_in) (void)hipFree(ctx->d_in);
     if (ctx->d_scalars) (void)hipFree(ctx->d_scalars);
     if (ctx->h_pinned_small) (void)hipHostFree(ctx->h_pinned_small);

@@ -72,6 +72,10 @@ struct ConvParams {
     const float *gn_stats;
     const T *gn_gamma, *gn_beta;
     int gn_G, gn_cpg;   // groups, channels per group (>= 8: a lane's 8 channels share a group)
+    // split-K (conv_deep_kernel only: mfma_pipe.hpp splitk_combine): the K-steps of a tile are dealt to split_k workgroups
+    int split_k;
+    hive_mfma::f32x4 *sk_ws;
+    unsigned *sk_count;
 };
 
 // epilogue: through the wave's 4 KiB of LDS (mfma_pipe.hpp staged_rows) so that the residual loads and the stores are 16 bytes
@@ -432,7 +436,164 @@ __global__ __launch_bounds__(512, 1) void conv_kernel(ConvParams<T> p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the redundant last stage
 }
 
-constexpr int conv_lds(int tm, int tn) { return 2 * (tm / 8 + tn / 8) * 1024 + hive_mfma::STAGED_ROWS_LDS; }  // two stages of (A tile + W tile), 128-byte rows; the epilogue's 8 x 4 KiB
+// The same convolution for launches that do NOT fill the chip (small batches -- the reference's literal loop is one frame per forward -- and the small
+// maps of the decoder): 128 x 128 tiles on a ring of NST = 4 stages (three in flight) and, for long K loops, split-K.  With fewer tiles than CUs a
+// launch lasts as long as ONE workgroup's K loop, and with two stages each of its steps waited a whole trip to L2 / HBM for the next stage (2 us
+// per step for a 48 KiB stage: 72 us for a 3 x 3 convolution of 256 channels on 6 tiles).  Differences from conv_kernel: the stage being issued runs
+// AHEAD = NST - 1 steps in front of the one being multiplied, along ONE stream of (item, K-step)s; the pieces are issued through
+// hive_mfma::lds_dma16_untracked and counted by hand (hipcc waits for every LDS-DMA it knows of in front of the next ds_read: vmcnt(0) every step);
+// an item = (tile, split s) multiplies K-steps [s KT / S, (s + 1) KT / S) and the last of a tile's items to finish adds the partials in a fixed
+// order and runs the epilogue (splitk_combine).  Epilogues, K order (channel block outer, tap inner) and results are conv_kernel's.
+template <typename T, int TN, int GN, int NST>
+__global__ __launch_bounds__(512, 1) void conv_deep_kernel(ConvParams<T> p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];  // NST stages x (A tile 128 x 64, W tile TN x 64) + 8 x 4 KiB for the epilogue
+    constexpr int TM = 128, AHEAD = NST - 1;
+    constexpr int A_GROUPS = TM / 8, A_PW = A_GROUPS / 8;
+    constexpr int W_GROUPS = TN / 8, GROUPS = A_GROUPS + W_GROUPS, PER_WAVE = GROUPS / 8;
+    constexpr int STAGE_BYTES = GROUPS * 1024;
+    constexpr int WN = TN / 64, WM = 8 / WN, RW = TM / WM, MT = RW / 16;
+    static_assert(AHEAD * PER_WAVE < 64, "vmcnt is a 6-bit counter");
+    const int tid = threadIdx.x;
+    int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WN, wc = wave % WN;
+    const int S = p.split_k, KT = p.taps * (p.Cin / BK);
+    const int tiles_n = p.Cout / TN, n_items = ((p.M + TM - 1) / TM) * tiles_n * S;
+    const int xcd = blockIdx.x & 7, per_xcd = gridDim.x >> 3, tq = n_items >> 3, tr = n_items & 7;
+    const int run0 = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq, run_n = tq + (xcd < tr ? 1 : 0);
+    int tl = blockIdx.x >> 3;  // position in the XCD's run of items
+    if (tl >= run_n) return;   // (whole workgroup)
+
+    struct Tile {
+        int m0, n0, kt, k1, tl;  // kt: the K-step to issue next
+        int py[A_PW], px[A_PW];
+        const T *pbase[A_PW];
+    };
+    int a_chunk[A_PW];
+    auto lane_constants = [&]() {
+#pragma unroll
+        for (int j = 0; j < A_PW; ++j) {
+            const int row = (wave + 8 * j) * 8 + (lane >> 3);
+            a_chunk[j] = ((lane & 7) ^ ((row >> 1) & 7)) * 8;
+        }
+    };
+    lane_constants();
+    auto coords = [&](int item, int &m0, int &n0, int &k0, int &k1) {
+        const int t = item / S, s = item - t * S;
+        m0 = (t / tiles_n) * TM;
+        n0 = (t % tiles_n) * TN;
+        k0 = s * KT / S;
+        k1 = (s + 1) * KT / S;
+    };
+    auto setup = [&](Tile &tile) {  // the rows this lane stages (the same ones in every K-step of the item)
+        coords(run0 + tile.tl, tile.m0, tile.n0, tile.kt, tile.k1);
+#pragma unroll
+        for (int j = 0; j < A_PW; ++j) {
+            const int row = (wave + 8 * j) * 8 + (lane >> 3);
+            const int m = min(tile.m0 + row, p.M - 1);
+            const int img = m / (p.Ho * p.Wo), rem = m - img * (p.Ho * p.Wo);
+            const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+            tile.py[j] = oy * p.stride - p.pad_t;
+            tile.px[j] = ox * p.stride - p.pad_l;
+            tile.pbase[j] = p.x + (((long long)img * p.H + tile.py[j]) * p.W + tile.px[j]) * p.Cin + a_chunk[j];
+        }
+    };
+    auto issue_piece = [&](const Tile &tile, int stage, int j) {
+        unsigned char *st = lds + stage * STAGE_BYTES;
+        const int cc = tile.kt / p.taps, tap = tile.kt - cc * p.taps;  // channel block outer, tap inner
+        if (j < A_PW) {
+            const int dy = tap / p.S, dx = tap - dy * p.S;
+            const long long shift = ((long long)dy * p.W + dx) * p.Cin + cc * BK;
+            const bool inside = (unsigned)(tile.py[j] + dy) < (unsigned)p.H && (unsigned)(tile.px[j] + dx) < (unsigned)p.W;
+            const T *g = inside ? tile.pbase[j] + shift : p.zeros + a_chunk[j];
+            hive_mfma::lds_dma16_untracked((const void *)g, __builtin_amdgcn_readfirstlane(hive_mfma::lds_address(st + (wave + 8 * j) * 1024)));
+        } else {
+            const int grp = wave + 8 * (j - A_PW);
+            const int row = grp * 8 + (lane >> 3);
+            const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+            const T *g = p.w + (size_t)(tile.n0 + row) * (p.taps * p.Cin) + tap * p.Cin + cc * BK + chunk * 8;
+            hive_mfma::lds_dma16_untracked((const void *)g, __builtin_amdgcn_readfirstlane(hive_mfma::lds_address(st + (A_GROUPS + grp) * 1024)));
+        }
+    };
+    // past the end of the stream the cursor parks on the last stage, issued again into a buffer nobody reads any more: every step issues a stage
+    auto advance = [&](Tile &tile) {
+        if (tile.kt + 1 < tile.k1) {
+            ++tile.kt;
+        } else if (tile.tl + per_xcd < run_n) {
+            tile.tl += per_xcd;
+            setup(tile);
+        }
+    };
+    Tile is;
+    is.tl = tl;
+    setup(is);
+#pragma unroll
+    for (int a = 0; a < AHEAD; ++a) {
+#pragma unroll
+        for (int j = 0; j < PER_WAVE; ++j) issue_piece(is, a, j);
+        advance(is);
+    }
+    int buf = 0;
+    for (;;) {
+        asm volatile("" : "+v"(lane));
+        lane_constants();
+        const int fr = lane & 15, fq = lane >> 4;
+        const bool has_next = tl + per_xcd < run_n;
+        int em0, en0, k0, k1;
+        coords(run0 + tl, em0, en0, k0, k1);
+        f32x4 acc[4][MT];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int kt = k0; kt < k1; ++kt) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * PER_WAVE) : "memory");  // this step's stage: all but the AHEAD - 1 younger ones have landed
+            __builtin_amdgcn_s_barrier();
+            const int ib = buf + AHEAD >= NST ? buf + AHEAD - NST : buf + AHEAD;  // the buffer the previous step read
+            const unsigned char *a_t = lds + buf * STAGE_BYTES, *w_t = a_t + A_GROUPS * 1024;
+            hive_mfma::kstep64<T, MT, false>(a_t, w_t, wr * RW, wc * 64, fr, fq, acc, PER_WAVE, [&](int j) { issue_piece(is, ib, j); });
+            advance(is);
+            buf = buf + 1 == NST ? 0 : buf + 1;
+        }
+        unsigned char *epi = lds + NST * STAGE_BYTES;
+        bool store = true;
+        if (S > 1) store = hive_mfma::splitk_combine<512>(S, p.sk_ws, p.sk_count, run0 + tl, acc, tid, reinterpret_cast<int *>(epi));
+        if (store) {
+            unsigned char *stage = epi + wave * 4096;
+            const int hw = p.Ho * p.Wo, boundary = (em0 / hw + 1) * hw;
+            if (!(GN == 1 && p.stats_only)) {
+                if (GN == 0 && p.res2)
+                    conv_epilogue<T, MT, GN, 2>(p, acc, em0 + wr * RW, en0 + wc * 64, stage, lane, boundary);
+                else
+                    conv_epilogue<T, MT, GN, 1>(p, acc, em0 + wr * RW, en0 + wc * 64, stage, lane, boundary);
+            }
+            if (GN == 1) {
+                __builtin_amdgcn_wave_barrier();
+                gn_sums_from_acc<T, MT>(p, acc, em0 + wr * RW, en0 + wc * 64, lane, boundary, reinterpret_cast<float *>(stage));
+                __syncthreads();
+                const int tile_m = em0 / TM;
+                for (int t = tid; t < 4 * TN; t += 512) {
+                    const int hq = t / TN, ch = t - hq * TN, cw = ch >> 6, c = ch & 63;
+                    float a = 0.f;
+#pragma unroll
+                    for (int w = 0; w < WM; ++w) a += reinterpret_cast<const float *>(epi + (w * WN + cw) * 4096)[hq * 64 + c];
+                    p.gn_partial[((size_t)tile_m * 4 + hq) * p.Cout + en0 + ch] = a;
+                }
+            }
+        }
+        if (!has_next) break;
+        // nothing but the ring's own pieces may be outstanding in the K loop, in fact (stores and loads retire in no common order) and in the
+        // compiler's books (a shortcut row loaded ahead for a row past M is never consumed: hipcc would wait for it at the top of every K-step)
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): a wait the compiler sees
+        __syncthreads();                     // (the GroupNorm sums' reads of the epilogue LDS stay in front of the next item's)
+        tl += per_xcd;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the parked cursor's stages
+}
+
+constexpr int conv_lds(int tm, int tn, int nst = 2) { return nst * (tm / 8 + tn / 8) * 1024 + hive_mfma::STAGED_ROWS_LDS; }  // two stages of (A tile + W tile), 128-byte rows; the epilogue's 8 x 4 KiB
+
+constexpr int CONV_DEEP_NST = 4;  // 4 x 32 KiB of stages + 32 KiB for the epilogue = the CU's 160 KiB
 
 template <typename T>
 int ensure_conv_attrs(hive_ctx *ctx) {
@@ -453,6 +614,8 @@ int ensure_conv_attrs(hive_ctx *ctx) {
     HIVE_CONV_ATTR(256, 256, 2);
     HIVE_CONV_ATTR(128, 256, 2);
 #undef HIVE_CONV_ATTR
+    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)conv_deep_kernel<T, 128, 0, CONV_DEEP_NST>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds(128, 128, CONV_DEEP_NST)));
+    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)conv_deep_kernel<T, 128, 1, CONV_DEEP_NST>, hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds(128, 128, CONV_DEEP_NST)));
     if (ctx->device < 64) set[ctx->device] = true;
     return HIVE_OK;
 }
@@ -528,6 +691,39 @@ int launch_conv_t(hive_ctx *ctx, const char *what, const void *d_x, int N, int H
                      gn_partial_floats, (long long)((p.M + tm - 1) / tm) * 4 * C_out);
         p.gn_partial = (float *)d_gn_partial;
         *gn_tile_rows = tm;
+    }
+    // Launches that do not fill the chip: conv_deep_kernel (128 x 128 tiles, four-stage ring, split-K for long K loops).  HIVE_CONV_DEEP=0 switches it off.
+    {
+        const long long tiles128 = (long long)((p.M + 127) / 128) * (C_out / 128);
+        const char *deep_env = getenv("HIVE_CONV_DEEP");
+        const bool allowed = !(deep_env && deep_env[0] == '0');
+        if (allowed && !p.gn_stats && C_out % 128 == 0 && tiles128 <= ctx->num_cus && tiles128 <= HIVE_SPLITK_TILES) {
+            const int KT = p.taps * (C_in / BK);
+            const char *sk_env = getenv("HIVE_SPLITK");
+            p.split_k = sk_env ? std::max(1, std::min(atoi(sk_env), KT)) : hive_mfma::splitk_ways(tiles128, KT, ctx->num_cus);
+            p.split_k = (int)std::max<long long>(1, std::min<long long>(p.split_k, ctx->num_cus / tiles128));
+            if (p.split_k > 1) {
+                void *ws = nullptr;
+                rc = hive_splitk_workspace(ctx, (size_t)tiles128 * p.split_k * 128 * 128 * sizeof(float), &ws, &p.sk_count);
+                if (rc) return rc;
+                p.sk_ws = reinterpret_cast<hive_mfma::f32x4 *>(ws);
+            }
+            const bool stats = d_gn_partial && gn_tile_rows && (long long)Ho * Wo >= 128 && !relu && !d_residual && !d_residual2 && !d_out_relu;
+            if (stats) {
+                HIVE_REQUIRE(ctx, (long long)((p.M + 127) / 128) * 4 * C_out <= gn_partial_floats, "%s: gn_partial holds %lld floats, %lld needed", what,
+                             gn_partial_floats, (long long)((p.M + 127) / 128) * 4 * C_out);
+                p.gn_partial = (float *)d_gn_partial;
+                *gn_tile_rows = 128;
+            }
+            const long long items = tiles128 * p.split_k;
+            const dim3 dgrid((unsigned)std::min<long long>((items + 7) / 8 * 8, (long long)ctx->num_cus / 8 * 8));
+            if (stats)
+                hipLaunchKernelGGL((conv_deep_kernel<T, 128, 1, CONV_DEEP_NST>), dgrid, dim3(512), (size_t)conv_lds(128, 128, CONV_DEEP_NST), ctx->stream, p);
+            else
+                hipLaunchKernelGGL((conv_deep_kernel<T, 128, 0, CONV_DEEP_NST>), dgrid, dim3(512), (size_t)conv_lds(128, 128, CONV_DEEP_NST), ctx->stream, p);
+            HIVE_CHECK_HIP(ctx, hipGetLastError());
+            return HIVE_OK;
+        }
     }
     // persistent workgroups, one per CU, a multiple of 8 so that every XCD gets the same number
     const long long tiles = (long long)((p.M + tm - 1) / tm) * (C_out / tn);

@@ -48,6 +48,10 @@ struct hive_ctx {
     unsigned *d_scalars = nullptr;  // [0]=max depth bits, [2..3]=u64 counter, ...
     void *h_pinned_small = nullptr;  // 256 bytes of pinned host memory for small read-backs (mesh totals)
     void *d_zeros = nullptr;        // 256 bytes of zeros: the source of padding taps in the implicit-GEMM convolutions
+    // split-K of the MFMA tile kernels at small batches (mfma_pipe.hpp splitk_*): f32 partial tiles + one arrival counter per tile (zero between launches)
+    void *d_splitk = nullptr;
+    size_t splitk_bytes = 0;
+    unsigned *d_splitk_count = nullptr;
 
     // HIP-event timing of the dominant kernel
     bool timing = false;
@@ -98,6 +102,9 @@ int hive_reserve_device(hive_ctx *ctx, void **ptr, size_t *cur, size_t bytes);
 int hive_upload(hive_ctx *ctx, void *dst, const void *src, size_t bytes);
 // dpt_ops.hip: (mean, rstd) per (sample, group) from the per-tile channel sums a GN convolution epilogue left (conv.hip)
 int hive_gn_finalize_tiles(hive_ctx *ctx, const float *d_partial, int N, int HW, int C, int G, int tile_rows, float eps, float *d_stats);
+// split-K workspace of at least `bytes` and the (zeroed) arrival counters (HIVE_SPLITK_TILES of them)
+constexpr int HIVE_SPLITK_TILES = 4096;
+int hive_splitk_workspace(hive_ctx *ctx, size_t bytes, void **ws, unsigned **count);
 // event helpers for kernel timing
 int hive_time_begin(hive_ctx *ctx);
 int hive_time_end(hive_ctx *ctx);

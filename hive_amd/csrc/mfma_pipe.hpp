@@ -17,6 +17,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 namespace hive_mfma {
 
 template <typename T, int N>
@@ -29,6 +31,17 @@ __device__ __forceinline__ f32x4 mfma16(vec<__bf16, 8> a, vec<__bf16, 8> b, f32x
 __device__ __forceinline__ f32x4 mfma16(vec<_Float16, 8> a, vec<_Float16, 8> b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x16 mfma32(vec<__bf16, 8> a, vec<__bf16, 8> b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x16 mfma32(vec<_Float16, 8> a, vec<_Float16, 8> b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+
+// One LDS-DMA wave instruction (64 lanes x 16 B, lane-linear, to the wave-uniform LDS address lds_dst) that the COMPILER DOES NOT SEE: hipcc cannot tell
+// which LDS bytes a global_load_lds writes, so in front of the first ds_read that follows one it waits for ALL of them (s_waitcnt vmcnt(0)) -- harmless with
+// two stages, where the step waits for everything anyway, but it silently drains a deeper ring every K-step.  The rings deeper than two stages issue their pieces
+// through this statement and count vmcnt by hand (the CDNA4 guide's recipe: M0 holds the LDS base and is compiler-reserved, so it is saved and put back).
+__device__ __forceinline__ void lds_dma16_untracked(const void *gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+// LDS byte address of a (generic) pointer into the kernel's LDS array: the low half of the flat address (the high half is the shared aperture)
+__device__ __forceinline__ unsigned lds_address(const void *p) { return (unsigned)(size_t)p; }
 
 // byte offset of 16-byte chunk `c` (0..7) of row `r` in a tile with 128-byte rows: the chunk is XORed with (r >> 1) & 7 so that
 // any 16 consecutive rows at one chunk index land on 16 distinct 16-byte slots
@@ -184,5 +197,67 @@ __device__ __forceinline__ void staged_rows(unsigned char *stage, const Acc &acc
 }
 
 constexpr int STAGED_ROWS_LDS = 8 * 4096;  // 8 waves
+
+// Split-K for small batches.  With fewer tiles than CUs a tile kernel lasts as long as ONE workgroup's K loop (12-48 steps of 1-2 us, each
+// waiting for a stage to arrive from L2 / HBM) while most of the chip idles, so the K-steps of a tile are dealt to S workgroups ("items":
+// item = tile * S + s multiplies steps [s KT / S, (s + 1) KT / S)).  Every item leaves its f32 accumulators in the workspace as they sit in
+// the registers (NT threads x R x C f32x4, lane-linear: 16 bytes per lane, whole lines per wave instruction) and counts itself in on the
+// tile's counter; the item whose add comes LAST adds the S partials in the order s = 0 .. S - 1 (its own included, re-read: the sum does not
+// depend on who is last) and runs the tile's ordinary epilogue.  No workgroup waits for another.
+// Visibility (gfx950: per-CU L1s, per-XCD L2s, none refreshed by another CU's stores) follows the in-launch split-K recipe of the CDNA4 guide:
+// the partials are stored WRITE-THROUGH (raw buffer stores with aux = sc1: they leave the XCD's L2, so no release fence -- a fence per workgroup
+// writes back and invalidates whole caches: 5.35 -> 8.7 ms per one-frame forward when first built that way), every storing wave drains its stores
+// (s_waitcnt vmcnt(0)), the workgroup meets at a barrier, ONE lane adds to the counter (relaxed, agent scope); the last arriver's lane makes ONE
+// agent-scope acquire (drops this CU's stale L1 lines), waits for it, and the workgroup meets again before anyone loads a partial.
+// Returns whether this workgroup holds the tile's sum; `flag`: 4 bytes of the kernel's one LDS array.  The last arriver puts the counter back to
+// zero for the stream's next launch (the counters are zeroed when allocated: hive_splitk_workspace).
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+template <int NT, int R, int C>
+__device__ __forceinline__ bool splitk_combine(int S, f32x4 *ws, unsigned *count, int item, f32x4 (&acc)[R][C], int tid, int *flag) {
+    constexpr unsigned SLAB = R * C * NT * 16;  // bytes per partial
+    const int tile = item / S;
+    {
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<unsigned char *>(ws) + (size_t)item * SLAB, 0, (int)SLAB, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < R; ++i)
+#pragma unroll
+            for (int j = 0; j < C; ++j) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rsrc, ((i * C + j) * NT + tid) * 16, 0, 16);  // aux 16 = sc1
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave, before the barrier
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned arrived = __hip_atomic_fetch_add(count + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (arrived == (unsigned)(S - 1)) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (holds the barrier below until the invalidate has completed)
+            __hip_atomic_store(count + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        *flag = (int)arrived;
+    }
+    __syncthreads();
+    const bool last = *flag == S - 1;
+    __syncthreads();  // (the caller's epilogue reuses flag's LDS)
+    if (!last) return false;
+#pragma unroll
+    for (int i = 0; i < R; ++i)
+#pragma unroll
+        for (int j = 0; j < C; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4 *src = ws + (size_t)tile * S * (R * C * NT) + tid;
+    for (int s = 0; s < S; ++s, src += R * C * NT) {
+#pragma unroll
+        for (int i = 0; i < R; ++i)
+#pragma unroll
+            for (int j = 0; j < C; ++j) acc[i][j] += src[(i * C + j) * NT];
+    }
+    return true;
+}
+
+// How many ways to split (measured, tools/probe_splitk.py): an item costs ~4 us of its own (write-through stores, the counter, the acquire) and the last
+// arriver ~1 us per 64 KiB partial it reads, a K-step of the deep ring 0.6-0.7 us: splitting pays for LONG K loops only (fc2's 48 steps: 32.6 -> 21 us four
+// ways; the 12-step GEMMs lose), and never beyond one round of workgroups on the CUs.
+inline int splitk_ways(long long tiles, int KT, long long cus) {
+    if (tiles <= 0 || KT < 32) return 1;
+    return (int)std::max<long long>(1, std::min<long long>(4, cus / tiles));
+}
 
 }  // namespace hive_mfma

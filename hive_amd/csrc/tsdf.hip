@@ -156,10 +156,12 @@ __device__ __forceinline__ void load_dilated_tiles(const unsigned *__restrict__ 
         atomicAdd(gsum, sum);
     }
 }
-// The per-row far cut pays where the depth map has large regions much nearer than its deepest pixel; walking a row's image segment over the tile
-// table costs ~9 us per four-frame sweep at 512^3 (a third of the work-list kernel), so a frame whose dilated tile maxima average above 85 % of its
-// maximum (nothing to cut: the benchmark's noise-like DPT maps, a room seen from inside) keeps the frame's bound for all rows.
-__device__ __forceinline__ bool row_far_pays(float gsum, unsigned gmax_bits, int tiles) { return gsum < 0.85f * (float)tiles * __uint_as_float(gmax_bits); }
+// The per-row far cut pays where the depth map has large regions much nearer than its deepest pixel (masked foreground / background depth, a near
+// object filling part of the view); walking a row's image segment over the tile table costs ~9 us per four-frame sweep at 512^3 (a third of the
+// work-list kernel).  Its best case removes (1 - mean(tile maxima) / max) of the rows' depth range, so a frame whose dilated tile maxima average
+// above 70 % of its maximum keeps the frame's bound for all rows: measured on the two bench scenes (probe_sweep_ab.py), where the cut removed
+// 0.7 % (room) and 0.01 % (DPT depth of the seeded weights) of the work list and cost 2-4 us per frame.  HIVE_TSDF_ROW_FAR=0 / 2 force it off / on.
+__device__ __forceinline__ bool row_far_pays(float gsum, unsigned gmax_bits, int tiles) { return gsum < 0.70f * (float)tiles * __uint_as_float(gmax_bits); }
 
 // Clip the row cam(tz) = a + b*tz against the padded frustum.  Conservative: pixel bounds widened by
 // half a pixel, the result by 2 voxels on each side.  far_frame: max(depth) of the frame; dil (or null): the dilated tile table.

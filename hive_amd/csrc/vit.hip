@@ -115,6 +115,10 @@ struct GemmParams {
     const float *ln_stats;  // consumer: [M][2] = (mean, rstd) of the rows of A, or null: the plain epilogue
     const float *ln_c1;     // consumer: [N]
     float *ln_partial;      // producer (EPI_BIAS_RESIDUAL), or null: [M][N / 64][2] = per 64 stored columns of a row (their sum, the sum of squares about their own mean)
+    // split-K (gemm_kernel only, small M: mfma_pipe.hpp splitk_combine): the K-steps of a tile are dealt to split_k workgroups
+    int split_k = 1;
+    hive_mfma::f32x4 *sk_ws = nullptr;
+    unsigned *sk_count = nullptr;
 };
 
 constexpr int BN = 128, BK = 64;
@@ -143,14 +147,17 @@ __device__ __forceinline__ f32x2 gelu_exact2(f32x2 x) {
 // Global -> LDS staging with LDS-DMA (global_load_lds_dwordx4): one wave instruction deposits 64 x 16 B =
 // 8 rows of 128 B, lane-linear.  The bank swizzle therefore lives on the SOURCE side: LDS slot (row, s)
 // receives global chunk s ^ ((row >> 1) & 7), and the fragment reads apply the same XOR (swz()).
-template <typename T>
+template <typename T, bool UNTRACKED = false>
 __device__ __forceinline__ void stage_group(const T *__restrict__ src, int ld, int row0, int row_max, int k0,
                                             unsigned char *tile, int grp, int lane) {
     const int row = grp * 8 + (lane >> 3);
     const int chunk = (lane & 7) ^ ((row >> 1) & 7);
     const int grow = min(row0 + row, row_max);  // clamp: rows past the end are never stored
     const T *g = src + (size_t)grow * ld + k0 + chunk * 8;
-    __builtin_amdgcn_global_load_lds((const void *)g, (__attribute__((address_space(3))) void *)(tile + grp * 1024), 16, 0, 0);
+    if constexpr (UNTRACKED)
+        hive_mfma::lds_dma16_untracked((const void *)g, __builtin_amdgcn_readfirstlane(hive_mfma::lds_address(tile + grp * 1024)));
+    else
+        __builtin_amdgcn_global_load_lds((const void *)g, (__attribute__((address_space(3))) void *)(tile + grp * 1024), 16, 0, 0);
 }
 
 // Sum over the 8 lanes 8 g .. 8 g + 7 (half of a 16-lane DPP row), left in all of them: two quad permutes and a half-row mirror, three DPP
@@ -329,7 +336,9 @@ __global__ __launch_bounds__(256) void ln_fold_weights_kernel(const T *__restric
 // NST-stage LDS ring filled by LDS-DMA, ONE raw s_barrier per K-step.
 //   NST = 3: stages kt+1 and kt+2 in flight while kt is multiplied, counted s_waitcnt vmcnt (never 0 in the loop);
 //            144 KiB at TM = 256: one workgroup per CU.
-//   NST = 2 (used): 64 KiB at TM = 128, so TWO workgroups share a CU and one's prologue (first stage in flight) and
+//   NST = 4 (round 4, where the items do not fill the CUs -- small batches): three stages in flight.  With one workgroup on a CU nothing hides a
+//            stage's trip from HBM / L2 (~1.2 us behind ~0.5 us of issue for 32 KiB), and with two stages a K-step lasted as long as that trip.
+//   NST = 2 (used otherwise): 64 KiB at TM = 128, so TWO workgroups share a CU and one's prologue (first stage in flight) and
 //            epilogue (GELU, stores) overlap the other's K loop -- at K = 768 a tile is only 12 K-steps long and those
 //            ends were a third of its time.  Measured at M = 19456: 640 -> 664 (qkv), 491 -> 529 (proj), 689 -> 730
 //            (fc2) TFLOP/s against TM = 256 / NST = 3.  Also measured and not kept: 256 x 256 tiles with 128 x 128 per
@@ -351,50 +360,78 @@ __global__ __launch_bounds__(TM * 2, 1) void gemm_kernel(GemmParams<T> p) {
     // and its workgroups walk the run with a stride of gridDim / 8.  The K-steps of a workgroup's tiles form ONE stream: the
     // first stage of the next tile is prefetched between the MFMAs of the last K-step of the current one and lands while its
     // epilogue (GELU, residual, stores) runs -- at K = 768 a tile is 12 steps, and its exposed first fill was a step's worth.
-    const int tiles_n = p.N / BN, n_tiles = ((p.M + TM - 1) / TM) * tiles_n;
+    // Items = tiles x split_k (split_k = 1 except at small M): item i multiplies K-steps [k0, k1) of tile i / split_k.
+    const int S = p.split_k, KT = p.K / BK;
+    const int tiles_n = p.N / BN, n_tiles = ((p.M + TM - 1) / TM) * tiles_n * S;
     const int xcd = blockIdx.x & 7, per_xcd = gridDim.x >> 3, tq = n_tiles >> 3, tr = n_tiles & 7;
     const int run0 = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq, run_n = tq + (xcd < tr ? 1 : 0);
     int tl = blockIdx.x >> 3;  // position in the XCD's run
     if (tl >= run_n) return;   // (whole workgroup)
-    int m0 = ((run0 + tl) / tiles_n) * TM, n0 = ((run0 + tl) % tiles_n) * BN;
+    auto coords = [&](int item, int &m, int &n, int &ka, int &kb) {
+        const int t = item / S, s = item - t * S;
+        m = (t / tiles_n) * TM;
+        n = (t % tiles_n) * BN;
+        ka = s * KT / S;
+        kb = (s + 1) * KT / S;
+    };
+    int m0, n0, k0, k1;
+    coords(run0 + tl, m0, n0, k0, k1);
 
-    static_assert(NST == 2, "the K-step below issues the next stage between its MFMA slots: two stages");
     // one LDS-DMA wave-instruction: group g = wave + j * NWAVES (8 rows x 128 B of A or of W) of K-step kt of tile (tm0, tn0)
     auto issue_piece = [&](int tm0, int tn0, int kt, int buf, int j) {
         unsigned char *st = lds + buf * STAGE_BYTES;
         const int g = wave + j * NWAVES;
         if (g < A_GROUPS)
-            stage_group(p.A, p.K, tm0, p.M - 1, kt * BK, st, g, lane);
+            stage_group<T, (NST > 2)>(p.A, p.K, tm0, p.M - 1, kt * BK, st, g, lane);
         else
-            stage_group(p.W, p.K, tn0, p.N - 1, kt * BK, st + A_GROUPS * 1024, g - A_GROUPS, lane);
+            stage_group<T, (NST > 2)>(p.W, p.K, tn0, p.N - 1, kt * BK, st + A_GROUPS * 1024, g - A_GROUPS, lane);
     };
-
-    const int KT = p.K / BK;
+    // The K-steps of a workgroup's items form ONE stream; the stage being ISSUED runs AHEAD = NST - 1 steps in front of the one being multiplied
+    // (across item boundaries: the next item's first stages land while this one's epilogue runs).  Past the end of the stream the cursor parks on
+    // the last stage, which is issued again into a buffer nobody reads any more: the counted waits below rely on every step issuing a stage.
+    constexpr int AHEAD = NST - 1;
+    struct Cursor {
+        int m0, n0, kt, k1, tl;
+    } is = {m0, n0, k0, k1, tl};
+    auto advance = [&](Cursor &c) {
+        if (c.kt + 1 < c.k1) {
+            ++c.kt;
+        } else if (c.tl + per_xcd < run_n) {
+            c.tl += per_xcd;
+            coords(run0 + c.tl, c.m0, c.n0, c.kt, c.k1);
+        }
+    };
 #pragma unroll
-    for (int j = 0; j < PER_WAVE; ++j) issue_piece(m0, n0, 0, 0, j);
+    for (int a = 0; a < AHEAD; ++a) {
+#pragma unroll
+        for (int j = 0; j < PER_WAVE; ++j) issue_piece(is.m0, is.n0, is.kt, a, j);
+        advance(is);
+    }
     const int fr = lane & 15, fq = lane >> 4;
-    int buf = 0;  // LDS stage of the current K-step (alternates along the whole stream)
+    int buf = 0;  // LDS stage of the current K-step (cycles along the whole stream)
     for (;;) {
     const bool has_next = tl + per_xcd < run_n;
-    const int nm0 = has_next ? ((run0 + tl + per_xcd) / tiles_n) * TM : m0, nn0 = has_next ? ((run0 + tl + per_xcd) % tiles_n) * BN : n0;
     f32x4 acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int kt = 0; kt < KT; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int kt = k0; kt < k1; ++kt) {
+        // this step's stage has landed when at most the AHEAD - 1 younger stages' pieces are outstanding (LDS-DMA loads retire in order)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AHEAD - 1) * PER_WAVE) : "memory");
         __builtin_amdgcn_s_barrier();  // everyone's current stage landed; everyone finished reading the previous one
-        // the next stage of the stream (next K-step; first K-step of the next tile; at the very end the last stage again,
-        // into the buffer nobody reads any more) goes out piece by piece between this step's MFMA slots (mfma_pipe.hpp)
-        const bool last = kt + 1 == KT;
-        const int sm0 = last ? nm0 : m0, sn0 = last ? nn0 : n0, sk = last ? (has_next ? 0 : KT - 1) : kt + 1;
+        // the stage AHEAD steps on goes out piece by piece between this step's MFMA slots (mfma_pipe.hpp), into the buffer the previous step read
+        const int ib = buf + AHEAD >= NST ? buf + AHEAD - NST : buf + AHEAD;
         const unsigned char *a_t = lds + buf * STAGE_BYTES, *w_t = a_t + A_GROUPS * 1024;
         // VT: acc[mt][nt] = A_frag . W_frag^T (rows = m, cols = n); else acc[nt][mt] = W_frag . A_frag^T (rows = n, cols = m)
-        hive_mfma::kstep64<T, 4, VT>(a_t, w_t, wr * 64, wc * 64, fr, fq, acc, PER_WAVE, [&](int j) { issue_piece(sm0, sn0, sk, buf ^ 1, j); });
-        buf ^= 1;
+        hive_mfma::kstep64<T, 4, VT>(a_t, w_t, wr * 64, wc * 64, fr, fq, acc, PER_WAVE, [&](int j) { issue_piece(is.m0, is.n0, is.kt, ib, j); });
+        advance(is);
+        buf = buf + 1 == NST ? 0 : buf + 1;
     }
 
+    bool store = true;
+    if (S > 1) store = hive_mfma::splitk_combine<TM * 2>(S, p.sk_ws, p.sk_count, run0 + tl, acc, tid, reinterpret_cast<int *>(lds + NST * STAGE_BYTES));
+    if (store) {
     // epilogue
     if constexpr (!VT) {
         gemm_store_rows<T, EPI, 4>(p, acc, m0 + wr * 64, n0 + wc * 64, lds + NST * STAGE_BYTES + wave * 4096, lane);
@@ -446,10 +483,15 @@ __global__ __launch_bounds__(TM * 2, 1) void gemm_kernel(GemmParams<T> p) {
             __builtin_amdgcn_wave_barrier();  // the second half's writes stay behind these reads
         }
     }
+    }  // store
     if (!has_next) break;
+    // The deep ring counts its own (untracked) pieces, so nothing else may be outstanding in the K loop -- neither in fact (an epilogue's stores and a
+    // stage's loads do not retire in one order) nor in the compiler's books: a residual row loaded ahead for a row past M is never consumed, and hipcc
+    // then waits for it where its register is next written -- an s_waitcnt vmcnt(0..1) at the top of EVERY K-step, which drained the ring.  A wait the
+    // compiler can see (the builtin, not an asm statement) settles both.
+    if constexpr (NST > 2) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), nothing else
     tl += per_xcd;
-    m0 = nm0;
-    n0 = nn0;
+    coords(run0 + tl, m0, n0, k0, k1);
     }  // persistent tile loop
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the redundant last stage
 }
@@ -986,8 +1028,9 @@ static int launch_layernorm(hive_ctx *ctx, const void *x, const float *g, const 
     return HIVE_OK;
 }
 
-constexpr int GEMM_TM = 128, GEMM_NST = 2;
-constexpr size_t GEMM_LDS = (size_t)GEMM_NST * (GEMM_TM / 8 + 16) * 1024 + (GEMM_TM / 32) * 4096;  // the stages + 4 KiB per wave for the epilogue: 80 KiB, two workgroups per CU
+constexpr int GEMM_TM = 128, GEMM_NST = 2, GEMM_NST_DEEP = 4;
+constexpr size_t gemm_lds(int nst) { return (size_t)nst * (GEMM_TM / 8 + 16) * 1024 + (GEMM_TM / 32) * 4096; }  // the stages + 4 KiB per wave for the epilogue
+constexpr size_t GEMM_LDS = gemm_lds(GEMM_NST), GEMM_LDS_DEEP = gemm_lds(GEMM_NST_DEEP);  // 80 KiB: two workgroups per CU; 144 KiB: one
 constexpr int GEMM256_LDS = 2 * T256_STAGE + hive_mfma::STAGED_ROWS_LDS;
 
 template <typename T>
@@ -1037,12 +1080,37 @@ static int launch_gemm(hive_ctx *ctx, int epi, const GemmParams<T> &p) {
     // (Round 4, measured and taken out: 64-row tiles (two waves, 56 KiB of LDS) where fewer 128-row tiles than CUs exist -- the reference's literal
     // loop is batch 1, M = 1216: 60 tiles for proj / fc2.  5.38 vs 5.35 ms per one-frame forward: at one tile per CU a GEMM is as long as its K loop
     // (12-48 steps of ~0.8-1.5 us), whatever the tile's height; small batches want the K loop split, not the tile.)
-    const dim3 grid((unsigned)std::min<long long>((tiles + 7) / 8 * 8, (long long)(2 * ctx->num_cus) / 8 * 8)), block(GEMM_TM * 2);
+    // Split-K for long K loops on few tiles (mfma_pipe.hpp splitk_combine / splitk_ways): the reference's literal loop is batch 1 -- M = 1216: 60 tiles
+    // for fc2, whose K loop of 48 steps WAS that GEMM's duration.  HIVE_SPLITK=0 switches it off, n forces n ways.
+    GemmParams<T> q = p;
+    const long long slots = (long long)(2 * ctx->num_cus) / 8 * 8;
+    const char *sk_env = getenv("HIVE_SPLITK");
+    q.split_k = sk_env ? std::max(1, std::min(atoi(sk_env), p.K / BK)) : hive_mfma::splitk_ways(tiles, p.K / BK, ctx->num_cus);
+    if (tiles > HIVE_SPLITK_TILES) q.split_k = 1;
+    if (q.split_k > 1) {
+        void *ws = nullptr;
+        int rc = hive_splitk_workspace(ctx, (size_t)tiles * q.split_k * GEMM_TM * BN * sizeof(float), &ws, &q.sk_count);
+        if (rc) return rc;
+        q.sk_ws = reinterpret_cast<hive_mfma::f32x4 *>(ws);
+    }
+    const long long items = tiles * q.split_k;
+    // the deep ring (one workgroup per CU) where the items fit the CUs in one round anyway; HIVE_GEMM_RING=2 / 4 forces a depth
+    const char *ring_env = getenv("HIVE_GEMM_RING");
+    const bool deep = ring_env ? ring_env[0] == '4' : items <= ctx->num_cus;
+    const dim3 grid((unsigned)std::min<long long>((items + 7) / 8 * 8, deep ? (long long)ctx->num_cus / 8 * 8 : slots)), block(GEMM_TM * 2);
+#define HIVE_GEMM_CASE(EPI_)                                                                                                          \
+    case EPI_:                                                                                                                        \
+        if (deep)                                                                                                                     \
+            hipLaunchKernelGGL((gemm_kernel<T, EPI_, GEMM_TM, GEMM_NST_DEEP>), grid, block, GEMM_LDS_DEEP, ctx->stream, q);            \
+        else                                                                                                                          \
+            hipLaunchKernelGGL((gemm_kernel<T, EPI_, GEMM_TM, GEMM_NST>), grid, block, GEMM_LDS, ctx->stream, q);                      \
+        break
     switch (epi) {
-        case EPI_BIAS: hipLaunchKernelGGL((gemm_kernel<T, EPI_BIAS, GEMM_TM, GEMM_NST>), grid, block, GEMM_LDS, ctx->stream, p); break;
-        case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm_kernel<T, EPI_BIAS_GELU, GEMM_TM, GEMM_NST>), grid, block, GEMM_LDS, ctx->stream, p); break;
-        case EPI_BIAS_RESIDUAL: hipLaunchKernelGGL((gemm_kernel<T, EPI_BIAS_RESIDUAL, GEMM_TM, GEMM_NST>), grid, block, GEMM_LDS, ctx->stream, p); break;
-        case EPI_QKV: hipLaunchKernelGGL((gemm_kernel<T, EPI_QKV, GEMM_TM, GEMM_NST>), grid, block, GEMM_LDS, ctx->stream, p); break;
+        HIVE_GEMM_CASE(EPI_BIAS);
+        HIVE_GEMM_CASE(EPI_BIAS_GELU);
+        HIVE_GEMM_CASE(EPI_BIAS_RESIDUAL);
+        HIVE_GEMM_CASE(EPI_QKV);
+#undef HIVE_GEMM_CASE
         default: return hive_fail(ctx, HIVE_ERR_INVALID, "gemm: unknown epilogue %d", epi);
     }
     HIVE_CHECK_HIP(ctx, hipGetLastError());
@@ -1055,6 +1123,7 @@ static int ensure_gemm_attrs(hive_ctx *ctx) {
     if (ctx->device < 64 && set[ctx->device]) return HIVE_OK;
 #define HIVE_GEMM_ATTR(EPI_)                                                                                                                                  \
     HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)gemm_kernel<T, EPI_, GEMM_TM, GEMM_NST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS)); \
+    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)gemm_kernel<T, EPI_, GEMM_TM, GEMM_NST_DEEP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_DEEP)); \
     HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)gemm256p_kernel<T, EPI_>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM256_LDS))
     HIVE_GEMM_ATTR(EPI_BIAS);
     HIVE_GEMM_ATTR(EPI_BIAS_GELU);

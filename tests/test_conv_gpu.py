@@ -218,6 +218,64 @@ def test_stem_conv_and_maxpool_match_torch(gpu_ctx, half, n, h, w):
     assert (one.float() - ref_n).abs().max().item() <= 4 * _ulp(half) * max(ref_n.abs().max().item(), 1.0)
 
 
+@pytest.mark.parametrize("n,cin,cout,h,w", [
+    (1, 256, 256, 24, 32),    # 6 x 2 tiles of 128 x 128, 36 K-steps: split four ways by the launch policy
+    (1, 256, 256, 15, 20),    # M = 300: a ragged last tile
+    (2, 512, 128, 30, 40),    # 72 K-steps, one column of tiles
+    (1, 64, 256, 60, 80),     # 9 K-steps: the ring alone
+])
+def test_conv_small_launches_deep_ring_and_split_k(gpu_ctx, half, monkeypatch, n, cin, cout, h, w):
+    """Launches that do not fill the chip (the reference's literal loop is one frame per forward) run conv_deep_kernel: 128 x 128 tiles, a four-stage
+    ring and, for long K loops, split-K.  Without the split (HIVE_SPLITK=0) its results are BIT-IDENTICAL to conv_kernel's (HIVE_CONV_DEEP=0): the same
+    K order into the same accumulators; split 2 / 5 / 7 ways and by the launch policy they are within the float32 reference's bound, reproducible
+    from run to run, and untouched by another input's partials left in the workspace.  All four epilogues: plain, bias + ReLU, two shortcuts, and
+    the GroupNorm statistics."""
+    from hive_amd.dpt import ops
+    x, conv = _mk(n, cin, cout, h, w, bias=True, seed=cin + h, half=half)
+    g = torch.Generator(device="cpu").manual_seed(3)
+    r1 = torch.randn(n, cout, h, w, generator=g).to(half).cuda().contiguous(memory_format=torch.channels_last)
+    r2 = torch.randn(n, cout, h, w, generator=g).to(half).cuda().contiguous(memory_format=torch.channels_last)
+    x2 = (x.float() * 0.5 + 1.0).to(half).contiguous(memory_format=torch.channels_last)
+    base = F.conv2d(x.float(), conv.weight.float(), conv.bias.float(), 1, 1)
+
+    def run(inp=x):
+        a = ops.conv3x3(inp, conv, relu=True)
+        b, b_relu = ops.conv3x3(inp, conv, residual=r1, residual2=r2, also_relu=True)
+        c = ops.conv2d(inp, conv, gn_stats=True)
+        partial, tile_rows = c.hive_gn_stats
+        used = ((c.numel() // cout + tile_rows - 1) // tile_rows) * 4 * cout if tile_rows else 0  # (the rest of the buffer is never written)
+        return a, b, b_relu, c, partial[:used].clone(), tile_rows
+
+    monkeypatch.setenv("HIVE_CONV_DEEP", "0")
+    plain = run()
+    monkeypatch.setenv("HIVE_CONV_DEEP", "1")
+    monkeypatch.setenv("HIVE_SPLITK", "0")
+    ring = run()
+    for got, want in zip(ring[:4], plain[:4]):
+        assert torch.equal(got, want), "the ring alone must not change a bit"
+    for ways in (None, "2", "5", "7"):
+        if ways is None:
+            monkeypatch.delenv("HIVE_SPLITK")
+        else:
+            monkeypatch.setenv("HIVE_SPLITK", ways)
+        first = run()
+        _check(first[0], F.relu(base), f"split {ways}: bias + relu")
+        _check(first[1], base + r1.float() + r2.float(), f"split {ways}: two shortcuts")
+        assert torch.equal(first[2], F.relu(first[1]))
+        _check(first[3], base, f"split {ways}: plain with statistics")
+        tile_rows = first[5]
+        if tile_rows:  # the sums are those of the stored values
+            rows = first[3].permute(0, 2, 3, 1).reshape(-1, cout).double()
+            n_tiles = (rows.shape[0] + tile_rows - 1) // tile_rows
+            got = first[4].view(n_tiles, 2, 2, cout).double().sum((0, 1))
+            assert torch.allclose(got[0], rows.sum(0), rtol=1e-5, atol=1e-2) and torch.allclose(got[1], (rows ** 2).sum(0), rtol=1e-5, atol=1e-2)
+        for _ in range(3):
+            run(x2)  # another input's partials at the same workspace addresses
+            again = run()
+            for got, want in zip(again[:5], first[:5]):
+                assert torch.equal(got, want), f"split {ways}: not reproducible"
+
+
 @pytest.mark.parametrize("n,cin,cout,k,stride,h,w", [
     (3, 64, 256, 1, 1, 20, 24),     # HW = 480: the 256-row tiles straddle the samples; 256 output channels (one N tile)
     (2, 256, 64, 1, 1, 40, 56),     # 64 output channels: 8 waves of 32 rows

@@ -514,3 +514,30 @@ def test_clip_of_rows_parallel_to_the_image_plane(gpu_ctx, oracle_lib):
     for i in (2, 3):
         ora_pair.integrate(seq["color"][i], depth[i], seq["K"], seq["poses"][i])
     assert np.array_equal(pair.get_volume(with_weight=True)[2], ora_pair._weight)
+
+
+@pytest.mark.parametrize("mode", ["0", "1", "2"])
+def test_per_row_far_cut_modes(gpu_ctx, oracle_lib, monkeypatch, mode):
+    """The work list's per-row far cut (largest depth in the tiles a row's image segment crosses) is chosen per frame from the tile table
+    (HIVE_TSDF_ROW_FAR=1, the default); 0 / 2 force it off / on.  All three give the oracle's volume on a scene where it cuts (foreground-masked
+    depth: most tiles empty) and on one where it does not (the room), fused sweeps and the single-frame kernel."""
+    import torch
+    from hive_amd import fusion, synthetic
+    monkeypatch.setenv("HIVE_TSDF_ROW_FAR", mode)
+    seq = synthetic.make_sequence(num_frames=6, height=240, width=320, yaw_step_deg=6.0, seed=11)
+    masks = synthetic.ellipse_masks(6, 240, 320, num_objects=2, seed=3)
+    items = {}
+    for name, depth in (("room", seq["depth"]), ("masked", np.where(masks > 0, seq["depth"], 0).astype(np.float32))):
+        ora = oracle_lib.TSDFVolume(synthetic.room_bounds(), 0.025)
+        for i in range(6):
+            ora.integrate(seq["color"][i], depth[i], seq["K"], seq["poses"][i])
+        fused = fusion.TSDFVolume(synthetic.room_bounds(), 0.025, ctx=gpu_ctx)
+        fused.integrate_batch(torch.from_numpy(seq["color"]).cuda(), torch.from_numpy(depth).cuda(), seq["K"], seq["poses"])
+        assert fused.last_batch_groups() == [4, 2]
+        items[name] = fused.last_sweep_voxels()
+        _volumes_equal(fused, ora)
+        one = fusion.TSDFVolume(synthetic.room_bounds(), 0.025, ctx=gpu_ctx)
+        for i in range(6):
+            one.integrate(seq["color"][i], depth[i], seq["K"], seq["poses"][i])
+        _volumes_equal(one, ora)
+    assert items["masked"] < items["room"]

@@ -81,6 +81,54 @@ def test_linear_epilogues(gpu_ctx, half, M, N, K, epi):
         assert torch.equal(inplace, C)
 
 
+@pytest.mark.parametrize("M,N,K,epi", [(1216, 768, 3072, 2), (1216, 3072, 768, 1), (769, 1536, 768, 0), (300, 768, 704, 2)])
+def test_linear_split_k(gpu_ctx, half, monkeypatch, M, N, K, epi):
+    """Small M (the reference's literal loop is batch 1): the K-steps of a tile are dealt to several workgroups, the last one to arrive adds the f32
+    partials in a fixed order and runs the epilogue (csrc/mfma_pipe.hpp splitk_combine).  HIVE_SPLITK = 0 (off), unset (the launch policy), 5 and 7
+    (ways that do not divide the 11 / 12 / 48 K-steps): all within the float32 reference's tolerance, each bit-identical from run to run (the arrival
+    order does not enter the sum; the counters are back at zero for the next launch), and within one 16-bit step of the unsplit result."""
+    import torch
+    torch.manual_seed(3)
+    A = torch.randn(M, K, device="cuda").to(half)
+    W = (torch.randn(N, K, device="cuda") / K ** 0.5).to(half)
+    bias = torch.randn(N, device="cuda") * 0.1
+    res = torch.randn(M, N, device="cuda").to(half)
+    ref = A.float() @ W.float().t() + bias
+    if epi == 1:
+        ref = torch.nn.functional.gelu(ref)
+    if epi == 2:
+        ref = ref + res.float()
+    out = {}
+    for ways in ("0", None, "5", "7"):
+        if ways is None:
+            monkeypatch.delenv("HIVE_SPLITK", raising=False)
+        else:
+            monkeypatch.setenv("HIVE_SPLITK", ways)
+        runs = []
+        for _ in range(3):
+            C = torch.empty(M, N, device="cuda", dtype=half)
+            gpu_ctx.check(gpu_ctx.lib.hive_vit_linear(gpu_ctx.handle, A.data_ptr(), _code(half), W.data_ptr(), bias.data_ptr(), res.data_ptr() if epi == 2 else None,
+                                                      C.data_ptr(), M, N, K, epi))
+            runs.append(C)
+        assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2]), f"split {ways}: not reproducible"
+        # the same workspace addresses carry another input's partials in between: a stale partial (a line a CU or an XCD still holds from the launch before)
+        # would show as the other input's numbers
+        A2, C2 = (A.float() * 0.5 + 1.0).to(half), torch.empty(M, N, device="cuda", dtype=half)
+        for _ in range(6):
+            gpu_ctx.check(gpu_ctx.lib.hive_vit_linear(gpu_ctx.handle, A2.data_ptr(), _code(half), W.data_ptr(), bias.data_ptr(), res.data_ptr() if epi == 2 else None,
+                                                      C2.data_ptr(), M, N, K, epi))
+            C = torch.empty(M, N, device="cuda", dtype=half)
+            gpu_ctx.check(gpu_ctx.lib.hive_vit_linear(gpu_ctx.handle, A.data_ptr(), _code(half), W.data_ptr(), bias.data_ptr(), res.data_ptr() if epi == 2 else None,
+                                                      C.data_ptr(), M, N, K, epi))
+            assert torch.equal(C, runs[0]), f"split {ways}: a launch saw another launch's partials"
+        _close(runs[0], ref, f"linear epi={epi} split={ways}")
+        out[ways] = runs[0].float()
+    step = 2.0 ** (-7 if half == torch.bfloat16 else -10)
+    for ways in (None, "5", "7"):
+        d = (out[ways] - out["0"]).abs()
+        assert bool((d <= step * out["0"].abs().clamp_min(2.0 ** -6) * 1.01).all()), f"split {ways}: more than one step from the unsplit result"
+
+
 def test_linear_asymmetric_identity(gpu_ctx, half):
     """A = I with an asymmetric W catches a transposed C write (a symmetric operand would hide it)."""
     import torch
