@@ -581,7 +581,7 @@ def main():
         return
     dims = "x".join(str(int(d)) for d in (merger.dims if exact else volume.vol_dim))
     merge_note = ""
-    scaling = None if world == 1 else ("strong" if headline_strong else "weak")
+    scaling = "strong" if headline_strong else "weak"  # (N = 1: the weak job's one-rank case -- per-GPU work fixed as N grows)
     if world > 1:
         share = (f"the same {args.steps} x {B} frames split in contiguous blocks over the ranks" if headline_strong
                  else f"{world} x {args.steps} x {B} frames, a contiguous block of {args.steps} steps per rank")

@@ -143,9 +143,14 @@ __device__ __forceinline__ void load_dilated_tiles(const unsigned *__restrict__ 
     __syncthreads();
     unsigned m_all = 0;
     float sum = 0.f;
+    const int reach = max(1, min(tiles_x, tiles_y) / 5);  // a row's image segment crosses many tiles: what it can gain is what a WIDE neighbourhood's maximum leaves
     for (int t = tid; t < tiles; t += nthreads) {
         m_all = max(m_all, bits[t]);
-        sum += dil[t];
+        const int ty = t / tiles_x, tx = t - ty * tiles_x;
+        unsigned w = 0u;
+        for (int yy = max(ty - reach, 0); yy <= min(ty + reach, tiles_y - 1); ++yy)
+            for (int xx = max(tx - reach, 0); xx <= min(tx + reach, tiles_x - 1); ++xx) w = max(w, bits[yy * tiles_x + xx]);
+        sum += __uint_as_float(w);
     }
     for (int off = 32; off > 0; off >>= 1) {
         m_all = max(m_all, (unsigned)__shfl_xor((int)m_all, off));
@@ -158,9 +163,10 @@ __device__ __forceinline__ void load_dilated_tiles(const unsigned *__restrict__ 
 }
 // The per-row far cut pays where the depth map has large regions much nearer than its deepest pixel (masked foreground / background depth, a near
 // object filling part of the view); walking a row's image segment over the tile table costs ~9 us per four-frame sweep at 512^3 (a third of the
-// work-list kernel).  Its best case removes (1 - mean(tile maxima) / max) of the rows' depth range, so a frame whose dilated tile maxima average
-// above 70 % of its maximum keeps the frame's bound for all rows: measured on the two bench scenes (probe_sweep_ab.py), where the cut removed
-// 0.7 % (room) and 0.01 % (DPT depth of the seeded weights) of the work list and cost 2-4 us per frame.  HIVE_TSDF_ROW_FAR=0 / 2 force it off / on.
+// work-list kernel).  Its best case removes about (1 - mean(w) / max) of the rows' depth range, w = the table's maximum over a neighbourhood a fifth of
+// the image wide (a row's segment crosses that many tiles), so a frame with mean(w) above 70 % of its maximum keeps the frame's bound for all rows:
+// on the two bench scenes (probe_sweep_ab.py) the cut removed 0.7 % (room) and 0.01 % (DPT depth of the seeded weights: noise-like, every region holds a
+// pixel near the maximum) of the work list and cost 2-4 us per frame.  HIVE_TSDF_ROW_FAR=0 / 2 force it off / on.
 __device__ __forceinline__ bool row_far_pays(float gsum, unsigned gmax_bits, int tiles) { return gsum < 0.70f * (float)tiles * __uint_as_float(gmax_bits); }
 
 // Clip the row cam(tz) = a + b*tz against the padded frustum.  Conservative: pixel bounds widened by
