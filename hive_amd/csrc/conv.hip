@@ -441,7 +441,7 @@ __global__ __launch_bounds__(512, 1) void conv_kernel(ConvParams<T> p) {
 // launch lasts as long as ONE workgroup's K loop, and with two stages each of its steps waited a whole trip to L2 / HBM for the next stage (2 us
 // per step for a 48 KiB stage: 72 us for a 3 x 3 convolution of 256 channels on 6 tiles).  Differences from conv_kernel: the stage being issued runs
 // AHEAD = NST - 1 steps in front of the one being multiplied, along ONE stream of (item, K-step)s; the pieces are issued through
-// hive_mfma::lds_dma16_untracked and counted by hand (hipcc waits for every LDS-DMA it knows of in front of the next ds_read: vmcnt(0) every step);
+// hive_mfma::lds_dma16_untracked and counted by hand (no wait of the compiler's own may sit in the K loop: mfma_pipe.hpp);
 // an item = (tile, split s) multiplies K-steps [s KT / S, (s + 1) KT / S) and the last of a tile's items to finish adds the partials in a fixed
 // order and runs the epilogue (splitk_combine).  Epilogues, K order (channel block outer, tap inner) and results are conv_kernel's.
 template <typename T, int TN, int GN, int NST>

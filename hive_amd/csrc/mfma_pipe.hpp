@@ -32,11 +32,17 @@ __device__ __forceinline__ f32x4 mfma16(vec<_Float16, 8> a, vec<_Float16, 8> b, 
 __device__ __forceinline__ f32x16 mfma32(vec<__bf16, 8> a, vec<__bf16, 8> b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x16 mfma32(vec<_Float16, 8> a, vec<_Float16, 8> b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 
-// One LDS-DMA wave instruction (64 lanes x 16 B, lane-linear, to the wave-uniform LDS address lds_dst) that the COMPILER DOES NOT SEE: hipcc cannot tell
-// which LDS bytes a global_load_lds writes, so in front of the first ds_read that follows one it waits for ALL of them (s_waitcnt vmcnt(0)) -- harmless with
-// two stages, where the step waits for everything anyway, but it silently drains a deeper ring every K-step.  The rings deeper than two stages issue their pieces
-// through this statement and count vmcnt by hand (the CDNA4 guide's recipe: M0 holds the LDS base and is compiler-reserved, so it is saved and put back).
+// One LDS-DMA wave instruction (64 lanes x 16 B, lane-linear, to the wave-uniform LDS address lds_dst) outside the compiler's wait-count bookkeeping.  The rings
+// deeper than two stages count vmcnt BY HAND (s_waitcnt vmcnt(pieces of the younger stages)): any wait hipcc adds inside the K loop on its own account
+// drains the ring every step, silently (it shows only in the ISA).  The one such wait found here came from ordinary loads (see the builtin s_waitcnt behind the
+// deep kernels' epilogues); hipcc 7.2 did not add one for the builtin LDS-DMA itself in these kernels (-DHIVE_LDSDMA_TRACKED builds them that way: same ISA
+// waits), but it can (the CDNA4 guide reports an s_waitcnt vmcnt(0) in front of the first ds_read of every K-step once a second LDS object exists), so the
+// deep rings keep their pieces out of its books altogether.  M0 holds the LDS base and is compiler-reserved: saved, set, put back (the guide's recipe).
 __device__ __forceinline__ void lds_dma16_untracked(const void *gsrc, unsigned lds_dst) {
+#ifdef HIVE_LDSDMA_TRACKED  // (tuning build: the compiler's own LDS-DMA)
+    __builtin_amdgcn_global_load_lds(gsrc, (__attribute__((address_space(3))) void *)(size_t)lds_dst, 16, 0, 0);
+    return;
+#endif
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
