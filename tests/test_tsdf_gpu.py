@@ -370,7 +370,7 @@ def test_multi_frame_grouping_edge_cases(gpu_ctx, oracle_lib, case):
     """How hive_tsdf_integrate_batch forms its sweeps (tsdf.hip `fusable`), each case bit for bit against the C oracle's serial
     loop and with the expected grouping asserted: five frames (4 + 1), a group broken by the camera moving more than a quarter
     of the volume's longest side, a group broken by the 36 degree limit to its FIRST frame, an all-zero depth map inside a
-    group, an observation weight other than 1, and Z % 4 != 0 (no fused sweep: the scalar kernel, one frame per launch)."""
+    group, an observation weight other than 1, and Z % 4 != 0 (rows of any length fuse since round 3: the same 4 + 1 sweeps, the rows' tails masked)."""
     import torch
     from hive_amd import fusion, synthetic
     bounds, voxel, obs_w, zero = synthetic.room_bounds(), 0.04, 1.0, ()

@@ -18,11 +18,15 @@ from hive_amd import _lib, depth as depth_mod, fusion, synthetic  # noqa: E402
 
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 scenes = sys.argv[2:] or ["room", "dpt"]
-seq = synthetic.make_sequence(num_frames=frames, yaw_step_deg=2.4)
+# PROBE_SIZE=HxW and PROBE_VOL=n (voxels per side of the 5.12 m room volume) select another shape (BASELINE config 4: 1080x1920, 1024; room scene only)
+H, W = (int(v) for v in os.environ.get("PROBE_SIZE", "480x640").split("x"))
+side = int(os.environ.get("PROBE_VOL", "512"))
+seq = synthetic.make_sequence(num_frames=frames, height=H, width=W, yaw_step_deg=2.4)
 ctx = _lib.default_context(0)
-n_vox = 512 ** 3
+n_vox = side ** 3
 storage = tuple(torch.empty(n_vox, dtype=torch.float32, device="cuda") for _ in range(3))
-vol = fusion.TSDFVolume(synthetic.room_bounds(), 0.01, ctx=ctx, storage=storage)
+vol = fusion.TSDFVolume(synthetic.room_bounds(), 5.12 / side, ctx=ctx, storage=storage)
+assert tuple(int(d) for d in vol.vol_dim) == (side, side, side), vol.vol_dim
 color = torch.from_numpy(seq["color"]).cuda()
 depths = {}
 if "room" in scenes:
