@@ -123,6 +123,10 @@ struct GemmParams {
 
 constexpr int BN = 128, BK = 64;
 
+#ifndef HIVE_GEMM_ABLATE
+#define HIVE_GEMM_ABLATE 0  // tuning builds only (make ablate_gemm; tools/probe_gemm_tiles.py with HIVE_AMD_LIB=...): 1 = gemm256p_kernel without its epilogue
+#endif
+
 // erf-GELU (nn.GELU default): 0.5 x (1 + erf(x / sqrt 2)).  erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7,
 // three orders of magnitude below the bf16 output step) on the hardware rcp / exp2: ~14 instructions
 // instead of libm erff's ~45 -- the GELU epilogue was 28 us of the 100 us fc1 GEMM.
@@ -228,7 +232,10 @@ __device__ __forceinline__ void gemm_store_rows(const GemmParams<T> &p, const f3
         vec<T, 8> ov;
 #pragma unroll
         for (int k = 0; k < 8; ++k) ov[k] = (T)o[k];
-        *reinterpret_cast<vec<T, 8> *>(p.C + (size_t)m * p.ldc + n) = ov;
+        if constexpr (HIVE_GEMM_ABLATE & 2)  // tuning build: everything but the store itself
+            asm volatile("" ::"v"(ov));
+        else
+            *reinterpret_cast<vec<T, 8> *>(p.C + (size_t)m * p.ldc + n) = ov;
         if (ln_out) {
             // statistics of the STORED (rounded) values of this row's 64 columns: the 8 lanes of the row sit side by side (lane & 7); the sum
             // of squares is taken about the 64 values' own mean (ln_finalize_kernel merges the groups exactly: no E[x^2] - mean^2 cancellation)
@@ -606,6 +613,13 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(GemmParams<T> p) {
 #endif
 }
 
+// What the epilogues cost at the bench batch (M = 130112; `make ablate_gemm`, tools/probe_gemm_tiles.py): without its epilogue the K loops of q|k run in 231 us
+// (1330 TFLOP/s) against 347 with it, proj 115 / 209, fc1 + GELU 417 / 756, fc2 507 / 572 -- 7.3 ms of a 76 ms forward; with everything but the store
+// instructions 261 / 174 / 587 / 541.  Measured INTERLEAVED in one process (the clock drifts over a run: a first comparison across processes showed gains that
+// were drift): non-temporal stores of C change nothing (+-0.5 %; fc1 1.4 % slower), nor does starting every other workgroup half a tile late so that the
+// epilogues' stores do not hit HBM together.  The epilogue cannot overlap the next tile's K loop inside one workgroup (the accumulators are the registers), and two
+// co-resident workgroups need tiles of 128 x 256 at most (LDS), whose operand stream -- 1.5 x the bytes per flop through the CU's ~26 B/clk vector-memory path --
+// costs what the overlap gains (the 128 x 128 two-workgroup form measures 450 vs 347 us on q|k).
 // The same tile as PERSISTENT workgroups (one per CU, XCD-aware runs of tiles as in csrc/conv.hip): the K-steps of a workgroup's tiles
 // form one stream, the first stage of the next tile is issued during the last K-step of the current one and lands under its epilogue.
 template <typename T, int EPI>
@@ -674,7 +688,12 @@ __global__ __launch_bounds__(512, 1) void gemm256p_kernel(GemmParams<T> p) {
             buf ^= 1;
         }
         pipe.flush(acc);
-        if constexpr (!VT) {
+        if constexpr (HIVE_GEMM_ABLATE & 1) {  // tuning build (make ablate_gemm): the K loops alone -- the accumulators are kept alive, nothing is stored
+#pragma unroll
+            for (int i = 0; i < (VT ? 8 : 4); ++i)
+#pragma unroll
+                for (int j = 0; j < (VT ? 4 : 8); ++j) asm volatile("" ::"v"(acc[i][j]));
+        } else if constexpr (!VT) {
             gemm_store_rows<T, EPI, 8>(p, acc, em0 + wr * 128, en0 + wc * 64, lds + 2 * T256_STAGE + wave * 4096, lane);
         } else {
             // v^T[b][h][c][token]: the wave's 128 tokens x 64 channels are two 64-token blocks of one head (Np % 64 == 0), each 64 rows of
@@ -1068,7 +1087,7 @@ static int launch_gemm(hive_ctx *ctx, int epi, const GemmParams<T> &p) {
     // wherever they fill the chip: one workgroup per CU, so what matters is how full the last round of tiles is -- at M = 29184,
     // N = 768 there are 342 tiles for 256 CUs (67 %), at M = 19456 228 (89 %: 970 TFLOP/s), at M = 9728 114 (44 %); below 60 % the persistent
     // 128-row tiles (two workgroups per CU, 1368 tiles for 512 slots) win.
-    static const char *force = getenv("HIVE_GEMM_TILE");  // "256" / "128": tuning override
+    const char *force = getenv("HIVE_GEMM_TILE");  // "256" / "128": tuning override (read per call: tools/probe_gemm_tiles.py switches it inside one process)
     const long long tiles256 = (long long)((p.M + T256 - 1) / T256) * (p.N / T256);
     const long long rounds = (tiles256 + ctx->num_cus - 1) / ctx->num_cus;
     const bool fills = tiles256 * 5 >= rounds * ctx->num_cus * 3;  // >= 60 % of the CU slots of its rounds (67 %: 635 / 763 vs 612 / 705 TFLOP/s for proj / fc2 at M = 29184; 44 %: 655 vs 858)

@@ -15,11 +15,29 @@ def timed(fn, reps=20):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e-3
 print("HIVE_GEMM_TILE =", os.environ.get("HIVE_GEMM_TILE"))
-for (M, N, K, epi) in [(29184, 1536, 768, 0), (29184, 768, 768, 2), (29184, 3072, 768, 1), (29184, 768, 3072, 2), (19456, 1536, 768, 0), (19456, 768, 768, 2), (19456, 3072, 768, 1), (19456, 768, 3072, 2), (9728, 3072, 768, 1), (9728, 768, 3072, 2), (4096, 4096, 4096, 0), (19456 - 100, 768, 768, 0)]:
+KEYS = ("HIVE_GEMM_TILE", "HIVE_GEMM_RING")
+VARIANTS = [("policy", {}), ("256", {"HIVE_GEMM_TILE": "256"}), ("128x2st", {"HIVE_GEMM_TILE": "128", "HIVE_GEMM_RING": "2"})]
+if os.environ.get("PROBE_TILE_FORMS"):
+    VARIANTS += [("128x2st", {"HIVE_GEMM_TILE": "128", "HIVE_GEMM_RING": "2"}), ("128x4st", {"HIVE_GEMM_TILE": "128", "HIVE_GEMM_RING": "4"})]
+for (M, N, K, epi) in [(130112, 1536, 768, 0), (130112, 768, 768, 2), (130112, 3072, 768, 1), (130112, 768, 3072, 2)] + [(29184, 1536, 768, 0), (29184, 768, 768, 2), (29184, 3072, 768, 1), (29184, 768, 3072, 2), (19456, 1536, 768, 0), (19456, 768, 768, 2), (19456, 3072, 768, 1), (19456, 768, 3072, 2), (9728, 3072, 768, 1), (9728, 768, 3072, 2), (4096, 4096, 4096, 0), (19456 - 100, 768, 768, 0)]:
     A = torch.randn(M, K, device="cuda").bfloat16(); W = (torch.randn(N, K, device="cuda") / K ** 0.5).bfloat16(); b = torch.randn(N, device="cuda") * 0.1
     R = torch.randn(M, N, device="cuda").bfloat16()
     C = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
     run = lambda: ctx.check(lib.hive_vit_linear(ctx.handle, A.data_ptr(), DT, W.data_ptr(), b.data_ptr(), R.data_ptr() if epi == 2 else None, C.data_ptr(), M, N, K, epi))
+    if M == 130112:  # the bench batch (107 x 1216 rows): every variant, interleaved round-robin in one process (the clock drifts over a run: medians of 7 rounds)
+        times = {name: [] for name, _ in VARIANTS}
+        for rnd in range(7):
+            for name, env in VARIANTS:
+                for k in KEYS:
+                    os.environ.pop(k, None)
+                os.environ.update(env)
+                times[name].append(timed(run, reps=8))
+        for k in KEYS:
+            os.environ.pop(k, None)
+        med = {name: sorted(v)[len(v) // 2] for name, v in times.items()}
+        print(f"M={M} N={N} K={K} epi={epi}: " + " | ".join(f"{name} {t*1e6:7.1f} us {2*M*N*K/t/1e12:6.0f} TF/s" for name, t in med.items()), flush=True)
+    if os.environ.get("PROBE_BENCH_ONLY") and M != 130112:
+        continue
     dt = timed(run)
     ref = A.float() @ W.float().t() + b
     if epi == 1: ref = torch.nn.functional.gelu(ref)
