@@ -18,7 +18,7 @@ print("HIVE_GEMM_TILE =", os.environ.get("HIVE_GEMM_TILE"))
 KEYS = ("HIVE_GEMM_TILE", "HIVE_GEMM_RING")
 VARIANTS = [("policy", {}), ("256", {"HIVE_GEMM_TILE": "256"}), ("128x2st", {"HIVE_GEMM_TILE": "128", "HIVE_GEMM_RING": "2"})]
 if os.environ.get("PROBE_TILE_FORMS"):
-    VARIANTS += [("128x2st", {"HIVE_GEMM_TILE": "128", "HIVE_GEMM_RING": "2"}), ("128x4st", {"HIVE_GEMM_TILE": "128", "HIVE_GEMM_RING": "4"})]
+    VARIANTS += [("128x4st", {"HIVE_GEMM_TILE": "128", "HIVE_GEMM_RING": "4"})]
 for (M, N, K, epi) in [(130112, 1536, 768, 0), (130112, 768, 768, 2), (130112, 3072, 768, 1), (130112, 768, 3072, 2)] + [(29184, 1536, 768, 0), (29184, 768, 768, 2), (29184, 3072, 768, 1), (29184, 768, 3072, 2), (19456, 1536, 768, 0), (19456, 768, 768, 2), (19456, 3072, 768, 1), (19456, 768, 3072, 2), (9728, 3072, 768, 1), (9728, 768, 3072, 2), (4096, 4096, 4096, 0), (19456 - 100, 768, 768, 0)]:
     A = torch.randn(M, K, device="cuda").bfloat16(); W = (torch.randn(N, K, device="cuda") / K ** 0.5).bfloat16(); b = torch.randn(N, device="cuda") * 0.1
     R = torch.randn(M, N, device="cuda").bfloat16()
