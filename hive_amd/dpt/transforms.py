@@ -17,59 +17,47 @@ INTER_AREA = 3
 
 
 class Resize:
+    """Target size of the network input.  Behaviour (what the published DPT pre-processing does; the sizing rule must give identical sizes):
+    per-axis scale factors towards (width, height); with ``keep_aspect_ratio`` both axes take ONE of the two factors -- the larger for
+    "lower_bound" (the result covers the target), the smaller for "upper_bound" (it fits inside), the one closer to 1 for "minimal";
+    each side is then snapped to a multiple of ``ensure_multiple_of``: to the nearest one, but never below the target for "lower_bound"
+    (snapped up) nor above it for "upper_bound" (snapped down)."""
+
+    _PICK = {"lower_bound": max, "upper_bound": min, "minimal": lambda a, b: a if abs(1.0 - a) < abs(1.0 - b) else b}
+
     def __init__(self, width, height, resize_target=True, keep_aspect_ratio=False, ensure_multiple_of=1,
                  resize_method="lower_bound", image_interpolation_method=INTER_AREA):
-        self.__width = width
-        self.__height = height
-        self.__resize_target = resize_target
-        self.__keep_aspect_ratio = keep_aspect_ratio
-        self.__multiple_of = ensure_multiple_of
-        self.__resize_method = resize_method
-        self.__image_interpolation_method = image_interpolation_method
+        if resize_method not in self._PICK:
+            raise ValueError(f"resize_method {resize_method} not implemented")
+        self._target = (int(width), int(height))
+        self._resize_target = resize_target
+        self._keep_aspect = bool(keep_aspect_ratio)
+        self._multiple = ensure_multiple_of
+        self._method = resize_method
+        self._interpolation = image_interpolation_method
 
     def constrain_to_multiple_of(self, x, min_val=0, max_val=None):
-        y = (np.round(x / self.__multiple_of) * self.__multiple_of).astype(int)
-        if max_val is not None and y > max_val:
-            y = (np.floor(x / self.__multiple_of) * self.__multiple_of).astype(int)
-        if y < min_val:
-            y = (np.ceil(x / self.__multiple_of) * self.__multiple_of).astype(int)
-        return y
+        """x snapped to the grid of multiples: nearest (ties to even, numpy's rounding), down if that exceeds max_val, up if it falls below min_val."""
+        steps = x / self._multiple
+        snapped = int(np.round(steps)) * self._multiple
+        if max_val is not None and snapped > max_val:
+            snapped = int(np.floor(steps)) * self._multiple
+        if snapped < min_val:
+            snapped = int(np.ceil(steps)) * self._multiple
+        return snapped
 
     def get_size(self, width, height):
-        scale_height = self.__height / height
-        scale_width = self.__width / width
-        if self.__keep_aspect_ratio:
-            if self.__resize_method == "lower_bound":
-                # scale such that output size is lower bound
-                if scale_width > scale_height:
-                    scale_height = scale_width
-                else:
-                    scale_width = scale_height
-            elif self.__resize_method == "upper_bound":
-                if scale_width < scale_height:
-                    scale_height = scale_width
-                else:
-                    scale_width = scale_height
-            elif self.__resize_method == "minimal":
-                # scale as little as possible
-                if abs(1 - scale_width) < abs(1 - scale_height):
-                    scale_height = scale_width
-                else:
-                    scale_width = scale_height
-            else:
-                raise ValueError(f"resize_method {self.__resize_method} not implemented")
-        if self.__resize_method == "lower_bound":
-            new_height = self.constrain_to_multiple_of(scale_height * height, min_val=self.__height)
-            new_width = self.constrain_to_multiple_of(scale_width * width, min_val=self.__width)
-        elif self.__resize_method == "upper_bound":
-            new_height = self.constrain_to_multiple_of(scale_height * height, max_val=self.__height)
-            new_width = self.constrain_to_multiple_of(scale_width * width, max_val=self.__width)
-        elif self.__resize_method == "minimal":
-            new_height = self.constrain_to_multiple_of(scale_height * height)
-            new_width = self.constrain_to_multiple_of(scale_width * width)
-        else:
-            raise ValueError(f"resize_method {self.__resize_method} not implemented")
-        return int(new_width), int(new_height)
+        target_w, target_h = self._target
+        factor_w, factor_h = target_w / width, target_h / height
+        if self._keep_aspect:
+            factor_w = factor_h = self._PICK[self._method](factor_w, factor_h)  # ("minimal": equally close factors -> the height's)
+        bounds_w, bounds_h = {}, {}
+        if self._method == "lower_bound":
+            bounds_w, bounds_h = {"min_val": target_w}, {"min_val": target_h}
+        elif self._method == "upper_bound":
+            bounds_w, bounds_h = {"max_val": target_w}, {"max_val": target_h}
+        return (int(self.constrain_to_multiple_of(factor_w * width, **bounds_w)),
+                int(self.constrain_to_multiple_of(factor_h * height, **bounds_h)))
 
     def __call__(self, sample):
         width, height = self.get_size(sample["image"].shape[1], sample["image"].shape[0])
@@ -85,12 +73,13 @@ class Resize:
 
 
 class NormalizeImage:
+    """(image - mean) / std, per channel."""
+
     def __init__(self, mean, std):
-        self.__mean = mean
-        self.__std = std
+        self._mean, self._std = mean, std
 
     def __call__(self, sample):
-        sample["image"] = (sample["image"] - self.__mean) / self.__std
+        sample["image"] = (sample["image"] - self._mean) / self._std
         return sample
 
 

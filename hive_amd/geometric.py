@@ -203,13 +203,19 @@ class Trajectory:
     """A sequence of camera poses, N x 7 rows of [scalar-last quaternion, xyz position]
     (/root/reference/hive/geometric.py:302-648)."""
 
+    # The container's public names are the reference's (its callers index, slice, iterate and copy trajectories): each is a view of `values`.
+    _QUAT, _XYZ = slice(0, 4), slice(4, 7)
+
     def __init__(self, values=None):
         if values is not None:
             validate_shape(values, 'values', (None, 7))
         self.values = values
 
     def __len__(self):
-        return len(self.values)
+        return self.values.shape[0]
+
+    def __iter__(self):
+        yield from self.values
 
     def __getitem__(self, index):
         return self.values[index]
@@ -217,38 +223,28 @@ class Trajectory:
     def __setitem__(self, index, value):
         self.values[index] = value
 
-    def __iter__(self):
-        return iter(self.values)
-
-    @property
-    def rotations(self) -> np.ndarray:
-        return self.values[:, :4]
-
-    @property
-    def positions(self) -> np.ndarray:
-        return self.values[:, 4:]
-
-    @property
-    def shape(self) -> tuple:
-        return self.values.shape
+    rotations = property(lambda self: self.values[:, Trajectory._QUAT], doc="(N, 4) scalar-last quaternions (a view)")
+    positions = property(lambda self: self.values[:, Trajectory._XYZ], doc="(N, 3) camera positions (a view)")
+    shape = property(lambda self: tuple(self.values.shape))
 
     def copy(self) -> 'Trajectory':
-        return Trajectory(self.values.copy())
+        return type(self)(np.array(self.values, copy=True))
 
     def save(self, f):
         np.savetxt(f, self.values)
 
     @classmethod
     def load(cls, f) -> 'Trajectory':
-        values = np.loadtxt(f, dtype=np.float32)
-        return Trajectory(values.reshape((1, -1)) if values.ndim == 1 else values)
+        rows = np.atleast_2d(np.loadtxt(f, dtype=np.float32))  # (a one-pose file loads as a vector)
+        return cls(rows)
 
     def to_homogenous_transforms(self) -> np.ndarray:
-        """(N, 7) -> (N, 4, 4) float64."""
-        T = np.tile(np.eye(4), (len(self), 1, 1))
-        T[:, :3, :3] = Rotation.from_quat(self.rotations).as_matrix()
-        T[:, :3, 3] = self.positions
-        return T
+        """(N, 7) -> (N, 4, 4) float64 camera matrices [R | t; 0 0 0 1]."""
+        out = np.zeros((len(self), 4, 4), dtype=np.float64)
+        out[:, 3, 3] = 1.0
+        out[:, :3, :3] = Rotation.from_quat(self.rotations).as_matrix()
+        out[:, :3, 3] = self.positions
+        return out
 
     @staticmethod
     def from_homogenous_transforms(camera_trajectory: np.ndarray) -> 'Trajectory':

@@ -22,34 +22,36 @@ from hive_amd.geometric import Trajectory, get_pose_components, pose_vec2mat
 
 
 class ImageFolderDataset:
-    """Sorted image files of a folder as numpy arrays (io.py:533-572): 16-bit PNGs stay uint16, 8-bit grey
-    stays uint8, everything else is converted to RGB."""
+    """The image files of a folder, in sorted order, as numpy arrays (the reference's loader of the same name, io.py:533-572, whose behaviour the
+    dataset code relies on): 32-bit integer PNGs come back as 16-bit ('I' -> 'I;16'), 16-bit and 8-bit grey images keep their type, every
+    other mode is converted to RGB; an optional ``transform`` is applied to the array."""
+    _KEEP_MODES = frozenset(('L', 'I;16'))
 
     def __init__(self, base_dir, transform=None):
         assert os.path.isdir(base_dir), f"Could not find the folder: {base_dir}"
-        self.base_dir = base_dir
-        self.transform = transform
-        filenames = list(sorted(os.listdir(base_dir)))
-        assert len(filenames) > 0, f"No files found in the folder: {base_dir}"
-        self.image_filenames = filenames
-        self.image_paths = [pjoin(base_dir, filename) for filename in filenames]
-
-    def __getitem__(self, idx) -> np.ndarray:
-        path = self.image_paths[idx]
-        if path.endswith('.raw'):
-            raise NotImplementedError("raw float32 depth (COLMAP) is outside the hot path")
-        image = Image.open(path)
-        if image.mode == 'I':
-            image = image.convert('I;16')
-        elif image.mode != 'L' and image.mode != 'I;16':
-            image = image.convert('RGB')
-        image = np.asarray(image)
-        if self.transform:
-            image = self.transform(image)
-        return image
+        names = sorted(os.listdir(base_dir))
+        assert names, f"No files found in the folder: {base_dir}"
+        self.base_dir, self.transform = base_dir, transform
+        self.image_filenames = names
+        self.image_paths = [pjoin(base_dir, name) for name in names]
 
     def __len__(self):
         return len(self.image_paths)
+
+    @classmethod
+    def _decode(cls, path) -> np.ndarray:
+        if path.endswith('.raw'):
+            raise NotImplementedError("raw float32 depth (COLMAP) is outside the hot path")
+        with Image.open(path) as image:
+            if image.mode == 'I':
+                image = image.convert('I;16')
+            elif image.mode not in cls._KEEP_MODES:
+                image = image.convert('RGB')
+            return np.asarray(image)
+
+    def __getitem__(self, idx) -> np.ndarray:
+        array = self._decode(self.image_paths[idx])
+        return self.transform(array) if self.transform else array
 
 
 class DatasetMetadata:
