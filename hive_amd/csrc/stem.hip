@@ -29,8 +29,8 @@ constexpr int ST_PH = 2 * ST_TH + 5, ST_PW = 2 * ST_TW + 5;  // input patch 21 x
 constexpr int ST_ROW = 240;                               // patch row pitch in elements (69 x 3 = 207, + slack for the 32-wide k-steps; 480 B)
 constexpr int ST_RD = 104;                                // dwords of a patch row that are loaded (208 elements >= 207)
 constexpr int ST_K = 7 * 32;                              // padded K
-constexpr int ST_WP = ST_K + 8;                           // weight row pitch in LDS: 464 B = 116 dwords, 116 mod 64 = 52 -> the 16 rows of a fragment
-                                                          // read (16 B per lane) start in 16 distinct 4-dword bank groups (pitch 448 B: 4-way conflicts)
+constexpr int ST_WP = ST_K + 16;                          // weight row pitch in LDS: 480 B = 30 chunks of 16 B (= 2 mod 4: conflict-free over the lane groups a
+                                                          // ds_read_b128 is really served in -- bneck.hip BN_WP; round 3's 29 chunks collided 5 of 16 times)
 constexpr int ST_RQ = ST_RD / 4;                          // 16-byte quads of a patch row (26)
 constexpr int ST_LOADS = (ST_PH * ST_RQ + 255) / 256;     // 16-byte loads per thread and patch (3)
 
