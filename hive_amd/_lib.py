@@ -108,6 +108,13 @@ SIGNATURES = {
                                         c_void_p, c_void_p, c_float, c_void_p, c_int, c_void_p, c_void_p, c_int64, P(c_int)]),
     "hive_nhwc_group_norm_stats": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_int,
                                            c_void_p, c_void_p, c_int]),
+    "hive_gn_gram_table_floats": (c_int64, [c_int, c_int]),
+    "hive_gn_gram_prepare": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "hive_gn_gram_parts": (c_int, [c_void_p, c_int, c_int, c_int, c_int]),
+    "hive_gn_gram_stats": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_float, c_void_p, c_void_p,
+                                   c_void_p]),
+    "hive_nhwc_conv_gn_apply_gram": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p,
+                                             c_void_p, c_float, c_void_p, c_int, c_void_p, c_void_p, c_int64, P(c_int)]),
     "hive_patch_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "hive_nhwc_pixel_shuffle_bias": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "hive_resnet_stem_conv": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),

@@ -162,6 +162,7 @@ int hive_ctx_destroy(hive_ctx *ctx) {
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->d_frame) (void)hipFree(ctx->d_frame);
     if (ctx->d_batch) (void)hipFree(ctx->d_batch);
+    if (ctx->d_gram) (void)hipFree(ctx->d_gram);
     if (ctx->d_splitk) (void)hipFree(ctx->d_splitk);
     if (ctx->d_splitk_count) (void)hipFree(ctx->d_splitk_count);
     if (ctx->d_in) (void)hipFree(ctx->d_in);

@@ -836,6 +836,36 @@ extern "C" int hive_nhwc_conv_gn_apply(hive_ctx *ctx, const void *d_x, int dtype
     return HIVE_OK;
 }
 
+// The same operation for 1 x 1 convolutions with the statistics from the input's Gram matrices (gram.hip) instead of a first pass of the convolution:
+// d_tables from hive_gn_gram_prepare(d_w).  d_scratch: float, >= 2 N G elements.  *fused = 0: not eligible (as above, or C_in not 64 / 128 / 256).
+extern "C" int hive_nhwc_conv_gn_apply_gram(hive_ctx *ctx, const void *d_x, int dtype, int N, int H, int W, int C_in, int C_out, int stride, int H_out, int W_out,
+                                            const void *d_w, const float *d_tables, int G, const void *d_gamma, const void *d_beta, float eps, const void *d_residual,
+                                            int relu, void *d_out, void *d_scratch, int64_t scratch_floats, int *fused) {
+    HIVE_ENTER(ctx);
+    if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
+    HIVE_REQUIRE(ctx, d_gamma && d_beta && d_scratch && d_tables && fused, "nhwc_conv_gn_apply_gram: NULL argument");
+    *fused = 0;
+    const long long hw = (long long)H_out * W_out;
+    if (G < 4 || 256 % G != 0 || G > 64 || C_out % 256 != 0 || C_out % G != 0 || (C_out / G) % 8 != 0 || hw < 256 || !(C_in == 64 || C_in == 128 || C_in == 256)) return HIVE_OK;
+    HIVE_REQUIRE(ctx, scratch_floats >= 2ll * N * G, "nhwc_conv_gn_apply_gram: scratch holds %lld floats, %lld needed", (long long)scratch_floats, 2ll * N * G);
+    HIVE_REQUIRE(ctx, (long long)(H_out - 1) * stride < H && (long long)(W_out - 1) * stride < W, "nhwc_conv_gn_apply_gram: output %d x %d reaches outside the %d x %d input", H_out,
+                 W_out, H, W);
+    float *stats = (float *)d_scratch;
+    int rc = hive_gram_gn_stats(ctx, d_x, dtype, N, H, W, C_in, C_out, stride, H_out, W_out, G, d_tables, eps, stats, nullptr, nullptr);
+    if (rc) return rc;
+    GnMode mode;
+    mode.gn_stats = stats;
+    mode.gn_gamma = d_gamma;
+    mode.gn_beta = d_beta;
+    mode.gn_G = G;
+    mode.gn_cpg = C_out / G;
+    rc = launch_conv(ctx, "nhwc_conv_gn_apply_gram", d_x, dtype, N, H, W, C_in, C_out, 1, stride, 0, 0, H_out, W_out, d_w, nullptr, relu, d_residual, nullptr, d_out, nullptr,
+                     nullptr, 0, nullptr, &mode);
+    if (rc) return rc;
+    *fused = 1;
+    return HIVE_OK;
+}
+
 extern "C" int hive_nhwc_conv(hive_ctx *ctx, const void *d_x, int dtype, int N, int H, int W, int C_in, int C_out, int kernel, int stride, int pad_top,
                               int pad_left, int H_out, int W_out, const void *d_w, const void *d_bias, int relu, const void *d_residual,
                               const void *d_residual2, void *d_out, void *d_out_relu) {

@@ -69,6 +69,7 @@ struct hive_dpt {
     hive_dpt_config cfg{};
     std::map<std::string, const void *> w;
     hive_vit *vit = nullptr;
+    std::map<std::string, float *> gram_tables;  // per 1 x 1 convolution weight: the tables of hive_gn_gram_prepare (made on first use)
     void *arena = nullptr;
     size_t arena_bytes = 0, arena_used = 0;
 
@@ -216,6 +217,21 @@ int run_forward(hive_dpt *d, bool dry, const uint8_t *d_rgb, int B, int H, int W
         DPT_TRY(need(norm_prefix + ".weight", &g));
         DPT_TRY(need(norm_prefix + ".bias", &b));
         int fused = 0;
+        // GroupNorm statistics from the input's Gram matrices where that is the cheaper way to them (csrc/gram.hip; tools/probe_gram.py at the bench batch: the
+        // whole operation 651 -> 532 us at 64 -> 256 channels, 378 -> 317 at 128 -> 512, 499 -> 472 for the stride-2 256 -> 512; 254 -> 262 at 256 -> 1024,
+        // which keeps the two-pass form).  HIVE_GN_GRAM=0 switches it off.
+        const char *gram_env = getenv("HIVE_GN_GRAM");
+        const bool gram = !(gram_env && gram_env[0] == '0') && eligible && (x.C == 64 || x.C == 128 || (x.C == 256 && stride == 2));
+        if (gram) {
+            float *&tables = d->gram_tables[wname];
+            if (!tables) {
+                HIVE_CHECK_HIP(ctx, hipMalloc((void **)&tables, (size_t)hive_gn_gram_table_floats(x.C, 32) * sizeof(float)));
+                DPT_TRY(hive_gn_gram_prepare(ctx, wp, dt, x.C, cout, 32, tables));
+            }
+            DPT_TRY(hive_nhwc_conv_gn_apply_gram(ctx, x.p, dt, B, x.H, x.W, x.C, cout, stride, oh, ow, wp, tables, 32, g, b, d->cfg.gn_eps, residual, relu, out->p, scratch,
+                                                 scratch_floats, &fused));
+            if (fused) return done(HIVE_OK);
+        }
         DPT_TRY(hive_nhwc_conv_gn_apply(ctx, x.p, dt, B, x.H, x.W, x.C, cout, 1, stride, 0, 0, oh, ow, wp, 32, g, b, d->cfg.gn_eps, residual, relu, out->p,
                                         scratch, scratch_floats, &fused));
         if (fused) return done(HIVE_OK);
@@ -557,6 +573,8 @@ int hive_dpt_destroy(hive_dpt *d) {
         (void)hipStreamSynchronize(d->ctx->stream);
         if (d->vit) hive_vit_destroy(d->vit);
         if (d->arena) (void)hipFree(d->arena);
+        for (auto &kv : d->gram_tables)
+            if (kv.second) (void)hipFree(kv.second);
     }
     delete d;
     return HIVE_OK;

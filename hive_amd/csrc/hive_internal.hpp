@@ -52,6 +52,8 @@ struct hive_ctx {
     void *d_splitk = nullptr;
     size_t splitk_bytes = 0;
     unsigned *d_splitk_count = nullptr;
+    void *d_gram = nullptr;  // partial Gram matrices / sums / quadratic forms of gram.hip (GroupNorm statistics of 1 x 1 convolutions)
+    size_t gram_bytes = 0;
 
     // HIP-event timing of the dominant kernel
     bool timing = false;
@@ -105,6 +107,9 @@ int hive_gn_finalize_tiles(hive_ctx *ctx, const float *d_partial, int N, int HW,
 // split-K workspace of at least `bytes` and the (zeroed) arrival counters (HIVE_SPLITK_TILES of them)
 constexpr int HIVE_SPLITK_TILES = 4096;
 int hive_splitk_workspace(hive_ctx *ctx, size_t bytes, void **ws, unsigned **count);
+// gram.hip: (mean, rstd)[N][G] of GroupNorm(conv1x1(x, w)) from the Gram matrices of x and the tables hive_gn_gram_prepare made of w
+int hive_gram_gn_stats(hive_ctx *ctx, const void *d_x, int dtype, int N, int H, int W, int C_in, int C_out, int stride, int Ho, int Wo, int G, const float *d_tables,
+                       float eps, float *d_stats, float *d_S_out, float *d_s_out);
 // event helpers for kernel timing
 int hive_time_begin(hive_ctx *ctx);
 int hive_time_end(hive_ctx *ctx);

@@ -5,6 +5,8 @@
 /root/reference/hive/dataset_adaptors.py:1394-1401) channels-last CUDA tensors; a layer the kernels do not cover raises
 ``HiveError`` -- there is no per-layer drop to a PyTorch operator.  ``engine="torch"`` is the plain PyTorch formulation: the
 float32 / CPU reference the numerics tests compare against (and ``estimate_depth_dpt(optimize=False)``'s float32 network)."""
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -205,6 +207,20 @@ def conv_gn_act(x, conv, norm, weight=None, same_pad=False, relu=True, residual=
     ctx = _lib.default_context(x.device.index or 0)
     scratch = torch.empty(int(ctx.lib.hive_nhwc_conv_gn_partial_floats(n * oh * ow, cout)) + 2 * n * g, dtype=torch.float32, device=x.device)
     fused = ctypes.c_int(0)
+    # 1 x 1 convolutions whose input is narrow enough: GroupNorm statistics from the input's Gram matrices (csrc/gram.hip) -- the rule of the network object
+    # (csrc/dpt_net.hip conv_norm), so that both orchestrations stay bit-identical; HIVE_GN_GRAM=0 switches it off
+    cin = conv.in_channels
+    if k == 1 and os.environ.get("HIVE_GN_GRAM", "1") != "0" and (cin in (64, 128) or (cin == 256 and st == 2)) and g == 32:
+        def tables():
+            t = torch.empty(int(ctx.lib.hive_gn_gram_table_floats(cin, g)), dtype=torch.float32, device=x.device)
+            ctx.check(ctx.lib.hive_gn_gram_prepare(ctx.handle, w.data_ptr(), _code(x.dtype), cin, cout, g, t.data_ptr()))
+            return t
+        tab = _cached(conv, ("gram", x.dtype, weight is not None), [conv.weight], tables)  # (the standardised weight is a function of conv.weight)
+        ctx.check(ctx.lib.hive_nhwc_conv_gn_apply_gram(ctx.handle, x.data_ptr(), _code(x.dtype), n, ih, iw, cin, cout, st, oh, ow, w.data_ptr(), tab.data_ptr(), g,
+                                                       norm.weight.data_ptr(), norm.bias.data_ptr(), float(norm.eps), _lib.ptr(residual), int(bool(relu)),
+                                                       out.data_ptr(), scratch.data_ptr(), scratch.numel(), ctypes.byref(fused)))
+        if fused.value:
+            return out
     ctx.check(ctx.lib.hive_nhwc_conv_gn_apply(ctx.handle, x.data_ptr(), _code(x.dtype), n, ih, iw, conv.in_channels, cout, k, st, pt, pl, oh, ow, w.data_ptr(), g,
                                               norm.weight.data_ptr(), norm.bias.data_ptr(), float(norm.eps), _lib.ptr(residual), int(bool(relu)),
                                               out.data_ptr(), scratch.data_ptr(), scratch.numel(), ctypes.byref(fused)))

@@ -410,6 +410,24 @@ int hive_nhwc_conv_gn_apply(hive_ctx *ctx, const void *d_x, int dtype, int N, in
                             const void *d_gamma, const void *d_beta, float eps, const void *d_residual, int relu, void *d_out,
                             void *d_scratch, int64_t scratch_floats, int *fused);
 
+/* The same for 1 x 1 convolutions (the only kind timm's ResNetV2 uses here) with the GroupNorm's statistics taken from the INPUT instead of a first pass of
+ * the convolution: y = W x is linear, so a group's sum is u_g . sum_p x_p and its sum of squares <G_g, sum_p x_p x_p^T> with u_g = sum_{c in g} w_c,
+ * G_g = sum_{c in g} w_c w_c^T -- one read of the C_in-wide input and its Gram matrix on the matrix cores (csrc/gram.hip).  hive_gn_gram_prepare makes the
+ * tables (hive_gn_gram_table_floats(C_in, G) floats) of a weight tensor [C_out][C_in] once; hive_nhwc_conv_gn_apply_gram then needs d_scratch >= 2 N G floats.
+ * These are the statistics of the exact products, not of the 16-bit-rounded outputs: (mean, rstd) agree with the two-pass form to ~1e-4 relative, the
+ * outputs to within one rounding in a few places.  *fused = 0: not eligible (hive_nhwc_conv_gn_apply's conditions, C_in in {64, 128, 256}, G % 4 == 0).
+ * hive_gn_gram_stats: the statistics alone ([N][G][2] = mean, rstd) and, for tests, the partial Gram matrices [N][parts][C_in][C_in] / sums
+ * [N][parts][C_in] (parts = hive_gn_gram_parts(...); d_S_out / d_s_out may be NULL).  Replaces nothing in the reference: an implementation choice behind
+ * `norm3(conv3(x))` of /root/reference's DPT-Hybrid backbone (hive/dataset_adaptors.py:1419 runs it). */
+int64_t hive_gn_gram_table_floats(int C_in, int G);
+int hive_gn_gram_prepare(hive_ctx *ctx, const void *d_w, int dtype, int C_in, int C_out, int G, float *d_tables);
+int hive_gn_gram_parts(hive_ctx *ctx, int N, int C_in, int H_out, int W_out);
+int hive_gn_gram_stats(hive_ctx *ctx, const void *d_x, int dtype, int N, int H, int W, int C_in, int C_out, int stride, int H_out, int W_out, int G,
+                       const float *d_tables, float eps, float *d_stats, float *d_S_out, float *d_s_out);
+int hive_nhwc_conv_gn_apply_gram(hive_ctx *ctx, const void *d_x, int dtype, int N, int H, int W, int C_in, int C_out, int stride, int H_out, int W_out,
+                                 const void *d_w, const float *d_tables, int G, const void *d_gamma, const void *d_beta, float eps,
+                                 const void *d_residual, int relu, void *d_out, void *d_scratch, int64_t scratch_floats, int *fused);
+
 /* DPT-Large (timm vit_large_patch16_384, `DPTDepthModel(backbone="vitl16_384")`) pieces that are not plain convolutions of
  * hive_nhwc_conv:
  *   hive_patch_rows: the patch embedding Conv2d(C, D, P, P) as a GEMM -- the channels-last frame d_x [N][H][W][C] is rearranged into

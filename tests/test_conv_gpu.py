@@ -393,10 +393,12 @@ def test_conv_gn_leaves_no_sums_behind_a_fused_epilogue(gpu_ctx, half):
     (2, 64, 256, 1, 9, 13, True),       # smaller than a tile: not fused (None)
     (2, 64, 128, 1, 20, 24, True),      # 128 output channels: not fused
 ])
-def test_conv_group_norm_two_pass_equals_the_pair(gpu_ctx, half, n, cin, cout, stride, h, w, with_residual):
+def test_conv_group_norm_two_pass_equals_the_pair(gpu_ctx, half, monkeypatch, n, cin, cout, stride, h, w, with_residual):
     """hive_nhwc_conv_gn_apply (convolution twice, its output never stored) is bit-identical to conv -> GroupNorm with the
-    epilogue's statistics, and within bf16 rounding of float32 torch."""
+    epilogue's statistics, and within bf16 rounding of float32 torch.  (HIVE_GN_GRAM=0: where the input is narrow the layer otherwise takes
+    its statistics from the input's Gram matrices -- the same outputs to within a rounding, test_group_norm_statistics_from_the_gram_matrix.)"""
     from hive_amd.dpt import ops
+    monkeypatch.setenv("HIVE_GN_GRAM", "0")
     from hive_amd.dpt.models import GroupNormAct, StdConv2dSame
     g = torch.Generator(device="cpu").manual_seed(cout + h)
     conv = StdConv2dSame(cin, cout, 1, stride=stride)
@@ -423,6 +425,76 @@ def test_conv_group_norm_two_pass_equals_the_pair(gpu_ctx, half, n, cin, cout, s
         ref = F.relu(ref + res.float())
     err = (fused.float() - ref).abs().max().item()
     assert err <= 0.04 * max(ref.abs().max().item(), 1.0), err
+
+
+@pytest.mark.parametrize("n,cin,cout,stride,h,w", [
+    (3, 64, 256, 1, 20, 24),      # conv3 of a stage-1 block: four waves split the pixels, HW = 480 is not a multiple of the 128-pixel tile
+    (2, 128, 512, 1, 37, 45),     # four 64 x 64 blocks, one per wave; ragged chunks
+    (2, 256, 1024, 1, 30, 40),    # sixteen blocks on eight waves
+    (3, 256, 512, 2, 47, 61),     # the downsample convolution of a stage: stride 2 (every other pixel of every other row)
+    (9, 64, 256, 1, 120, 160),    # a full-size map: several chunks per sample
+])
+def test_group_norm_statistics_from_the_gram_matrix(gpu_ctx, half, n, cin, cout, stride, h, w):
+    """GroupNorm statistics of a 1 x 1 convolution from the input's Gram matrix (csrc/gram.hip: sum y^2 = <sum_c w_c w_c^T, sum_p x_p x_p^T>): the partial Gram
+    matrices and channel sums add up to X^T X and X^T 1 of the sampled pixels (float64 reference of the same 16-bit values: 1e-5 relative -- float32
+    accumulation on the matrix cores), (mean, rstd) equal those of the float64 convolution output to 2e-4 relative, and hive_nhwc_conv_gn_apply_gram equals
+    the two-pass form that takes its statistics from the convolution itself to within one rounding in a few places."""
+    import ctypes
+    from hive_amd import _lib
+    from hive_amd.dpt import ops
+    from hive_amd.dpt.models import GroupNormAct, StdConv2dSame
+    g = torch.Generator(device="cpu").manual_seed(cout + h)
+    conv = StdConv2dSame(cin, cout, 1, stride=stride)
+    norm = GroupNormAct(cout, apply_act=False)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g))
+        norm.weight.copy_(torch.rand(cout, generator=g) + 0.5)
+        norm.bias.copy_(torch.randn(cout, generator=g) * 0.2)
+    conv = conv.to(memory_format=torch.channels_last).to(half).cuda().eval()
+    norm = norm.to(half).cuda().eval()
+    x = F.relu(torch.randn(n, cin, h, w, generator=g) + 0.3).to(half).cuda().contiguous(memory_format=torch.channels_last)  # (the backbone's inputs are post-ReLU)
+    wstd = conv.standardized_weight().contiguous(memory_format=torch.channels_last)
+    oh, ow = (h + stride - 1) // stride, (w + stride - 1) // stride
+    ctx, lib, G = gpu_ctx, gpu_ctx.lib, 32
+    tables = torch.empty(int(lib.hive_gn_gram_table_floats(cin, G)), dtype=torch.float32, device="cuda")
+    ctx.check(lib.hive_gn_gram_prepare(ctx.handle, wstd.data_ptr(), _lib.dtype_code(half), cin, cout, G, tables.data_ptr()))
+    parts = int(lib.hive_gn_gram_parts(ctx.handle, n, cin, oh, ow))
+    S = torch.empty(n, parts, cin, cin, dtype=torch.float32, device="cuda")
+    s = torch.empty(n, parts, cin, dtype=torch.float32, device="cuda")
+    stats = torch.empty(n, G, 2, dtype=torch.float32, device="cuda")
+    ctx.check(lib.hive_gn_gram_stats(ctx.handle, x.data_ptr(), _lib.dtype_code(half), n, h, w, cin, cout, stride, oh, ow, G, tables.data_ptr(), norm.eps,
+                                     stats.data_ptr(), S.data_ptr(), s.data_ptr()))
+    xs = x[:, :, ::stride, ::stride].permute(0, 2, 3, 1).reshape(n, oh * ow, cin).double()  # the pixels a 1 x 1 convolution of this stride reads
+    S_ref, s_ref = xs.transpose(1, 2) @ xs, xs.sum(1)
+    assert ((S.double().sum(1) - S_ref).abs().max() / S_ref.abs().max()).item() < 1e-5
+    assert ((s.double().sum(1) - s_ref).abs().max() / s_ref.abs().max()).item() < 1e-5
+    w2 = wstd.reshape(cout, cin).double()
+    y = xs @ w2.t()                                                                        # [n][pixels][cout]
+    yg = y.reshape(n, oh * ow, G, cout // G)
+    mean_ref = yg.mean(dim=(1, 3))
+    rstd_ref = 1.0 / torch.sqrt(yg.var(dim=(1, 3), unbiased=False) + norm.eps)
+    scale = y.std().item()
+    assert (stats[..., 0].double() - mean_ref).abs().max().item() < 2e-4 * scale
+    assert ((stats[..., 1].double() - rstd_ref).abs() / rstd_ref).max().item() < 2e-4
+    # the whole operation against the two-pass form
+    res = torch.randn(n, cout, oh, ow, generator=g).to(half).cuda().contiguous(memory_format=torch.channels_last)
+    two_pass = ops.conv_gn_act(x, conv, norm, weight=wstd, same_pad=True, relu=True, residual=res)
+    assert two_pass is not None
+    out = torch.empty_like(two_pass)
+    scratch = torch.empty(2 * n * G, dtype=torch.float32, device="cuda")
+    fused = ctypes.c_int(0)
+    ctx.check(lib.hive_nhwc_conv_gn_apply_gram(ctx.handle, x.data_ptr(), _lib.dtype_code(half), n, h, w, cin, cout, stride, oh, ow, wstd.data_ptr(), tables.data_ptr(), G,
+                                               norm.weight.data_ptr(), norm.bias.data_ptr(), norm.eps, res.data_ptr(), 1, out.data_ptr(), scratch.data_ptr(),
+                                               scratch.numel(), ctypes.byref(fused)))
+    assert fused.value == 1
+    diff = (out.float() - two_pass.float()).abs()
+    assert diff.max().item() <= 2 * _ulp(half) * max(two_pass.float().abs().max().item(), 1.0)
+    assert (diff > 0).float().mean().item() < 5e-3, "more than a few one-rounding differences"
+    again = torch.empty_like(out)
+    ctx.check(lib.hive_nhwc_conv_gn_apply_gram(ctx.handle, x.data_ptr(), _lib.dtype_code(half), n, h, w, cin, cout, stride, oh, ow, wstd.data_ptr(), tables.data_ptr(), G,
+                                               norm.weight.data_ptr(), norm.bias.data_ptr(), norm.eps, res.data_ptr(), 1, again.data_ptr(), scratch.data_ptr(),
+                                               scratch.numel(), ctypes.byref(fused)))
+    assert torch.equal(again, out), "reproducible: fixed summation orders"
 
 
 def test_patch_embed_and_conv_transpose_match_torch(gpu_ctx, half):
