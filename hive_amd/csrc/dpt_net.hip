@@ -221,7 +221,11 @@ int run_forward(hive_dpt *d, bool dry, const uint8_t *d_rgb, int B, int H, int W
         // whole operation 651 -> 532 us at 64 -> 256 channels, 378 -> 317 at 128 -> 512, 499 -> 472 for the stride-2 256 -> 512; 254 -> 262 at 256 -> 1024,
         // which keeps the two-pass form).  HIVE_GN_GRAM=0 switches it off.
         const char *gram_env = getenv("HIVE_GN_GRAM");
-        const bool gram = !(gram_env && gram_env[0] == '0') && eligible && (x.C == 64 || x.C == 128 || (x.C == 256 && stride == 2));
+        // ... and only for large outputs: the three small kernels behind the Gram matrices cost 40-60 us whatever the batch (break-even at ~32 frames for the
+        // 64- / 128-channel inputs, ~100 for the stride-2 one): >= 150 M output elements, 250 M for C_in = 256
+        const long long out_elems = (long long)B * oh * ow * cout;
+        const bool gram = !(gram_env && gram_env[0] == '0') && eligible &&
+                          (((x.C == 64 || x.C == 128) && out_elems >= 150000000ll) || (x.C == 256 && stride == 2 && out_elems >= 250000000ll));
         if (gram) {
             float *&tables = d->gram_tables[wname];
             if (!tables) {

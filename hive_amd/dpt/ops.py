@@ -210,7 +210,9 @@ def conv_gn_act(x, conv, norm, weight=None, same_pad=False, relu=True, residual=
     # 1 x 1 convolutions whose input is narrow enough: GroupNorm statistics from the input's Gram matrices (csrc/gram.hip) -- the rule of the network object
     # (csrc/dpt_net.hip conv_norm), so that both orchestrations stay bit-identical; HIVE_GN_GRAM=0 switches it off
     cin = conv.in_channels
-    if k == 1 and os.environ.get("HIVE_GN_GRAM", "1") != "0" and (cin in (64, 128) or (cin == 256 and st == 2)) and g == 32:
+    out_elems = n * oh * ow * cout
+    if k == 1 and os.environ.get("HIVE_GN_GRAM", "1") != "0" and g == 32 and ((cin in (64, 128) and out_elems >= 150_000_000) or
+                                                                               (cin == 256 and st == 2 and out_elems >= 250_000_000)):
         def tables():
             t = torch.empty(int(ctx.lib.hive_gn_gram_table_floats(cin, g)), dtype=torch.float32, device=x.device)
             ctx.check(ctx.lib.hive_gn_gram_prepare(ctx.handle, w.data_ptr(), _code(x.dtype), cin, cout, g, t.data_ptr()))
