@@ -370,6 +370,36 @@ def test_native_network_object_equals_python_orchestration(gpu_ctx, half):
         hip.forward_frames(frames[:, :90], max_depth=10.0)  # 90 rows: not a multiple of 32
 
 
+def test_large_batch_paths_of_the_network_object(gpu_ctx, monkeypatch):
+    """At the benchmark's batch sizes the network object takes paths the small-batch tests never reach: the GroupNorm statistics of the bottlenecks' expanding
+    convolutions from the input's Gram matrices (csrc/gram.hip: >= 150 M output elements, i.e. >= 31 frames of 480 x 640) and the 256 x 256 GEMM tiles.  48 frames:
+    the depth with the Gram statistics is reproducible, equals the Python orchestration bit for bit (same rule there), and is within rounding noise of the two-pass
+    statistics (HIVE_GN_GRAM=0) -- which in turn are what the small-batch parity tests pin."""
+    from hive_amd import depth as depth_mod
+    _, hip = _pair()
+    rng = np.random.default_rng(5)
+    frames = torch.from_numpy(rng.integers(0, 256, (48, 480, 640, 3), dtype=np.uint8)).cuda()
+    with torch.no_grad():
+        d_gram, _, _ = hip.forward_frames(frames, max_depth=10.0)
+        d_again, _, _ = hip.forward_frames(frames, max_depth=10.0)
+        d_py, _, _ = hip(depth_mod.preprocess_on_device(frames[:33], torch.bfloat16), handoff=(10.0,))
+        d_c33, _, _ = hip.forward_frames(frames[:33], max_depth=10.0)
+        monkeypatch.setenv("HIVE_GN_GRAM", "0")
+        d_two, _, _ = hip.forward_frames(frames, max_depth=10.0)
+    assert torch.isfinite(d_gram).all() and torch.equal(d_gram, d_again)
+    assert torch.equal(d_c33, d_py), "network object and Python orchestration take the same statistics path"
+    assert not torch.equal(d_gram, d_two), "48 frames are past the threshold: the Gram path must have been taken"
+    # the two forms differ by 16-bit roundings that the rest of the network amplifies (two bfloat16 implementations of this network are ~18 mm apart in the
+    # median, smoke()): what counts is that neither is further from the float32 network than the other
+    ref, _ = _pair()
+    x4 = ((frames[:4].float() / 255.0 - 0.5) / 0.5).permute(0, 3, 1, 2).contiguous()  # (dataset_adaptors.py:1407 + NormalizeImage(0.5, 0.5))
+    with torch.no_grad():
+        d_ref = ref.cuda()(x4)
+    e_gram, e_two = _median_mm(d_gram[:4], d_ref), _median_mm(d_two[:4], d_ref)
+    assert e_gram <= 1.15 * e_two + 1.0, (e_gram, e_two)
+    assert _median_mm(d_gram, d_two) <= 0.75 * max(e_gram, e_two) + 1.0, (_median_mm(d_gram, d_two), e_gram, e_two)
+
+
 def test_native_network_object_dpt_large(gpu_ctx):
     """hive_dpt_create(backbone = 1): DPT-Large (vitl16_384) as one C-ABI object -- patch embedding as rows + GEMM, 24 blocks, four
     readouts, ConvTranspose reassembly -- bit-identical to the Python orchestration of the same kernels, at two frame sizes."""
