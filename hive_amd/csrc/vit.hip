@@ -617,7 +617,8 @@ __global__ __launch_bounds__(512, 1) void gemm256_kernel(GemmParams<T> p) {
 // (1330 TFLOP/s) against 347 with it, proj 115 / 209, fc1 + GELU 417 / 756, fc2 507 / 572 -- 7.3 ms of a 76 ms forward; with everything but the store
 // instructions 261 / 174 / 587 / 541.  Measured INTERLEAVED in one process (the clock drifts over a run: a first comparison across processes showed gains that
 // were drift): non-temporal stores of C change nothing (+-0.5 %; fc1 1.4 % slower), nor does starting every other workgroup half a tile late so that the
-// epilogues' stores do not hit HBM together.  The epilogue cannot overlap the next tile's K loop inside one workgroup (the accumulators are the registers), and two
+// epilogues' stores do not hit HBM together, nor does letting a tile's first K-step start before the previous tile's stores have retired (vmcnt(16) instead of
+// vmcnt(0): the stage it needs is older than those stores).  The epilogue cannot overlap the next tile's K loop inside one workgroup (the accumulators are the registers), and two
 // co-resident workgroups need tiles of 128 x 256 at most (LDS), whose operand stream -- 1.5 x the bytes per flop through the CU's ~26 B/clk vector-memory path --
 // costs what the overlap gains (the 128 x 128 two-workgroup form measures 450 vs 347 us on q|k).
 // The same tile as PERSISTENT workgroups (one per CU, XCD-aware runs of tiles as in csrc/conv.hip): the K-steps of a workgroup's tiles
