@@ -193,18 +193,19 @@ __device__ __forceinline__ void gemm_store_rows(const GemmParams<T> &p, const f3
     // mt are written -- no hazard, but the compiler cannot know, so the order is set by hand.
     constexpr int AHEAD = HIVE_GEMM_AHEAD;  // fragment rows the residual loads run ahead (a row's turn is ~0.5 us, a trip to HBM under load 2 us: conv.hip)
     vec<T, 8> rs[AHEAD + 1][2];
+    float2 lst[AHEAD + 1][2];  // ln_in: (mean, rstd) of the rows, loaded with the same lead -- a load inside `finish` is waited for with vmcnt(0), i.e. behind the
+                               // previous row's STORE as well (vmcnt retires in order): 16 trips to memory in series per tile
     auto pre = [&](int mt, int j) {
-        if (EPI == EPI_BIAS_RESIDUAL) {
-            const int m = min(m_base + mt * 16 + 8 * j + rr, p.M - 1);
-            rs[mt % (AHEAD + 1)][j] = *reinterpret_cast<const vec<T, 8> *>(p.residual + (size_t)m * p.ldc + n);
-        }
+        const int m = min(m_base + mt * 16 + 8 * j + rr, p.M - 1);
+        if (EPI == EPI_BIAS_RESIDUAL) rs[mt % (AHEAD + 1)][j] = *reinterpret_cast<const vec<T, 8> *>(p.residual + (size_t)m * p.ldc + n);
+        if (ln_in) lst[mt % (AHEAD + 1)][j] = *reinterpret_cast<const float2 *>(p.ln_stats + 2 * (size_t)m);
     };
     hive_mfma::staged_rows<MT, AHEAD>(stage, acc, lane, pre, [&](int r, int, const f32x4 &lo, const f32x4 &hi, int mt, int j) {
         const int m = m_base + r;
         if (m >= p.M) return;
         float o[8];
         if (ln_in) {
-            const float2 st = *reinterpret_cast<const float2 *>(p.ln_stats + 2 * (size_t)m);  // (mean, rstd) of row m
+            const float2 st = lst[mt % (AHEAD + 1)][j];  // (mean, rstd) of row m
             o[0] = st.y * (lo[0] - st.x * c0.x) + b0.x, o[1] = st.y * (lo[1] - st.x * c0.y) + b0.y;
             o[2] = st.y * (lo[2] - st.x * c0.z) + b0.z, o[3] = st.y * (lo[3] - st.x * c0.w) + b0.w;
             o[4] = st.y * (hi[0] - st.x * c1.x) + b1.x, o[5] = st.y * (hi[1] - st.x * c1.y) + b1.y;
@@ -451,6 +452,14 @@ __global__ __launch_bounds__(TM * 2, 1) void gemm_kernel(GemmParams<T> p) {
         unsigned char *ot = lds + NST * STAGE_BYTES + wave * 4096;
         const int mw = m0 + wr * 64;  // M = B Np is a multiple of 64: the block is inside or outside as a whole
         const int fqs = ((fq & 1) << 1) | (fq >> 1);
+        float4 ls[4][2];  // LayerNorm folded in: (mean, rstd) of the lane's 4 tokens per fragment row, loaded once up front (not per channel block, each wait behind a store)
+        if (p.ln_stats) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const float *st = p.ln_stats + 2 * (size_t)min(mw + mt * 16 + fq * 4, p.M - 4);
+                ls[mt][0] = *reinterpret_cast<const float4 *>(st), ls[mt][1] = *reinterpret_cast<const float4 *>(st + 4);
+            }
+        }
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
 #pragma unroll
@@ -462,8 +471,7 @@ __global__ __launch_bounds__(TM * 2, 1) void gemm_kernel(GemmParams<T> p) {
                 for (int mt = 0; mt < 4; ++mt) {
                     vec<T, 4> ov;
                     if (p.ln_stats) {  // (kernel-uniform) LayerNorm folded in: the lane's 4 tokens' (mean, rstd)
-                        const float *st = p.ln_stats + 2 * (size_t)min(mw + mt * 16 + fq * 4, p.M - 4);
-                        const float4 s0 = *reinterpret_cast<const float4 *>(st), s1 = *reinterpret_cast<const float4 *>(st + 4);
+                        const float4 s0 = ls[mt][0], s1 = ls[mt][1];
                         ov[0] = (T)(s0.y * (acc[mt][nt][0] - s0.x * c1v) + b);
                         ov[1] = (T)(s0.w * (acc[mt][nt][1] - s0.z * c1v) + b);
                         ov[2] = (T)(s1.y * (acc[mt][nt][2] - s1.x * c1v) + b);
@@ -714,7 +722,8 @@ __global__ __launch_bounds__(512, 1) void gemm256p_kernel(GemmParams<T> p) {
 #pragma unroll
                         for (int mtl = 0; mtl < 4; ++mtl) {
                             vec<T, 4> ov;
-                            if (p.ln_stats) {  // (kernel-uniform) LayerNorm folded in: the lane's 4 tokens' (mean, rstd)
+                            if (p.ln_stats) {  // (kernel-uniform) LayerNorm folded in: the lane's 4 tokens' (mean, rstd).  (Hoisting the 8 float4 of a 64-token
+                                // block out of the channel loops spills 27 registers here; gemm_kernel's v^T path has the room and does.)
                                 const float *st = p.ln_stats + 2 * (size_t)min(mw + mtl * 16 + fq * 4, p.M - 4);
                                 const float4 s0 = *reinterpret_cast<const float4 *>(st), s1 = *reinterpret_cast<const float4 *>(st + 4);
                                 ov[0] = (T)(s0.y * (acc[blk * 4 + mtl][nt][0] - s0.x * c1v) + bv);
