@@ -294,6 +294,7 @@ int launch_gram(hive_ctx *ctx, const GramParams<T> &p, int chunks, int N) {
 void gram_chunks(int num_cus, int N, int HW, int C_in, int *chunks, int *chunk_px) {
     const int slots = (C_in == 64 ? 4 : (C_in == 128 ? 2 : 1)) * num_cus;
     int c = std::max(1, std::min((HW + 255) / 256, slots / std::max(N, 1)));
+    if (const char *e = getenv("HIVE_GRAM_CHUNKS")) c = std::max(1, std::min((HW + 255) / 256, atoi(e)));  // tuning override
     *chunk_px = ((HW + c - 1) / c + 127) / 128 * 128;
     *chunks = (HW + *chunk_px - 1) / *chunk_px;
 }
