@@ -123,6 +123,11 @@ struct GemmParams {
 
 constexpr int BN = 128, BK = 64;
 
+#ifndef HIVE_ATT_LSUM_MFMA
+#define HIVE_ATT_LSUM_MFMA 0  // attention_kernel, tuning build: 1 = the softmax denominators from an extra all-ones channel block of P.V instead of 32 v_add_f32 per tile.
+                              // Measured (round 4, alternating runs of both libraries, 107-frame forward): 75.41 -> 75.85 ms -- the four extra MFMAs per tile cost more than
+                              // the additions they replace, although the VALU is the busier pipe by the counters.
+#endif
 #ifndef HIVE_GEMM_ABLATE
 #define HIVE_GEMM_ABLATE 0  // tuning builds only (make ablate_gemm; tools/probe_gemm_tiles.py with HIVE_AMD_LIB=...): 1 = gemm256p_kernel without its epilogue
 #endif
@@ -814,6 +819,12 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams<T> p) {
     f32x16 oacc[2];
     for (int i = 0; i < 16; ++i) oacc[0][i] = oacc[1][i] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
+    // (HIVE_ATT_LSUM_MFMA, a tuning build that lost: one more V^T "channel block" whose rows are all ones makes O^T's extra rows the sums over the keys of the
+    // rounded probabilities; all 16 registers of lacc then hold the lane's query's sum over both key halves)
+    f32x16 lacc;
+    for (int i = 0; i < 16; ++i) lacc[i] = 0.f;
+    vec<T, 8> ones8;
+    for (int k = 0; k < 8; ++k) ones8[k] = (T)1.0f;
     f32x16 neg_m;  // -m_run in every element (0 before the first tile)
     for (int i = 0; i < 16; ++i) neg_m[i] = 0.f;
 
@@ -873,6 +884,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams<T> p) {
             l_run *= alpha;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
+                if (HIVE_ATT_LSUM_MFMA) lacc[i] *= alpha;
                 oacc[0][i] *= alpha;
                 oacc[1][i] *= alpha;
                 sacc[0][i] -= delta;
@@ -887,7 +899,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams<T> p) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const float e = __builtin_amdgcn_exp2f(sacc[kb][i]);
-                l_tile += e;
+                if (!HIVE_ATT_LSUM_MFMA) l_tile += e;
                 pf[kb][i >> 3][i & 7] = (T)e;
             }
         l_run += l_tile;
@@ -903,10 +915,16 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams<T> p) {
                     const vec<T, 8> vf = *reinterpret_cast<const vec<T, 8> *>(v_t + swz(db * 32 + lq, 4 * kb + 2 * s + hh));
                     oacc[db] = hive_mfma::mfma32(vf, pf[kb][s], oacc[db]);
                 }
+        if (HIVE_ATT_LSUM_MFMA) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) lacc = hive_mfma::mfma32(ones8, pf[kb][s2], lacc);
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my pieces of tile t+1 have landed
         __syncthreads();
     }
-    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float l_tot = HIVE_ATT_LSUM_MFMA ? lacc[0] : l_run + __shfl_xor(l_run, 32);
     const float inv = 1.0f / l_tot;
     // O leaves through LDS (the K / V stages are free: the loop's last barrier is behind every wave): in the accumulator layout a lane
     // owns 4 consecutive channels of its query, so a direct store is 32 rows x 16 bytes per instruction (8 per wave, store-issue
