@@ -13,7 +13,8 @@ has surfaces inside the volume; bf16 or --dtype fp16, HIP engine) -> f32 depth t
 + uint16-mm hand-off -> TSDF integrate.
 
 One run prints ONE JSON line that covers the BASELINE configurations this command can reach:
-  N = 1: the headline (configs[1], `value`), the same job in float16 -- the reference's own type -- as `value_fp16`, and a bounded `config4` leg
+  N = 1: the headline (configs[1], `value`), the same job in float16 -- the reference's own type -- as `value_fp16` (with `small_batch`: the network object at
+         batches of 1 and 8 in that type, the reference's literal one-frame loop), and a bounded `config4` leg
          (configs[3]: 1920 x 1080 frames, DPT-Large at the reference's 864 x 480 network size, 1024^3 volume).
   N > 1: frames are independent units.  The headline `value` is the WEAK job ("scaling": "weak": N * K * B frames, a contiguous block of K
          steps per rank, per-GPU work = the N = 1 job, no collective on the data path, the shared volume merged ONCE inside the timed
@@ -566,6 +567,28 @@ def main():
         stream = make_stream(other_dtype)
         f_elapsed, f_total, _, _ = timed_job(stream, False)
         fp16 = {"dtype": other_dtype, "value": f_total / f_elapsed, "ms_per_step": f_elapsed / args.steps * 1e3}
+        # the reference's literal call pattern is ONE frame per forward (hive/dataset_adaptors.py:1406-1419): the drop-in network object at batches of 1 and 8,
+        # device-resident frames, in the reference's dtype (the whole sweep: tools/batch_sweep.py -> profiles/r04_batch_sweep.json)
+        small_batch = {}
+        fmodel = stream.model
+        few = torch.from_numpy(seq["color"][:8]).to(device)
+        with torch.no_grad():
+            for b in (1, 8):
+                fr = few[:b].contiguous()
+                for _ in range(3):
+                    fmodel.forward_frames(fr, max_depth=10.0)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(20):
+                    fmodel.forward_frames(fr, max_depth=10.0)
+                e1.record()
+                e1.synchronize()
+                small_batch[f"batch_{b}"] = {"ms_per_frame": e0.elapsed_time(e1) / 20 / b, "frames_per_s": b * 20 / (e0.elapsed_time(e1) * 1e-3)}
+        small_batch["dtype"] = other_dtype
+        small_batch["note"] = "hive_dpt_forward alone (DPT-Hybrid, 480 x 640, frames resident on the device), 20 calls after 3"
+        fp16["small_batch"] = small_batch
+        del fmodel, few
     del stream
     torch.cuda.empty_cache()
 
@@ -619,6 +642,7 @@ def main():
     if fp16 is not None:
         out["value_" + fp16["dtype"]] = fp16["value"]
         out["ms_per_step_" + fp16["dtype"]] = fp16["ms_per_step"]
+        out["small_batch"] = fp16["small_batch"]
     if config4 is not None:
         out["config4"] = config4
     if world == 1 and not args.no_cpu_baseline:
