@@ -265,13 +265,32 @@ def config4_leg(device, ctx, steps=2, batch=8):
     return out
 
 
+def self_launch(n_ranks):
+    """`python bench.py --gpus N` without a launcher: start N FRESH rank processes with torch.distributed.run (rendezvous on 127.0.0.1, a free
+    port) and hand their exit status on.  Runs before this process has touched the GPU or the library -- nothing that has initialised HIP is ever
+    re-exec'ed; the ranks are ordinary children and rank 0 prints the line on the stdout they inherit."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # (dmabuf IPC: RCCL's device-memory exchange needs it on these hosts)
+    sys.stdout.flush()
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))
     from hive_amd import _lib, depth as depth_mod, distributed as hdist, fusion, synthetic
 
     rank, world, local_rank = hdist.init_from_env()
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus} (or with no launcher at all)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback); the CPU baseline is only the comparison leg")
     dev_index = local_rank % torch.cuda.device_count()  # one GPU per rank on a node; wraps only in 1-GPU rehearsals
@@ -301,11 +320,11 @@ def main():
         volume = fusion.TSDFVolume(synthetic.room_bounds(), args.voxel, ctx=vctx)
     feeder = FrameFeeder(frames_host, B, device)
 
-    def make_stream(dtype_name):
+    def make_stream(dtype_name, vol=None, ovl=None):
         # seeded non-degenerate weights (hive_amd/dpt/init.py): PyTorch's default initialisation predicts a constant 7.25 m, i.e. a
         # TSDF scene with no surface (free space only); these give depth maps of 1-7 m with surfaces inside the volume
         model = depth_mod.build_model(None, device=device, dtype=torch_dtype[dtype_name], engine=args.engine, init_seed=1234)
-        return depth_mod.DepthFusionStream(model, volume, K, overlap=overlap)
+        return depth_mod.DepthFusionStream(model, vol or volume, K, overlap=overlap if ovl is None else ovl)
 
     # strong: the job is frames [0, K B) of the wrapping sequence, this rank takes its contiguous share of every stretch asked for;
     # weak: the job is frames [0, N (W + K) B), this rank owns the contiguous block [rank (W + K) B, + (W + K) B) (W warm-up steps first)
@@ -346,9 +365,36 @@ def main():
             all_ids = [(first_step * B + j) % T for j in range(n_steps * B)]
             merger.integrate(color, depth, K, poses[all_ids], counts)
 
-    def timed_job(stream, strong):
+    def volume_check(vol, merged, frames_mine):
+        """Proof of work, read from the TIMED volume right after the clock stopped: how many frames / integrate launches this rank's volume was handed since
+        the reset in front of the job (hive_tsdf_stats) and its weight plane's maximum and sum.  Every update adds the observation weight 1, so the sum
+        is exactly the number of (frame, voxel) updates the job made: sum over the job's frames of N_upd -- `expected_weight_sum` is added further down
+        from the counting kernel's N_upd of exactly those frames (an independent volume, the single-frame kernel).  At N > 1 the sums of the ranks'
+        volumes are in the merged volume (reduce-scatter of the sums), so weight_sum is already the whole job's; frames are summed over the ranks."""
+        frames, launches = vol.stats()
+        w = (merged if merged is not None else vol).device_tensors()[1]
+        chk = {"frames_integrated": frames, "integrate_launches": launches, "weight_max": float(w.max().item()), "weight_sum": int(w.double().sum().item()),
+               "voxels_observed": int((w > 0).sum().item())}
+        del w
+        if world > 1:
+            t = torch.tensor([float(frames), float(launches)], dtype=torch.float64, device="cpu" if hdist._host_staged() else device)
+            per_rank = [torch.zeros_like(t) for _ in range(world)]
+            torch.distributed.all_gather(per_rank, t)
+            chk["frames_per_rank"] = [int(x[0].item()) for x in per_rank]
+            chk["launches_per_rank"] = [int(x[1].item()) for x in per_rank]
+            chk["frames_integrated"] = sum(chk["frames_per_rank"])
+            chk["integrate_launches"] = sum(chk["launches_per_rank"])
+            if exact:  # every rank's slab saw every frame: the job's frames are one rank's count
+                chk["frames_integrated"] = chk["frames_per_rank"][0]
+        chk["frames_expected"] = frames_mine
+        return chk
+
+    def timed_job(stream, strong, vol=None):
         """W untimed warm-up steps, then EXACTLY K timed steps between barrier + synchronize on both sides; at N > 1 the one merge of the shared volume is
-        inside the timed region.  Returns (max-over-ranks seconds, frames of the whole job, sweep launches, sweep kernel ms of this rank)."""
+        inside the timed region.  Returns (max-over-ranks seconds, frames of the whole job, sweep launches, sweep kernel ms of this rank, proof-of-work
+        record of the timed volume)."""
+        vol = vol or volume
+        tctx = vol._ctx
         for s in range(0, args.warmup):
             run_job(stream, strong, s, 1)
         if strong and args.warmup > 0:  # the timed job's own batch sizes (this rank's share of K * B frames) also run once untimed:
@@ -362,11 +408,11 @@ def main():
                 merger.gather()
             else:
                 stream.join()
-                hdist.fuse_sharded(volume)
+                hdist.fuse_sharded(vol)
         torch.cuda.synchronize()
-        volume.reset()  # the timed job starts from an empty scene
+        vol.reset()  # the timed job starts from an empty scene
         torch.cuda.synchronize()
-        vctx.set_timing(True)
+        tctx.set_timing(True)
         hdist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -378,32 +424,34 @@ def main():
         stream.join()  # the merge (and the end of the job) behind the last sweeps
         merged = None
         if world > 1:
-            merged = merger.gather() if exact else hdist.fuse_sharded(volume)
+            merged = merger.gather() if exact else hdist.fuse_sharded(vol)
         torch.cuda.synchronize()
         hdist.barrier()
         elapsed = time.perf_counter() - t0
-        n_launch, kernel_ms = vctx.kernel_time_total()
-        vctx.set_timing(False)
+        n_launch, kernel_ms = tctx.kernel_time_total()
+        tctx.set_timing(False)
         elapsed = hdist.max_over_ranks(elapsed, device=device if world > 1 else "cpu")
-        del merged
         total = args.steps * B * (1 if strong or world == 1 else world)
-        return elapsed, total, n_launch, kernel_ms
+        check = volume_check(vol, merged if exact else None, total)
+        del merged
+        return elapsed, total, n_launch, kernel_ms, check
 
     stream = make_stream(args.dtype)
-    elapsed, total_frames, n_launch, kernel_ms = timed_job(stream, headline_strong)
+    elapsed, total_frames, n_launch, kernel_ms, volume_proof = timed_job(stream, headline_strong)
 
     if args.timed_only:
         if rank == 0:
             print(json.dumps({"value": total_frames / elapsed, "unit": "frames/s", "ms_per_step": elapsed / args.steps * 1e3,
-                              "avg_integrate_us": kernel_ms / max(n_launch, 1) * 1e3, "note": "--timed-only: no roofline / cpu_baseline / extra legs"}))
+                              "avg_integrate_us": kernel_ms / max(n_launch, 1) * 1e3, "integrate_launches": n_launch, "tsdf_overlap": overlap,
+                              "timed_volume_check": volume_proof, "note": "--timed-only: no roofline / cpu_baseline / extra legs"}))
         return
 
     # ---- the other scaling mode at N > 1 (BASELINE configs[2] literally when the headline is the weak job) -------------------------------------
     other = None
     if world > 1 and extra_legs and not exact:
-        o_elapsed, o_total, _, _ = timed_job(stream, not headline_strong)
+        o_elapsed, o_total, _, _, o_check = timed_job(stream, not headline_strong)
         other = {"scaling": "weak" if headline_strong else "strong", "value": o_total / o_elapsed, "unit": "frames/s", "frames_total": o_total,
-                 "ms_total": o_elapsed * 1e3, "steps": args.steps, "frames_per_step": B,
+                 "ms_total": o_elapsed * 1e3, "steps": args.steps, "frames_per_step": B, "timed_volume_check": o_check,
                  "note": ("BASELINE configs[2] literally: the SAME K x B frames split in contiguous blocks over the ranks, one merge of the shared volume inside the timed "
                           "region; value / (the N = 1 line's value) is the strong-scaling speed-up" if not headline_strong else
                           "N x K x B frames, a contiguous block of K steps per rank, one merge inside the timed region")}
@@ -418,16 +466,18 @@ def main():
     mvol = fusion.TSDFVolume(synthetic.room_bounds(), args.voxel, ctx=ctx, storage=storage, x_range=x_range)
     w_plane = storage[1]
 
-    def measure(frame_sets, depth_of, time_kernel=False):
-        """Over all frames: per-frame N_upd, per-sweep (frames, N_union, work-list voxels), ms per frame of the TSDF leg (prep + work list + sweep), and
-        with time_kernel the HIP-event time of the sweep launches."""
+    def measure(frame_sets, depth_of, time_kernel=False, replay_sets=4):
+        """Over all frames: per-frame N_upd (the counting variant of the single-frame kernel); over the first `replay_sets` sets also: per-sweep (frames,
+        N_union, work-list voxels), ms per frame of the TSDF leg (prep + work list + sweep), and with time_kernel the HIP-event time of the sweep launches."""
         n_upd, sweeps, leg_ms, k_ms, k_n = [], [], [], 0.0, 0
-        for ids in frame_sets:
+        for si, ids in enumerate(frame_sets):
             fr = torch.from_numpy(seq["color"][ids]).to(device)
             depth_m = depth_of(fr, ids)
             for j, i in enumerate(ids):
                 n_upd.append(mvol.integrate(fr[j], depth_m[j], K, poses[i], return_n_updated=True))
             mvol.reset()  # (also: every weight a whole number again -- the sweep's fast colour update, as in the timed job)
+            if si >= replay_sets:
+                continue
             if time_kernel:
                 ctx.set_timing(True)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -497,13 +547,30 @@ def main():
             timed_sets = batches(job_frames(True, args.warmup, args.steps)[0])
         else:
             timed_sets = [job_frames(False, args.warmup + s, 1)[0] for s in range(args.steps)]
-        timed_sets = timed_sets[:4]  # (the sequence wraps: a few steps cover every frame of it)
-        n_upd_dpt, sweeps_dpt, leg_dpt, (us_dpt, _) = measure(timed_sets, lambda fr, ids: stream.depth(fr)[0], time_kernel=True)
+        # N_upd of EVERY frame of the timed job (this rank's): their sum is what the timed volume's weight plane must add up to; the sweep replays (N_union, work
+        # list, kernel time) over the first four sets only (the sequence wraps: a few steps cover every frame of it)
+        n_upd_job, sweeps_dpt, leg_dpt, (us_dpt, _) = measure(timed_sets, lambda fr, ids: stream.depth(fr)[0], time_kernel=True, replay_sets=4)
+        n_upd_dpt = n_upd_job[:sum(len(t) for t in timed_sets[:4])]
+        expected = float(sum(n_upd_job))
+        if world > 1:  # (every rank counted its own frames -- exact mode: every frame on its own slab; the job's total is the sum)
+            t = torch.tensor([expected], dtype=torch.float64, device="cpu" if hdist._host_staged() else device)
+            torch.distributed.all_reduce(t)
+            expected = float(t.item())
+        volume_proof["expected_weight_sum"] = int(expected)
+        volume_proof["expected_note"] = ("sum over the timed job's frames of N_upd, counted by the single-frame kernel's counting variant on a separate volume from the same "
+                                         "depth maps (same batches through the network) and poses; every update adds weight 1, so the timed volume's weight plane must "
+                                         "sum to exactly this")
+        w_ok = volume_proof["weight_sum"] == volume_proof["expected_weight_sum"]
+        if exact:  # (the ranks' depth maps come from other batch sizes than this recount's: split-K / Gram thresholds move a few last bits of a few pixels)
+            w_ok = abs(volume_proof["weight_sum"] - volume_proof["expected_weight_sum"]) <= 1e-3 * max(volume_proof["expected_weight_sum"], 1)
+        volume_proof["pass"] = bool(w_ok and volume_proof["frames_integrated"] == volume_proof["frames_expected"])
         # the launch duration the roofline uses is the kernel's OWN (HIP events, the same frames swept again with nothing else on the GPU);
         # inside the timed job the sweeps share the chip with the next batch's network (second stream, lowest priority) and take longer
         main_roof = roofline(n_upd_dpt, sweeps_dpt, us_dpt, "bench")
         main_roof["launches"] = n_launch
         main_roof["avg_launch_us_in_job"] = kernel_ms / max(n_launch, 1) * 1e3
+        main_roof["frac_in_job"] = main_roof["frac"] * main_roof["avg_launch_us"] / max(main_roof["avg_launch_us_in_job"], 1e-9)
+        main_roof["must_move"]["frac_in_job"] = main_roof["must_move"]["frac"] * main_roof["avg_launch_us"] / max(main_roof["avg_launch_us_in_job"], 1e-9)
         main_roof["overlap"] = ("the timed job runs the sweeps of batch i on a second, lowest-priority HIP stream under the network of batch i + 1: "
                                 "avg_launch_us_in_job is their duration there, avg_launch_us the kernel alone") if overlap else "none (--no-overlap / exact merge): the sweeps run on the network's stream"
         main_roof["tsdf_leg_us_per_frame"] = leg_dpt * 1e3
@@ -558,6 +625,18 @@ def main():
     mvol.close()
     del mvol, w_plane, storage
 
+    # ---- the same job with the sweeps on the network's stream (N = 1): the overlap's A/B inside the one line -------------------------------------
+    no_overlap = None
+    if world == 1 and extra_legs and overlap and args.engine == "hip":
+        vol2 = fusion.TSDFVolume(synthetic.room_bounds(), args.voxel, ctx=ctx)
+        stream2 = make_stream(args.dtype, vol=vol2, ovl=False)
+        n_elapsed, n_total, n_n, n_ms, n_check = timed_job(stream2, False, vol=vol2)
+        no_overlap = {"value": n_total / n_elapsed, "ms_per_step": n_elapsed / args.steps * 1e3, "avg_launch_us_in_job": n_ms / max(n_n, 1) * 1e3,
+                      "weight_sum": n_check["weight_sum"], "frames_integrated": n_check["frames_integrated"]}
+        vol2.close()
+        del stream2, vol2
+        torch.cuda.empty_cache()
+
     # ---- the reference's dtype: the same timed job in float16 (N = 1) ------------------------------------------------------------------------
     fp16 = None
     if world == 1 and extra_legs and args.engine == "hip":
@@ -565,7 +644,7 @@ def main():
         del stream
         torch.cuda.empty_cache()
         stream = make_stream(other_dtype)
-        f_elapsed, f_total, _, _ = timed_job(stream, False)
+        f_elapsed, f_total, _, _, _ = timed_job(stream, False)
         fp16 = {"dtype": other_dtype, "value": f_total / f_elapsed, "ms_per_step": f_elapsed / args.steps * 1e3}
         # the reference's literal call pattern is ONE frame per forward (hive/dataset_adaptors.py:1406-1419): the drop-in network object at batches of 1 and 8,
         # device-resident frames, in the reference's dtype (the whole sweep: tools/batch_sweep.py -> profiles/r04_batch_sweep.json)
@@ -602,7 +681,9 @@ def main():
 
     if rank != 0:
         return
-    dims = "x".join(str(int(d)) for d in (merger.dims if exact else volume.vol_dim))
+    dim_list = [int(d) for d in (merger.dims if exact else volume.vol_dim)]
+    dims = "x".join(str(d) for d in dim_list)
+    vol_name = f"{dim_list[0]}^3" if len(set(dim_list)) == 1 else dims  # (the real dims: --voxel changes them)
     merge_note = ""
     scaling = "strong" if headline_strong else "weak"  # (N = 1: the weak job's one-rank case -- per-GPU work fixed as N grows)
     if world > 1:
@@ -612,7 +693,7 @@ def main():
                       if exact else f", frame-sharded ({share}), shared volume merged once by reduce-scatter of the 5 accumulator planes + all-gather of the 3 "
                                     f"volumes (RCCL), inside the timed region")
     out = {
-        "metric": "frames/sec (depth+TSDF integrate) @640x480, 512^3 vol" + ("" if world == 1 else f", {world} GPUs, {scaling} scaling ({total_frames} frames)"),
+        "metric": f"frames/sec (depth+TSDF integrate) @{W}x{H}, {vol_name} vol" + ("" if world == 1 else f", {world} GPUs, {scaling} scaling ({total_frames} frames)"),
         "value": total_frames / elapsed,
         "unit": "frames/s",
         "n_gpus": world,
@@ -631,6 +712,7 @@ def main():
             "n_upd_mean": main_roof["n_upd_mean"], "n_upd_fraction": main_roof["n_upd_fraction"], "merge": (args.merge if world > 1 else None),
             "tsdf_overlap": overlap, "scaling_mode": scaling,
         },
+        "timed_volume_check": volume_proof,
         "roofline": main_roof,
         "roofline_room": room_roof,
         "roofline_dpt": dpt_roof,
@@ -643,6 +725,9 @@ def main():
         out["value_" + fp16["dtype"]] = fp16["value"]
         out["ms_per_step_" + fp16["dtype"]] = fp16["ms_per_step"]
         out["small_batch"] = fp16["small_batch"]
+    if no_overlap is not None:
+        out["value_no_overlap"] = no_overlap["value"]
+        out["no_overlap"] = no_overlap
     if config4 is not None:
         out["config4"] = config4
     if world == 1 and not args.no_cpu_baseline:

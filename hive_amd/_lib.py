@@ -52,6 +52,7 @@ SIGNATURES = {
                                           c_int]),
     "hive_tsdf_last_batch_groups": (c_int, [c_void_p, c_void_p, c_int, P(c_int)]),
     "hive_tsdf_last_sweep_items": (c_int, [c_void_p, P(ctypes.c_uint64), P(c_int)]),
+    "hive_tsdf_stats": (c_int, [c_void_p, P(c_int64), P(c_int64)]),
     "hive_tsdf_get_volume": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "hive_tsdf_set_volume": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "hive_tsdf_extract_mesh": (c_int, [c_void_p, P(c_int64), P(c_int64)]),

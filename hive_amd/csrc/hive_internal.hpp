@@ -136,6 +136,8 @@ struct hive_tsdf {
     // set_volume / set_volume_range / accum_finalize, hive_tsdf_planes_modified).  Selects the division-free colour update (tsdf.hip).
     bool unit_weights = true;
     int64_t unit_frames = 0;
+    // frames handed to the integrate entry points / integrate launches since creation or the last reset (hive_tsdf_stats)
+    int64_t frames_seen = 0, launches_seen = 0;
     // device word holding the work-list length of the most recent sweep (valid until the next sweep but one on this context)
     const unsigned *last_n_items = nullptr;
     // mesh extraction results (device)

@@ -1350,6 +1350,7 @@ static int launch_integrate_multi(hive_tsdf *v, int nf, int H, int W, const floa
     }
 #undef HIVE_LAUNCH
     HIVE_CHECK_HIP(ctx, hipGetLastError());
+    ++v->launches_seen;
     return hive_time_end(ctx);
 }
 
@@ -1392,6 +1393,7 @@ static int launch_integrate(hive_tsdf *v, float *accum, int H, int W, const floa
     }
 #undef HIVE_LAUNCH
     HIVE_CHECK_HIP(ctx, hipGetLastError());
+    ++v->launches_seen;
     return hive_time_end(ctx);
 }
 
@@ -1399,6 +1401,7 @@ static int launch_integrate(hive_tsdf *v, float *accum, int H, int W, const floa
 static void note_observations(hive_tsdf *v, float obs_w, int64_t n) {
     if (obs_w != 1.0f) v->unit_weights = false;
     v->unit_frames += n;
+    v->frames_seen += n;
     if (v->unit_frames > 65533) v->unit_weights = false;  // (w + 1 stays below 65536: the bound of the division-free colour update)
 }
 
@@ -1518,6 +1521,7 @@ int hive_tsdf_reset(hive_tsdf *v) {
     if (!v) return hive_fail(nullptr, HIVE_ERR_INVALID, "vol is NULL");
     v->unit_weights = true;
     v->unit_frames = 0;
+    v->frames_seen = v->launches_seen = 0;
     return fill_volume(v);
 }
 
@@ -1539,6 +1543,13 @@ int hive_tsdf_info(hive_tsdf *v, int64_t vol_dim[3], float origin[3], double vol
     if (vol_bnds) memcpy(vol_bnds, v->bnds, sizeof(v->bnds));
     if (voxel_size) *voxel_size = v->voxel_size;
     if (trunc_margin) *trunc_margin = v->trunc;
+    return HIVE_OK;
+}
+
+int hive_tsdf_stats(hive_tsdf *v, int64_t *frames, int64_t *launches) {
+    if (!v) return hive_fail(nullptr, HIVE_ERR_INVALID, "vol is NULL");
+    if (frames) *frames = v->frames_seen;
+    if (launches) *launches = v->launches_seen;
     return HIVE_OK;
 }
 
@@ -1709,6 +1720,7 @@ int hive_tsdf_accum_integrate(hive_tsdf *vol, float *d_accum, const uint8_t *col
     const uint8_t *d_color;
     const float *d_depth;
     if ((rc = prepare_frame(vol, color, depth, H, W, mem, &d_color, &d_depth))) return rc;
+    ++vol->frames_seen;  // (the volume's own planes are untouched: unit_weights / unit_frames do not move)
     return launch_integrate<true>(vol, d_accum, H, W, K, cam_pose, obs_weight, false);
 }
 

@@ -174,6 +174,12 @@ class TSDFVolume:
         self._ctx.check(self._ctx.lib.hive_tsdf_last_sweep_items(self._handle, ctypes.byref(n), ctypes.byref(seg)))
         return int(n.value) * int(seg.value)
 
+    def stats(self):
+        """(frames, launches) this volume has been given since its creation / last ``reset`` (``hive_tsdf_stats``; no sync)."""
+        f, n = ctypes.c_int64(0), ctypes.c_int64(0)
+        self._ctx.check(self._ctx.lib.hive_tsdf_stats(self._handle, ctypes.byref(f), ctypes.byref(n)))
+        return int(f.value), int(n.value)
+
     def get_volume(self, with_weight=False):
         shape = tuple(int(v) for v in self._vol_dim)
         tsdf = np.empty(shape, np.float32)

@@ -157,3 +157,14 @@ class Pipeline:
         with open(os.path.join(dataset.base_path, "profiling.json"), "w") as f:  # pipeline.py:251
             json.dump(self.profiling, f, indent=2)
         return mesh
+
+
+def main(argv=None):
+    """`python -m hive_amd ...` / `python -m hive_amd.pipeline ...`: /root/reference/hive/pipeline.py:1337-1339 (and hive/__main__.py:17-20) --
+    build the pipeline from the command line and run it."""
+    program = Pipeline.from_command_line(argv)
+    return program.run()
+
+
+if __name__ == '__main__':
+    main()

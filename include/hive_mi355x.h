@@ -140,6 +140,11 @@ int hive_tsdf_last_batch_groups(hive_tsdf *vol, int *sizes, int capacity, int *n
  * that survive the per-row frustum / depth clip); forces a stream sync.  Diagnostic: n_items * segment_voxels against the voxels
  * a sweep updates is the share of its arithmetic that can change a voxel (bench.py reports it). */
 int hive_tsdf_last_sweep_items(hive_tsdf *vol, uint64_t *n_items, int *segment_voxels);
+/* What the volume has been given since its creation / last hive_tsdf_reset: frames handed to integrate / integrate_batch /
+ * accum_integrate (`frames`) and the integrate launches that applied them (`launches`: one per single-frame kernel, one per fused
+ * sweep).  Host-side bookkeeping, no stream sync.  bench.py prints it next to the weight plane's sum as the timed job's proof of work
+ * (one TSDFVolume.integrate call of hive/fusion.py:124 = one frame here). */
+int hive_tsdf_stats(hive_tsdf *vol, int64_t *frames, int64_t *launches);
 /* TSDFVolume.get_volume(): copies tsdf and colour (and weight) out (any may be NULL).  The destinations / sources of
  * get_volume / set_volume may be host OR device memory (unified addressing decides the copy direction). */
 int hive_tsdf_get_volume(hive_tsdf *vol, float *h_tsdf, float *h_color, float *h_weight);

@@ -215,3 +215,19 @@ def test_two_rank_scene_bounds_union(tmp_path):
     out = str(tmp_path / "bounds.npy")
     mp.start_processes(_bounds_worker, args=(2, _free_port(), out), nprocs=2, join=True, start_method="spawn")
     assert np.array_equal(np.load(out), np.array([[-2.5, 1.25], [0.0, 2.0], [-0.25, 7.0]]))
+
+
+def test_bench_starts_its_own_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment (the driver's plain command form) must start two fresh rank processes itself --
+    before anything touches the GPU -- and hand their exit status on.  Without an MI355X both ranks get as far as the rendezvous (gloo) and then refuse to
+    run (no CPU fallback): two refusals, a non-zero status, and not the old "launch with torch.distributed.run" exit."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HIVE_DIST_BACKEND"] = "gloo"
+    env["CUDA_VISIBLE_DEVICES"] = env["HIP_VISIBLE_DEVICES"] = ""  # (also on a GPU box: this test is about the launch, not the job)
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True,
+                         timeout=300)
+    out = run.stdout + run.stderr
+    assert run.returncode != 0
+    assert out.count("bench.py needs an MI355X") == 2, out[-2000:]
+    assert "launch with torch.distributed.run" not in out

@@ -201,6 +201,12 @@ def test_option_groups_and_entrypoints_keep_the_reference_api(tmp_path):
     assert pipe.decimation_options.num_faces_object == 512 and pipe.webxr_options.webxr_add_sky_box and pipe.mesh_path == os.path.join('out', 'mesh')
     with pytest.raises(SystemExit):  # --dataset_path / --output_path are required, as in the reference
         Pipeline.from_command_line(['--num_frames', '3'])
+    # `python -m hive_amd` = `python -m hive` (hive/__main__.py:17-20 -> pipeline.py:1337-1339): main() builds the pipeline from the command line and runs it
+    import hive_amd.__main__ as entry
+    from hive_amd import pipeline as pipeline_mod
+    assert entry.main is pipeline_mod.main
+    with pytest.raises(SystemExit):
+        pipeline_mod.main(['--num_frames', '3'])
     # every group registers on a shared parser without flag clashes
     parser = argparse.ArgumentParser()
     for group in (PipelineOptions, StorageOptions, MaskDilationOptions, MeshFilteringOptions, MeshDecimationOptions, COLMAPOptions, BackgroundMeshOptions, WebXROptions,
