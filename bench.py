@@ -180,16 +180,17 @@ def load_profile(name):
 
 
 def config4_leg(device, ctx, steps=2, batch=8):
-    """BASELINE configs[3], bounded: 1920 x 1080 frames (host-resident, uploaded in the timed region) -> the reference's resize rule (640 x 480 target, keep
-    aspect ratio, lower bound, multiple of 32: 864 x 480) -> DPT-Large depth (hive_dpt_forward, backbone vitl16_384, bf16, seeded weights) -> nearest
-    back to 1080p (estimate_depth_dpt's rule) -> uint16-mm hand-off -> integrate into a 1024^3 volume (5 mm voxels).  `steps` timed steps of
-    `batch` frames after one warm-up step; the sweep's roofline (SURVEY 8d bytes and must-move bytes) from the frames of the last step."""
+    """BASELINE configs[3], bounded, through the PRODUCT path: 1920 x 1080 frames (host-resident, uploaded in the timed region) -> `DepthFusionStream.step`:
+    the reference's resize rule (640 x 480 target, keep aspect ratio, "minimal", multiple of 32: 864 x 480 -- hive_amd.depth.network_size) and its cv2.INTER_CUBIC
+    resize + normalisation as one HIP kernel -> DPT-Large depth (backbone vitl16_384, bf16, seeded weights) -> nearest back to 1080p + uint16-mm hand-off as
+    one HIP kernel (all of it ONE C-ABI call, hive_dpt_forward_frames) -> integrate into a 1024^3 volume (5 mm voxels).  No torch operator in the timed
+    region but the upload.  `steps` timed steps of `batch` frames after one warm-up step; the sweep's roofline (SURVEY 8d bytes and must-move bytes) from the
+    frames of the last step."""
     from hive_amd import depth as depth_mod, fusion, synthetic
     from hive_amd.dpt.init import seeded_init
     from hive_amd.dpt.models import DPTDepthModel
-    from hive_amd.dpt.transforms import Resize
     H, W, T = 1080, 1920, batch * (steps + 1)
-    net_w, net_h = Resize(640, 480, resize_target=None, keep_aspect_ratio=True, ensure_multiple_of=32, resize_method="lower_bound").get_size(W, H)
+    net_h, net_w = depth_mod.network_size(H, W)
     seq = synthetic.make_sequence(num_frames=T, height=H, width=W, yaw_step_deg=2.4)
     model = DPTDepthModel(path=None, scale=depth_mod.DPT_SCALE, shift=depth_mod.DPT_SHIFT, invert=True, backbone="vitl16_384", engine="hip")
     seeded_init(model, seed=1234)
@@ -198,18 +199,14 @@ def config4_leg(device, ctx, steps=2, batch=8):
     vol = fusion.TSDFVolume(synthetic.room_bounds(), 0.005, ctx=ctx, storage=storage)
     assert tuple(int(d) for d in vol.vol_dim) == (1024, 1024, 1024)
     host = torch.from_numpy(seq["color"]).pin_memory()
+    stream = depth_mod.DepthFusionStream(model, vol, seq["K"])
 
     def dpt(fr):
-        small = torch.nn.functional.interpolate(fr.permute(0, 3, 1, 2).float(), size=(net_h, net_w), mode="area").round().clamp(0, 255).to(torch.uint8)
-        d, _, _ = model.forward_frames(small.permute(0, 2, 3, 1).contiguous(), max_depth=None)
-        full = torch.nn.functional.interpolate(d[:, None], size=(H, W), mode="nearest")[:, 0]
-        m = (full * 1000.0).to(torch.int32).clamp(0, 65535).float() * (1.0 / 1000.0)
-        return torch.where(m > 10.0, torch.zeros_like(m), m).contiguous()
+        return stream.depth(fr)[0]
 
     def step(i):
         fr = host[i * batch:(i + 1) * batch].to(device, non_blocking=True)
-        dm = dpt(fr)
-        vol.integrate_batch(fr, dm, seq["K"], seq["poses"][i * batch:(i + 1) * batch])
+        dm = stream.step(fr, seq["poses"][i * batch:(i + 1) * batch])
         return fr, dm
 
     with torch.no_grad():
@@ -222,6 +219,7 @@ def config4_leg(device, ctx, steps=2, batch=8):
             fr, dm = step(i)
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
+        timed_frames = vol.stats()[0]  # (frames the volume was handed since the reset in front of the timed steps)
         # the sweep alone, on the last step's frames: launch duration (HIP events inside the library), N_upd per frame (counting kernel), N_union per sweep
         ids = list(range(steps * batch, (steps + 1) * batch))
         n_upd = [vol.integrate(fr[j], dm[j], seq["K"], seq["poses"][i], return_n_updated=True) for j, i in enumerate(ids)]
@@ -252,7 +250,8 @@ def config4_leg(device, ctx, steps=2, batch=8):
     out = {"workload": f"synthetic {W}x{H} RGB (room trajectory, 2.4 degrees per frame), DPT-Large (vitl16_384, bf16, seeded weights) at {net_w}x{net_h} + "
                        f"{'x'.join(str(int(d)) for d in vol.vol_dim)} TSDF integrate, {steps} steps of {batch} frames, uploads in the timed region",
            "value": steps * batch / elapsed, "unit": "frames/s", "ms_per_step": elapsed / steps * 1e3, "frames_per_step": batch, "steps": steps,
-           "dpt_ms_per_frame": dpt_ms / batch,
+           "dpt_ms_per_frame": dpt_ms / batch, "network_size": [net_h, net_w], "resize_method": "minimal",
+           "frames_integrated": timed_frames,
            "roofline": {"kernel": "integrate_multi_kernel", "bound": "hbm", "achieved": serial / (launch_us * 1e-6) / 1e9, "peak": 8000.0, "unit": "GB/s",
                         "frac": serial / (launch_us * 1e-6) / 1e9 / 8000.0, "algorithmic_bytes_per_launch": serial, "frames_per_launch": fpl,
                         "avg_launch_us": launch_us, "us_per_frame": launch_us / fpl, "n_upd_mean": float(np.mean(n_upd)),
@@ -676,8 +675,8 @@ def main():
     if world == 1 and extra_legs and args.engine == "hip":
         try:
             config4 = config4_leg(device, ctx)
-        except Exception as e:  # (a leg beside the headline must not take the line down with it)
-            config4 = {"error": f"{type(e).__name__}: {e}"}
+        except (_lib.HiveError, torch.cuda.OutOfMemoryError) as e:  # the library refusing, or the 13 GB volume not fitting beside what else runs on the card: say so in
+            config4 = {"error": f"{type(e).__name__}: {e}"}          # the line; anything else (a bug in this file) propagates
 
     if rank != 0:
         return

@@ -127,6 +127,9 @@ SIGNATURES = {
                                                   c_int]),
     "hive_dpt_create": (c_int, [c_void_p, c_void_p, c_void_p, c_int, P(c_void_p)]),
     "hive_dpt_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p]),
+    "hive_dpt_forward_frames": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_void_p]),
+    "hive_dpt_resize_preprocess": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_int, c_void_p]),
+    "hive_depth_resize_nearest": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p]),
     "hive_dpt_arena_bytes": (c_int, [c_void_p, P(c_int64)]),
     "hive_dpt_destroy": (c_int, [c_void_p]),
     "hive_depth_quantize": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p]),

@@ -153,9 +153,16 @@ struct Map {  // a channels-last activation [N][H][W][C]
     } while (0)
 
 // One forward.  dry = true only walks the allocation sequence (arena sizing); the launches are skipped.
-int run_forward(hive_dpt *d, bool dry, const uint8_t *d_rgb, int B, int H, int W, const void *d_pos, float *d_depth, float max_depth,
+// Frames are FH x FW; the network runs at H x W (both multiples of 32).  Where the two differ the frames enter through the reference's bicubic resize
+// (csrc/resize.hip) and the depth map leaves through its nearest-neighbour resize back to the frame size, hand-off included.
+int run_forward(hive_dpt *d, bool dry, const uint8_t *d_rgb, int B, int FH, int FW, int H, int W, const void *d_pos, float *d_depth, float max_depth,
                 uint16_t *d_mm, float *d_m) {
     hive_ctx *ctx = d->ctx;
+    const bool resized = FH != H || FW != W;
+    auto preprocess = [&](half_t *xin) -> int {
+        if (resized) return hive_dpt_resize_preprocess(ctx, d_rgb, B, FH, FW, H, W, 0.5f, 0.5f, d->cfg.dtype, xin);
+        return hive_dpt_preprocess(ctx, d_rgb, (int64_t)B * H * W * 3, 0.5f, 0.5f, d->cfg.dtype, xin);
+    };
     const int dt = d->cfg.dtype;
     const std::string bb = "pretrained.model.patch_embed.backbone.";
     auto need = [&](const std::string &n, const void **out) -> int {
@@ -261,7 +268,7 @@ int run_forward(hive_dpt *d, bool dry, const uint8_t *d_rgb, int B, int H, int W
         const int64_t stem_floats = hive_nhwc_conv_gn_partial_floats((int64_t)B * s0.H * s0.W, 64);
         s0.gn = (float *)d->alloc((size_t)stem_floats * 2);  // the GroupNorm's sums, left by the convolution's epilogue
         if (!dry) {
-            DPT_TRY(hive_dpt_preprocess(ctx, d_rgb, (int64_t)B * H * W * 3, 0.5f, 0.5f, dt, xin));
+            DPT_TRY(preprocess(xin));
             const void *sw;
             DPT_TRY(need(bb + "stem.conv.weight", &sw));
             DPT_TRY(hive_resnet_stem_conv_gn(ctx, xin, dt, B, H, W, sw, s0.p, s0.gn, stem_floats, &s0.gn_tm));
@@ -381,7 +388,7 @@ int run_forward(hive_dpt *d, bool dry, const uint8_t *d_rgb, int B, int H, int W
             maps[r] = Map{d->alloc((size_t)B * n_patch * D), gh, gw, D};
         }
         if (!dry) {
-            DPT_TRY(hive_dpt_preprocess(ctx, d_rgb, (int64_t)B * H * W * 3, 0.5f, 0.5f, dt, xin));
+            DPT_TRY(preprocess(xin));
             DPT_TRY(hive_patch_rows(ctx, xin, dt, B, H, W, 3, 16, cols));
             const void *pw, *pb, *cls;
             DPT_TRY(need("pretrained.model.patch_embed.proj.weight", &pw));    // [D][16][16][3] = [D][768]
@@ -493,12 +500,19 @@ int run_forward(hive_dpt *d, bool dry, const uint8_t *d_rgb, int B, int H, int W
     Map lo;
     DPT_TRY(conv(path, "scratch.output_conv.0.weight", "scratch.output_conv.0.bias", 128, 3, 1, false, 0, nullptr, nullptr, false, &lo, nullptr));
     drop(path);
+    float *net_depth = resized ? (float *)d->alloc((size_t)B * H * W * 2) : nullptr;  // f32 depth at the network's size (2 half_t per float)
     if (dry) return HIVE_OK;
     const void *w3;
     DPT_TRY(need("scratch.output_conv.2.weight", &w3));  // [ky][kx][32][128]
-    HIVE_REQUIRE(ctx, 2 * lo.H == H && 2 * lo.W == W, "hive_dpt: frame size %d x %d must be a multiple of 32", H, W);
-    return hive_dpt_head_fused(ctx, lo.p, nullptr, dt, B, lo.H, lo.W, 128, 32, w3, d->cfg.head_b3, d->cfg.head_w1, d->cfg.head_b1,
-                               d->cfg.non_negative, d->cfg.invert, d->cfg.scale, d->cfg.shift, d_depth, 1.0f / 1000.0f, max_depth, d_mm, d_m);
+    HIVE_REQUIRE(ctx, 2 * lo.H == H && 2 * lo.W == W, "hive_dpt: network size %d x %d must be a multiple of 32", H, W);
+    if (!resized)
+        return hive_dpt_head_fused(ctx, lo.p, nullptr, dt, B, lo.H, lo.W, 128, 32, w3, d->cfg.head_b3, d->cfg.head_w1, d->cfg.head_b1,
+                                   d->cfg.non_negative, d->cfg.invert, d->cfg.scale, d->cfg.shift, d_depth, 1.0f / 1000.0f, max_depth, d_mm, d_m);
+    // frames of another size: the head leaves float32 depth at the network's size, the nearest-neighbour resize back to the frame size
+    // (dataset_adaptors.py:1421-1426) carries the uint16-mm hand-off
+    DPT_TRY(hive_dpt_head_fused(ctx, lo.p, nullptr, dt, B, lo.H, lo.W, 128, 32, w3, d->cfg.head_b3, d->cfg.head_w1, d->cfg.head_b1, d->cfg.non_negative, d->cfg.invert,
+                                d->cfg.scale, d->cfg.shift, net_depth, 1.0f / 1000.0f, max_depth, nullptr, nullptr));
+    return hive_depth_resize_nearest(ctx, net_depth, B, H, W, FH, FW, 1.0f / 1000.0f, max_depth, d_depth, d_mm, d_m);
 }
 
 }  // namespace
@@ -544,24 +558,31 @@ int hive_dpt_create(hive_ctx *ctx, const hive_dpt_config *config, const hive_dpt
     return HIVE_OK;
 }
 
-int hive_dpt_forward(hive_dpt *d, const uint8_t *d_rgb, int B, int H, int W, const void *d_pos_embed, float *d_depth, float max_depth,
-                     uint16_t *d_out_mm, float *d_out_m) {
+int hive_dpt_forward_frames(hive_dpt *d, const uint8_t *d_rgb, int B, int frame_h, int frame_w, int net_h, int net_w, const void *d_pos_embed, float *d_depth,
+                            float max_depth, uint16_t *d_out_mm, float *d_out_m) {
     HIVE_ENTER(d ? d->ctx : nullptr);
     if (!d) return hive_fail(nullptr, HIVE_ERR_INVALID, "dpt is NULL");
     hive_ctx *ctx = d->ctx;
+    const int H = net_h, W = net_w;
     HIVE_REQUIRE(ctx, d_rgb && d_pos_embed && (d_depth || d_out_mm || d_out_m), "hive_dpt_forward: NULL argument");
-    HIVE_REQUIRE(ctx, B > 0 && H >= 32 && W >= 32 && H % 32 == 0 && W % 32 == 0, "hive_dpt_forward: frames must be a multiple of 32 (%d x %d x %d)", B, H, W);
+    HIVE_REQUIRE(ctx, B > 0 && frame_h > 0 && frame_w > 0, "hive_dpt_forward: bad frame batch %d x %d x %d", B, frame_h, frame_w);
+    HIVE_REQUIRE(ctx, H >= 32 && W >= 32 && H % 32 == 0 && W % 32 == 0, "hive_dpt_forward: the network's input size must be a multiple of 32 (%d x %d)", H, W);
     // size the activation arena with a dry run of the same allocation sequence, then launch
     void *arena = d->arena;
     d->arena = nullptr;
     d->reset_arena();
-    int rc = run_forward(d, true, d_rgb, B, H, W, d_pos_embed, d_depth, max_depth, d_out_mm, d_out_m);
+    int rc = run_forward(d, true, d_rgb, B, frame_h, frame_w, H, W, d_pos_embed, d_depth, max_depth, d_out_mm, d_out_m);
     d->arena = arena;
     if (rc) return rc;
     const size_t need = d->arena_used;  // the high-water mark of the dry run
     if ((rc = hive_reserve_device(ctx, &d->arena, &d->arena_bytes, need))) return rc;
     d->reset_arena();
-    return run_forward(d, false, d_rgb, B, H, W, d_pos_embed, d_depth, max_depth, d_out_mm, d_out_m);
+    return run_forward(d, false, d_rgb, B, frame_h, frame_w, H, W, d_pos_embed, d_depth, max_depth, d_out_mm, d_out_m);
+}
+
+int hive_dpt_forward(hive_dpt *d, const uint8_t *d_rgb, int B, int H, int W, const void *d_pos_embed, float *d_depth, float max_depth,
+                     uint16_t *d_out_mm, float *d_out_m) {
+    return hive_dpt_forward_frames(d, d_rgb, B, H, W, H, W, d_pos_embed, d_depth, max_depth, d_out_mm, d_out_m);
 }
 
 int hive_dpt_arena_bytes(hive_dpt *d, int64_t *bytes) {

@@ -42,6 +42,44 @@ def make_transform():
     ])
 
 
+def network_size(frame_h, frame_w):
+    """(net_h, net_w) the reference runs the network at for frames of this size: its ``Resize(640, 480, keep_aspect_ratio=True,
+    ensure_multiple_of=32, resize_method="minimal")`` (dataset_adaptors.py:1363-1387) -- 480 x 640 frames stay as they are, 1080 x 1920 become 480 x 864."""
+    net_w, net_h = dpt_transforms.Resize(NET_W, NET_H, resize_target=None, keep_aspect_ratio=True, ensure_multiple_of=32,
+                                         resize_method="minimal").get_size(int(frame_w), int(frame_h))
+    return int(net_h), int(net_w)
+
+
+def resize_preprocess_on_device(frames_u8, net_size, dtype=torch.bfloat16, ctx=None):
+    """uint8 [B, H, W, 3] on the GPU -> the network input [B, 3, net_h, net_w] (channels-last) through the reference's cv2.INTER_CUBIC resize +
+    normalisation (dataset_adaptors.py:1376-1392, 1407-1417), one HIP kernel (``hive_dpt_resize_preprocess``).  ``dtype=torch.float32`` for checks."""
+    assert frames_u8.dtype == torch.uint8 and frames_u8.is_cuda and frames_u8.dim() == 4 and frames_u8.shape[-1] == 3
+    frames_u8 = frames_u8.contiguous()
+    b, h, w, _ = frames_u8.shape
+    net_h, net_w = int(net_size[0]), int(net_size[1])
+    ctx = ctx or _lib.default_context(frames_u8.device.index or 0)
+    code = _lib.F32 if dtype == torch.float32 else _lib.dtype_code(dtype)
+    out = torch.empty((b, 3, net_h, net_w), dtype=dtype, device=frames_u8.device, memory_format=torch.channels_last)
+    ctx.check(ctx.lib.hive_dpt_resize_preprocess(ctx.handle, frames_u8.data_ptr(), b, h, w, net_h, net_w, 0.5, 0.5, code, out.data_ptr()))
+    return out
+
+
+def resize_depth_nearest(depth, frame_size, max_depth=None, ctx=None):
+    """depth f32 [B, h, w] on the GPU -> (depth [B, H, W], depth_mm, depth_m): torch's ``interpolate(mode="nearest")`` back to the frame size
+    (dataset_adaptors.py:1421-1426) with the uint16-mm hand-off (``hive_depth_resize_nearest``); mm / m are None without ``max_depth``."""
+    assert depth.dtype == torch.float32 and depth.is_cuda and depth.dim() == 3
+    depth = depth.contiguous()
+    b, h, w = depth.shape
+    H, W = int(frame_size[0]), int(frame_size[1])
+    ctx = ctx or _lib.default_context(depth.device.index or 0)
+    out = torch.empty((b, H, W), dtype=torch.float32, device=depth.device)
+    mm = torch.empty((b, H, W), dtype=torch.int16, device=depth.device) if max_depth is not None else None
+    m = torch.empty((b, H, W), dtype=torch.float32, device=depth.device) if max_depth is not None else None
+    ctx.check(ctx.lib.hive_depth_resize_nearest(ctx.handle, depth.data_ptr(), b, h, w, H, W, 1.0 / 1000.0, float(max_depth or 0.0), out.data_ptr(), _lib.ptr(mm),
+                                                _lib.ptr(m)))
+    return out, mm, m
+
+
 def preprocess_on_device(frames_u8, dtype=torch.bfloat16, ctx=None):
     """uint8 [B, H, W, 3] on the GPU -> normalised channels-last network input [B, 3, H, W]:
     ``((x / 255) - 0.5) / 0.5`` (dataset_adaptors.py:1407 + NormalizeImage), one fused HIP kernel."""
@@ -90,24 +128,46 @@ def estimate_depth_dpt(rgb_dataset, output_path: str, weights_filename='dpt_hybr
     os.makedirs(output_path, exist_ok=True)
     transform = make_transform()
     n = len(rgb_dataset)
-    with torch.no_grad():
-        for start in range(0, n, batch_size):
-            images = [np.asarray(rgb_dataset[i]) for i in range(start, min(n, start + batch_size))]
-            same = all(im.shape == (NET_H, NET_W, 3) and im.dtype == np.uint8 for im in images)
-            if same and dtype is not None:
-                frames = torch.from_numpy(np.stack(images)).cuda()
-                sample = preprocess_on_device(frames, dtype)
-            else:
-                batch = np.stack([transform({"image": im / 255.0})["image"] for im in images])
-                sample = torch.from_numpy(batch).cuda().contiguous(memory_format=torch.channels_last)
-                if dtype is not None:
-                    sample = sample.to(dtype)
-            prediction = model(sample)
-            if prediction.shape[-2:] != images[0].shape[:2]:
-                prediction = torch.nn.functional.interpolate(prediction.unsqueeze(1), size=images[0].shape[:2], mode="nearest").squeeze(1)
-            depth_mm = (prediction * 1000.0).clamp(0, 65535).to(torch.int32).cpu().numpy().astype(np.uint16)
-            for j in range(len(images)):
-                _write_png16(os.path.join(output_path, f"{start + j:06d}.png"), depth_mm[j])
+    # The PNG encoder (zlib, one core per file) is the slowest stage by far next to ~1 ms of GPU work per frame: the files of batch i are written by a small
+    # thread pool while the GPU works on batch i + 1 (zlib releases the GIL); at most two batches of depth maps are in flight.
+    from concurrent.futures import ThreadPoolExecutor
+    writers = ThreadPoolExecutor(max_workers=max(1, min(8, (os.cpu_count() or 2) - 1)))
+    pending = []
+
+    def write_batch(start, depth_mm):
+        return [writers.submit(_write_png16, os.path.join(output_path, f"{start + j:06d}.png"), depth_mm[j]) for j in range(len(depth_mm))]
+
+    try:
+        with torch.no_grad():
+            for start in range(0, n, batch_size):
+                images = [np.asarray(rgb_dataset[i]) for i in range(start, min(n, start + batch_size))]
+                same = all(im.shape == images[0].shape and im.ndim == 3 and im.shape[2] == 3 and im.dtype == np.uint8 for im in images)
+                if same and dtype is not None:
+                    # uint8 frames of one size: resize (if any), normalisation, network, nearest resize back and the uint16-mm quantisation in ONE C-ABI call
+                    frames = torch.from_numpy(np.stack(images)).cuda()
+                    h, w = images[0].shape[:2]
+                    _, mm, _ = model.forward_frames(frames, max_depth=65.535, net_size=network_size(h, w))
+                    depth_mm = mm.cpu().numpy().view(np.uint16)
+                else:  # optimize=False (PyTorch float32) or frames that are not uint8 RGB of one size: the host transform, frame by frame
+                    preds = []
+                    for im in images:
+                        sample = torch.from_numpy(transform({"image": im / 255.0})["image"][None]).cuda().contiguous(memory_format=torch.channels_last)
+                        if dtype is not None:
+                            sample = sample.to(dtype)
+                        prediction = model(sample)
+                        if prediction.shape[-2:] != im.shape[:2]:
+                            prediction = torch.nn.functional.interpolate(prediction.unsqueeze(1), size=im.shape[:2], mode="nearest").squeeze(1)
+                        preds.append((prediction[0] * 1000.0).clamp(0, 65535).to(torch.int32).cpu().numpy().astype(np.uint16))
+                    depth_mm = preds
+                pending.append(write_batch(start, depth_mm))
+                while len(pending) > 2:
+                    for f in pending.pop(0):
+                        f.result()
+        for batch in pending:
+            for f in batch:
+                f.result()  # (re-raises a writer's exception)
+    finally:
+        writers.shutdown(wait=True)
 
 
 class DepthFusionStream:
@@ -118,7 +178,7 @@ class DepthFusionStream:
     frame-sharded multi-GPU fusion (``hive_amd.distributed``).
     """
 
-    def __init__(self, model, volume, cam_intr, max_depth=10.0, accumulate=False, native=True, overlap=False):
+    def __init__(self, model, volume, cam_intr, max_depth=10.0, accumulate=False, native=True, overlap=False, net_size=None):
         """``overlap=True``: the TSDF sweeps of batch i run on a second HIP stream while the network already works on batch
         i + 1.  The network's MFMA kernels leave the vector ALUs idle and whole CUs idle in the tails of their tile rounds; the sweep
         is vector-ALU work with 8 KB of LDS.  ``volume`` must then live on a context of that stream
@@ -127,7 +187,8 @@ class DepthFusionStream:
         recycles frame buffers takes it right after the call); ``join()`` orders the caller's stream behind all sweeps queued so far
         (before reading or merging the volume)."""
         self.model = model
-        self.native = native  # run the network as one hive_dpt_forward call where it applies (frame size % 32 == 0)
+        self.native = native  # run the network as one hive_dpt_forward_frames call (a 16-bit model on the HIP engine)
+        self.net_size = None if net_size is None else (int(net_size[0]), int(net_size[1]))  # (net_h, net_w); None: the reference's rule for the frame size
         self.volume = volume
         self.K = np.ascontiguousarray(cam_intr, dtype=np.float32)
         self.max_depth = float(max_depth)
@@ -158,13 +219,18 @@ class DepthFusionStream:
 
     @torch.no_grad()
     def depth(self, frames_u8):
-        """[B, H, W, 3] uint8 (GPU) -> (depth_m f32 [B, H, W] after the hand-off, depth_mm int16-viewed-as-uint16)."""
-        if (self.native and self.dtype in (torch.bfloat16, torch.float16) and frames_u8.shape[1] % 32 == 0 and frames_u8.shape[2] % 32 == 0
-                and getattr(self.model, "engine", None) == "hip"):
-            _, mm, m = self.model.forward_frames(frames_u8, max_depth=self.max_depth)  # ONE C-ABI call: hive_dpt_forward
+        """[B, H, W, 3] uint8 (GPU) -> (depth_m f32 [B, H, W] after the hand-off, depth_mm int16-viewed-as-uint16).  Frames of any size: the
+        network runs at the reference's size for them (``network_size``: 480 x 640 frames as they are, 1080 x 1920 at 480 x 864), resizes on the device."""
+        h, w = int(frames_u8.shape[1]), int(frames_u8.shape[2])
+        net = self.net_size or network_size(h, w)
+        if self.native and self.dtype in (torch.bfloat16, torch.float16) and getattr(self.model, "engine", None) == "hip":
+            _, mm, m = self.model.forward_frames(frames_u8, max_depth=self.max_depth, net_size=net)  # ONE C-ABI call: hive_dpt_forward_frames
             return m, mm
-        x = preprocess_on_device(frames_u8, self.dtype)
-        _, mm, m = self.model(x, handoff=(self.max_depth,))
+        x = preprocess_on_device(frames_u8, self.dtype) if net == (h, w) else resize_preprocess_on_device(frames_u8, net, self.dtype)
+        if net == (h, w):
+            _, mm, m = self.model(x, handoff=(self.max_depth,))
+            return m, mm
+        _, mm, m = resize_depth_nearest(self.model(x), (h, w), self.max_depth)
         return m, mm
 
     @torch.no_grad()

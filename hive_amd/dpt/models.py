@@ -616,10 +616,11 @@ class DPTDepthModel(DPT):
             self._native = cur = NativeDPT(self)
         return cur
 
-    def forward_frames(self, frames_u8, max_depth=None):
-        """uint8 frames [B, H, W, 3] in HBM -> (depth, depth_mm, depth_m) through ``hive_dpt_forward``: pre-processing, the whole
-        network and the depth hand-off in one C-ABI call (H, W multiples of 32)."""
-        return self.native().forward(frames_u8, max_depth=max_depth)
+    def forward_frames(self, frames_u8, max_depth=None, net_size=None):
+        """uint8 frames [B, H, W, 3] in HBM -> (depth, depth_mm, depth_m) through ``hive_dpt_forward_frames``: pre-processing, the whole
+        network and the depth hand-off in one C-ABI call.  ``net_size=(net_h, net_w)`` (multiples of 32; default: the frame size, which must then be
+        one): frames of any other size go through the reference's bicubic / nearest resizes on the device."""
+        return self.native().forward(frames_u8, max_depth=max_depth, net_size=net_size)
 
     def forward_head_features(self, x):
         """Everything up to (and including) the ReLU before the last 1x1 convolution: [B, 32, h, w]."""

@@ -105,19 +105,23 @@ class NativeDPT:
         return self._pos[key]
 
     @torch.no_grad()
-    def forward(self, frames_u8, max_depth=None, want_depth=True):
-        """frames_u8 [B, H, W, 3] uint8 on the GPU -> (depth f32 [B, H, W], depth_mm int16-viewed-uint16 or None, depth_m or None)."""
+    def forward(self, frames_u8, max_depth=None, want_depth=True, net_size=None):
+        """frames_u8 [B, H, W, 3] uint8 on the GPU -> (depth f32 [B, H, W], depth_mm int16-viewed-uint16 or None, depth_m or None).
+        ``net_size=(net_h, net_w)``: the size the network runs at (multiples of 32) when it is not the frames' -- the frames enter through the reference's
+        bicubic resize and the depth maps come back through its nearest-neighbour resize, both on the device inside the one C-ABI call
+        (``hive_dpt_forward_frames``; /root/reference/hive/dataset_adaptors.py:1376-1389, 1421-1426)."""
         assert frames_u8.dtype == torch.uint8 and frames_u8.is_cuda and frames_u8.dim() == 4 and frames_u8.shape[-1] == 3
         frames_u8 = frames_u8.contiguous()
         b, h, w, _ = frames_u8.shape
+        net_h, net_w = (h, w) if net_size is None else (int(net_size[0]), int(net_size[1]))
         self.ctx.follow_torch_stream()
         dev = frames_u8.device
         depth = torch.empty((b, h, w), dtype=torch.float32, device=dev) if want_depth else None
         mm = torch.empty((b, h, w), dtype=torch.int16, device=dev) if max_depth is not None else None
         m = torch.empty((b, h, w), dtype=torch.float32, device=dev) if max_depth is not None else None
-        pos = self._pos_embed(h // 16, w // 16)
-        self.ctx.check(self.ctx.lib.hive_dpt_forward(self.handle, frames_u8.data_ptr(), b, h, w, pos.data_ptr(), _lib.ptr(depth),
-                                                     float(max_depth or 0.0), _lib.ptr(mm), _lib.ptr(m)))
+        pos = self._pos_embed(net_h // 16, net_w // 16)
+        self.ctx.check(self.ctx.lib.hive_dpt_forward_frames(self.handle, frames_u8.data_ptr(), b, h, w, net_h, net_w, pos.data_ptr(), _lib.ptr(depth),
+                                                            float(max_depth or 0.0), _lib.ptr(mm), _lib.ptr(m)))
         return depth, mm, m
 
     def arena_bytes(self):

@@ -326,6 +326,19 @@ int hive_vit_attention(hive_ctx *ctx, const void *qk, int dtype, const void *vT,
  * batch becomes the channels-last network input) -- hive/dataset_adaptors.py:1407-1417 */
 int hive_dpt_preprocess(hive_ctx *ctx, const uint8_t *d_rgb, int64_t n_values, float mean, float std,
                         int dtype, void *d_out);
+/* The same for frames that are not the network's size -- hive/dataset_adaptors.py:1376-1389: `dpt.transforms.Resize(net_w, net_h, ...,
+ * image_interpolation_method=cv2.INTER_CUBIC)` applied to `image / 255.0`, then NormalizeImage / PrepareForNet / the 16-bit cast:
+ * d_rgb u8 [B][H][W][3] -> d_out [B][out_h][out_w][3] in `dtype` (HIVE_F16 / HIVE_BF16; HIVE_F32 for checks).  The output size is the
+ * caller's (hive_amd.dpt.transforms.Resize.get_size restates the reference's sizing rule); the arithmetic is cv2.resize's INTER_CUBIC:
+ * a = -0.75 cubic, four taps per axis at floor((d + 0.5) * src / dst - 0.5) - 1 .. + 2, indices clamped to the image, no anti-aliasing,
+ * float32 weights, rows first.  (cv2 is not available to this build: parity with cv2 itself is unpinned; see csrc/resize.hip.) */
+int hive_dpt_resize_preprocess(hive_ctx *ctx, const uint8_t *d_rgb, int B, int H, int W, int out_h, int out_w, float mean, float std,
+                               int dtype, void *d_out);
+/* hive/dataset_adaptors.py:1421-1426 `torch.nn.functional.interpolate(prediction, size=frame.shape[:2], mode="nearest")` fused with the
+ * hand-off of :1432-1433 / hive/io.py:1032-1039: d_depth f32 [B][h][w] -> [B][H][W] outputs (any may be NULL, not all): d_out_depth f32,
+ * d_out_mm = uint16(depth * 1000), d_out_m = depth_scale * mm with > max_depth -> 0.  Source index = min((int)floorf(dst * (float)src / dst_size), src - 1). */
+int hive_depth_resize_nearest(hive_ctx *ctx, const float *d_depth, int B, int h, int w, int H, int W, float depth_scale, float max_depth,
+                              float *d_out_depth, uint16_t *d_out_mm, float *d_out_m);
 /* Last layer of the depth head, fused, in float32: 1x1 conv C -> 1 on the channels-last f16 / bf16 map
  * d_feat [n_px][C] (weights / bias on the host), ReLU if non_negative, depth = 1 / max(scale x + shift, 1e-8)
  * if invert (DPTDepthModel.forward).  h_pre_bias (optional, host, [C]) and pre_relu apply the bias and ReLU of the
@@ -515,6 +528,12 @@ int hive_dpt_create(hive_ctx *ctx, const hive_dpt_config *config, const hive_dpt
  * all): d_depth f32 metres; d_out_mm = uint16(depth * 1000); d_out_m = mm / 1000 with > max_depth -> 0. */
 int hive_dpt_forward(hive_dpt *dpt, const uint8_t *d_rgb, int B, int H, int W, const void *d_pos_embed, float *d_depth, float max_depth,
                      uint16_t *d_out_mm, float *d_out_m);
+/* Frames of ANY size (BASELINE config 4: 1920 x 1080): d_rgb u8 [B][frame_h][frame_w][3] enters through hive_dpt_resize_preprocess at the network's
+ * net_h x net_w (multiples of 32; the reference's rule gives 864 x 480 for 1080p, hive/dataset_adaptors.py:1376-1389), the depth map leaves through
+ * hive_depth_resize_nearest at the frame size (:1421-1426): outputs [B][frame_h][frame_w].  d_pos_embed is the embedding of the NETWORK's token grid
+ * (net_h / 16)(net_w / 16) + 1.  With net == frame size this is hive_dpt_forward. */
+int hive_dpt_forward_frames(hive_dpt *dpt, const uint8_t *d_rgb, int B, int frame_h, int frame_w, int net_h, int net_w, const void *d_pos_embed,
+                            float *d_depth, float max_depth, uint16_t *d_out_mm, float *d_out_m);
 /* Bytes of the activation arena (grown to the largest forward seen: the high-water mark of its maps, which are released behind
  * their last consumer -- ~10 GB for 96 frames of 480 x 640, where the maps total 38 GB). */
 int hive_dpt_arena_bytes(hive_dpt *dpt, int64_t *bytes);

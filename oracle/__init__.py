@@ -122,6 +122,64 @@ def depth_quantize(depth_m, depth_scale=1.0 / 1000.0, max_depth=10.0, mask=None)
     return mm, m
 
 
+def _cubic_taps_cv2(dst, src):
+    """Tap indices [dst, 4] and float32 weights [dst, 4] of cv2.resize(..., interpolation=cv2.INTER_CUBIC) along one axis (published algorithm,
+    modules/imgproc/src/resize.cpp: `fx = (float)((dx + 0.5) * scale - 0.5); sx = cvFloor(fx); fx -= sx; interpolateCubic(fx, cbuf)` with
+    scale = 1 / (dst / src) in double and A = -0.75; taps sx - 1 .. sx + 2 clamped to the image).  PARITY UNPINNED against cv2 itself (not in this image,
+    no fixture in the reference); pinned against torch's bicubic by tests/test_oracle_cpu.py."""
+    scale = 1.0 / (np.float64(dst) / np.float64(src))
+    f = ((np.arange(dst, dtype=np.float64) + 0.5) * scale - 0.5).astype(np.float32)
+    s = np.floor(f).astype(np.int64)
+    f = (f - s.astype(np.float32)).astype(np.float32)
+    A = np.float32(-0.75)
+    one = np.float32(1.0)
+    w = np.empty((dst, 4), np.float32)
+    w[:, 0] = ((A * (f + one) - np.float32(5.0) * A) * (f + one) + np.float32(8.0) * A) * (f + one) - np.float32(4.0) * A
+    w[:, 1] = ((A + np.float32(2.0)) * f - (A + np.float32(3.0))) * f * f + one
+    w[:, 2] = ((A + np.float32(2.0)) * (one - f) - (A + np.float32(3.0))) * (one - f) * (one - f) + one
+    w[:, 3] = one - w[:, 0] - w[:, 1] - w[:, 2]
+    idx = np.clip(s[:, None] + np.arange(-1, 3)[None, :], 0, src - 1)
+    return idx, w
+
+
+def resize_bicubic_cv2(image, out_w, out_h):
+    """cv2.resize(image, (out_w, out_h), interpolation=cv2.INTER_CUBIC) for a float64 image [H, W, C] -- what the reference's
+    `dpt.transforms.Resize` runs on `image / 255.0` (/root/reference/hive/dataset_adaptors.py:1376-1389, 1407): float32 weights, float64 sums, the
+    horizontal pass first, each sum left to right (HResizeCubic / VResizeCubic)."""
+    image = np.asarray(image, np.float64)
+    H, W = image.shape[:2]
+    ix, wx = _cubic_taps_cv2(int(out_w), W)
+    iy, wy = _cubic_taps_cv2(int(out_h), H)
+    wx, wy = wx.astype(np.float64), wy.astype(np.float64)
+    rows = image[:, ix[:, 0]] * wx[None, :, 0, None]
+    for k in range(1, 4):
+        rows = rows + image[:, ix[:, k]] * wx[None, :, k, None]  # [H, out_w, C]
+    out = rows[iy[:, 0]] * wy[:, 0, None, None]
+    for k in range(1, 4):
+        out = out + rows[iy[:, k]] * wy[:, k, None, None]
+    return out
+
+
+def dpt_resize_preprocess(frames_u8, net_h, net_w):
+    """The reference's network input for frames [B, H, W, 3] uint8 that are not the network's size: Resize(cubic) of `image / 255.0`, NormalizeImage(0.5, 0.5),
+    PrepareForNet's float32 (dataset_adaptors.py:1376-1392, 1407) -> float32 [B, net_h, net_w, 3] (channels-last; the 16-bit cast is the caller's)."""
+    out = [((resize_bicubic_cv2(f / 255.0, net_w, net_h) - 0.5) / 0.5).astype(np.float32) for f in np.asarray(frames_u8)]
+    return np.stack(out)
+
+
+def nearest_index(dst, src):
+    """Source indices of torch.nn.functional.interpolate(mode="nearest") along one axis (ATen nearest_neighbor_compute_source_index:
+    min((int)floorf(dst_index * scale), src - 1), scale = (float)src / dst) -- dataset_adaptors.py:1421-1426."""
+    scale = np.float32(src) / np.float32(dst)
+    return np.minimum(np.floor(np.arange(dst, dtype=np.float32) * scale).astype(np.int64), src - 1)
+
+
+def resize_nearest(depth, out_h, out_w):
+    """depth [..., h, w] -> [..., out_h, out_w], torch's nearest rule."""
+    depth = np.asarray(depth)
+    return depth[..., nearest_index(out_h, depth.shape[-2])[:, None], nearest_index(out_w, depth.shape[-1])[None, :]]
+
+
 class TSDFVolume:
     """CPU oracle with the call signatures of the reference library's ``fusion.TSDFVolume``
     (call sites /root/reference/hive/fusion.py:104,124,127)."""

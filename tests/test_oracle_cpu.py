@@ -313,3 +313,32 @@ def test_depth_quantize(oracle_lib):
     np.testing.assert_array_equal(m[0], np.array([0, 0, np.float32(0.001) * np.float32(1234), np.float32(0.001) * np.float32(7256),
                                                   np.float32(0.001) * np.float32(9999), np.float32(0.001) * np.float32(10000), 0],
                                                  np.float32))
+
+
+def test_cubic_resize_restatement_against_torch_bicubic():
+    """`resize_bicubic_cv2` restates cv2.resize(INTER_CUBIC) from its published source (cv2 is not installed here and the reference holds no fixture of it:
+    parity with cv2 itself is UNPINNED).  What pins the restatement: torch's bicubic with align_corners=False is an independent implementation of the same
+    a = -0.75 kernel with the same index clamping, evaluated in float64; the only stated difference is that cv2 rounds the source coordinate and the four
+    weights to float32 -- a coordinate of ~1000 carries 6e-5 of rounding, so the agreement is ~1e-5 when shrinking and exact-ish when the scale is a
+    power of two.  Also: torch's nearest rule (exact) and the sizing rule of the reference's Resize for the frame sizes BASELINE names."""
+    import torch
+    import oracle
+    from hive_amd import depth as depth_mod
+    rng = np.random.default_rng(0)
+    for (H, W, oh, ow), tol in (((108, 192, 48, 86), 5e-5), ((48, 64, 96, 128), 1e-12), ((31, 45, 32, 64), 1e-5), ((270, 480, 96, 160), 1e-4)):
+        img = rng.random((H, W, 3))
+        mine = oracle.resize_bicubic_cv2(img, ow, oh)
+        ref = torch.nn.functional.interpolate(torch.from_numpy(img).permute(2, 0, 1)[None], size=(oh, ow), mode="bicubic", align_corners=False)[0].permute(1, 2, 0).numpy()
+        assert mine.shape == (oh, ow, 3) and np.abs(mine - ref).max() <= tol, (H, W, oh, ow, np.abs(mine - ref).max())
+    # a constant image stays constant (the weights sum to 1 by construction), overshoot is not clipped (float images)
+    assert np.allclose(oracle.resize_bicubic_cv2(np.full((20, 30, 3), 0.25), 13, 7), 0.25, atol=1e-7)
+    step = np.zeros((16, 16, 1))
+    step[:, 8:] = 1.0
+    r = oracle.resize_bicubic_cv2(step, 40, 16)
+    assert r.min() < -0.01 and r.max() > 1.01
+    d = rng.random((2, 48, 86)).astype(np.float32)
+    for size in ((108, 192), (1080, 1920), (48, 86), (31, 57)):
+        ref = torch.nn.functional.interpolate(torch.from_numpy(d)[:, None], size=size, mode="nearest")[:, 0].numpy()
+        assert np.array_equal(oracle.resize_nearest(d, *size), ref)
+    assert depth_mod.network_size(480, 640) == (480, 640) and depth_mod.network_size(1080, 1920) == (480, 864)
+    assert depth_mod.network_size(240, 320) == (480, 640) and depth_mod.network_size(720, 1280) == (480, 864) and depth_mod.network_size(1920, 1080) == (1152, 640)
