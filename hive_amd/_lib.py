@@ -33,6 +33,8 @@ SIGNATURES = {
     "hive_last_error": (ctypes.c_char_p, [c_void_p]),
     "hive_ctx_set_stream": (c_int, [c_void_p, c_void_p]),
     "hive_ctx_set_round_mode": (c_int, [c_void_p, c_int]),
+    "hive_ctx_set_deterministic": (c_int, [c_void_p, c_int]),
+    "hive_ctx_launch_stats": (c_int, [c_void_p, P(c_int64), P(c_int64), c_int]),
     "hive_ctx_set_timing": (c_int, [c_void_p, c_int]),
     "hive_ctx_last_kernel_ms": (c_int, [c_void_p, P(c_float)]),
     "hive_ctx_kernel_time_total": (c_int, [c_void_p, P(c_int), P(c_float)]),
@@ -83,6 +85,7 @@ SIGNATURES = {
     "hive_dilate_mask_se": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "hive_depth_apply_mask_se": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "hive_vit_create": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, P(c_void_p)]),
+    "hive_vit_weights_modified": (c_int, [c_void_p]),
     "hive_vit_destroy": (c_int, [c_void_p]),
     "hive_vit_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
     "hive_vit_layernorm": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float]),
@@ -131,6 +134,7 @@ SIGNATURES = {
     "hive_dpt_resize_preprocess": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_int, c_void_p]),
     "hive_depth_resize_nearest": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p]),
     "hive_dpt_arena_bytes": (c_int, [c_void_p, P(c_int64)]),
+    "hive_dpt_weights_modified": (c_int, [c_void_p]),
     "hive_dpt_destroy": (c_int, [c_void_p]),
     "hive_depth_quantize": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p]),
 }
@@ -224,6 +228,7 @@ class Context:
         handle = c_void_p()
         self._follow_torch = stream == "torch"
         self._stream = None
+        self.deterministic = False
         self._side_stream = None  # the torch.cuda.Stream this context was made for (DepthFusionStream.side_stream_context)
         if stream == "torch":
             import torch
@@ -278,6 +283,17 @@ class Context:
 
     def set_round_mode(self, mode):
         self.check(self.lib.hive_ctx_set_round_mode(self.handle, int(mode)))
+
+    def set_deterministic(self, enabled):
+        """No split-K, no Gram-matrix GroupNorm statistics: see ``hive_ctx_set_deterministic`` in include/hive_mi355x.h."""
+        self.check(self.lib.hive_ctx_set_deterministic(self.handle, int(bool(enabled))))
+        self.deterministic = bool(enabled)
+
+    def launch_stats(self, reset=False):
+        """(split-K launches, four-stage-ring launches) since creation / the last reset."""
+        a, b = c_int64(0), c_int64(0)
+        self.check(self.lib.hive_ctx_launch_stats(self.handle, ctypes.byref(a), ctypes.byref(b), int(bool(reset))))
+        return int(a.value), int(b.value)
 
     def set_timing(self, enabled):
         self.check(self.lib.hive_ctx_set_timing(self.handle, int(bool(enabled))))

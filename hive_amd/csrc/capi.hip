@@ -220,6 +220,20 @@ int hive_ctx_set_round_mode(hive_ctx *ctx, int mode) {
     return HIVE_OK;
 }
 
+int hive_ctx_set_deterministic(hive_ctx *ctx, int enabled) {
+    if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
+    ctx->deterministic = enabled != 0;
+    return HIVE_OK;
+}
+
+int hive_ctx_launch_stats(hive_ctx *ctx, int64_t *splitk_launches, int64_t *deep_ring_launches, int reset) {
+    if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
+    if (splitk_launches) *splitk_launches = ctx->n_splitk_launches;
+    if (deep_ring_launches) *deep_ring_launches = ctx->n_deep_ring_launches;
+    if (reset) ctx->n_splitk_launches = ctx->n_deep_ring_launches = 0;
+    return HIVE_OK;
+}
+
 int hive_ctx_set_timing(hive_ctx *ctx, int enabled) {
     HIVE_ENTER(ctx);
     if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");

@@ -702,7 +702,10 @@ int launch_conv_t(hive_ctx *ctx, const char *what, const void *d_x, int N, int H
             const char *sk_env = getenv("HIVE_SPLITK");
             p.split_k = sk_env ? std::max(1, std::min(atoi(sk_env), KT)) : hive_mfma::splitk_ways(tiles128, KT, ctx->num_cus);
             p.split_k = (int)std::max<long long>(1, std::min<long long>(p.split_k, ctx->num_cus / tiles128));
+            if (ctx->deterministic) p.split_k = 1;
+            ++ctx->n_deep_ring_launches;
             if (p.split_k > 1) {
+                ++ctx->n_splitk_launches;
                 void *ws = nullptr;
                 rc = hive_splitk_workspace(ctx, (size_t)tiles128 * p.split_k * 128 * 128 * sizeof(float), &ws, &p.sk_count);
                 if (rc) return rc;

@@ -231,7 +231,7 @@ int run_forward(hive_dpt *d, bool dry, const uint8_t *d_rgb, int B, int FH, int 
         // ... and only for large outputs: the three small kernels behind the Gram matrices cost 40-60 us whatever the batch (break-even at ~32 frames for the
         // 64- / 128-channel inputs, ~100 for the stride-2 one): >= 150 M output elements, 250 M for C_in = 256
         const long long out_elems = (long long)B * oh * ow * cout;
-        const bool gram = !(gram_env && gram_env[0] == '0') && eligible &&
+        const bool gram = !(gram_env && gram_env[0] == '0') && !ctx->deterministic && eligible &&
                           (((x.C == 64 || x.C == 128) && out_elems >= 150000000ll) || (x.C == 256 && stride == 2 && out_elems >= 250000000ll));
         if (gram) {
             float *&tables = d->gram_tables[wname];
@@ -583,6 +583,18 @@ int hive_dpt_forward_frames(hive_dpt *d, const uint8_t *d_rgb, int B, int frame_
 int hive_dpt_forward(hive_dpt *d, const uint8_t *d_rgb, int B, int H, int W, const void *d_pos_embed, float *d_depth, float max_depth,
                      uint16_t *d_out_mm, float *d_out_m) {
     return hive_dpt_forward_frames(d, d_rgb, B, H, W, H, W, d_pos_embed, d_depth, max_depth, d_out_mm, d_out_m);
+}
+
+int hive_dpt_weights_modified(hive_dpt *d) {
+    HIVE_ENTER(d ? d->ctx : nullptr);
+    if (!d) return hive_fail(nullptr, HIVE_ERR_INVALID, "dpt is NULL");
+    // everything derived from the caller's tensors: the ViT engine's folded LayerNorm weights (rebuilt now, on the context's stream) and the Gram tables of
+    // the 1 x 1 convolutions (dropped; rebuilt by the forward that next needs them).  All other weights are read through the caller's pointers at every forward.
+    HIVE_CHECK_HIP(d->ctx, hipStreamSynchronize(d->ctx->stream));  // (a forward in flight may still read the tables)
+    for (auto &kv : d->gram_tables)
+        if (kv.second) (void)hipFree(kv.second);
+    d->gram_tables.clear();
+    return hive_vit_weights_modified(d->vit);
 }
 
 int hive_dpt_arena_bytes(hive_dpt *d, int64_t *bytes) {

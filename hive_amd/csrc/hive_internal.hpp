@@ -55,6 +55,11 @@ struct hive_ctx {
     void *d_gram = nullptr;  // partial Gram matrices / sums / quadratic forms of gram.hip (GroupNorm statistics of 1 x 1 convolutions)
     size_t gram_bytes = 0;
 
+    // hive_ctx_set_deterministic: no split-K, no Gram-matrix GroupNorm statistics (the two paths whose use depends on the batch size and the CU count)
+    bool deterministic = false;
+    // launches of the small-launch paths since creation / the last reset (hive_ctx_launch_stats): split-K items, four-stage-ring kernels
+    int64_t n_splitk_launches = 0, n_deep_ring_launches = 0;
+
     // HIP-event timing of the dominant kernel
     bool timing = false;
     std::vector<hipEvent_t> ev_pool;

@@ -1317,7 +1317,9 @@ static int launch_integrate_multi(hive_tsdf *v, int nf, int H, int W, const floa
         fill_frame_params(v, H, W, K, poses + 16 * (size_t)f, obs_weight, mp.f[f]);
         mp.f[f].frame = texels + (size_t)f * npx;
         mp.f[f].tile_max = tiles + (size_t)f * tile_stride;
-        if (env_flag("HIVE_TSDF_TIMING_SAME_TEXELS", false)) mp.f[f].frame = texels;  // TIMING EXPERIMENT ONLY (wrong results): every frame gathers from frame 0's texels
+#ifdef HIVE_TSDF_TUNING  // tuning builds only (make tsdf_variants): a TIMING experiment with WRONG results -- every frame gathers from frame 0's texels
+        if (env_flag("HIVE_TSDF_TIMING_SAME_TEXELS", false)) mp.f[f].frame = texels;
+#endif
     }
     for (int f = nf; f < MAXF; ++f) mp.f[f] = mp.f[0];
     const FrameParams &p = mp.f[0];

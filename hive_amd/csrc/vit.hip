@@ -1133,8 +1133,9 @@ static int launch_gemm(hive_ctx *ctx, int epi, const GemmParams<T> &p) {
     const long long slots = (long long)(2 * ctx->num_cus) / 8 * 8;
     const char *sk_env = getenv("HIVE_SPLITK");
     q.split_k = sk_env ? std::max(1, std::min(atoi(sk_env), p.K / BK)) : hive_mfma::splitk_ways(tiles, p.K / BK, ctx->num_cus);
-    if (tiles > HIVE_SPLITK_TILES) q.split_k = 1;
+    if (tiles > HIVE_SPLITK_TILES || ctx->deterministic) q.split_k = 1;
     if (q.split_k > 1) {
+        ++ctx->n_splitk_launches;
         void *ws = nullptr;
         int rc = hive_splitk_workspace(ctx, (size_t)tiles * q.split_k * GEMM_TM * BN * sizeof(float), &ws, &q.sk_count);
         if (rc) return rc;
@@ -1144,6 +1145,7 @@ static int launch_gemm(hive_ctx *ctx, int epi, const GemmParams<T> &p) {
     // the deep ring (one workgroup per CU) where the items fit the CUs in one round anyway; HIVE_GEMM_RING=2 / 4 forces a depth
     const char *ring_env = getenv("HIVE_GEMM_RING");
     const bool deep = ring_env ? ring_env[0] == '4' : items <= ctx->num_cus;
+    if (deep) ++ctx->n_deep_ring_launches;
     const dim3 grid((unsigned)std::min<long long>((items + 7) / 8 * 8, deep ? (long long)ctx->num_cus / 8 * 8 : slots)), block(GEMM_TM * 2);
 #define HIVE_GEMM_CASE(EPI_)                                                                                                          \
     case EPI_:                                                                                                                        \
@@ -1266,6 +1268,35 @@ static int attention_t(hive_ctx *ctx, const void *qk, const void *vT, void *out,
 }
 
 #define HIVE_REQUIRE_16BIT(ctx, dtype, what) HIVE_REQUIRE(ctx, (dtype) == HIVE_BF16 || (dtype) == HIVE_F16, what ": dtype must be HIVE_F16 or HIVE_BF16, got %d", (int)(dtype))
+
+// (Re)build the private copies hive_vit_forward reads instead of the caller's tensors: W' = gamma o W for qkv / fc1 and the two constant rows c1, c2 of the folded
+// LayerNorm.  Launched on the context's stream: ordered behind whatever wrote the caller's weights there, in front of the next forward.
+static void fold_layernorm_weights(hive_vit *v) {
+    hive_ctx *ctx = v->ctx;
+    const int dim = v->dim, mlp_dim = v->mlp, depth = v->depth;
+    const size_t esz = sizeof(half_bits), rows = (size_t)3 * dim + mlp_dim;
+    const size_t w_bytes = (rows * dim * esz + 255) & ~(size_t)255, c_bytes = (2 * rows * sizeof(float) + 255) & ~(size_t)255;
+    for (int i = 0; i < depth; ++i) {
+        char *base = (char *)v->fold_mem + (size_t)i * (w_bytes + c_bytes);
+        float *c = (float *)(base + w_bytes);
+        hive_vit::Folded &f = v->folded[i];
+        f.qkv_w = base;
+        f.fc1_w = base + (size_t)3 * dim * dim * esz;
+        f.qkv_c1 = c, f.qkv_c2 = c + 3 * dim, f.fc1_c1 = c + 6 * dim, f.fc1_c2 = c + 6 * dim + mlp_dim;
+        const hive_vit_block_weights &b = v->blocks[i];
+#define HIVE_FOLD(T_)                                                                                                                                   \
+    hipLaunchKernelGGL(ln_fold_weights_kernel<T_>, dim3(3 * dim), dim3(256), 0, ctx->stream, (const T_ *)b.qkv_w, (const float *)b.qkv_b, (const float *)b.ln1_g, \
+                       (const float *)b.ln1_b, dim, (T_ *)f.qkv_w, (float *)f.qkv_c1, (float *)f.qkv_c2);                                                \
+    hipLaunchKernelGGL(ln_fold_weights_kernel<T_>, dim3(mlp_dim), dim3(256), 0, ctx->stream, (const T_ *)b.fc1_w, (const float *)b.fc1_b, (const float *)b.ln2_g, \
+                       (const float *)b.ln2_b, dim, (T_ *)f.fc1_w, (float *)f.fc1_c1, (float *)f.fc1_c2)
+        if (v->dtype == HIVE_BF16) {
+            HIVE_FOLD(__bf16);
+        } else {
+            HIVE_FOLD(_Float16);
+        }
+#undef HIVE_FOLD
+    }
+}
 
 extern "C" {
 
@@ -1393,26 +1424,7 @@ int hive_vit_create(hive_ctx *ctx, int dtype, int depth, int dim, int heads, int
             return rc;
         }
         v->folded.resize(depth);
-        for (int i = 0; i < depth; ++i) {
-            char *base = (char *)v->fold_mem + (size_t)i * (w_bytes + c_bytes);
-            float *c = (float *)(base + w_bytes);
-            hive_vit::Folded &f = v->folded[i];
-            f.qkv_w = base;
-            f.fc1_w = base + (size_t)3 * dim * dim * esz;
-            f.qkv_c1 = c, f.qkv_c2 = c + 3 * dim, f.fc1_c1 = c + 6 * dim, f.fc1_c2 = c + 6 * dim + mlp_dim;
-            const hive_vit_block_weights &b = blocks[i];
-#define HIVE_FOLD(T_)                                                                                                                                   \
-    hipLaunchKernelGGL(ln_fold_weights_kernel<T_>, dim3(3 * dim), dim3(256), 0, ctx->stream, (const T_ *)b.qkv_w, (const float *)b.qkv_b, (const float *)b.ln1_g, \
-                       (const float *)b.ln1_b, dim, (T_ *)f.qkv_w, (float *)f.qkv_c1, (float *)f.qkv_c2);                                                \
-    hipLaunchKernelGGL(ln_fold_weights_kernel<T_>, dim3(mlp_dim), dim3(256), 0, ctx->stream, (const T_ *)b.fc1_w, (const float *)b.fc1_b, (const float *)b.ln2_g, \
-                       (const float *)b.ln2_b, dim, (T_ *)f.fc1_w, (float *)f.fc1_c1, (float *)f.fc1_c2)
-            if (dtype == HIVE_BF16) {
-                HIVE_FOLD(__bf16);
-            } else {
-                HIVE_FOLD(_Float16);
-            }
-#undef HIVE_FOLD
-        }
+        fold_layernorm_weights(v);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // the caller may free or overwrite its weight tensors' temporaries after create
         if (e != hipSuccess) {
@@ -1423,6 +1435,14 @@ int hive_vit_create(hive_ctx *ctx, int dtype, int depth, int dim, int heads, int
         }
     }
     *out = v;
+    return HIVE_OK;
+}
+
+int hive_vit_weights_modified(hive_vit *v) {
+    HIVE_ENTER(v ? v->ctx : nullptr);
+    if (!v) return hive_fail(nullptr, HIVE_ERR_INVALID, "vit is NULL");
+    fold_layernorm_weights(v);
+    HIVE_CHECK_HIP(v->ctx, hipGetLastError());
     return HIVE_OK;
 }
 

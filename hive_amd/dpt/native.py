@@ -124,6 +124,13 @@ class NativeDPT:
                                                             float(max_depth or 0.0), _lib.ptr(mm), _lib.ptr(m)))
         return depth, mm, m
 
+    def weights_modified(self):
+        """The tensors of the table were overwritten IN PLACE (same pointers): refresh what the object derived from them at creation / first use (the folded
+        LayerNorm weights, the Gram tables) -- ``hive_dpt_weights_modified``.  (``DPTDepthModel.native()`` does not need it: it rebuilds the object when a
+        parameter's version or address changed.)"""
+        self.ctx.follow_torch_stream()
+        self.ctx.check(self.ctx.lib.hive_dpt_weights_modified(self.handle))
+
     def arena_bytes(self):
         """Bytes of the activation arena (high-water mark of the largest forward so far)."""
         n = ctypes.c_int64(0)

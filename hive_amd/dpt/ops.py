@@ -211,7 +211,7 @@ def conv_gn_act(x, conv, norm, weight=None, same_pad=False, relu=True, residual=
     # (csrc/dpt_net.hip conv_norm), so that both orchestrations stay bit-identical; HIVE_GN_GRAM=0 switches it off
     cin = conv.in_channels
     out_elems = n * oh * ow * cout
-    if k == 1 and os.environ.get("HIVE_GN_GRAM", "1") != "0" and g == 32 and ((cin in (64, 128) and out_elems >= 150_000_000) or
+    if k == 1 and os.environ.get("HIVE_GN_GRAM", "1") != "0" and not getattr(ctx, "deterministic", False) and g == 32 and ((cin in (64, 128) and out_elems >= 150_000_000) or
                                                                                (cin == 256 and st == 2 and out_elems >= 250_000_000)):
         def tables():
             t = torch.empty(int(ctx.lib.hive_gn_gram_table_floats(cin, g)), dtype=torch.float32, device=x.device)

@@ -65,6 +65,11 @@ class VitEngine:
                                                      ctypes.cast(tap_ptr, ctypes.c_void_p)))
         return tuple(outs)
 
+    def weights_modified(self):
+        """The packed weight tensors were overwritten in place: re-fold what ``hive_vit_create`` captured (``hive_vit_weights_modified``)."""
+        self.ctx.follow_torch_stream()
+        self.ctx.check(self.ctx.lib.hive_vit_weights_modified(self.handle))
+
     def close(self):
         if getattr(self, "handle", None) and _lib.alive():
             self.ctx.lib.hive_vit_destroy(self.handle)

@@ -78,6 +78,16 @@ const char *hive_last_error(hive_ctx *ctx);
 int hive_ctx_set_stream(hive_ctx *ctx, void *stream);
 /* Rounding used by hive_project / hive_project_bbox, and the mode a volume created afterwards on this context starts with. */
 int hive_ctx_set_round_mode(hive_ctx *ctx, int mode);
+/* Deterministic mode (off by default): the network kernels stop using the two paths whose USE depends on the batch size and on the device's CU count --
+ * split-K of long K loops at small launches (another, fixed, order of float32 additions) and the Gram-matrix form of the GroupNorm statistics of the
+ * bottlenecks' 1 x 1 convolutions (statistics of the exact products instead of the rounded outputs) -- so that a frame's depth map no longer changes
+ * with the size of the batch it was in beyond what is stated next.  What remains: a GroupNorm's per-tile partial sums are cut at 128- / 256-pixel
+ * tile boundaries counted from the START OF THE BATCH, so a frame's (mean, rstd) still depend on its position in the batch by float32 re-association
+ * (~1e-7 relative).  Frame-sharded multi-GPU runs that want one-GPU depth maps to the last bit must also keep the per-rank batch composition. */
+int hive_ctx_set_deterministic(hive_ctx *ctx, int enabled);
+/* Launch counters of the small-launch paths since creation (or the last call with reset != 0): GEMM / convolution launches that split their K loop,
+ * and launches of the four-stage-ring kernels (csrc/mfma_pipe.hpp).  Diagnostic: the one-frame parity tests assert with it that those paths ran. */
+int hive_ctx_launch_stats(hive_ctx *ctx, int64_t *splitk_launches, int64_t *deep_ring_launches, int reset);
 /* HIP-event timing of the most recent kernel launched by a *_timed call on this context. */
 int hive_ctx_set_timing(hive_ctx *ctx, int enabled);
 int hive_ctx_last_kernel_ms(hive_ctx *ctx, float *ms);
@@ -299,6 +309,11 @@ typedef struct hive_vit_block_weights {
 /* head dim must be 64 (D = 64 * heads), D a multiple of 256 and <= 1024, F a multiple of 128. */
 int hive_vit_create(hive_ctx *ctx, int dtype, int depth, int dim, int heads, int mlp_dim, float ln_eps,
                     const hive_vit_block_weights *blocks, hive_vit **out);
+/* WEIGHT SNAPSHOT CONTRACT.  hive_vit_create copies what the folded LayerNorm needs -- gamma o W of qkv / fc1 and the constant rows c1 = sum_k (gamma o W)[n][k],
+ * c2 = sum_k beta[k] W[n][k] + bias[n] -- into private buffers; proj / fc2 and every bias other than those two are read through the caller's pointers at
+ * every forward.  A caller that overwrites weights IN PLACE after create must call hive_vit_weights_modified (re-folds on the context's stream, ordered
+ * behind the writes there) before the next forward, or gets old LayerNorm / qkv / fc1 with new proj / fc2.  (hive_dpt: hive_dpt_weights_modified.) */
+int hive_vit_weights_modified(hive_vit *vit);
 int hive_vit_destroy(hive_vit *vit);
 /* x 16-bit [B][N][D] -> runs all blocks; after block tap_blocks[t] its output is copied to tap_out[t]
  * (16-bit [B][N][D]).  x = x + proj(attn(LN1 x)); x = x + fc2(gelu(fc1(LN2 x))). */
@@ -537,6 +552,10 @@ int hive_dpt_forward_frames(hive_dpt *dpt, const uint8_t *d_rgb, int B, int fram
 /* Bytes of the activation arena (grown to the largest forward seen: the high-water mark of its maps, which are released behind
  * their last consumer -- ~10 GB for 96 frames of 480 x 640, where the maps total 38 GB). */
 int hive_dpt_arena_bytes(hive_dpt *dpt, int64_t *bytes);
+/* The table's tensors were overwritten in place: refresh what the object derived from them -- the ViT engine's folded LayerNorm weights (captured at
+ * hive_dpt_create, see hive_vit_weights_modified) and the Gram tables of the bottlenecks' 1 x 1 convolutions (made on the first forward that needs them).
+ * Everything else is read through the table's pointers at every forward.  Pointers must stay the same; new tensors need a new object. */
+int hive_dpt_weights_modified(hive_dpt *dpt);
 int hive_dpt_destroy(hive_dpt *dpt);
 
 #ifdef __cplusplus
