@@ -179,13 +179,15 @@ def load_profile(name):
         return None
 
 
-def config4_leg(device, ctx, steps=2, batch=8):
+def config4_leg(device, ctx, steps=3, batch=8, overlap=True):
     """BASELINE configs[3], bounded, through the PRODUCT path: 1920 x 1080 frames (host-resident, uploaded in the timed region) -> `DepthFusionStream.step`:
     the reference's resize rule (640 x 480 target, keep aspect ratio, "minimal", multiple of 32: 864 x 480 -- hive_amd.depth.network_size) and its cv2.INTER_CUBIC
     resize + normalisation as one HIP kernel -> DPT-Large depth (backbone vitl16_384, bf16, seeded weights) -> nearest back to 1080p + uint16-mm hand-off as
-    one HIP kernel (all of it ONE C-ABI call, hive_dpt_forward_frames) -> integrate into a 1024^3 volume (5 mm voxels).  No torch operator in the timed
-    region but the upload.  `steps` timed steps of `batch` frames after one warm-up step; the sweep's roofline (SURVEY 8d bytes and must-move bytes) from the
-    frames of the last step."""
+    one HIP kernel (all of it ONE C-ABI call, hive_dpt_forward_frames) -> integrate into a 1024^3 volume (5 mm voxels), the sweeps of a batch on the side
+    stream under the next batch's network as in the headline job.  No torch operator in the timed region but the upload.  `steps` timed steps of `batch` frames
+    after one warm-up step.  The sweep's roofline (SURVEY 8d bytes and must-move bytes) on two scenes, as for the headline: the DPT depth of the last step's
+    frames (`roofline`: seeded random weights give a noise-like depth map -- two thirds of the voxels the sweep must test cannot update) and the analytic
+    ray-cast depth of the same frames (`roofline_room`: the room's walls)."""
     from hive_amd import depth as depth_mod, fusion, synthetic
     from hive_amd.dpt.init import seeded_init
     from hive_amd.dpt.models import DPTDepthModel
@@ -196,70 +198,88 @@ def config4_leg(device, ctx, steps=2, batch=8):
     seeded_init(model, seed=1234)
     model = model.eval().to(memory_format=torch.channels_last).to(torch.bfloat16).to(device)
     storage = tuple(torch.empty(1024 ** 3, dtype=torch.float32, device=device) for _ in range(3))  # caller-owned planes: the weight plane is read below
-    vol = fusion.TSDFVolume(synthetic.room_bounds(), 0.005, ctx=ctx, storage=storage)
+    vctx = depth_mod.DepthFusionStream.side_stream_context(device.index or 0) if overlap else ctx
+    vol = fusion.TSDFVolume(synthetic.room_bounds(), 0.005, ctx=vctx, storage=storage)
     assert tuple(int(d) for d in vol.vol_dim) == (1024, 1024, 1024)
     host = torch.from_numpy(seq["color"]).pin_memory()
-    stream = depth_mod.DepthFusionStream(model, vol, seq["K"])
+    stream = depth_mod.DepthFusionStream(model, vol, seq["K"], overlap=overlap)
+    w_plane = storage[1]
 
-    def dpt(fr):
-        return stream.depth(fr)[0]
+    feeder = FrameFeeder(host, batch, device)  # uploads one batch ahead on a copy stream, as the headline job
 
-    def step(i):
-        fr = host[i * batch:(i + 1) * batch].to(device, non_blocking=True)
-        dm = stream.step(fr, seq["poses"][i * batch:(i + 1) * batch])
-        return fr, dm
+    def run_steps(first, count):
+        token = feeder.prefetch(list(range(first * batch, (first + 1) * batch)))
+        for i in range(first, first + count):
+            fr = feeder.acquire(token)
+            nxt = feeder.prefetch(list(range((i + 1) * batch, (i + 2) * batch))) if i + 1 < first + count else None
+            dm = stream.step(fr, seq["poses"][i * batch:(i + 1) * batch])
+            feeder.release(token, stream.side)  # the buffer is free once the sweeps that read its colours are done
+            token = nxt
+        return fr, dm  # (the feeder buffer holding the last batch is not written again)
+
+    def sweep_roofline(fr, dm, ids):
+        """The sweep alone on these frames: launch duration (HIP events inside the library), N_upd per frame (counting kernel), N_union of the last sweep."""
+        torch.cuda.synchronize()  # (the frames / depth maps were made on torch's stream, the volume's kernels run on its own)
+        n_upd = [vol.integrate(fr[j], dm[j], seq["K"], seq["poses"][i], return_n_updated=True) for j, i in enumerate(ids)]
+        vol.reset()
+        torch.cuda.synchronize()
+        vctx.set_timing(True)
+        vol.integrate_batch(fr, dm, seq["K"], seq["poses"][ids])
+        vctx.synchronize()
+        n_launch, k_ms = vctx.kernel_time_total()
+        vctx.set_timing(False)
+        groups = vol.last_batch_groups()
+        wl = vol.last_sweep_voxels()
+        w_before = w_plane.clone()
+        torch.cuda.synchronize()  # (the copy runs on torch's stream, the sweep below on the volume's)
+        nf = groups[-1]
+        vol.integrate_batch(fr[-nf:], dm[-nf:], seq["K"], seq["poses"][ids[-nf:]])
+        vctx.synchronize()
+        n_union = int((w_plane != w_before).sum().item())
+        del w_before
+        launch_us = k_ms / max(n_launch, 1) * 1e3
+        fpl = len(ids) / max(len(groups), 1)
+        serial = (24.0 * float(np.mean(n_upd)) + 8.0 * H * W) * fpl
+        must = 24.0 * n_union + 8.0 * H * W * nf
+        return {"kernel": "integrate_multi_kernel", "bound": "hbm", "achieved": serial / (launch_us * 1e-6) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                "frac": serial / (launch_us * 1e-6) / 1e9 / 8000.0, "algorithmic_bytes_per_launch": serial, "frames_per_launch": fpl,
+                "avg_launch_us": launch_us, "us_per_frame": launch_us / fpl, "n_upd_mean": float(np.mean(n_upd)),
+                "must_move": {"bytes_per_launch": must, "gbs": must / (launch_us * 1e-6) / 1e9, "frac": must / (launch_us * 1e-6) / 1e9 / 8000.0,
+                              "n_union_last_sweep": n_union},
+                "worklist": {"voxels_last_sweep": wl, "updated_share": n_union / max(wl, 1)}}
 
     with torch.no_grad():
-        step(0)
+        run_steps(0, 1)
+        stream.join()
         torch.cuda.synchronize()
         vol.reset()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for i in range(1, steps + 1):
-            fr, dm = step(i)
+        fr, dm = run_steps(1, steps)
+        stream.join()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         timed_frames = vol.stats()[0]  # (frames the volume was handed since the reset in front of the timed steps)
-        # the sweep alone, on the last step's frames: launch duration (HIP events inside the library), N_upd per frame (counting kernel), N_union per sweep
+        weight_sum = int(w_plane.double().sum().item())
         ids = list(range(steps * batch, (steps + 1) * batch))
-        n_upd = [vol.integrate(fr[j], dm[j], seq["K"], seq["poses"][i], return_n_updated=True) for j, i in enumerate(ids)]
-        ctx.set_timing(True)
-        vol.integrate_batch(fr, dm, seq["K"], seq["poses"][ids])
-        torch.cuda.synchronize()
-        n_launch, k_ms = ctx.kernel_time_total()
-        ctx.set_timing(False)
-        groups = vol.last_batch_groups()
-        wl = vol.last_sweep_voxels()
-        w_plane = storage[1]
-        w_before = w_plane.clone()
-        nf = groups[-1]
-        vol.integrate_batch(fr[-nf:], dm[-nf:], seq["K"], seq["poses"][ids[-nf:]])
-        n_union = int((w_plane != w_before).sum().item())
-        del w_before, w_plane
+        roof = sweep_roofline(fr, dm, ids)
+        roof["scene"] = "DPT-Large depth (seeded weights) of the last step's frames"
+        roof_room = sweep_roofline(fr, torch.from_numpy(seq["depth"][ids]).to(device), ids)
+        roof_room["scene"] = "analytic ray-cast depth of the same frames (the room's walls inside the volume)"
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(2):
-            dpt(fr)
+            stream.depth(fr)
         e1.record()
         e1.synchronize()
         dpt_ms = e0.elapsed_time(e1) / 2
-    launch_us = k_ms / max(n_launch, 1) * 1e3
-    fpl = batch / max(len(groups), 1)
-    serial = (24.0 * float(np.mean(n_upd)) + 8.0 * H * W) * fpl
-    must = 24.0 * n_union + 8.0 * H * W * nf
     out = {"workload": f"synthetic {W}x{H} RGB (room trajectory, 2.4 degrees per frame), DPT-Large (vitl16_384, bf16, seeded weights) at {net_w}x{net_h} + "
                        f"{'x'.join(str(int(d)) for d in vol.vol_dim)} TSDF integrate, {steps} steps of {batch} frames, uploads in the timed region",
            "value": steps * batch / elapsed, "unit": "frames/s", "ms_per_step": elapsed / steps * 1e3, "frames_per_step": batch, "steps": steps,
-           "dpt_ms_per_frame": dpt_ms / batch, "network_size": [net_h, net_w], "resize_method": "minimal",
-           "frames_integrated": timed_frames,
-           "roofline": {"kernel": "integrate_multi_kernel", "bound": "hbm", "achieved": serial / (launch_us * 1e-6) / 1e9, "peak": 8000.0, "unit": "GB/s",
-                        "frac": serial / (launch_us * 1e-6) / 1e9 / 8000.0, "algorithmic_bytes_per_launch": serial, "frames_per_launch": fpl,
-                        "avg_launch_us": launch_us, "us_per_frame": launch_us / fpl, "n_upd_mean": float(np.mean(n_upd)),
-                        "must_move": {"bytes_per_launch": must, "gbs": must / (launch_us * 1e-6) / 1e9, "frac": must / (launch_us * 1e-6) / 1e9 / 8000.0,
-                                      "n_union_last_sweep": n_union},
-                        "worklist_voxels_last_sweep": wl}}
+           "dpt_ms_per_frame": dpt_ms / batch, "network_size": [net_h, net_w], "resize_method": "minimal", "tsdf_overlap": overlap,
+           "frames_integrated": timed_frames, "weight_sum": weight_sum, "roofline": roof, "roofline_room": roof_room}
     vol.close()
-    del model, vol, storage
+    del model, vol, storage, stream, w_plane
     torch.cuda.empty_cache()
     return out
 

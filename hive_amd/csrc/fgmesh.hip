@@ -78,9 +78,11 @@ __device__ __forceinline__ int pixel_faces(const GridParams &p, const float *dep
             }
         }
     }
-    if (!px_valid(depth, mask, i) && v > 0 && v + 1 < p.H && u > 0 && u + 1 < p.W) {  // a hole strictly inside the image
+    if (!px_valid(depth, mask, i)) {  // a hole: bridged where at least three of its 4-neighbours are valid -- a neighbour outside the image counts as invalid, so a
+        // one-pixel hole ON the border with its three in-image neighbours valid gets its (sqrt 2, sqrt 2, 2) triangle too, as Delaunay gives it
         const int nn = i - p.W, ss = i + p.W, ww = i - 1, ee = i + 1;
-        const bool vn = px_valid(depth, mask, nn), vs = px_valid(depth, mask, ss), vw = px_valid(depth, mask, ww), ve = px_valid(depth, mask, ee);
+        const bool vn = v > 0 && px_valid(depth, mask, nn), vs = v + 1 < p.H && px_valid(depth, mask, ss);
+        const bool vw = u > 0 && px_valid(depth, mask, ww), ve = u + 1 < p.W && px_valid(depth, mask, ee);
         if (vn + vs + vw + ve >= 3) {
             const bool e_we = vw && ve && edge_ok(p, depth, ww, ee, 2, 0), e_ns = vn && vs && edge_ok(p, depth, nn, ss, 0, 2);
             const bool e_wn = vw && vn && edge_ok(p, depth, ww, nn, 1, 1), e_ne = vn && ve && edge_ok(p, depth, nn, ee, 1, 1);

@@ -497,6 +497,44 @@ def test_group_norm_statistics_from_the_gram_matrix(gpu_ctx, half, n, cin, cout,
     assert torch.equal(again, out), "reproducible: fixed summation orders"
 
 
+@pytest.mark.parametrize("n,cin,cout,h,w", [(2, 64, 256, 120, 160), (2, 128, 512, 60, 80)])
+def test_gram_statistics_with_large_means_and_outlier_channels(gpu_ctx, half, n, cin, cout, h, w):
+    """the Gram form takes var = E[y^2] - mean^2 from float32 Gram matrices; inputs whose channels carry a large common component (post-ReLU maps with
+    means of many sigma, a few outlier channels tens of times larger than the rest) make the gross terms large against the net variance.  (mean, rstd) against
+    the float64 statistics of the same 16-bit inputs and weights: the mean to 1e-3 of the outputs' spread, rstd to 2e-3 relative -- the bound a GroupNorm output
+    rounded to 8 significant bits (bfloat16) cannot see."""
+    from hive_amd import _lib
+    from hive_amd.dpt.models import StdConv2dSame
+    g = torch.Generator(device="cpu").manual_seed(cin + h)
+    conv = StdConv2dSame(cin, cout, 1)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g))
+    conv = conv.to(memory_format=torch.channels_last).to(half).cuda().eval()
+    mu = torch.full((cin,), 0.3)
+    mu[torch.randperm(cin, generator=g)[:cin // 6]] = 5.0     # channels that sit 5 sigma above zero
+    mu[torch.randperm(cin, generator=g)[:cin // 16]] = 20.0   # ... and 20 sigma
+    amp = torch.ones(cin)
+    amp[torch.randperm(cin, generator=g)[:2]] = 30.0           # two outlier channels
+    x = F.relu((torch.randn(n, cin, h, w, generator=g) + mu[None, :, None, None]) * amp[None, :, None, None])
+    x = x.to(half).cuda().contiguous(memory_format=torch.channels_last)
+    wstd = conv.standardized_weight().contiguous(memory_format=torch.channels_last)
+    ctx, lib, G = gpu_ctx, gpu_ctx.lib, 32
+    tables = torch.empty(int(lib.hive_gn_gram_table_floats(cin, G)), dtype=torch.float32, device="cuda")
+    ctx.check(lib.hive_gn_gram_prepare(ctx.handle, wstd.data_ptr(), _lib.dtype_code(half), cin, cout, G, tables.data_ptr()))
+    stats = torch.empty(n, G, 2, dtype=torch.float32, device="cuda")
+    ctx.check(lib.hive_gn_gram_stats(ctx.handle, x.data_ptr(), _lib.dtype_code(half), n, h, w, cin, cout, 1, h, w, G, tables.data_ptr(), 1e-5, stats.data_ptr(), None, None))
+    xs = x.permute(0, 2, 3, 1).reshape(n, h * w, cin).double()
+    y = xs @ wstd.reshape(cout, cin).double().t()
+    yg = y.reshape(n, h * w, G, cout // G)
+    mean_ref = yg.mean(dim=(1, 3))
+    std_ref = torch.sqrt(yg.var(dim=(1, 3), unbiased=False) + 1e-5)
+    gross = ((yg ** 2).mean(dim=(1, 3)) / std_ref ** 2).max().item()
+    e_mean = ((stats[..., 0].double() - mean_ref).abs() / std_ref).max().item()
+    e_rstd = ((stats[..., 1].double() * std_ref) - 1.0).abs().max().item()
+    print(f"gram statistics under stress ({half}, C_in {cin}): E[y^2] / var up to {gross:.1f}; mean error {e_mean:.2e} sigma, rstd error {e_rstd:.2e} relative")
+    assert e_mean < 1e-3 and e_rstd < 2e-3, (e_mean, e_rstd, gross)
+
+
 def test_patch_embed_and_conv_transpose_match_torch(gpu_ctx, half):
     """DPT-Large's non-standard convolutions through the hand-written kernels: the 16 x 16 / 16 patch embedding (hive_patch_rows +
     the GEMM) and ConvTranspose2d with kernel == stride 4 and 2 (1 x 1 convolution + hive_nhwc_pixel_shuffle_bias), against float32 torch."""

@@ -20,7 +20,7 @@ def _numpy_filter_faces(points2d, depth, faces, max_px, max_depth):
 def _numpy_grid_faces(depth, mask):
     """The implicit triangulation's rule, restated with loops.  Per pixel (v, u) in row-major order: first the 2 x 2 block whose top-left
     corner it is -- all four corners valid -> the two halves across the b-c diagonal, exactly three -> their triangle -- then, where the
-    pixel itself is invalid and lies strictly inside the image, the triangles that bridge it: all four 4-neighbours valid -> the diamond
+    pixel itself is invalid, the triangles that bridge it (a 4-neighbour outside the image counts as invalid): all four 4-neighbours valid -> the diamond
     split west - east, exactly three -> their triangle.  Wound with a negative (u, v) cross product."""
     valid = mask & (depth > 0)
     vid = -np.ones(depth.shape, np.int64)
@@ -36,9 +36,9 @@ def _numpy_grid_faces(depth, mask):
                     faces += [(a, c, b), (b, c, d)]
                 elif sum(ok) == 3:
                     faces.append({0: (b, c, d), 1: (a, c, d), 2: (a, d, b), 3: (a, c, b)}[ok.index(False)])
-            if not valid[v, u] and 0 < v < H - 1 and 0 < u < W - 1:
+            if not valid[v, u]:
                 n, s, w, e = (v - 1, u), (v + 1, u), (v, u - 1), (v, u + 1)
-                ok = {k: valid[p] for k, p in zip("nswe", (n, s, w, e))}
+                ok = {k: (0 <= p[0] < H and 0 <= p[1] < W and bool(valid[p])) for k, p in zip("nswe", (n, s, w, e))}
                 if sum(ok.values()) == 4:
                     faces += [(w, e, n), (w, s, e)]
                 elif sum(ok.values()) == 3:
@@ -102,6 +102,36 @@ def _cells(points2d, faces):
         n, verts = cells.get(key, (0, frozenset()))
         cells[key] = (n + 1, verts | frozenset(int(x) for x in f))
     return cells
+
+
+def test_border_holes_are_bridged_like_delaunay(gpu_ctx):
+    """One-pixel gaps ON the image border (all four border rows / columns): Delaunay bridges such a gap with the (sqrt 2, sqrt 2, 2) triangle of its three
+    in-image neighbours -- its long side lies on the convex hull -- and that triangle passes the default 2-pixel filter.  The implicit triangulation treats a
+    neighbour outside the image as invalid and emits the same triangle: face sets compared per cell against scipy + the reference's filter."""
+    from scipy.spatial import Delaunay
+    from hive_amd import foreground
+    from hive_amd.options import MeshFilteringOptions
+    H, W = 24, 32
+    mask = np.ones((H, W), bool)
+    for u in (3, 9, 20, 27):
+        mask[0, u] = mask[H - 1, u + 1] = False
+    for v in (4, 11, 17):
+        mask[v, 0] = mask[v + 2, W - 1] = False
+    mask[10, 15] = False  # (and an interior hole)
+    depth = np.full((H, W), 2.0, np.float32)
+    valid = mask & (depth > 0)
+    vv, uu = valid.nonzero()
+    points2d = np.vstack((uu, vv)).T
+    opts = MeshFilteringOptions()
+    faces = np.asarray(Delaunay(points2d).simplices)[:, ::-1]
+    expect = _numpy_filter_faces(points2d, depth[valid], faces, opts.max_pixel_distance, opts.max_depth_distance)
+    grid = foreground.grid_faces(depth, mask, opts, ctx=gpu_ctx)
+    ref_cells, grid_cells = _cells(points2d, expect), _cells(points2d, grid)
+    border = [k for k in ref_cells if k[0] == "dm" and (k[1] in (0, W - 1) or k[2] in (0, H - 1))]
+    assert len(border) == 14, "scipy bridges every border gap"
+    assert ref_cells == grid_cells
+    rule, _ = _numpy_grid_faces(depth, mask)
+    assert np.array_equal(grid, _numpy_filter_faces(points2d, depth[valid], rule, opts.max_pixel_distance, opts.max_depth_distance))
 
 
 @pytest.mark.parametrize("seed", [3, 5])
