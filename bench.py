@@ -179,19 +179,20 @@ def load_profile(name):
         return None
 
 
-def config4_leg(device, ctx, steps=3, batch=8, overlap=True):
+def config4_leg(device, ctx, steps=2, batch=16, overlap=True, prefetch=True, unique_frames=24):
     """BASELINE configs[3], bounded, through the PRODUCT path: 1920 x 1080 frames (host-resident, uploaded in the timed region) -> `DepthFusionStream.step`:
     the reference's resize rule (640 x 480 target, keep aspect ratio, "minimal", multiple of 32: 864 x 480 -- hive_amd.depth.network_size) and its cv2.INTER_CUBIC
     resize + normalisation as one HIP kernel -> DPT-Large depth (backbone vitl16_384, bf16, seeded weights) -> nearest back to 1080p + uint16-mm hand-off as
     one HIP kernel (all of it ONE C-ABI call, hive_dpt_forward_frames) -> integrate into a 1024^3 volume (5 mm voxels), the sweeps of a batch on the side
     stream under the next batch's network as in the headline job.  No torch operator in the timed region but the upload.  `steps` timed steps of `batch` frames
-    after one warm-up step.  The sweep's roofline (SURVEY 8d bytes and must-move bytes) on two scenes, as for the headline: the DPT depth of the last step's
+    after one warm-up step, wrapping around `unique_frames` distinct frames (ray-casting a 1080p frame on the host takes about a second).  The sweep's roofline (SURVEY 8d bytes and must-move bytes) on two scenes, as for the headline: the DPT depth of the last step's
     frames (`roofline`: seeded random weights give a noise-like depth map -- two thirds of the voxels the sweep must test cannot update) and the analytic
     ray-cast depth of the same frames (`roofline_room`: the room's walls)."""
     from hive_amd import depth as depth_mod, fusion, synthetic
     from hive_amd.dpt.init import seeded_init
     from hive_amd.dpt.models import DPTDepthModel
-    H, W, T = 1080, 1920, batch * (steps + 1)
+    H, W, T = 1080, 1920, min(unique_frames, batch * (steps + 1))  # (the job wraps around a short sequence, as the headline job does: ray-casting a 1080p frame on the host takes a second)
+    frame_ids = lambda i: [(i * batch + j) % T for j in range(batch)]
     net_h, net_w = depth_mod.network_size(H, W)
     seq = synthetic.make_sequence(num_frames=T, height=H, width=W, yaw_step_deg=2.4)
     model = DPTDepthModel(path=None, scale=depth_mod.DPT_SCALE, shift=depth_mod.DPT_SHIFT, invert=True, backbone="vitl16_384", engine="hip")
@@ -208,11 +209,16 @@ def config4_leg(device, ctx, steps=3, batch=8, overlap=True):
     feeder = FrameFeeder(host, batch, device)  # uploads one batch ahead on a copy stream, as the headline job
 
     def run_steps(first, count):
-        token = feeder.prefetch(list(range(first * batch, (first + 1) * batch)))
+        if not prefetch:  # (A/B: the upload in line on the compute stream)
+            for i in range(first, first + count):
+                fr = host[frame_ids(i)].to(device, non_blocking=True)
+                dm = stream.step(fr, seq["poses"][frame_ids(i)])
+            return fr, dm
+        token = feeder.prefetch(frame_ids(first))
         for i in range(first, first + count):
             fr = feeder.acquire(token)
-            nxt = feeder.prefetch(list(range((i + 1) * batch, (i + 2) * batch))) if i + 1 < first + count else None
-            dm = stream.step(fr, seq["poses"][i * batch:(i + 1) * batch])
+            nxt = feeder.prefetch(frame_ids(i + 1)) if i + 1 < first + count else None
+            dm = stream.step(fr, seq["poses"][frame_ids(i)])
             feeder.release(token, stream.side)  # the buffer is free once the sweeps that read its colours are done
             token = nxt
         return fr, dm  # (the feeder buffer holding the last batch is not written again)
@@ -261,7 +267,9 @@ def config4_leg(device, ctx, steps=3, batch=8, overlap=True):
         elapsed = time.perf_counter() - t0
         timed_frames = vol.stats()[0]  # (frames the volume was handed since the reset in front of the timed steps)
         weight_sum = int(w_plane.double().sum().item())
-        ids = list(range(steps * batch, (steps + 1) * batch))
+        fr_step = fr
+        ids = frame_ids(steps)[:8]  # (eight frames of the last step: two sweeps of four)
+        fr, dm = fr[:8].contiguous(), dm[:8].contiguous()
         roof = sweep_roofline(fr, dm, ids)
         roof["scene"] = "DPT-Large depth (seeded weights) of the last step's frames"
         roof_room = sweep_roofline(fr, torch.from_numpy(seq["depth"][ids]).to(device), ids)
@@ -269,7 +277,7 @@ def config4_leg(device, ctx, steps=3, batch=8, overlap=True):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(2):
-            stream.depth(fr)
+            stream.depth(fr_step)
         e1.record()
         e1.synchronize()
         dpt_ms = e0.elapsed_time(e1) / 2
@@ -277,7 +285,7 @@ def config4_leg(device, ctx, steps=3, batch=8, overlap=True):
                        f"{'x'.join(str(int(d)) for d in vol.vol_dim)} TSDF integrate, {steps} steps of {batch} frames, uploads in the timed region",
            "value": steps * batch / elapsed, "unit": "frames/s", "ms_per_step": elapsed / steps * 1e3, "frames_per_step": batch, "steps": steps,
            "dpt_ms_per_frame": dpt_ms / batch, "network_size": [net_h, net_w], "resize_method": "minimal", "tsdf_overlap": overlap,
-           "frames_integrated": timed_frames, "weight_sum": weight_sum, "roofline": roof, "roofline_room": roof_room}
+           "frames_integrated": timed_frames, "weight_sum": weight_sum, "unique_frames": T, "roofline": roof, "roofline_room": roof_room}
     vol.close()
     del model, vol, storage, stream, w_plane
     torch.cuda.empty_cache()

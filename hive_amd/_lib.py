@@ -79,6 +79,8 @@ SIGNATURES = {
                              c_void_p]),
     "hive_project_bbox": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "hive_grid_mesh": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_double, c_double, c_int, c_void_p, c_int64, P(c_int64), P(c_int64)]),
+    "hive_fg_frame_mesh": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_double, c_void_p, c_int64, c_void_p, c_int64,
+                                   c_void_p, P(c_int64), P(c_int64), c_void_p]),
     "hive_filter_faces": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_double, c_double, c_int, c_void_p, P(c_int64)]),
     "hive_texture_window": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_double, c_int, c_void_p, c_void_p]),
     "hive_dilate_mask": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

@@ -156,6 +156,58 @@ __global__ __launch_bounds__(1024) void scan_blocks_kernel(unsigned *__restrict_
     }
 }
 
+
+// hive_fg_frame_mesh: both block-count arrays scanned by ONE workgroup (threads 0..511: valid pixels, 512..1023: faces), totals[0..1] = sums, and the texture
+// window's bounding box initialised for the atomics of window_project_kernel (no host-to-device copy in the call)
+__global__ __launch_bounds__(1024) void scan_blocks2_kernel(unsigned *__restrict__ a, unsigned *__restrict__ b, int nb, unsigned *totals, int *bbox) {
+    __shared__ unsigned part[1024];
+    const int half = threadIdx.x >> 9, t = threadIdx.x & 511;
+    unsigned *arr = half ? b : a;
+    const int per = (nb + 511) / 512;
+    const int lo = min(t * per, nb), hi = min(lo + per, nb);
+    unsigned s = 0;
+    for (int i = lo; i < hi; ++i) s += arr[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (t == 0) {
+        unsigned r = 0;
+        for (int i = 0; i < 512; ++i) {
+            const unsigned v = part[half * 512 + i];
+            part[half * 512 + i] = r;
+            r += v;
+        }
+        totals[half] = r;
+    }
+    if (threadIdx.x == 1) {
+        bbox[0] = bbox[1] = 0x7fffffff;
+        bbox[2] = bbox[3] = (int)0x80000000;
+    }
+    __syncthreads();
+    unsigned r = part[threadIdx.x];
+    for (int i = lo; i < hi; ++i) {
+        const unsigned v = arr[i];
+        arr[i] = r;
+        r += v;
+    }
+}
+
+// point_cloud_from_depth's rows (csrc/geometry.hip unproject_write_kernel's arithmetic, verbatim): vertex vid[i] of valid pixel i
+struct FrameMeshCam {
+    double Kinv[9], R[9], t[3];
+};
+__global__ __launch_bounds__(256) void grid_vertices_kernel(const float *__restrict__ depth, const int *__restrict__ vid, int n, int W, FrameMeshCam p,
+                                                            double *__restrict__ out_xyz, long long capacity) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const long long id = vid[i];
+    if (id < 0 || id >= capacity) return;
+    const double d = (double)depth[i];
+    const double pu = (double)(i % W), pv = (double)(i / W);
+    double cam[3];
+    for (int r = 0; r < 3; ++r) cam[r] = d * (p.Kinv[3 * r + 0] * pu + p.Kinv[3 * r + 1] * pv + p.Kinv[3 * r + 2]) - p.t[r];
+    for (int r = 0; r < 3; ++r) out_xyz[3 * id + r] = p.R[0 * 3 + r] * cam[0] + p.R[1 * 3 + r] * cam[1] + p.R[2 * 3 + r] * cam[2];
+}
+
 // block-wide exclusive offset of this thread's count `c` (4 consecutive items per thread keep row-major order)
 __device__ __forceinline__ unsigned block_exclusive(unsigned c, unsigned *lds) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -316,6 +368,47 @@ __global__ __launch_bounds__(256) void window_shift_kernel(int32_t *__restrict__
     uv[2 * i + 1] -= bbox[1];
 }
 
+// the same two steps with the point count in device memory (hive_fg_frame_mesh: the vertex count is known to the device only)
+__global__ __launch_bounds__(256) void window_project_dev_kernel(const double *__restrict__ pts, const unsigned *__restrict__ n_ptr, long long capacity, WindowParams p,
+                                                                 int32_t *__restrict__ uv, int *__restrict__ out) {
+    const long long n = min((long long)*n_ptr, capacity);
+    int mn_u = 0x7fffffff, mn_v = 0x7fffffff, mx_u = (int)0x80000000, mx_v = (int)0x80000000;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const double X[3] = {pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]};
+        double cam[3], c[3];
+        for (int r = 0; r < 3; ++r) cam[r] = p.R[3 * r + 0] * X[0] + p.R[3 * r + 1] * X[1] + p.R[3 * r + 2] * X[2] + p.t[r];
+        for (int r = 0; r < 3; ++r) c[r] = p.K[3 * r + 0] * cam[0] + p.K[3 * r + 1] * cam[1] + p.K[3 * r + 2] * cam[2];
+        const double u = c[0] / c[2] / p.scale, v = c[1] / c[2] / p.scale;
+        const int ru = (int)rint(u), rv = (int)rint(v);  // np.round: half to even
+        uv[2 * i + 0] = ru;
+        uv[2 * i + 1] = rv;
+        mn_u = min(mn_u, ru);
+        mx_u = max(mx_u, ru);
+        mn_v = min(mn_v, rv);
+        mx_v = max(mx_v, rv);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        mn_u = min(mn_u, __shfl_xor(mn_u, off));
+        mx_u = max(mx_u, __shfl_xor(mx_u, off));
+        mn_v = min(mn_v, __shfl_xor(mn_v, off));
+        mx_v = max(mx_v, __shfl_xor(mx_v, off));
+    }
+    if ((threadIdx.x & 63) == 0 && mn_u != 0x7fffffff) {
+        atomicMin(out + 0, mn_u);
+        atomicMin(out + 1, mn_v);
+        atomicMax(out + 2, mx_u);
+        atomicMax(out + 3, mx_v);
+    }
+}
+
+__global__ __launch_bounds__(256) void window_shift_dev_kernel(int32_t *__restrict__ uv, const unsigned *__restrict__ n_ptr, long long capacity, const int *__restrict__ bbox) {
+    const long long n = min((long long)*n_ptr, capacity);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        uv[2 * i + 0] -= bbox[0];
+        uv[2 * i + 1] -= bbox[1];
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -370,6 +463,62 @@ int hive_grid_mesh(hive_ctx *ctx, const float *depth, const uint8_t *mask, int H
         const size_t nf = (size_t)std::min<int64_t>(capacity, (int64_t)tot[1]);
         if (nf) HIVE_CHECK_HIP(ctx, hipMemcpy(out_faces, d_faces, nf * 12, hipMemcpyDeviceToHost));
     }
+    return HIVE_OK;
+}
+
+int hive_fg_frame_mesh(hive_ctx *ctx, const float *d_depth, const uint8_t *d_mask, int H, int W, const double Kinv[9], const double K[9], const double R[9],
+                       const double t[3], double max_pixel_distance, double max_depth_distance, double *d_vertices, int64_t vertex_capacity, int32_t *d_faces,
+                       int64_t face_capacity, int32_t *d_uv, int64_t *n_vertices, int64_t *n_faces, int32_t bbox[4]) {
+    HIVE_ENTER(ctx);
+    if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
+    HIVE_REQUIRE(ctx, d_depth && Kinv && K && R && t && d_vertices && d_faces && d_uv && n_vertices && n_faces && bbox, "fg_frame_mesh: NULL argument");
+    HIVE_REQUIRE(ctx, H > 0 && W > 0 && (long long)H * W < (1ll << 30), "fg_frame_mesh: bad image size %dx%d", H, W);
+    HIVE_REQUIRE(ctx, vertex_capacity > 0 && face_capacity > 0, "fg_frame_mesh: empty output buffers");
+    const int n = H * W, nb = (n + TILE - 1) / TILE;
+    auto align = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t off_bf = align((size_t)nb * 4), off_vid = off_bf + align((size_t)nb * 4);
+    int rc = hive_reserve_device(ctx, &ctx->d_scratch, &ctx->scratch_bytes, off_vid + align((size_t)n * 4));
+    if (rc) return rc;
+    char *base = (char *)ctx->d_scratch;
+    unsigned *bv = (unsigned *)base, *bf = (unsigned *)(base + off_bf);
+    int *vid = (int *)(base + off_vid);
+    unsigned *d_tot = ctx->d_scalars + 32;  // [32] = vertices, [33] = faces, [34..37] = the texture window's box
+    int *d_box = (int *)(ctx->d_scalars + 34);
+    GridParams p{H, W, max_pixel_distance, (float)max_depth_distance};
+    FrameMeshCam cam;
+    memcpy(cam.Kinv, Kinv, sizeof(cam.Kinv));
+    memcpy(cam.R, R, sizeof(cam.R));
+    memcpy(cam.t, t, sizeof(cam.t));
+    WindowParams wp;
+    memcpy(wp.K, K, sizeof(wp.K));
+    memcpy(wp.R, R, sizeof(wp.R));
+    memcpy(wp.t, t, sizeof(wp.t));
+    wp.scale = 1.0;
+    hipLaunchKernelGGL(grid_count_kernel, dim3(nb), dim3(256), 0, ctx->stream, d_depth, d_mask, p, bv, bf);
+    hipLaunchKernelGGL(scan_blocks2_kernel, dim3(1), dim3(1024), 0, ctx->stream, bv, bf, nb, d_tot, d_box);
+    hipLaunchKernelGGL(grid_vid_kernel, dim3(nb), dim3(256), 0, ctx->stream, d_depth, d_mask, n, (const unsigned *)bv, vid);
+    hipLaunchKernelGGL(grid_vertices_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_depth, (const int *)vid, n, W, cam, d_vertices, (long long)vertex_capacity);
+    hipLaunchKernelGGL(grid_faces_kernel, dim3(nb), dim3(256), 0, ctx->stream, d_depth, d_mask, p, (const unsigned *)bf, (const int *)vid, d_faces,
+                       (long long)face_capacity);
+    const dim3 wgrid((unsigned)std::min<long long>((std::min<long long>(n, vertex_capacity) + 255) / 256, (long long)ctx->num_cus * 4));
+    hipLaunchKernelGGL(window_project_dev_kernel, wgrid, dim3(256), 0, ctx->stream, (const double *)d_vertices, (const unsigned *)d_tot, (long long)vertex_capacity, wp, d_uv,
+                       d_box);
+    hipLaunchKernelGGL(window_shift_dev_kernel, wgrid, dim3(256), 0, ctx->stream, d_uv, (const unsigned *)d_tot, (long long)vertex_capacity, (const int *)d_box);
+    HIVE_CHECK_HIP(ctx, hipGetLastError());
+    // ONE read-back for the whole frame mesh: {vertices, faces, box[4]} through pinned memory
+    if (!ctx->h_pinned_small) HIVE_CHECK_HIP(ctx, hipHostMalloc(&ctx->h_pinned_small, 256, hipHostMallocDefault));
+    HIVE_CHECK_HIP(ctx, hipMemcpyAsync(ctx->h_pinned_small, d_tot, 6 * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+    HIVE_CHECK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const unsigned *tot = (const unsigned *)ctx->h_pinned_small;
+    const int *box = (const int *)(tot + 2);
+    *n_vertices = tot[0];
+    *n_faces = tot[1];
+    bbox[0] = box[0];
+    bbox[1] = box[1];
+    bbox[2] = tot[0] ? box[2] + 1 : box[2];
+    bbox[3] = tot[0] ? box[3] + 1 : box[3];
+    HIVE_REQUIRE(ctx, (int64_t)tot[0] <= vertex_capacity && (int64_t)tot[1] <= face_capacity, "fg_frame_mesh: %u vertices / %u faces do not fit the buffers (%lld / %lld)",
+                 tot[0], tot[1], (long long)vertex_capacity, (long long)face_capacity);
     return HIVE_OK;
 }
 

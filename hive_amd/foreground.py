@@ -106,3 +106,61 @@ def get_mesh_texture_and_uv(vertices, image, camera_matrix, rotation=np.eye(3), 
     min_u, min_v, max_u, max_v = (int(b) for b in box)
     texture = image[min_v:max_v, min_u:max_u, :].copy()
     return texture, uv
+
+
+class FrameMeshBuffers:
+    """Device buffers of worst-case size for ``frame_mesh`` (H W vertices, 4 H W faces), reused from frame to frame."""
+
+    def __init__(self, height, width, device="cuda"):
+        import torch
+        n = int(height) * int(width)
+        self.shape = (int(height), int(width))
+        self.vertices = torch.empty((n, 3), dtype=torch.float64, device=device)
+        self.faces = torch.empty((4 * n, 3), dtype=torch.int32, device=device)
+        self.uv = torch.empty((n, 2), dtype=torch.int32, device=device)
+
+
+def frame_mesh(depth, mask, image, camera_matrix, rotation=np.eye(3), translation=np.zeros((3, 1)), options: MeshFilteringOptions = None, ctx=None,
+               buffers: FrameMeshBuffers = None):
+    """One object of one frame, device-resident, in ONE library call (``hive_fg_frame_mesh``): what the loop body of ``process_frame``
+    (/root/reference/hive/pipeline.py:383-461) computes between the binary mask and the texture atlas, minus its CPU-library stages (decimation, connected
+    components, billboard) --
+
+        vertices = point_cloud_from_depth(depth, mask, K, R, t)             (:386)
+        faces    = _filter_faces(points2d, depth[valid], _triangulate_faces(points2d), options)   (:402-408)
+        texture, uv = _get_mesh_texture_and_uv(vertices, rgb, K, R, t)      (:453)
+
+    ``depth`` float32 (H, W), ``mask`` bool / uint8 (H, W) or None, ``image`` uint8 (H, W, 3): device tensors (numpy arrays are uploaded).  Returns a dict of
+    device tensors -- ``vertices`` float64 (V, 3), ``faces`` int32 (F, 3), ``uv`` int32 (V, 2), ``texture`` uint8 crop -- and ``bbox`` (min_u, min_v, max_u, max_v);
+    views into ``buffers`` (valid until its next use) when one is given.  Bit-identical to the three separate functions; seven launches and one read-back instead
+    of sixteen launches, four read-backs and the host round trip of the vertices.  An object with no valid pixel gives V = F = 0 and ``texture`` None."""
+    import torch
+    options = options or MeshFilteringOptions()
+    validate_camera_parameter_shapes(camera_matrix, rotation, translation)
+    dev = depth.device if _is_torch(depth) else torch.device("cuda", torch.cuda.current_device())
+    ctx = ctx or _lib.default_context(dev.index or 0)
+    ctx.follow_torch_stream()
+    as_dev = lambda a, dt: (a if _is_torch(a) else torch.from_numpy(np.ascontiguousarray(a))).to(device=dev, dtype=dt).contiguous()
+    d = as_dev(depth, torch.float32)
+    m = None if mask is None else as_dev(mask, torch.uint8)
+    img = None if image is None else as_dev(image, torch.uint8)
+    assert d.dim() == 2 and (m is None or tuple(m.shape) == tuple(d.shape)), "depth (H, W) and mask (H, W)"
+    h, w = (int(v) for v in d.shape)
+    buffers = buffers or FrameMeshBuffers(h, w, dev)
+    assert buffers.shape == (h, w), "buffers were sized for another frame size"
+    from hive_amd.geometric import _kinv
+    K = np.ascontiguousarray(camera_matrix, dtype=np.float64).reshape(3, 3)
+    Kinv = _kinv(np.asarray(camera_matrix).reshape(3, 3))  # as point_cloud_from_depth computes it: inverted in K's own dtype (geometric.py:203)
+    R = np.ascontiguousarray(rotation, dtype=np.float64).reshape(3, 3)
+    t = np.ascontiguousarray(translation, dtype=np.float64).reshape(3)
+    nv, nf = ctypes.c_int64(0), ctypes.c_int64(0)
+    box = np.zeros(4, np.int32)
+    ctx.check(ctx.lib.hive_fg_frame_mesh(ctx.handle, ptr(d), ptr(m), h, w, ptr(Kinv), ptr(K), ptr(R), ptr(t), float(options.max_pixel_distance),
+                                         float(options.max_depth_distance), ptr(buffers.vertices), buffers.vertices.shape[0], ptr(buffers.faces), buffers.faces.shape[0],
+                                         ptr(buffers.uv), ctypes.byref(nv), ctypes.byref(nf), ptr(box)))
+    min_u, min_v, max_u, max_v = (int(b) for b in box)
+    texture = None
+    if nv.value and img is not None:
+        texture = img[max(min_v, 0):max_v, max(min_u, 0):max_u, :].clone()  # `image[min_v:max_v, min_u:max_u, :].copy()` (pipeline.py:805)
+    return {"vertices": buffers.vertices[:nv.value], "faces": buffers.faces[:nf.value], "uv": buffers.uv[:nv.value], "texture": texture,
+            "bbox": (min_u, min_v, max_u, max_v)}

@@ -246,6 +246,16 @@ int hive_project_bbox(hive_ctx *ctx, const double *points, int64_t n, const doub
 int hive_grid_mesh(hive_ctx *ctx, const float *depth, const uint8_t *mask, int H, int W, double max_pixel_distance,
                    double max_depth_distance, int mem, int32_t *out_faces, int64_t capacity, int64_t *n_faces,
                    int64_t *n_vertices);
+/* One object of one frame in ONE call (the body of process_frame's loop, hive/pipeline.py:383-461, without the CPU-library stages between -- decimation, connected
+ * components, billboard): point_cloud_from_depth (:386; hive_unproject's rows) -> _triangulate_faces + _filter_faces (:402-408; hive_grid_mesh's faces) ->
+ * _get_mesh_texture_and_uv (:453; hive_texture_window's uv and crop box), everything device-resident: d_depth f32 [H][W], d_mask u8 [H][W] (NULL = all pixels) in;
+ * d_vertices f64 [vertex_capacity][3], d_faces i32 [face_capacity][3], d_uv i32 [vertex_capacity][2] out (H W and 4 H W are always enough).  Kinv = inverse
+ * intrinsics as the caller computes it (numpy.linalg.inv, as hive/geometric.py:201), K, R, t the camera as for hive_unproject / hive_project.  Seven launches and
+ * ONE read-back (through pinned memory): *n_vertices, *n_faces, bbox = {min_u, min_v, max_u + 1, max_v + 1} (the texture is image[min_v:max_v, min_u:max_u]).
+ * Results are bit-identical to the three separate entry points on the same inputs. */
+int hive_fg_frame_mesh(hive_ctx *ctx, const float *d_depth, const uint8_t *d_mask, int H, int W, const double Kinv[9], const double K[9], const double R[9],
+                       const double t[3], double max_pixel_distance, double max_depth_distance, double *d_vertices, int64_t vertex_capacity, int32_t *d_faces,
+                       int64_t face_capacity, int32_t *d_uv, int64_t *n_vertices, int64_t *n_faces, int32_t bbox[4]);
 /* _filter_faces (:670-694) for an explicit face list of any triangulation: points2d i32 [n][2] (u, v), depth f32 [n], faces i32
  * [F][3] -> the faces whose three edges pass both limits, order preserved, into out_faces (capacity F). */
 int hive_filter_faces(hive_ctx *ctx, const int32_t *points2d, const float *depth, int64_t n_points, const int32_t *faces,

@@ -228,3 +228,41 @@ def test_texture_window_and_uv_match_numpy(gpu_ctx):
     assert tex.shape == exp_tex.shape and np.array_equal(tex, exp_tex)
     assert tex.shape[:2] == (45, 81), "projecting the unprojected pixels gives back the mask's bounding box"
     assert got_uv.dtype == np.int32 and np.array_equal(got_uv, exp_uv)
+
+
+@pytest.mark.parametrize("on_device", [False, True])
+def test_frame_mesh_in_one_call_equals_the_separate_functions(gpu_ctx, on_device):
+    """hive_fg_frame_mesh (one call, device-resident, one read-back) == point_cloud_from_depth + grid_faces + get_mesh_texture_and_uv on the same object
+    mask, bit for bit: vertices (float64), faces, uv, crop box and texture -- /root/reference/hive/pipeline.py:383-461 without its CPU-library stages."""
+    import torch
+    from hive_amd import foreground, geometric, synthetic
+    from hive_amd.options import MeshFilteringOptions
+    seq = synthetic.make_sequence(num_frames=2, height=240, width=320, yaw_step_deg=20.0)
+    masks = synthetic.ellipse_masks(2, 240, 320, num_objects=2, seed=7)
+    K = seq["K"]  # float32, as loaded from disk: inverted in its own dtype
+    opts = MeshFilteringOptions()
+    buffers = foreground.FrameMeshBuffers(240, 320)
+    for f in range(2):
+        w2c = np.linalg.inv(seq["poses"][f])
+        R, t = w2c[:3, :3], w2c[:3, 3:4]
+        depth, rgb = seq["depth"][f], seq["color"][f]
+        for obj in (1, 2, 0):  # (0: no pixel of the mask is set below)
+            mask = (masks[f] == obj) if obj else np.zeros_like(masks[f], bool)
+            want_v = geometric.point_cloud_from_depth(depth, mask, K, R, t)
+            if on_device:
+                got = foreground.frame_mesh(torch.from_numpy(depth).cuda(), torch.from_numpy(mask).cuda(), torch.from_numpy(rgb).cuda(), K, R, t, opts, ctx=gpu_ctx,
+                                            buffers=buffers)
+            else:
+                got = foreground.frame_mesh(depth, mask, rgb, K, R, t, opts, ctx=gpu_ctx)
+            assert np.array_equal(got["vertices"].cpu().numpy(), want_v)
+            if len(want_v) == 0:
+                assert got["faces"].shape[0] == 0 and got["texture"] is None
+                continue
+            want_f = foreground.grid_faces(depth, mask, opts, ctx=gpu_ctx)
+            want_tex, want_uv = foreground.get_mesh_texture_and_uv(want_v, rgb, K, R, t, ctx=gpu_ctx)
+            assert len(want_f) > 100
+            assert np.array_equal(got["faces"].cpu().numpy(), want_f)
+            assert np.array_equal(got["uv"].cpu().numpy(), want_uv)
+            assert np.array_equal(got["texture"].cpu().numpy(), want_tex)
+            vv, uu = (mask & (depth > 0)).nonzero()
+            assert got["bbox"] == (uu.min(), vv.min(), uu.max() + 1, vv.max() + 1), "an unprojected pixel projects back onto itself"
