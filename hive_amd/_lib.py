@@ -31,6 +31,7 @@ SIGNATURES = {
     "hive_ctx_get_stream": (c_int, [c_void_p, P(c_void_p)]),
     "hive_ctx_synchronize": (c_int, [c_void_p]),
     "hive_last_error": (ctypes.c_char_p, [c_void_p]),
+    "hive_ctx_release_stream": (c_int, [c_void_p]),
     "hive_ctx_set_stream": (c_int, [c_void_p, c_void_p]),
     "hive_ctx_set_round_mode": (c_int, [c_void_p, c_int]),
     "hive_ctx_set_deterministic": (c_int, [c_void_p, c_int]),
@@ -278,6 +279,9 @@ class Context:
         if self._side_stream is None:
             import torch
             self._side_stream = torch.cuda.ExternalStream(self.stream_handle(), device=self.device)
+            # torch now refers to the stream beyond this context's life (the caching allocator records an event on it whenever a tensor used there is
+            # freed; process groups cache the streams they synchronised with): the library must not destroy it with the context
+            self.check(self.lib.hive_ctx_release_stream(self.handle))
         return self._side_stream
 
     def synchronize(self):

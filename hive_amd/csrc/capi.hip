@@ -175,6 +175,12 @@ int hive_ctx_destroy(hive_ctx *ctx) {
     return HIVE_OK;
 }
 
+int hive_ctx_release_stream(hive_ctx *ctx) {
+    if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
+    ctx->owns_stream = false;  // hive_ctx_destroy leaves the stream alive: somebody else (a torch ExternalStream, a caching allocator's recorded uses) refers to it
+    return HIVE_OK;
+}
+
 int hive_ctx_set_stream(hive_ctx *ctx, void *stream) {
     HIVE_ENTER(ctx);
     if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");

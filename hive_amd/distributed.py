@@ -8,9 +8,17 @@ directly (``accum_integrate``); ONE all-reduce (RCCL over xGMI; ``backend="nccl"
 the 5 N floats merges them -- issued as ONE reduce-scatter + ONE all-gather (``fuse_sharded``) -- after which every rank holds the
 merged volume.
 
-Parity (stated): the merged tsdf equals the sequential running average up to float32 re-association
+Parity (stated): GIVEN THE SAME DEPTH MAPS the merged tsdf equals the sequential running average up to float32 re-association
 (abs 1e-5), weights are exact (small integers), colours differ by at most 2 levels (the sequential
 reference rounds and clamps after every frame), the set of observed voxels is exact.
+
+Caveat on the depth maps themselves: a frame's DPT depth is not bit-independent of the batch it was computed in.  Launches that do not
+fill the chip split long K loops (another, fixed, order of float32 additions), the GroupNorm statistics of the bottlenecks' 1 x 1 convolutions switch
+to their Gram-matrix form above a size threshold, both thresholds depend on the batch size and on the device's CU count, and a GroupNorm's partial
+sums are cut at tile boundaries counted from the start of the batch.  Frame-sharded runs with other per-rank batch sizes than the one-GPU run
+therefore integrate depth maps that differ from the one-GPU run's within the network's stated tolerance (median < 1 mm in float16, < 9 mm in
+bfloat16: tools/diag_splitk_bound.py) before the merge's own tolerance applies.  ``Context.set_deterministic(True)`` (hive_ctx_set_deterministic)
+removes the two threshold effects; the tile-boundary effect (~1e-7 relative in (mean, rstd)) remains unless the batch composition is kept.
 """
 import os
 
@@ -161,6 +169,9 @@ def fuse_sharded(volume, stream_or_accum=None):
     place.  Against all-reduce + full finalize on every rank this moves 8 / 10 of the bytes ((5 + 3) N (W - 1) / W instead of
     2 x 5 N (W - 1) / W floats per GPU) and divides the finalize pass by W.
 
+    Parity with the sequential one-GPU fusion of the SAME depth maps: tsdf <= 1e-5, weights exact, colours +-2 (module docstring; depth maps computed in
+    other batch sizes than the one-GPU run's differ within the network's tolerance first).
+
     ``stream_or_accum=None`` (what ``bench.py --gpus N`` does): every rank fused its own frames with the ordinary
     ``integrate`` (same kernel and cost as on one GPU); its volumes are converted to the sums
     ``[tsdf * w, w, r * w, g * w, b * w]`` straight into the piece-major buffer.  Otherwise: the accumulators of a
@@ -219,7 +230,8 @@ def tsdf_fusion_fg_bg_sharded(dataset, options=None, num_frames=-1, frame_set=No
     block of the frame set into its own pair of volumes -- on the grid of the whole set: the ranks' scene bounds are all-reduced (min / max, exact)
     before the volumes are created -- and each of the two volumes is merged once with ``fuse_sharded`` (reduce-scatter of its sums, all-gather of
     the result).  Returns {"bg": TSDFVolume, "fg": TSDFVolume}, the merged volumes, on every rank.  Parity with one GPU: as ``fuse_sharded``
-    (tsdf <= 1e-5, weights exact, colours +-2)."""
+    (tsdf <= 1e-5, weights exact, colours +-2) -- for the dataset's OWN depth maps, which this driver reads from disk; depth maps estimated per rank by
+    the DPT network carry the batch-size caveat of this module's docstring on top."""
     import numpy as np
     from hive_amd import fusion
     from hive_amd.options import BackgroundMeshOptions

@@ -72,6 +72,12 @@ int hive_ctx_destroy(hive_ctx *ctx);
 int hive_ctx_get_stream(hive_ctx *ctx, void **stream);
 int hive_ctx_synchronize(hive_ctx *ctx);
 const char *hive_last_error(hive_ctx *ctx);
+/* Give up ownership of a private stream (HIVE_STREAM_OWN / _OWN_LOW): hive_ctx_destroy will then NOT destroy it.  For callers that hand the stream to a
+ * framework which keeps referring to it after the context is gone -- PyTorch's caching allocator records an event on every stream a tensor was used on
+ * (`Tensor.record_stream`) when the tensor is freed, possibly long after the context died, and process groups cache streams too; recording on a destroyed
+ * stream crashes the process (found by tests/test_distributed_gpu.py::test_rccl_merge_of_a_volume_on_the_overlap_side_stream).  The Python binding calls
+ * this as soon as it wraps the stream for torch (`Context.torch_stream()`): such a stream lives until the process ends. */
+int hive_ctx_release_stream(hive_ctx *ctx);
 /* Re-binds the context to another hipStream_t (NULL = the default stream).  The new stream is ordered behind
  * everything already queued on the old one.  The Python binding calls this when torch's current stream changes
  * (e.g. inside `with torch.cuda.stream(s)`), so that hive kernels stay ordered with the surrounding torch ops. */

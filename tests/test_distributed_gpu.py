@@ -116,6 +116,37 @@ def test_rccl_runs_the_merge_collectives(gpu_ctx, nccl_group, monkeypatch):
         assert torch.equal(a, b)
 
 
+def test_rccl_merge_of_a_volume_on_the_overlap_side_stream(gpu_ctx, nccl_group):
+    """The combination the default `bench.py --gpus N` job uses at N > 1: the volume lives on the lowest-priority side stream of an overlapping
+    DepthFusionStream (`side_stream_context`), its sweeps are queued there behind depth maps made on torch's stream, and `fuse_sharded` must issue its
+    RCCL collectives (and its torch buffers) on THAT stream, in order with the sweeps -- no synchronize in between.  Single-rank RCCL group: the very calls
+    of the 8-GPU job.  The merged volume must equal the same frames fused on the ordinary stream (weights and colours exactly, tsdf to tsdf * w / w)."""
+    import torch
+    from hive_amd import depth as depth_mod, distributed as hdist, fusion, synthetic
+    seq = synthetic.make_sequence(num_frames=8, height=120, width=160, yaw_step_deg=4.0)
+    color_d, depth_d = torch.from_numpy(seq["color"]).cuda(), torch.from_numpy(seq["depth"]).cuda()
+    bounds = synthetic.room_bounds()
+    ref = fusion.TSDFVolume(bounds, 0.04, ctx=gpu_ctx)
+    ref.integrate_batch(color_d, depth_d, seq["K"], seq["poses"])
+    want = [t.clone() for t in ref.device_tensors()]
+    vctx = depth_mod.DepthFusionStream.side_stream_context(0)
+    side = vctx.torch_stream()
+    vol = fusion.TSDFVolume(bounds, 0.04, ctx=vctx)
+    main = torch.cuda.current_stream()
+    for rep in range(3):  # (repeated: an ordering bug between the streams shows as a volume merged before its sweeps landed)
+        vol.reset()
+        scaled = depth_d * 1.0  # produced on torch's stream just before the hand-over, as a network's depth maps are
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            vol.integrate_batch(color_d, scaled, seq["K"], seq["poses"])
+        scaled.record_stream(side)
+        hdist.fuse_sharded(vol)  # no synchronize: the merge must order itself behind the sweeps
+        got = vol.device_tensors()
+        torch.cuda.synchronize()
+        assert torch.equal(got[1], want[1]) and torch.equal(got[2], want[2]) and float((got[0] - want[0]).abs().max()) <= 1e-6, rep
+    assert vol.stats()[0] == 8
+
+
 # ---- BASELINE config 5's multi-GPU form: the dynamic path with the frames sharded over TWO ranks (both on this box's one GPU, collectives
 # through gloo: what is exercised is the sharding, the all-reduced bounds and the two merges, not RCCL) --------------------------------------
 class _ShardedFake:
