@@ -132,13 +132,13 @@ constexpr int BN = 128, BK = 64;
 #define HIVE_GEMM_ABLATE 0  // tuning builds only (make ablate_gemm; tools/probe_gemm_tiles.py with HIVE_AMD_LIB=...): 1 = gemm256p_kernel without its epilogue
 #endif
 
-// erf-GELU (nn.GELU default): 0.5 x (1 + erf(x / sqrt 2)).  erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7,
-// three orders of magnitude below the bf16 output step) on the hardware rcp / exp2: ~14 instructions
-// instead of libm erff's ~45 -- the GELU epilogue was 28 us of the 100 us fc1 GEMM.
+// erf-GELU (nn.GELU default): 0.5 x (1 + erf(x / sqrt 2)) = max(x, 0) - |x| E(|x|) / 2 with E(a) = erfc(a / sqrt 2).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// evaluated for two values at once on the packed f32 pipe (v_pk_mul / v_pk_fma, IEEE per element): the fc1 epilogue is as
-// long as the 12-step K loop of its tile, and the packed form is 5 % faster end to end (222 -> 210 us at M = 29184)
+#ifndef HIVE_GELU_AS
+#define HIVE_GELU_AS 0  // tuning build (make gelu_as): 1 = rounds 1-4's form, erf by Abramowitz-Stegun 7.1.26 on rcp + exp2 (two transcendentals, ~16 issue slots per value)
+#endif
+#if HIVE_GELU_AS
 __device__ __forceinline__ f32x2 gelu_exact2(f32x2 x) {
     const f32x2 ax = f32x2{fabsf(x.x), fabsf(x.y)};
     const f32x2 z = ax * 0.70710678118654752440f;
@@ -151,6 +151,23 @@ __device__ __forceinline__ f32x2 gelu_exact2(f32x2 x) {
     const f32x2 s = f32x2{copysignf(erf_abs.x, x.x), copysignf(erf_abs.y, x.y)};
     return 0.5f * x * (1.0f + s);
 }
+#else
+// Round 5: ONE transcendental per value.  E(a) / 2 = 2^-(1 + a q(a)) with q a degree-4 polynomial fitted (weighted minimax of the GELU's absolute error,
+// tools/fit_gelu.py) so that |gelu - exact| <= 6e-7 for every float32 x -- the size of Abramowitz-Stegun's 1.5e-7 |x| / 2 at |x| = 4-8, three orders of
+// magnitude below a bfloat16 / two below a float16 output step -- and 1 + a q(a) increases monotonically to +inf, so large |x| need no clamp (2^-inf = 0).
+// Evaluated for two values at once on the packed f32 pipe (v_pk_fma_f32: IEEE per element): 5 packed + 2 v_and + 2 v_exp per pair, ~9.5 issue slots per value
+// against ~16.5 -- the fc1 epilogue was as long as its tile's 12-step K loop, 6,600 of its 13,800 cycles the GELU arithmetic.
+__device__ __forceinline__ f32x2 gelu_exact2(f32x2 x) {
+    const f32x2 ax = f32x2{fabsf(x.x), fabsf(x.y)};
+    f32x2 q = 4.88117491e-04f * ax - 7.19880622e-03f;
+    q = q * ax + 5.21468023e-02f;
+    q = q * ax + 4.59595714e-01f;
+    q = q * ax + 1.15100057e+00f;
+    const f32x2 P = ax * q + 1.0f;
+    const f32x2 e = f32x2{__builtin_amdgcn_exp2f(-P.x), __builtin_amdgcn_exp2f(-P.y)};
+    return (x + ax) * 0.5f - ax * e;  // max(x, 0) = (x + |x|) / 2 exactly
+}
+#endif
 
 
 // Global -> LDS staging with LDS-DMA (global_load_lds_dwordx4): one wave instruction deposits 64 x 16 B =
