@@ -166,7 +166,7 @@ def source_stamp():
     """sha256 of the TSDF kernel source: profiles/*_integrate_pmc.json carry the stamp of the source they were measured on, and the counter figures
     are only merged into the line when it matches (a kernel change without a profile refresh must not mix generations)."""
     h = hashlib.sha256()
-    for name in ("tsdf.hip", "hive_internal.hpp"):
+    for name in ("tsdf.hip",):  # (round 5: the kernel file alone -- hive_internal.hpp holds host-side structs of every translation unit)
         with open(os.path.join(ROOT, "hive_amd", "csrc", name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
@@ -550,11 +550,11 @@ def main():
                "worklist": {"voxels_per_launch": wl, "updated_share": n_union / max(wl, 1.0),
                             "note": "voxels on the sweep's work list (64-voxel segments that survive the per-row frustum / depth clip): every one runs every frame's projection, "
                                     "texel gather and tests; updated_share = N_union / that"}}
-        pmc = load_profile("r04_integrate_pmc.json")
+        pmc = load_profile("r05_integrate_pmc.json") or load_profile("r04_integrate_pmc.json")
         if pmc and scene_key in pmc:
             if pmc.get("source_stamp") != stamp:
-                out["traffic_note"] = (f"profiles/r04_integrate_pmc.json was measured on TSDF kernel source {pmc.get('source_stamp')}, this build is {stamp}: "
-                                       f"counter figures withheld (refresh the profile: tools/profile_r04.sh)")
+                out["traffic_note"] = (f"profiles/r0x_integrate_pmc.json was measured on TSDF kernel source {pmc.get('source_stamp')}, this build is {stamp}: "
+                                       f"counter figures withheld (refresh the profile: tools/profile_r05.sh)")
             else:
                 t = pmc[scene_key]
                 out["traffic"] = t.get("hbm_bytes_per_launch")
@@ -564,7 +564,7 @@ def main():
                     issue_us = v["SQ_INSTS_VALU"] * 4.0 / 1024.0 / (v["clock_ghz"] * 1e3)
                     out["valu_issue"] = {"insts_per_launch": v["SQ_INSTS_VALU"], "cycles_per_inst": 4, "simds": 1024, "clock_ghz": v["clock_ghz"], "min_us": issue_us,
                                          "frac_of_launch": issue_us / launch_us, "simd_busy_valu": v.get("simd_busy_valu"),
-                                         "note": "profiles/r04_integrate_pmc.json (rocprofv3 --pmc of the same kernel source and scene)"}
+                                         "note": "profiles/r05_integrate_pmc.json (rocprofv3 --pmc of the same kernel source and scene)"}
         return out
 
     with torch.no_grad():
@@ -629,8 +629,8 @@ def main():
         dpt_roof = {"kernel": "hive_dpt_forward (MFMA GEMM / attention / implicit-GEMM convolutions + glue, one C-ABI call)", "bound": "mfma", "achieved": tflops, "peak": 2500.0,
                     "unit": "TFLOP/s", "frac": tflops / 2500.0, "dtype": args.dtype, "flops_per_frame": flops["total"], "frames": int(fr.shape[0]), "ms_per_batch": dpt_ms,
                     "ms_per_frame": dpt_ms / fr.shape[0], "note": "algorithmic FLOPs (2 x MACs, hive_amd.dpt.models.count_flops) x frames / time of the whole network, "
-                    "glue kernels included; per-kernel mfma_busy: profiles/r04_mfma_pmc.json"}
-        busy = load_profile("r04_mfma_pmc.json") or load_profile("r03_mfma_pmc.json")
+                    "glue kernels included; per-kernel mfma_busy: profiles/r05_mfma_pmc.json"}
+        busy = load_profile("r05_mfma_pmc.json") or load_profile("r04_mfma_pmc.json")
         if busy:
             dpt_roof["mfma_busy"] = busy.get("mfma_busy")
 
