@@ -95,6 +95,10 @@ __device__ __forceinline__ void kstep64(const unsigned char *a_t, const unsigned
 // fragments are in registers), and the next step, after the barrier, first issues its fragment reads (`begin`), then runs the
 // held-back MFMAs under that latency (`flush`), then its own slots (`body`).  Per tile: begin/body for the first step, barrier +
 // begin/flush/body for the others, one flush before the epilogue.
+#ifndef HIVE_PIPE_ABLATE_READS
+#define HIVE_PIPE_ABLATE_READS 0  // tuning build (make ablate_reads; WRONG results): 1 = a third of KPipe's fragment reads left out -- what a 128 x 128-per-wave register
+                                  // blocking would save of the LDS port's 192 KiB per K-step -- to see whether the K loop is LDS-port-bound before building that kernel
+#endif
 template <typename T, int MT, bool SWAP>
 struct KPipe {
     typedef vec<T, 8> frag;
@@ -105,8 +109,14 @@ struct KPipe {
     const unsigned char *a_t, *w_t;
     int a_row0, w_row0, fr, fq;
 
-    __device__ __forceinline__ frag rd_a(int sl) const { return *reinterpret_cast<const frag *>(a_t + swz(a_row0 + (sl % MT) * 16 + fr, (sl / MT) * 4 + fq)); }
-    __device__ __forceinline__ frag rd_w(int sub, int t) const { return *reinterpret_cast<const frag *>(w_t + swz(w_row0 + t * 16 + fr, sub * 4 + fq)); }
+    __device__ __forceinline__ frag rd_a(int sl) const {
+        if (HIVE_PIPE_ABLATE_READS && sl >= MT + MT / 2) return wfr[0][sl & 3];  // (timing experiment: no LDS read for the second half of sub-step 1's A fragments)
+        return *reinterpret_cast<const frag *>(a_t + swz(a_row0 + (sl % MT) * 16 + fr, (sl / MT) * 4 + fq));
+    }
+    __device__ __forceinline__ frag rd_w(int sub, int t) const {
+        if (HIVE_PIPE_ABLATE_READS && sub == 1) return wfr[0][t];  // (timing experiment: sub-step 1 reuses sub-step 0's W fragments)
+        return *reinterpret_cast<const frag *>(w_t + swz(w_row0 + t * 16 + fr, sub * 4 + fq));
+    }
     template <typename Acc>
     __device__ __forceinline__ void mfma_slot(int sl, Acc &acc) {
         const int sub = sl / MT, mt = sl % MT;

@@ -215,19 +215,45 @@ __device__ __forceinline__ void gemm_store_rows(const GemmParams<T> &p, const f3
     // mt are written -- no hazard, but the compiler cannot know, so the order is set by hand.
     constexpr int AHEAD = HIVE_GEMM_AHEAD;  // fragment rows the residual loads run ahead (a row's turn is ~0.5 us, a trip to HBM under load 2 us: conv.hip)
     vec<T, 8> rs[AHEAD + 1][2];
-    float2 lst[AHEAD + 1][2];  // ln_in: (mean, rstd) of the rows, loaded with the same lead -- a load inside `finish` is waited for with vmcnt(0), i.e. behind the
-                               // previous row's STORE as well (vmcnt retires in order): 16 trips to memory in series per tile
+    // Round 5: FEWER vector-memory instructions.  A CU's vector-memory path takes one wave-instruction per ~45 cycles whatever its width, and the epilogue is paced
+    // by it: the q|k / fc1 epilogues issued as many (mean, rstd) loads -- one 8-byte broadcast load per fragment-row half -- as stores (16 + 16 per wave and tile), the
+    // proj / fc2 epilogues 16 eight-lane stores of the LayerNorm partials beside their 16 + 16.  Now the wave's rows' statistics come in with TWO loads per tile:
+    // "pair" q = 2 mt + j of the epilogue's 2 MT steps covers rows 16 mt + 8 j + rr; lane (rr, c) loads the rows of pairs c and c + 8, and step q takes its values
+    // from lane c = q & 7 of its own 8-lane group with a ds_swizzle broadcast (LDS crossbar, no memory, no address register).  The partials go the other way: at
+    // step q lane c = q & 7 keeps the group's (sum, M2), and two 64-lane stores write them all at the end.
+    float2 st_in[2] = {float2{0.f, 0.f}, float2{0.f, 0.f}}, st_out[2] = {float2{0.f, 0.f}, float2{0.f, 0.f}};
+    const int pc = lane & 7;
+    auto pair_row = [&](int q) { return m_base + (q >> 1) * 16 + 8 * (q & 1) + rr; };
+    if (ln_in) {
+        st_in[0] = *reinterpret_cast<const float2 *>(p.ln_stats + 2 * (size_t)min(pair_row(pc), p.M - 1));
+        if (MT > 4) st_in[1] = *reinterpret_cast<const float2 *>(p.ln_stats + 2 * (size_t)min(pair_row(pc + 8), p.M - 1));
+    }
     auto pre = [&](int mt, int j) {
         const int m = min(m_base + mt * 16 + 8 * j + rr, p.M - 1);
         if (EPI == EPI_BIAS_RESIDUAL) rs[mt % (AHEAD + 1)][j] = *reinterpret_cast<const vec<T, 8> *>(p.residual + (size_t)m * p.ldc + n);
-        if (ln_in) lst[mt % (AHEAD + 1)][j] = *reinterpret_cast<const float2 *>(p.ln_stats + 2 * (size_t)m);
     };
+    // value of lane (lane & ~7) | k, for all lanes: ds_swizzle in bit-mask mode (and 0x18, or k, xor 0 -- within each 32-lane half)
+#define HIVE_BCAST8(v, k) __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, (v)), 0x18 | ((k) << 5)))
     hive_mfma::staged_rows<MT, AHEAD>(stage, acc, lane, pre, [&](int r, int, const f32x4 &lo, const f32x4 &hi, int mt, int j) {
         const int m = m_base + r;
         if (m >= p.M) return;
         float o[8];
         if (ln_in) {
-            const float2 st = lst[mt % (AHEAD + 1)][j];  // (mean, rstd) of row m
+            float2 st;  // (mean, rstd) of row m: held by lane q & 7 of this 8-lane group, slot q >> 3 (q = 2 mt + j: compile-time after unrolling)
+            {
+                const int q = 2 * mt + j;
+                const float2 src = st_in[q >> 3];
+                switch (q & 7) {
+                    case 0: st = float2{HIVE_BCAST8(src.x, 0), HIVE_BCAST8(src.y, 0)}; break;
+                    case 1: st = float2{HIVE_BCAST8(src.x, 1), HIVE_BCAST8(src.y, 1)}; break;
+                    case 2: st = float2{HIVE_BCAST8(src.x, 2), HIVE_BCAST8(src.y, 2)}; break;
+                    case 3: st = float2{HIVE_BCAST8(src.x, 3), HIVE_BCAST8(src.y, 3)}; break;
+                    case 4: st = float2{HIVE_BCAST8(src.x, 4), HIVE_BCAST8(src.y, 4)}; break;
+                    case 5: st = float2{HIVE_BCAST8(src.x, 5), HIVE_BCAST8(src.y, 5)}; break;
+                    case 6: st = float2{HIVE_BCAST8(src.x, 6), HIVE_BCAST8(src.y, 6)}; break;
+                    default: st = float2{HIVE_BCAST8(src.x, 7), HIVE_BCAST8(src.y, 7)}; break;
+                }
+            }
             o[0] = st.y * (lo[0] - st.x * c0.x) + b0.x, o[1] = st.y * (lo[1] - st.x * c0.y) + b0.y;
             o[2] = st.y * (lo[2] - st.x * c0.z) + b0.z, o[3] = st.y * (lo[3] - st.x * c0.w) + b0.w;
             o[4] = st.y * (hi[0] - st.x * c1.x) + b1.x, o[5] = st.y * (hi[1] - st.x * c1.y) + b1.y;
@@ -274,9 +300,20 @@ __device__ __forceinline__ void gemm_store_rows(const GemmParams<T> &p, const f3
 #pragma unroll
             for (int k = 0; k < 8; ++k) m2 += (v[k] - mean) * (v[k] - mean);
             m2 = dpp_oct_total(m2);
-            if ((lane & 7) == 0) *reinterpret_cast<float2 *>(p.ln_partial + 2 * ((size_t)m * (p.N >> 6) + (n_base >> 6))) = float2{sum, m2};
+            {  // lane q & 7 of the row's group keeps the pair's partial; stored behind the loop, two instructions per wave
+                const int q = 2 * mt + j;
+                if (pc == (q & 7)) st_out[q >> 3] = float2{sum, m2};
+            }
         }
     });
+    if (ln_out) {
+#pragma unroll
+        for (int h = 0; h < (MT > 4 ? 2 : 1); ++h) {
+            const int m = pair_row(pc + 8 * h);
+            if (m < p.M) *reinterpret_cast<float2 *>(p.ln_partial + 2 * ((size_t)m * (p.N >> 6) + (n_base >> 6))) = st_out[h];
+        }
+    }
+#undef HIVE_BCAST8
 }
 
 // (mean, rstd) of every row of x [M][256 CH], exactly as layernorm_kernel computes them: the statistics of a ViT's first LayerNorm, whose input no
