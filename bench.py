@@ -63,8 +63,23 @@ def parse_args():
     ap.add_argument("--no-overlap", action="store_true", help="TSDF sweeps on the network's stream (default: on a second stream, under the next batch's network)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the legs beside the headline job (fp16 job, config4, the other scaling mode at N > 1)")
+    ap.add_argument("--notes", action="store_true", help="keep the explanatory note strings in the JSON line (default: numbers only -- the notes are DESIGN.md section 6; "
+                                                         "the full line is ~10 KB, the compact one ~4 KB, which a log tail does not cut)")
     ap.add_argument("--timed-only", action="store_true", help="profiling runs: only the headline timed job (no roofline / cpu_baseline / extra legs)")
     return ap.parse_args()
+
+
+def compact(obj, keep_notes=False):
+    """The JSON line without its prose: floats to 6 significant digits, the explanatory strings (`note`, `*_note`, `overlap`, `scene`, per-kernel counter tables) dropped
+    unless --notes.  Every number stays."""
+    drop = ("note", "expected_note", "algorithmic_bytes_note", "traffic_note", "overlap", "traffic_detail")
+    if isinstance(obj, dict):
+        return {k: compact(v, keep_notes) for k, v in obj.items() if keep_notes or not (k in drop or k.endswith("_note"))}
+    if isinstance(obj, (list, tuple)):
+        return [compact(v, keep_notes) for v in obj]
+    if isinstance(obj, float):
+        return float(f"{obj:.6g}")
+    return obj
 
 
 def host_cores():
@@ -739,27 +754,30 @@ def main():
             "n_upd_mean": main_roof["n_upd_mean"], "n_upd_fraction": main_roof["n_upd_fraction"], "merge": (args.merge if world > 1 else None),
             "tsdf_overlap": overlap, "scaling_mode": scaling,
         },
-        "timed_volume_check": volume_proof,
-        "roofline": main_roof,
-        "roofline_room": room_roof,
-        "roofline_dpt": dpt_roof,
-        "mesh": mesh,
         "tsdf_source_stamp": stamp,
     }
-    if other is not None:
-        out[other["scaling"]] = other
+    # key order: a log TAIL shows the end of the line (the driver's tail cut the middle out) -- the side legs first, then the other scaling mode, and
+    # the contract's objects last: proof of work, the dominant kernel's roofline, the CPU baseline
+    if config4 is not None:
+        out["config4"] = config4
+    out["mesh"] = mesh
+    if fp16 is not None:
+        out["small_batch"] = fp16["small_batch"]
+    out["roofline_room"] = room_roof
+    out["roofline_dpt"] = dpt_roof
     if fp16 is not None:
         out["value_" + fp16["dtype"]] = fp16["value"]
         out["ms_per_step_" + fp16["dtype"]] = fp16["ms_per_step"]
-        out["small_batch"] = fp16["small_batch"]
     if no_overlap is not None:
         out["value_no_overlap"] = no_overlap["value"]
         out["no_overlap"] = no_overlap
-    if config4 is not None:
-        out["config4"] = config4
+    if other is not None:
+        out[other["scaling"]] = other
+    out["timed_volume_check"] = volume_proof
+    out["roofline"] = main_roof
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(seq, args.voxel, K)
-    print(json.dumps(out))
+    print(json.dumps(compact(out, args.notes)))
 
 
 if __name__ == "__main__":
