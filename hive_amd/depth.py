@@ -131,7 +131,8 @@ def estimate_depth_dpt(rgb_dataset, output_path: str, weights_filename='dpt_hybr
     # The PNG encoder (zlib, one core per file) is the slowest stage by far next to ~1 ms of GPU work per frame: the files of batch i are written by a small
     # thread pool while the GPU works on batch i + 1 (zlib releases the GIL); at most two batches of depth maps are in flight.
     from concurrent.futures import ThreadPoolExecutor
-    writers = ThreadPoolExecutor(max_workers=max(1, min(8, (os.cpu_count() or 2) - 1)))
+    from hive_amd.utils import usable_cores
+    writers = ThreadPoolExecutor(max_workers=max(1, min(32, usable_cores() - 1)))  # (a 640 x 480 depth map takes 20-60 ms of one core to compress)
     pending = []
 
     def write_batch(start, depth_mm):
@@ -160,7 +161,7 @@ def estimate_depth_dpt(rgb_dataset, output_path: str, weights_filename='dpt_hybr
                         preds.append((prediction[0] * 1000.0).clamp(0, 65535).to(torch.int32).cpu().numpy().astype(np.uint16))
                     depth_mm = preds
                 pending.append(write_batch(start, depth_mm))
-                while len(pending) > 2:
+                while len(pending) > 4:
                     for f in pending.pop(0):
                         f.result()
         for batch in pending:

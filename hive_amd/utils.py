@@ -7,6 +7,20 @@ from typing import Optional
 import numpy as np
 
 
+def usable_cores() -> int:
+    """Cores this process may really use: the scheduler affinity, cut down to the cgroup's CPU quota where one is set (a container on a 256-thread host is often given a
+    share of 8-16: sizing a thread pool by os.cpu_count() there makes it slower, not faster)."""
+    import os
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return cores
+
+
 def num2str(num: Optional[int]):
     return '?' if num is None else str(num)
 
