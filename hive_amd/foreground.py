@@ -164,3 +164,82 @@ def frame_mesh(depth, mask, image, camera_matrix, rotation=np.eye(3), translatio
         texture = img[max(min_v, 0):max_v, max(min_u, 0):max_u, :].clone()  # `image[min_v:max_v, min_u:max_u, :].copy()` (pipeline.py:805)
     return {"vertices": buffers.vertices[:nv.value], "faces": buffers.faces[:nf.value], "uv": buffers.uv[:nv.value], "texture": texture,
             "bbox": (min_u, min_v, max_u, max_v)}
+
+
+def pack_textures_row(textures, uvs):
+    """``Pipeline._pack_textures(textures_atlas, uvs_atlas, n_rows=1)`` (/root/reference/hive/pipeline.py:811-866) for the one form the reference calls: the objects' texture
+    crops side by side in ONE row (top-aligned, zero below the shorter ones), every object's u shifted by the widths in front of it, then u / atlas width and
+    v -> 1 - v / atlas height.  ``textures``: uint8 (h_i, w_i, 3) device tensors, ``uvs``: (V_i, 2) integer tensors relative to their crop.  Returns (atlas uint8
+    (max h, sum w, 3), uv float64 (sum V, 2)) on the device."""
+    import torch
+    assert len(textures) == len(uvs) and len(textures) > 0
+    height, width = max(int(t.shape[0]) for t in textures), sum(int(t.shape[1]) for t in textures)
+    atlas = torch.zeros((height, width, 3), dtype=torch.uint8, device=textures[0].device)
+    shifted, x = [], 0
+    for tex, uv in zip(textures, uvs):
+        h, w = int(tex.shape[0]), int(tex.shape[1])
+        atlas[:h, x:x + w] = tex
+        moved = uv.to(torch.float64)
+        moved[:, 0] += x
+        shifted.append(moved)
+        x += w
+    out = torch.cat(shifted)
+    # (tensor / tensor: torch turns a division by a Python scalar into a multiplication by its reciprocal on the GPU -- one ulp off numpy's `/=` in places)
+    size = torch.tensor([float(width), float(height)], dtype=torch.float64, device=out.device)
+    out = out / size
+    out[:, 1] = 1.0 - out[:, 1]
+    return atlas, out
+
+
+def process_frame(rgb, depth, mask_encoded, camera_matrix, pose, dilation_options=None, filtering_options: MeshFilteringOptions = None,
+                  disable_coverage_constraint=False, ctx=None, buffers: FrameMeshBuffers = None):
+    """The body of ``process_frame`` in ``Pipeline._create_scene`` (/root/reference/hive/pipeline.py:340-483) for the dynamic objects of ONE frame, device-resident:
+    for every object id 1 .. mask_encoded.max(): the binary mask, dilated (``dilate_mask``, :369-370); skipped when it covers less than 1 % of the frame (:374-379); its
+    mesh in one library call (``frame_mesh``: point cloud, triangulation + face filter, texture window); skipped with fewer than 9 vertices or no face (:388-391, 410-413);
+    the objects' vertices stacked, their faces offset by the vertices in front, their textures packed in one atlas row (:463-468, 811-866).  The reference's CPU-library
+    stages in between -- decimation (openmesh), connected components (trimesh), billboard -- are outside this build's scope and are NOT applied.
+
+    ``rgb`` uint8 (H, W, 3+), ``depth`` float32 (H, W), ``mask_encoded`` uint8 (H, W) instance ids (0 = background), ``pose`` the frame's 4 x 4 world-to-camera transform
+    (``dataset.camera_trajectory.to_homogenous_transforms()[index]``).  Numpy arrays or device tensors.  Returns None for a frame without a surviving object (the reference
+    returns an empty ``trimesh.Trimesh()``), else a dict of device tensors: ``vertices`` float64 (V, 3), ``faces`` int64 (F, 3), ``uv`` float64 (V, 2) in atlas
+    coordinates, ``texture`` uint8 atlas, and ``objects`` = the ids that survived."""
+    import torch
+    from hive_amd.options import MaskDilationOptions
+    dilation_options = dilation_options or MaskDilationOptions()
+    filtering_options = filtering_options or MeshFilteringOptions()
+    dev = depth.device if _is_torch(depth) else torch.device("cuda", torch.cuda.current_device())
+    ctx = ctx or _lib.default_context(dev.index or 0)
+    as_dev = lambda a, dt: (a if _is_torch(a) else torch.from_numpy(np.ascontiguousarray(a))).to(device=dev, dtype=dt).contiguous()
+    rgb_d = as_dev(rgb, torch.uint8)[:, :, :3].contiguous()  # (`rgb[:, :, :3]`, :355)
+    depth_d = as_dev(depth, torch.float32)
+    ids = as_dev(mask_encoded, torch.uint8)
+    h, w = (int(v) for v in depth_d.shape)
+    buffers = buffers or FrameMeshBuffers(h, w, dev)
+    pose = np.asarray(pose, dtype=np.float64).reshape(4, 4)
+    rotation, translation = pose[:3, :3], pose[:3, 3:4]  # get_pose_components
+    se = dilation_options.structuring_element()
+    n_objects = int(ids.max().item())
+    vertices, faces, uvs, textures, kept = [], [], [], [], []
+    vertex_count = 0
+    for object_id in range(1, n_objects + 1):
+        mask = (ids == object_id).to(torch.uint8)
+        if dilation_options.num_iterations > 0:
+            ctx.follow_torch_stream()
+            grown = torch.empty_like(mask)
+            ctx.check(ctx.lib.hive_dilate_mask_se(ctx.handle, ptr(mask), h, w, ptr(se), se.shape[0], se.shape[1], int(dilation_options.num_iterations), MEM_DEVICE, ptr(grown)))
+            mask = grown
+        if float(mask.float().mean().item()) < 0.01 and not disable_coverage_constraint:
+            continue
+        mesh = frame_mesh(depth_d, mask, rgb_d, camera_matrix, rotation, translation, filtering_options, ctx=ctx, buffers=buffers)
+        if mesh["vertices"].shape[0] < 9 or mesh["faces"].shape[0] < 1:
+            continue
+        vertices.append(mesh["vertices"].clone())
+        faces.append(mesh["faces"].to(torch.int64) + vertex_count)
+        uvs.append(mesh["uv"].clone())
+        textures.append(mesh["texture"])
+        vertex_count += int(mesh["vertices"].shape[0])
+        kept.append(object_id)
+    if not kept:
+        return None
+    atlas, uv = pack_textures_row(textures, uvs)
+    return {"vertices": torch.cat(vertices), "faces": torch.cat(faces), "uv": uv, "texture": atlas, "objects": kept}

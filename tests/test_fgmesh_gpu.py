@@ -266,3 +266,68 @@ def test_frame_mesh_in_one_call_equals_the_separate_functions(gpu_ctx, on_device
             assert np.array_equal(got["texture"].cpu().numpy(), want_tex)
             vv, uu = (mask & (depth > 0)).nonzero()
             assert got["bbox"] == (uu.min(), vv.min(), uu.max() + 1, vv.max() + 1), "an unprojected pixel projects back onto itself"
+
+
+def _reference_pack_textures(textures_atlas, uvs_atlas, n_rows=1):
+    """What Pipeline._pack_textures computes for n_rows = 1 (pipeline.py:811-866), restated directly: one row, u offsets by the running width, normalisation."""
+    heights, widths = [t.shape[0] for t in textures_atlas], [t.shape[1] for t in textures_atlas]
+    atlas = np.zeros((max(heights), sum(widths), 3), np.uint8)
+    out, x = [], 0
+    for t, uv in zip(textures_atlas, uvs_atlas):
+        atlas[:t.shape[0], x:x + t.shape[1]] = t
+        uv = uv.astype(np.float64).copy()
+        uv[:, 0] += x
+        out.append(uv)
+        x += t.shape[1]
+    final = np.vstack(out)
+    final[:, 0] /= atlas.shape[1]
+    final[:, 1] = 1.0 - final[:, 1] / atlas.shape[0]
+    return atlas, final
+
+
+def test_process_frame_stacks_the_objects_like_the_reference_loop(gpu_ctx):
+    """`foreground.process_frame` == the reference's loop over a frame's object ids (pipeline.py:357-468) restated with the per-function entry points: dilated binary
+    masks, the 1 % coverage rule, vertices stacked, faces offset by the vertex count, textures packed in one row with normalised uv; an object too small to cover
+    1 % of the frame is skipped, and with the coverage constraint disabled it comes back."""
+    import torch
+    from hive_amd import foreground, geometric, synthetic
+    from hive_amd.image_processing import dilate_mask
+    from hive_amd.options import MaskDilationOptions, MeshFilteringOptions
+    H, W = 240, 320
+    seq = synthetic.make_sequence(num_frames=1, height=H, width=W)
+    ids = synthetic.ellipse_masks(1, H, W, num_objects=2, seed=3)[0].copy()
+    ids[5:12, 5:14] = 3  # a third object of 63 pixels: 0.08 % of the frame
+    depth, rgb = seq["depth"][0], seq["color"][0]
+    pose = np.linalg.inv(seq["poses"][0])
+    R, t = pose[:3, :3], pose[:3, 3:4]
+    dil, flt = MaskDilationOptions(num_iterations=2), MeshFilteringOptions()
+    K = seq["K"]
+
+    def reference(disable_coverage):
+        verts, faces, texs, uvs, count, kept = [], [], [], [], 0, []
+        for oid in range(1, int(ids.max()) + 1):
+            mask = dilate_mask(ids == oid, dil)
+            if mask.mean() < 0.01 and not disable_coverage:
+                continue
+            v = geometric.point_cloud_from_depth(depth, mask, K, R, t)
+            if len(v) < 9:
+                continue
+            f = foreground.grid_faces(depth, mask, flt, ctx=gpu_ctx)
+            if len(f) < 1:
+                continue
+            tex, uv = foreground.get_mesh_texture_and_uv(v, rgb, K, R, t, ctx=gpu_ctx)
+            verts.append(v), faces.append(f.astype(np.int64) + count), texs.append(tex), uvs.append(uv), kept.append(oid)
+            count += len(v)
+        atlas, uv = _reference_pack_textures(texs, uvs)
+        return np.vstack(verts), np.vstack(faces), uv, atlas, kept
+
+    for disable in (False, True):
+        want_v, want_f, want_uv, want_atlas, want_kept = reference(disable)
+        got = foreground.process_frame(torch.from_numpy(rgb).cuda(), torch.from_numpy(depth).cuda(), torch.from_numpy(ids).cuda(), K, pose, dil, flt,
+                                       disable_coverage_constraint=disable, ctx=gpu_ctx)
+        assert got["objects"] == want_kept == ([1, 2, 3] if disable else [1, 2])
+        assert np.array_equal(got["vertices"].cpu().numpy(), want_v) and np.array_equal(got["faces"].cpu().numpy(), want_f)
+        assert np.array_equal(got["texture"].cpu().numpy(), want_atlas) and np.array_equal(got["uv"].cpu().numpy(), want_uv)
+        assert 0.0 <= float(got["uv"].min()) and float(got["uv"].max()) <= 1.0
+    empty = foreground.process_frame(rgb, depth, np.zeros_like(ids), K, pose, dil, flt, ctx=gpu_ctx)
+    assert empty is None
