@@ -128,6 +128,10 @@ constexpr int BN = 128, BK = 64;
                               // Measured (round 4, alternating runs of both libraries, 107-frame forward): 75.41 -> 75.85 ms -- the four extra MFMAs per tile cost more than
                               // the additions they replace, although the VALU is the busier pipe by the counters.
 #endif
+#ifndef HIVE_ATT_PK_SUM
+#define HIVE_ATT_PK_SUM 0  // attention_kernel, tuning build: 1 = the softmax denominators as 16 v_pk_add_f32 per tile instead of 32 v_add_f32.  Measured (round 5, alternating
+                           // runs of both libraries, 107-frame forward): 75.78-75.99 -> 75.96-76.19 ms -- packed f32 issues slowly beside the MFMAs here too.
+#endif
 #ifndef HIVE_GEMM_ABLATE
 #define HIVE_GEMM_ABLATE 0  // tuning builds only (make ablate_gemm; tools/probe_gemm_tiles.py with HIVE_AMD_LIB=...): 1 = gemm256p_kernel without its epilogue
 #endif
@@ -946,8 +950,22 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams<T> p) {
                 neg_m[i] = -m_new;
             }
         }
-        float l_tile = 0.f;
         vec<T, 8> pf[2][2];
+#if HIVE_ATT_PK_SUM
+        // (tuning build: the 32 probabilities of a tile summed as 16 packed additions)
+        f32x2 l2 = f32x2{0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int i = 0; i < 16; i += 2) {
+                const f32x2 e = f32x2{__builtin_amdgcn_exp2f(sacc[kb][i]), __builtin_amdgcn_exp2f(sacc[kb][i + 1])};
+                l2 += e;
+                pf[kb][i >> 3][i & 7] = (T)e.x;
+                pf[kb][i >> 3][(i & 7) + 1] = (T)e.y;
+            }
+        l_run += l2.x + l2.y;
+#else
+        float l_tile = 0.f;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -957,6 +975,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams<T> p) {
                 pf[kb][i >> 3][i & 7] = (T)e;
             }
         l_run += l_tile;
+#endif
         // O^T[ch][q] += V^T[ch][key] P^T[key][q]; k index j of half hh <-> key 32 kb + 16 s + 8 (j >> 2) + 4 hh + (j & 3) (see vt_slot)
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
