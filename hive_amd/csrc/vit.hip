@@ -38,7 +38,7 @@ using hive_mfma::vec;  // vec<T, 8>: 8 elements of the 16-bit element type T = _
 #ifndef HIVE_GEMM_AHEAD
 #define HIVE_GEMM_AHEAD 3
 #endif
-enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RESIDUAL = 2, EPI_QKV = 3 };
+enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_RESIDUAL = 2, EPI_QKV = 3, EPI_QKV_ALL = 4 };  // (_ALL: gemm_kernel only -- q | k and v^T tiles in ONE launch, chosen per tile)
 
 // v^T key order.  The attention's P.V step holds the probabilities of a lane in accumulator order: its 8 k-slots of one
 // 32x32x16 MFMA are keys {0..3, 8..11} (+ 4 for the upper half-wave) of a 16-key group -- the S^T accumulator layout, not a
@@ -423,6 +423,7 @@ __global__ __launch_bounds__(TM * 2, 1) void gemm_kernel(GemmParams<T> p) {
     constexpr int A_GROUPS = TM / 8, GROUPS = A_GROUPS + 16, PER_WAVE = GROUPS / NWAVES;
     constexpr int STAGE_BYTES = GROUPS * 1024;
     constexpr bool VT = (EPI == EPI_QKV);
+    constexpr bool ALL = (EPI == EPI_QKV_ALL);  // round 5, small batches: tiles with n0 < n_split are q | k tiles (EPI_BIAS), the others v^T tiles -- one launch instead of two
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
@@ -495,7 +496,10 @@ __global__ __launch_bounds__(TM * 2, 1) void gemm_kernel(GemmParams<T> p) {
         const int ib = buf + AHEAD >= NST ? buf + AHEAD - NST : buf + AHEAD;
         const unsigned char *a_t = lds + buf * STAGE_BYTES, *w_t = a_t + A_GROUPS * 1024;
         // VT: acc[mt][nt] = A_frag . W_frag^T (rows = m, cols = n); else acc[nt][mt] = W_frag . A_frag^T (rows = n, cols = m)
-        hive_mfma::kstep64<T, 4, VT>(a_t, w_t, wr * 64, wc * 64, fr, fq, acc, PER_WAVE, [&](int j) { issue_piece(is.m0, is.n0, is.kt, ib, j); });
+        if (ALL && n0 >= p.n_split)  // (workgroup-uniform)
+            hive_mfma::kstep64<T, 4, true>(a_t, w_t, wr * 64, wc * 64, fr, fq, acc, PER_WAVE, [&](int j) { issue_piece(is.m0, is.n0, is.kt, ib, j); });
+        else
+            hive_mfma::kstep64<T, 4, VT>(a_t, w_t, wr * 64, wc * 64, fr, fq, acc, PER_WAVE, [&](int j) { issue_piece(is.m0, is.n0, is.kt, ib, j); });
         advance(is);
         buf = buf + 1 == NST ? 0 : buf + 1;
     }
@@ -504,9 +508,9 @@ __global__ __launch_bounds__(TM * 2, 1) void gemm_kernel(GemmParams<T> p) {
     if (S > 1) store = hive_mfma::splitk_combine<TM * 2>(S, p.sk_ws, p.sk_count, run0 + tl, acc, tid, reinterpret_cast<int *>(lds + NST * STAGE_BYTES));
     if (store) {
     // epilogue
-    if constexpr (!VT) {
-        gemm_store_rows<T, EPI, 4>(p, acc, m0 + wr * 64, n0 + wc * 64, lds + NST * STAGE_BYTES + wave * 4096, lane);
-    } else {
+    if (!VT && !(ALL && n0 >= p.n_split)) {
+        if constexpr (!VT) gemm_store_rows<T, ALL ? EPI_BIAS : EPI, 4>(p, acc, m0 + wr * 64, n0 + wc * 64, lds + NST * STAGE_BYTES + wave * 4096, lane);
+    } else if constexpr (VT || ALL) {
         // v^T[b][h][c][token]: the wave's 64 tokens x 64 channels are one head of one image (Np % 64 == 0): 64 rows of 128 contiguous
         // bytes.  A lane owns 4 consecutive tokens of one channel, so a direct store is 16 rows x 32 bytes per instruction; instead
         // the block is turned around in the wave's 4 KiB of LDS, 32 channels at a time ([channel][64 token slots] bf16, 16-byte chunk c
@@ -550,7 +554,7 @@ __global__ __launch_bounds__(TM * 2, 1) void gemm_kernel(GemmParams<T> p) {
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             if (mw < p.M) {
-                const int img = mw / p.Np, tok0 = mw - img * p.Np, head = (n0 + wc * 64) >> 6;
+                const int img = mw / p.Np, tok0 = mw - img * p.Np, head = (n0 - (ALL ? p.n_split : 0) + wc * 64) >> 6;  // (_ALL: n0 counts from the q columns)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int row = 8 * i + (lane >> 3), c = lane & 7;
@@ -1252,6 +1256,8 @@ static int ensure_gemm_attrs(hive_ctx *ctx) {
     HIVE_GEMM_ATTR(EPI_BIAS_RESIDUAL);
     HIVE_GEMM_ATTR(EPI_QKV);
 #undef HIVE_GEMM_ATTR
+    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)gemm_kernel<T, EPI_QKV_ALL, GEMM_TM, GEMM_NST_DEEP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS_DEEP));
+    HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)gemm_kernel<T, EPI_QKV_ALL, GEMM_TM, GEMM_NST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS));
     HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)gemm256_kernel<T, EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM256_LDS));
     HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)gemm256_kernel<T, EPI_BIAS_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM256_LDS));
     HIVE_CHECK_HIP(ctx, hipFuncSetAttribute((const void *)gemm256_kernel<T, EPI_BIAS_RESIDUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM256_LDS));
@@ -1305,6 +1311,31 @@ static int qkv_t(hive_ctx *ctx, const void *x, const void *W, const float *bias,
     p.q_scale = 0.125f * 1.44269504088896340736f;
     p.ln_stats = ln.stats;
     p.ln_c1 = ln.c1;
+    // Round 5, small batches (the reference's literal loop is one frame per forward): where ALL 3 D columns' 128 x 128 tiles fit the CUs in one round, q | k and v^T are ONE launch
+    // of the four-stage-ring kernel -- 180 tiles at one frame instead of 120 + 60 in two dependent launches of ~14 us each; a tile's arithmetic is what it was (same K order, same
+    // epilogue), so the results are bit-identical.  HIVE_QKV_MERGE=0 keeps the two launches.
+    {
+        const long long tiles_all = (long long)((p.M + GEMM_TM - 1) / GEMM_TM) * (3 * D / BN);
+        const char *merge_env = getenv("HIVE_QKV_MERGE");
+        const long long merge_max = merge_env && merge_env[0] == '2' ? (long long)(2 * ctx->num_cus) / 8 * 8 : ctx->num_cus;  // ("2": also where the tiles fit two workgroups per CU -- measured below)
+        if (!(merge_env && merge_env[0] == '0') && tiles_all <= merge_max && !getenv("HIVE_GEMM_TILE") && !getenv("HIVE_GEMM_RING")) {
+            GemmParams<T> q = p;
+            q.N = 3 * D;
+            q.n_split = 2 * D;
+            q.vT = (T *)vT;
+            q.Np = Np;
+            q.H = H;
+            const bool deep = tiles_all <= ctx->num_cus;
+            if (deep) ++ctx->n_deep_ring_launches;
+            const dim3 grid((unsigned)((tiles_all + 7) / 8 * 8)), block(GEMM_TM * 2);
+            if (deep)
+                hipLaunchKernelGGL((gemm_kernel<T, EPI_QKV_ALL, GEMM_TM, GEMM_NST_DEEP>), grid, block, GEMM_LDS_DEEP, ctx->stream, q);
+            else
+                hipLaunchKernelGGL((gemm_kernel<T, EPI_QKV_ALL, GEMM_TM, GEMM_NST>), grid, block, GEMM_LDS, ctx->stream, q);
+            HIVE_CHECK_HIP(ctx, hipGetLastError());
+            return HIVE_OK;
+        }
+    }
     if ((rc = launch_gemm<T>(ctx, EPI_BIAS, p))) return rc;
     // v columns: transposed store into vT [B][H][64][Np]
     GemmParams<T> pv{};

@@ -153,9 +153,10 @@ def test_linear_rejects_bad_shapes(gpu_ctx, half):
 
 
 @pytest.mark.parametrize("B,N", [(1, 1201), (2, 77), (1, 64), (3, 130), (24, 1201)])  # 24 x 1216 rows: q|k and v^T on the persistent 256-tile kernel
-def test_qkv_and_attention(gpu_ctx, half, B, N):
+def test_qkv_and_attention(gpu_ctx, half, B, N, monkeypatch):
     """qkv projection (q|k row-major, v transposed) + softmax(q k^T / 8) v, incl. ragged N (key masking),
-    and a spiked key row that forces the online-softmax rescale branch."""
+    and a spiked key row that forces the online-softmax rescale branch.  At small batches q | k and v^T are ONE launch (vit.hip qkv_t, round 5): the
+    two-launch orchestration (HIVE_QKV_MERGE=0) and the two-workgroups-per-CU merge ("2") must give the same bits."""
     import torch
     torch.manual_seed(2)
     D, H = 768, 12
@@ -182,6 +183,12 @@ def test_qkv_and_attention(gpu_ctx, half, B, N):
     slot = (tok & ~12) | ((tok & 4) << 1) | ((tok & 8) >> 1)
     vT_tokens = vT[..., slot]  # column t of the logical v^T lives in column slot[t]
     _close(vT_tokens, ref_v, "v^T")
+    for mode in ("0", "2"):
+        monkeypatch.setenv("HIVE_QKV_MERGE", mode)
+        qk2, vT2 = torch.full_like(qk, 7.0), torch.full_like(vT, 7.0)
+        gpu_ctx.check(gpu_ctx.lib.hive_vit_qkv(gpu_ctx.handle, x.data_ptr(), _code(half), W.data_ptr(), bias.data_ptr(), qk2.data_ptr(), vT2.data_ptr(), B, Np, D, H))
+        assert torch.equal(qk2, qk) and torch.equal(vT2, vT), f"HIVE_QKV_MERGE={mode}"
+    monkeypatch.delenv("HIVE_QKV_MERGE")
     out = torch.empty(B * Np, D, device="cuda", dtype=half)
     gpu_ctx.check(gpu_ctx.lib.hive_vit_attention(gpu_ctx.handle, qk.data_ptr(), _code(half), vT.data_ptr(), out.data_ptr(), B, N, Np, D, H))
     # reference on the kernel's own 16-bit q, k, v
