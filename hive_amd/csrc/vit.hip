@@ -846,7 +846,8 @@ __device__ __forceinline__ float max3_raw(float a, float b, float c) {
 template <typename T>
 __global__ __launch_bounds__(256) void attention_kernel(AttnParams<T> p) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * ATT_KV * 128];  // 2 stages x (K tile, V^T tile)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q_blocks = (p.Np + 127) / 128;
     const int qb = blockIdx.x % q_blocks;
     const int head = (blockIdx.x / q_blocks) % p.H;
@@ -862,20 +863,28 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams<T> p) {
     for (int ks = 0; ks < 4; ++ks)
         qf[ks] = *reinterpret_cast<const vec<T, 8> *>(p.qk + (row0 + q_tok) * ld + head * 64 + ks * 16 + hh * 8);
 
-    // staging of one K tile [64 keys][64 ch] and one V^T tile [64 ch][64 keys] by LDS-DMA: 8 + 8 groups of 8 rows x 128 B,
-    // 4 per wave, with the GEMM's source-side chunk swizzle (slot = chunk ^ ((row >> 1) & 7))
-    const T *k_base = p.qk + row0 * ld + p.D + head * 64;
-    const T *v_base = p.vT + ((size_t)img * p.H + head) * 64 * p.Np;
-    auto issue_tile = [&](int t, int stage) {
-        unsigned char *k_t = lds + stage * 2 * ATT_KV * 128, *v_t = k_t + ATT_KV * 128;
+    // staging of one K tile [64 keys][64 ch] and one V^T tile [64 ch][64 keys] by LDS-DMA: 8 + 8 groups of 8 rows x 128 B, a wave takes groups
+    // wave and wave + 4 of each, with the GEMM's source-side chunk swizzle (slot = chunk ^ ((row >> 1) & 7)).  Round 5: the lane's four byte offsets are
+    // loop constants and a tile's base is a scalar (Np % 64 == 0: no row of a tile is past the end) -- the address arithmetic was ~45 of a tile's ~200
+    // vector instructions in a kernel the vector ALU bounds.
+    const char *k_base = reinterpret_cast<const char *>(p.qk + row0 * ld + p.D + head * 64);
+    const char *v_base = reinterpret_cast<const char *>(p.vT + ((size_t)img * p.H + head) * 64 * p.Np);
+    unsigned k_off[2], v_off[2];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int g = wave + 4 * j;  // 0..15
-            if (g < 8)
-                stage_group(k_base, ld, t * ATT_KV, p.Np - 1, 0, k_t, g, lane);
-            else
-                stage_group(v_base + t * ATT_KV, p.Np, 0, 63, 0, v_t, g - 8, lane);
-        }
+    for (int j = 0; j < 2; ++j) {
+        const int row = (wave + 4 * j) * 8 + (lane >> 3), chunk = (lane & 7) ^ ((row >> 1) & 7);
+        k_off[j] = (unsigned)row * (unsigned)ld * 2u + (unsigned)chunk * 16u;
+        v_off[j] = (unsigned)row * (unsigned)p.Np * 2u + (unsigned)chunk * 16u;
+    }
+    auto issue_tile = [&](int t, int stage) {
+        unsigned char *k_t = lds + stage * 2 * ATT_KV * 128 + wave * 1024, *v_t = k_t + ATT_KV * 128;
+        const char *kp = k_base + (size_t)t * ((size_t)ATT_KV * ld * 2), *vp = v_base + (size_t)t * (ATT_KV * 2);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_global_load_lds((const void *)(kp + k_off[j]), (__attribute__((address_space(3))) void *)(k_t + j * 4096), 16, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_global_load_lds((const void *)(vp + v_off[j]), (__attribute__((address_space(3))) void *)(v_t + j * 4096), 16, 0, 0);
     };
 
     f32x16 oacc[2];
