@@ -291,7 +291,7 @@ class Context:
         self.check(self.lib.hive_ctx_set_round_mode(self.handle, int(mode)))
 
     def set_deterministic(self, enabled):
-        """No split-K, no Gram-matrix GroupNorm statistics: see ``hive_ctx_set_deterministic`` in include/hive_mi355x.h."""
+        """No split-K, no key split in attention, no Gram-matrix GroupNorm statistics: see ``hive_ctx_set_deterministic`` in include/hive_mi355x.h."""
         self.check(self.lib.hive_ctx_set_deterministic(self.handle, int(bool(enabled))))
         self.deterministic = bool(enabled)
 

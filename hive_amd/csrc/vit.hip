@@ -123,15 +123,8 @@ struct GemmParams {
 
 constexpr int BN = 128, BK = 64;
 
-#ifndef HIVE_ATT_LSUM_MFMA
-#define HIVE_ATT_LSUM_MFMA 0  // attention_kernel, tuning build: 1 = the softmax denominators from an extra all-ones channel block of P.V instead of 32 v_add_f32 per tile.
-                              // Measured (round 4, alternating runs of both libraries, 107-frame forward): 75.41 -> 75.85 ms -- the four extra MFMAs per tile cost more than
-                              // the additions they replace, although the VALU is the busier pipe by the counters.
-#endif
-#ifndef HIVE_ATT_PK_SUM
-#define HIVE_ATT_PK_SUM 0  // attention_kernel, tuning build: 1 = the softmax denominators as 16 v_pk_add_f32 per tile instead of 32 v_add_f32.  Measured (round 5, alternating
-                           // runs of both libraries, 107-frame forward): 75.78-75.99 -> 75.96-76.19 ms -- packed f32 issues slowly beside the MFMAs here too.
-#endif
+// (attention_kernel, tuning builds of rounds 4-5 that lost and were taken out: the softmax denominators from an extra all-ones channel block of P.V instead of 32 v_add_f32 per
+// tile -- 75.41 -> 75.85 ms per 107-frame forward, the four extra MFMAs cost more than the additions; the same sums as 16 v_pk_add_f32 -- 75.78-75.99 -> 75.96-76.19 ms.)
 #ifndef HIVE_GEMM_ABLATE
 #define HIVE_GEMM_ABLATE 0  // tuning builds only (make ablate_gemm; tools/probe_gemm_tiles.py with HIVE_AMD_LIB=...): 1 = gemm256p_kernel without its epilogue
 #endif
@@ -843,11 +836,16 @@ __device__ __forceinline__ float max3_raw(float a, float b, float c) {
     return r;
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void attention_kernel(AttnParams<T> p) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * ATT_KV * 128];  // 2 stages x (K tile, V^T tile)
+// KS = 2 (round 5, small grids -- the reference's one-frame forward is 120 workgroups on 256 CUs, each a chain of 19 key tiles of ~1.2 us): eight waves, the
+// second four take the second half of the KEYS for the same 128 queries with a ring of their own, and the halves' (m, l, O) are merged through LDS at the end
+// (the usual two-way merge of online softmax).  Another summation order than KS = 1: results agree to rounding, not bit for bit.
+template <typename T, int KS>
+__global__ __launch_bounds__(256 * KS) void attention_kernel(AttnParams<T> p) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds_all[KS * 2 * 2 * ATT_KV * 128];  // per key half: 2 stages x (K tile, V^T tile)
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = wave_all & 3, kh = KS > 1 ? wave_all >> 2 : 0;  // query group of 32, key half
+    unsigned char *lds = lds_all + kh * (2 * 2 * ATT_KV * 128);
     const int q_blocks = (p.Np + 127) / 128;
     const int qb = blockIdx.x % q_blocks;
     const int head = (blockIdx.x / q_blocks) % p.H;
@@ -890,133 +888,136 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams<T> p) {
     f32x16 oacc[2];
     for (int i = 0; i < 16; ++i) oacc[0][i] = oacc[1][i] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
-    // (HIVE_ATT_LSUM_MFMA, a tuning build that lost: one more V^T "channel block" whose rows are all ones makes O^T's extra rows the sums over the keys of the
-    // rounded probabilities; all 16 registers of lacc then hold the lane's query's sum over both key halves)
-    f32x16 lacc;
-    for (int i = 0; i < 16; ++i) lacc[i] = 0.f;
-    vec<T, 8> ones8;
-    for (int k = 0; k < 8; ++k) ones8[k] = (T)1.0f;
     f32x16 neg_m;  // -m_run in every element (0 before the first tile)
     for (int i = 0; i < 16; ++i) neg_m[i] = 0.f;
 
     const int n_tiles = p.Np / ATT_KV;
-    issue_tile(0, 0);
+    const int per_half = (n_tiles + KS - 1) / KS;  // every wave runs per_half iterations (the barriers are the workgroup's); the last half may have fewer tiles
+    const int t_begin = kh * per_half, t_end = min(n_tiles, t_begin + per_half);
+    if (KS == 1 || t_begin < t_end) issue_tile(t_begin, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int t = 0; t < n_tiles; ++t) {
-        const int stage = t & 1;
-        if (t + 1 < n_tiles) issue_tile(t + 1, stage ^ 1);  // that buffer was last read in tile t-1, before its barrier
-        const unsigned char *k_t = lds + stage * 2 * ATT_KV * 128, *v_t = k_t + ATT_KV * 128;
-        // S^T[key][q] for 64 keys x 32 queries: rows (keys) in registers, query on the lane
-        // q is pre-scaled, so the products are the softmax's base-2 exponents; the accumulators start at -m (the running maximum of
-        // this lane's query), so they come out of the MFMAs already shifted: p = exp2(acc) -- no multiply-subtract per score
-        // (-m sits in 16 registers of its own, rewritten only when the maximum moves, and is the C operand of each chain's first MFMA:
-        // no per-tile initialisation of the 32 accumulators)
-        const float m_used = t == 0 ? 0.f : m_run;
-        f32x16 sacc[2];
+    for (int it = 0; it < per_half; ++it) {
+        const int t = t_begin + it;
+        const int stage = it & 1;
+        if (t + 1 < t_end) issue_tile(t + 1, stage ^ 1);  // that buffer was last read in the previous iteration, before its barrier
+        if (KS == 1 || t < t_end) {
+            const unsigned char *k_t = lds + stage * 2 * ATT_KV * 128, *v_t = k_t + ATT_KV * 128;
+            // S^T[key][q] for 64 keys x 32 queries: rows (keys) in registers, query on the lane
+            // q is pre-scaled, so the products are the softmax's base-2 exponents; the accumulators start at -m (the running maximum of
+            // this lane's query), so they come out of the MFMAs already shifted: p = exp2(acc) -- no multiply-subtract per score
+            // (-m sits in 16 registers of its own, rewritten only when the maximum moves, and is the C operand of each chain's first MFMA:
+            // no per-tile initialisation of the 32 accumulators)
+            const float m_used = it == 0 ? 0.f : m_run;
+            f32x16 sacc[2];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
+            for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                const vec<T, 8> kf = *reinterpret_cast<const vec<T, 8> *>(k_t + swz(kb * 32 + lq, ks * 2 + hh));
-                sacc[kb] = hive_mfma::mfma32(kf, qf[ks], ks == 0 ? neg_m : sacc[kb]);
-            }
-        // key row of register i: 32 kb + (i & 3) + 8 (i >> 2) + 4 hh.  Keys >= N exist only in the last tile.
-        if (t == n_tiles - 1) {
-            asm volatile("; pad keys: last tile only" ::: "memory");  // keeps this a branch (if-converted it is 31 v_cndmask in EVERY tile)
-            const int key0 = t * ATT_KV + 4 * hh;
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int i = 0; i < 16; ++i)
-                    if (key0 + kb * 32 + (i & 3) + 8 * (i >> 2) >= p.N) sacc[kb][i] = -INFINITY;
-        }
-        // v_max3_f32 by hand: fmaxf() makes the compiler canonicalise every MFMA result first (one v_max_f32 x, x, x per score:
-        // 50 v_max + 8 v_max3 per tile where 16 v_max3 do; the softmax VALU work, not the MFMAs, bounds this kernel)
-        float m_tile = max3_raw(sacc[0][0], sacc[1][0], sacc[0][1]);
-        m_tile = max3_raw(m_tile, sacc[1][1], sacc[0][2]);
-#pragma unroll
-        for (int i = 2; i < 16; i += 2) {
-            m_tile = max3_raw(m_tile, sacc[1][i], sacc[0][i + 1]);
-            if (i + 2 < 16)
-                m_tile = max3_raw(m_tile, sacc[1][i + 1], sacc[0][i + 2]);
-            else
-                m_tile = max3_raw(m_tile, sacc[1][i + 1], sacc[1][i + 1]);
-        }
-        m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32));  // the tile's maximum RELATIVE to m_used
-        // deferred maximum: the running maximum only moves when some query of the wave exceeds it by more than ATT_DEFER
-        // (probabilities then stay below 2^8 -- harmless in f32 / bf16), so the rescale of the O accumulators and the re-shift of
-        // the scores are skipped for almost every tile.  Any m gives the same softmax.
-        if (t == 0 || __any(m_tile > ATT_DEFER)) {
-            const float m_new = t == 0 ? m_tile : fmaxf(m_run, m_used + m_tile);
-            const float delta = m_new - m_used;
-            const float alpha = t == 0 ? 0.f : __builtin_amdgcn_exp2f(m_run - m_new);
-            m_run = m_new;
-            l_run *= alpha;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                if (HIVE_ATT_LSUM_MFMA) lacc[i] *= alpha;
-                oacc[0][i] *= alpha;
-                oacc[1][i] *= alpha;
-                sacc[0][i] -= delta;
-                sacc[1][i] -= delta;
-                neg_m[i] = -m_new;
-            }
-        }
-        vec<T, 8> pf[2][2];
-#if HIVE_ATT_PK_SUM
-        // (tuning build: the 32 probabilities of a tile summed as 16 packed additions)
-        f32x2 l2 = f32x2{0.f, 0.f};
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int i = 0; i < 16; i += 2) {
-                const f32x2 e = f32x2{__builtin_amdgcn_exp2f(sacc[kb][i]), __builtin_amdgcn_exp2f(sacc[kb][i + 1])};
-                l2 += e;
-                pf[kb][i >> 3][i & 7] = (T)e.x;
-                pf[kb][i >> 3][(i & 7) + 1] = (T)e.y;
-            }
-        l_run += l2.x + l2.y;
-#else
-        float l_tile = 0.f;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float e = __builtin_amdgcn_exp2f(sacc[kb][i]);
-                if (!HIVE_ATT_LSUM_MFMA) l_tile += e;
-                pf[kb][i >> 3][i & 7] = (T)e;
-            }
-        l_run += l_tile;
-#endif
-        // O^T[ch][q] += V^T[ch][key] P^T[key][q]; k index j of half hh <-> key 32 kb + 16 s + 8 (j >> 2) + 4 hh + (j & 3) (see vt_slot)
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-#pragma unroll
-                for (int db = 0; db < 2; ++db) {
-                    // the lane's 8 keys {16 s + 4 hh + 0..3, + 8..11} of key block kb sit in slots 16 s + 8 hh .. + 7 of the stored
-                    // (quad-swapped) order: chunk 4 kb + 2 s + hh of the row, one 16-byte read through the tile's swizzle
-                    const vec<T, 8> vf = *reinterpret_cast<const vec<T, 8> *>(v_t + swz(db * 32 + lq, 4 * kb + 2 * s + hh));
-                    oacc[db] = hive_mfma::mfma32(vf, pf[kb][s], oacc[db]);
+                for (int kb = 0; kb < 2; ++kb) {
+                    const vec<T, 8> kf = *reinterpret_cast<const vec<T, 8> *>(k_t + swz(kb * 32 + lq, ks * 2 + hh));
+                    sacc[kb] = hive_mfma::mfma32(kf, qf[ks], ks == 0 ? neg_m : sacc[kb]);
                 }
-        if (HIVE_ATT_LSUM_MFMA) {
+            // key row of register i: 32 kb + (i & 3) + 8 (i >> 2) + 4 hh.  Keys >= N exist only in the last tile.
+            if (t == n_tiles - 1) {
+                asm volatile("; pad keys: last tile only" ::: "memory");  // keeps this a branch (if-converted it is 31 v_cndmask in EVERY tile)
+                const int key0 = t * ATT_KV + 4 * hh;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i)
+                        if (key0 + kb * 32 + (i & 3) + 8 * (i >> 2) >= p.N) sacc[kb][i] = -INFINITY;
+            }
+            // v_max3_f32 by hand: fmaxf() makes the compiler canonicalise every MFMA result first (one v_max_f32 x, x, x per score:
+            // 50 v_max + 8 v_max3 per tile where 16 v_max3 do; the softmax VALU work, not the MFMAs, bounds this kernel)
+            float m_tile = max3_raw(sacc[0][0], sacc[1][0], sacc[0][1]);
+            m_tile = max3_raw(m_tile, sacc[1][1], sacc[0][2]);
+#pragma unroll
+            for (int i = 2; i < 16; i += 2) {
+                m_tile = max3_raw(m_tile, sacc[1][i], sacc[0][i + 1]);
+                if (i + 2 < 16)
+                    m_tile = max3_raw(m_tile, sacc[1][i + 1], sacc[0][i + 2]);
+                else
+                    m_tile = max3_raw(m_tile, sacc[1][i + 1], sacc[1][i + 1]);
+            }
+            m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32));  // the tile's maximum RELATIVE to m_used
+            // deferred maximum: the running maximum only moves when some query of the wave exceeds it by more than ATT_DEFER
+            // (probabilities then stay below 2^8 -- harmless in f32 / bf16), so the rescale of the O accumulators and the re-shift of
+            // the scores are skipped for almost every tile.  Any m gives the same softmax.
+            if (it == 0 || __any(m_tile > ATT_DEFER)) {
+                const float m_new = it == 0 ? m_tile : fmaxf(m_run, m_used + m_tile);
+                const float delta = m_new - m_used;
+                const float alpha = it == 0 ? 0.f : __builtin_amdgcn_exp2f(m_run - m_new);
+                m_run = m_new;
+                l_run *= alpha;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    oacc[0][i] *= alpha;
+                    oacc[1][i] *= alpha;
+                    sacc[0][i] -= delta;
+                    sacc[1][i] -= delta;
+                    neg_m[i] = -m_new;
+                }
+            }
+            vec<T, 8> pf[2][2];
+            float l_tile = 0.f;
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) lacc = hive_mfma::mfma32(ones8, pf[kb][s2], lacc);
+                for (int i = 0; i < 16; ++i) {
+                    const float e = __builtin_amdgcn_exp2f(sacc[kb][i]);
+                    l_tile += e;
+                    pf[kb][i >> 3][i & 7] = (T)e;
+                }
+            l_run += l_tile;
+            // O^T[ch][q] += V^T[ch][key] P^T[key][q]; k index j of half hh <-> key 32 kb + 16 s + 8 (j >> 2) + 4 hh + (j & 3) (see vt_slot)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int db = 0; db < 2; ++db) {
+                        // the lane's 8 keys {16 s + 4 hh + 0..3, + 8..11} of key block kb sit in slots 16 s + 8 hh .. + 7 of the stored
+                        // (quad-swapped) order: chunk 4 kb + 2 s + hh of the row, one 16-byte read through the tile's swizzle
+                        const vec<T, 8> vf = *reinterpret_cast<const vec<T, 8> *>(v_t + swz(db * 32 + lq, 4 * kb + 2 * s + hh));
+                        oacc[db] = hive_mfma::mfma32(vf, pf[kb][s], oacc[db]);
+                    }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my pieces of tile t+1 have landed
         __syncthreads();
     }
-    const float l_tot = HIVE_ATT_LSUM_MFMA ? lacc[0] : l_run + __shfl_xor(l_run, 32);
+    float l_tot = l_run + __shfl_xor(l_run, 32);
+    if constexpr (KS > 1) {
+        // the second key half hands over (O, m, l) -- 34 floats per lane, behind the four 4 KiB turn-around blocks below (the stages are free: the loop's last
+        // barrier is behind every wave) -- and leaves; the first merges: m = max(m0, m1), O = O0 2^(m0 - m) + O1 2^(m1 - m), l likewise.  Every half has at least
+        // one tile with a real key (n_tiles >= 4 and Np - N < 64: checked on the host), so both maxima are finite.
+        float *xch = reinterpret_cast<float *>(lds_all + 4 * 4096) + wave * (34 * 64) + lane;
+        if (kh == 1) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                xch[i * 64] = oacc[0][i];
+                xch[(16 + i) * 64] = oacc[1][i];
+            }
+            xch[32 * 64] = m_run;
+            xch[33 * 64] = l_tot;
+        }
+        __syncthreads();
+        if (kh == 1) return;  // (whole waves; nothing below synchronises the workgroup)
+        const float m1 = xch[32 * 64], l1 = xch[33 * 64];
+        const float m = fmaxf(m_run, m1);
+        const float a0 = __builtin_amdgcn_exp2f(m_run - m), a1 = __builtin_amdgcn_exp2f(m1 - m);
+        l_tot = l_tot * a0 + l1 * a1;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            oacc[0][i] = oacc[0][i] * a0 + xch[i * 64] * a1;
+            oacc[1][i] = oacc[1][i] * a0 + xch[(16 + i) * 64] * a1;
+        }
+    }
     const float inv = 1.0f / l_tot;
     // O leaves through LDS (the K / V stages are free: the loop's last barrier is behind every wave): in the accumulator layout a lane
     // owns 4 consecutive channels of its query, so a direct store is 32 rows x 16 bytes per instruction (8 per wave, store-issue
     // bound); turned around in the wave's private 4 KiB -- [query][64 channels], 16-byte chunk c of row r at slot c ^ (r & 7) -- the
     // wave stores 4 x (8 rows x 128 contiguous bytes).
-    unsigned char *ot = lds + wave * 4096;
+    unsigned char *ot = lds_all + wave * 4096;
 #pragma unroll
     for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -1375,7 +1376,14 @@ static int attention_t(hive_ctx *ctx, const void *qk, const void *vT, void *out,
     p.Np = Np;
     p.D = D;
     const int q_blocks = (p.Np + 127) / 128;
-    hipLaunchKernelGGL(attention_kernel<T>, dim3((unsigned)(p.B * p.H * q_blocks)), dim3(256), 0, ctx->stream, p);
+    // the keys split two ways inside the workgroup where the grid leaves a CU one workgroup at most (HIVE_ATT_KSPLIT=0 / 1 overrides: read per call)
+    const long long grid = (long long)p.B * p.H * q_blocks;
+    const char *ks_env = getenv("HIVE_ATT_KSPLIT");
+    const bool split = p.Np / ATT_KV >= 4 && (ks_env ? ks_env[0] == '1' : (grid <= ctx->num_cus && !ctx->deterministic));  // (deterministic: no path whose use depends on the batch size)
+    if (split)
+        hipLaunchKernelGGL((attention_kernel<T, 2>), dim3((unsigned)grid), dim3(512), 0, ctx->stream, p);
+    else
+        hipLaunchKernelGGL((attention_kernel<T, 1>), dim3((unsigned)grid), dim3(256), 0, ctx->stream, p);
     HIVE_CHECK_HIP(ctx, hipGetLastError());
     return HIVE_OK;
 }
@@ -1448,7 +1456,7 @@ int hive_vit_attention(hive_ctx *ctx, const void *qk, int dtype, const void *vT,
     if (!ctx) return hive_fail(nullptr, HIVE_ERR_INVALID, "ctx is NULL");
     HIVE_REQUIRE(ctx, qk && vT && out, "attention: NULL argument");
     HIVE_REQUIRE_16BIT(ctx, dtype, "attention");
-    HIVE_REQUIRE(ctx, B > 0 && N > 0 && N <= Np && Np % 64 == 0 && D == H * 64, "attention: need N <= Np, Np %% 64 == 0, head dim 64");
+    HIVE_REQUIRE(ctx, B > 0 && N > 0 && N <= Np && Np % 64 == 0 && Np - N < 64 && D == H * 64, "attention: need Np - 64 < N <= Np, Np %% 64 == 0, head dim 64");
     // the kernel masks pad keys in the LAST 64-key tile only: Np must be N rounded up to a multiple of 64
     HIVE_REQUIRE(ctx, Np - N < 64, "attention: Np (%d) must be N (%d) rounded up to a multiple of 64", Np, N);
     return dtype == HIVE_BF16 ? attention_t<__bf16>(ctx, qk, vT, out, B, N, Np, D, H) : attention_t<_Float16>(ctx, qk, vT, out, B, N, Np, D, H);

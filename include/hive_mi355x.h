@@ -84,9 +84,10 @@ int hive_ctx_release_stream(hive_ctx *ctx);
 int hive_ctx_set_stream(hive_ctx *ctx, void *stream);
 /* Rounding used by hive_project / hive_project_bbox, and the mode a volume created afterwards on this context starts with. */
 int hive_ctx_set_round_mode(hive_ctx *ctx, int mode);
-/* Deterministic mode (off by default): the network kernels stop using the two paths whose USE depends on the batch size and on the device's CU count --
- * split-K of long K loops at small launches (another, fixed, order of float32 additions) and the Gram-matrix form of the GroupNorm statistics of the
- * bottlenecks' 1 x 1 convolutions (statistics of the exact products instead of the rounded outputs) -- so that a frame's depth map no longer changes
+/* Deterministic mode (off by default): the network kernels stop using the three paths whose USE depends on the batch size and on the device's CU count --
+ * split-K of long K loops at small launches (another, fixed, order of float32 additions), the attention kernel's two-way split of the keys at small grids
+ * (likewise) and the Gram-matrix form of the GroupNorm statistics of the bottlenecks' 1 x 1 convolutions (statistics of the exact products instead of the
+ * rounded outputs) -- so that a frame's depth map no longer changes
  * with the size of the batch it was in beyond what is stated next.  What remains: a GroupNorm's per-tile partial sums are cut at 128- / 256-pixel
  * tile boundaries counted from the START OF THE BATCH, so a frame's (mean, rstd) still depend on its position in the batch by float32 re-association
  * (~1e-7 relative).  Frame-sharded multi-GPU runs that want one-GPU depth maps to the last bit must also keep the per-rank batch composition. */

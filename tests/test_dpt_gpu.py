@@ -190,8 +190,9 @@ def _median_mm(a, b):
 def test_batch_independence_and_determinism(gpu_ctx, monkeypatch):
     """Frame i of a batch of 6 == the same frame run alone (no cross-frame leakage through the padded token rows, the
     batched GroupNorm statistics or the attention masks); the hand-written ViT engine is bit-reproducible.  A lone frame's fc2 GEMMs split
-    their K loop over several workgroups (csrc/mfma_pipe.hpp splitk_combine: another, fixed, order of float32 additions), so the bitwise
-    comparison runs with HIVE_SPLITK=0; with the split the frame alone is reproducible and within rounding noise of the frame in the batch."""
+    their K loop over several workgroups (csrc/mfma_pipe.hpp splitk_combine) and its attention launches their keys over two groups of waves (vit.hip
+    attention_kernel KS = 2) -- other, fixed, orders of float32 additions -- so the bitwise comparison runs with HIVE_SPLITK=0 HIVE_ATT_KSPLIT=0; with the
+    splits the frame alone is reproducible and within rounding noise of the frame in the batch."""
     from hive_amd.dpt.vit_engine import VitEngine
     _, hip = _pair()
     eng = VitEngine(hip.pretrained.model, ctx=gpu_ctx)
@@ -202,8 +203,10 @@ def test_batch_independence_and_determinism(gpu_ctx, monkeypatch):
     t_split = eng.forward(tokens[4:5].contiguous(), taps=(8, 11))
     t_split_again = eng.forward(tokens[4:5].contiguous(), taps=(8, 11))
     monkeypatch.setenv("HIVE_SPLITK", "0")
+    monkeypatch.setenv("HIVE_ATT_KSPLIT", "0")
     t_one = eng.forward(tokens[4:5].contiguous(), taps=(8, 11))
     monkeypatch.delenv("HIVE_SPLITK")
+    monkeypatch.delenv("HIVE_ATT_KSPLIT")
     assert torch.equal(t_all[0], t_again[0]) and torch.equal(t_all[1], t_again[1]), "ViT engine: two runs differ"
     assert torch.equal(t_all[1][4:5], t_one[1]), "ViT engine: an image in a batch differs from the image alone"
     assert torch.equal(t_split[0], t_split_again[0]) and torch.equal(t_split[1], t_split_again[1]), "ViT engine (split K): two runs differ"

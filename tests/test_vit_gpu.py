@@ -152,7 +152,8 @@ def test_linear_rejects_bad_shapes(gpu_ctx, half):
         gpu_ctx.check(gpu_ctx.lib.hive_vit_linear(gpu_ctx.handle, t.data_ptr(), _code(half), t.data_ptr(), f.data_ptr(), None, t.data_ptr(), 128, 128, 64, 2))
 
 
-@pytest.mark.parametrize("B,N", [(1, 1201), (2, 77), (1, 64), (3, 130), (24, 1201)])  # 24 x 1216 rows: q|k and v^T on the persistent 256-tile kernel
+@pytest.mark.parametrize("B,N", [(1, 1201), (2, 77), (1, 64), (3, 130), (24, 1201), (2, 500), (1, 300)])  # 24 x 1216 rows: q|k and v^T on the persistent 256-tile kernel;
+# 1 x 1201, 2 x 500, 1 x 300: grids of at most one workgroup per CU -- the keys split two ways inside the workgroup (19 = 10 + 9, 8 = 4 + 4, 5 = 3 + 2 tiles)
 def test_qkv_and_attention(gpu_ctx, half, B, N, monkeypatch):
     """qkv projection (q|k row-major, v transposed) + softmax(q k^T / 8) v, incl. ragged N (key masking),
     and a spiked key row that forces the online-softmax rescale branch.  At small batches q | k and v^T are ONE launch (vit.hip qkv_t, round 5): the
@@ -198,6 +199,14 @@ def test_qkv_and_attention(gpu_ctx, half, B, N, monkeypatch):
     attn = torch.softmax(q @ k.transpose(-1, -2) * 0.6931471805599453, dim=-1)  # exp2(q' k^T) with the stored q' = c q
     ref = (attn @ v).permute(0, 2, 1, 3).reshape(B, N, D)
     _close(out.reshape(B, Np, D)[:, :N], ref, "attention")
+    # both forms of the kernel (keys in one chain / split two ways and merged: vit.hip attention_kernel KS) against the same reference, and against each other
+    for ks in ("0", "1"):
+        monkeypatch.setenv("HIVE_ATT_KSPLIT", ks)
+        out2 = torch.full_like(out, 3.0)
+        gpu_ctx.check(gpu_ctx.lib.hive_vit_attention(gpu_ctx.handle, qk.data_ptr(), _code(half), vT.data_ptr(), out2.data_ptr(), B, N, Np, D, H))
+        _close(out2.reshape(B, Np, D)[:, :N], ref, f"attention, HIVE_ATT_KSPLIT={ks}")
+        _close(out2.reshape(B, Np, D)[:, :N], out.reshape(B, Np, D)[:, :N].float(), f"attention forms, HIVE_ATT_KSPLIT={ks}")
+    monkeypatch.delenv("HIVE_ATT_KSPLIT")
 
 
 @pytest.mark.parametrize("N,C,H,W,relu,res", [(2, 64, 24, 32, True, False), (1, 256, 30, 40, False, True), (3, 1024, 6, 8, True, False),
