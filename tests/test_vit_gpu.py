@@ -152,15 +152,16 @@ def test_linear_rejects_bad_shapes(gpu_ctx, half):
         gpu_ctx.check(gpu_ctx.lib.hive_vit_linear(gpu_ctx.handle, t.data_ptr(), _code(half), t.data_ptr(), f.data_ptr(), None, t.data_ptr(), 128, 128, 64, 2))
 
 
-@pytest.mark.parametrize("B,N", [(1, 1201), (2, 77), (1, 64), (3, 130), (24, 1201), (2, 500), (1, 300)])  # 24 x 1216 rows: q|k and v^T on the persistent 256-tile kernel;
-# 1 x 1201, 2 x 500, 1 x 300: grids of at most one workgroup per CU -- the keys split two ways inside the workgroup (19 = 10 + 9, 8 = 4 + 4, 5 = 3 + 2 tiles)
-def test_qkv_and_attention(gpu_ctx, half, B, N, monkeypatch):
+@pytest.mark.parametrize("B,N,D,H", [(1, 1201, 768, 12), (2, 77, 768, 12), (1, 64, 768, 12), (3, 130, 768, 12), (24, 1201, 768, 12), (2, 500, 768, 12), (1, 300, 768, 12),
+                                     (1, 577, 1024, 16)])
+# 24 x 1216 rows: q|k and v^T on the persistent 256-tile kernel; 1 x 1201, 2 x 500, 1 x 300: grids of at most one workgroup per CU -- the keys split two ways inside the
+# workgroup (19 = 10 + 9, 8 = 4 + 4, 5 = 3 + 2 tiles); 1 x 577 at D = 1024, 16 heads: DPT-Large's one-frame shapes (384 x 384) on the merged q | k | v^T launch and the key split
+def test_qkv_and_attention(gpu_ctx, half, B, N, D, H, monkeypatch):
     """qkv projection (q|k row-major, v transposed) + softmax(q k^T / 8) v, incl. ragged N (key masking),
     and a spiked key row that forces the online-softmax rescale branch.  At small batches q | k and v^T are ONE launch (vit.hip qkv_t, round 5): the
     two-launch orchestration (HIVE_QKV_MERGE=0) and the two-workgroups-per-CU merge ("2") must give the same bits."""
     import torch
     torch.manual_seed(2)
-    D, H = 768, 12
     Np = (N + 63) // 64 * 64
     x = torch.zeros(B, Np, D, device="cuda")
     x[:, :N] = torch.randn(B, N, D, device="cuda")
