@@ -194,13 +194,14 @@ def load_profile(name):
         return None
 
 
-def config4_leg(device, ctx, steps=2, batch=16, overlap=True, prefetch=True, unique_frames=24):
+def config4_leg(device, ctx, steps=2, batch=48, overlap=True, prefetch=True, unique_frames=48):
     """BASELINE configs[3], bounded, through the PRODUCT path: 1920 x 1080 frames (host-resident, uploaded in the timed region) -> `DepthFusionStream.step`:
     the reference's resize rule (640 x 480 target, keep aspect ratio, "minimal", multiple of 32: 864 x 480 -- hive_amd.depth.network_size) and its cv2.INTER_CUBIC
     resize + normalisation as one HIP kernel -> DPT-Large depth (backbone vitl16_384, bf16, seeded weights) -> nearest back to 1080p + uint16-mm hand-off as
     one HIP kernel (all of it ONE C-ABI call, hive_dpt_forward_frames) -> integrate into a 1024^3 volume (5 mm voxels), the sweeps of a batch on the side
     stream under the next batch's network as in the headline job.  No torch operator in the timed region but the upload.  `steps` timed steps of `batch` frames
-    after one warm-up step, wrapping around `unique_frames` distinct frames (ray-casting a 1080p frame on the host takes about a second).  The sweep's roofline (SURVEY 8d bytes and must-move bytes) on two scenes, as for the headline: the DPT depth of the last step's
+    after one warm-up step, wrapping around `unique_frames` distinct frames (ray-casting a 1080p frame on the host takes about a second).  Batches of 48 (round 5: 389 frames/s at
+    16, 396 at 32, 409 at 48 -- tools/probe_config4_batch.py; the network's per-frame time still falls with the batch, 1.94 -> 1.81 ms).  The sweep's roofline (SURVEY 8d bytes and must-move bytes) on two scenes, as for the headline: the DPT depth of the last step's
     frames (`roofline`: seeded random weights give a noise-like depth map -- two thirds of the voxels the sweep must test cannot update) and the analytic
     ray-cast depth of the same frames (`roofline_room`: the room's walls)."""
     from hive_amd import depth as depth_mod, fusion, synthetic
