@@ -349,7 +349,9 @@ int hive_vit_linear(hive_ctx *ctx, const void *A, int dtype, const void *W, cons
 int hive_vit_qkv(hive_ctx *ctx, const void *x, int dtype, const void *W, const float *bias, void *qk, void *vT,
                  int B, int Np, int D, int H);
 /* softmax(q k^T / 8) v over the first N keys of each image -> out [B*Np][D]; Np = N rounded up to a multiple of 64; qk, vT as
- * hive_vit_qkv writes them (q pre-scaled: the kernel evaluates exp2(q' k^T - max)) */
+ * hive_vit_qkv writes them (q pre-scaled: the kernel evaluates exp2(q' k^T - max)).  Where the launch leaves a CU one workgroup at most (one or two 480 x 640
+ * frames) each workgroup splits its keys over two groups of waves and merges the halves: another order of float32 additions than at larger batches
+ * (hive_ctx_set_deterministic keeps the one-chain form everywhere). */
 int hive_vit_attention(hive_ctx *ctx, const void *qk, int dtype, const void *vT, void *out, int B, int N, int Np,
                        int D, int H);
 
